@@ -1,0 +1,487 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REAL reference.
+
+This script only runs in the build container: it imports the reference package from
+/root/reference/fithic (read-only), runs its unmodified `main()` and library calls
+(scipy.special.bdtrc, scipy.interpolate.UnivariateSpline, sklearn IsotonicRegression,
+myStats.benjamini_hochberg_correction) and records inputs + outputs as DATA.  No reference
+source text is stored; the reference never travels to the GPU box - these fixtures do.
+
+Fixture sets:
+  F1  bundled hESC chr1 40 kb (the reference's own tests/data files, copied as data):
+        f1_nobias   -r 40000 -L 50000 -U 5000000 -b 50 -p 1 -x All            (run_tests-git.sh:34-36)
+        f1_bias     ... -t bias -x intraOnly -p 2                               (run_tests-git.sh:40-42, +pass 2)
+  F2  synthetic contacts over the bundled IMR90 1 Mb fragments/bias, 24 chromosomes
+        f2_all (All, -p 2, bias) / f2_inter (interOnly, bias) / f2_intra (intraOnly, -p 2, bias, -L/-U)
+        f2_all_nobias (All, no bias, -L/-U)
+  F3  scipy.special.bdtrc / betaln / log known-answer vectors (bit patterns)
+  F4  UnivariateSpline known-answer vectors (t, c, fp, ier; incl. nest restarts, s=0)
+  F5  myStats.benjamini_hochberg_correction known-answer vectors
+  F6  quirk probes (small hand-made inputs through the full reference main())
+
+Usage:  python tests/golden/make_golden.py [f1] [f2] [f3] [f4] [f5] [f6]     (default: all)
+"""
+import sys
+import os
+import io
+import gzip
+import json
+import copy
+import time
+import math
+import hashlib
+import shutil
+import tempfile
+import contextlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DATA = os.path.join(HERE, "data")
+REF_PKG = "/root/reference/fithic"
+
+sys.path.insert(0, REF_PKG)
+import fithic as F          # noqa: E402  (the reference module itself)
+import myStats as REF_STATS  # noqa: E402
+import scipy.special as scsp  # noqa: E402
+from scipy.interpolate import UnivariateSpline  # noqa: E402
+
+_STAGES = ("read_Interactions", "makeBinsFromInteractions", "generate_FragPairs",
+           "calculateProbabilities", "fit_Spline")
+
+
+def _bins_snapshot(binStats):
+    """binStats: {idx: [(lb,ub), poss, sumCC, sumDist, avgCC, avgDist, [dists], poss7]} -> arrays"""
+    n = len(binStats)
+    out = dict(lb=np.zeros(n, np.int64), ub=np.zeros(n, np.int64), s1=np.zeros(n, np.int64),
+               s2=np.zeros(n, np.int64), s3=np.zeros(n, np.float64), s7=np.zeros(n, np.int64),
+               ndist=np.zeros(n, np.int64))
+    for i in range(n):
+        b = binStats[i]
+        out["lb"][i], out["ub"][i] = b[0]
+        out["s1"][i] = b[1]
+        out["s2"][i] = b[2]
+        out["s3"][i] = b[3]
+        out["s7"][i] = b[7]
+        out["ndist"][i] = len(b[6])
+    return out
+
+
+def run_reference(argv, quiet=True):
+    """Run the reference's main() on argv; capture every stage's outputs through a profile hook."""
+    passes = []          # one dict per pass
+    cur = {}
+    ref_file = os.path.join(REF_PKG, "fithic.py")
+
+    def hook(frame, event, arg):
+        if event != "return":
+            return
+        code = frame.f_code
+        name = code.co_name
+        if name not in _STAGES or code.co_filename != ref_file:
+            return
+        nonlocal cur
+        if name == "read_Interactions":
+            cur = {}
+            passes.append(cur)
+            mainDic, interCnt, interSum, intraAllSum, inRangeSum = arg
+            keys = np.array(sorted(mainDic.keys()), np.int64)
+            cur["dist_keys"] = keys
+            cur["dist_sumcc"] = np.array([mainDic[int(k)][1] for k in keys], np.int64)
+            cur["sums"] = np.array([interCnt, interSum, intraAllSum, inRangeSum], np.int64)
+        elif name == "makeBinsFromInteractions":
+            for k, v in _bins_snapshot(arg).items():
+                cur["bins0_" + k] = v
+        elif name == "generate_FragPairs":
+            (binStats, noOfFrags, maxPossDist, possIntraInRange, possInterAll, interChrProb, baseProb) = arg
+            for k, v in _bins_snapshot(binStats).items():
+                cur["bins1_" + k] = v
+            cur["frag_scalars"] = np.array([noOfFrags, maxPossDist, possIntraInRange, possInterAll,
+                                            interChrProb, baseProb], np.float64)
+            cur["possibleIntraInRangeCount"] = np.array([int(possIntraInRange)], np.int64)
+        elif name == "calculateProbabilities":
+            cur["x"] = np.array(arg[0], np.float64)
+            cur["y"] = np.array(arg[1], np.float64)
+        elif name == "fit_Spline":
+            loc = frame.f_locals
+            cur["p"] = np.array(loc["p_vals"], np.float64)
+            cur["q"] = np.array(loc["q_vals"], np.float64)
+            cur["expcc"] = np.array(loc["expCC_List"], np.float64)
+            cur["b1"] = np.array(loc["biasl"], np.float64)
+            cur["b2"] = np.array(loc["biasr"], np.float64)
+            cur["outlierThres"] = np.array([loc["outlierThres"]], np.float64)
+            cur["n_outlier_lines"] = np.array([len(loc["outliersline"])], np.int64)
+            cur["outliersline"] = np.array(list(loc["outliersline"]), np.int64)
+            cur["outliersdist"] = np.array(list(loc["outliersdist"]), np.int64)
+            cur["fdr_y"] = np.array(loc["FDRy"], np.int64)
+            if loc.get("splineX") is not None:
+                ius = loc["ius"]
+                t, c, k = ius._eval_args
+                cur["spl_t"] = np.array(t, np.float64)
+                cur["spl_c"] = np.array(c, np.float64)[:len(t) - 4]
+                cur["spl_s_fp_ier"] = np.array([loc["splineError"], ius._data[10], ius._data[-1]], np.float64)
+                cur["splineX"] = np.array(loc["splineX"], np.int64)
+                cur["splineY"] = np.array(loc["splineY"], np.float64)
+                cur["newSplineY"] = np.array(loc["newSplineY"], np.float64)
+                cur["residual"] = np.array([loc["residual"]], np.float64)
+                cur["x_sorted"] = np.array(loc["x"], np.float64)
+                cur["y_sorted"] = np.array(loc["y"], np.float64)
+
+    old_argv = sys.argv
+    sys.argv = ["fithic"] + list(argv)
+    sink = io.StringIO()
+    t0 = time.time()
+    try:
+        sys.setprofile(hook)
+        with (contextlib.redirect_stdout(sink) if quiet else contextlib.nullcontext()):
+            F.main()
+    finally:
+        sys.setprofile(None)
+        sys.argv = old_argv
+    return passes, time.time() - t0
+
+
+def _md5_decompressed(path):
+    h = hashlib.md5()
+    with gzip.open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def _collect_outputs(outdir, lib, res, npasses):
+    meta = {}
+    for i in range(1, npasses + 1):
+        sig = os.path.join(outdir, "%s.spline_pass%d.res%d.significances.txt.gz" % (lib, i, res))
+        if os.path.exists(sig):
+            meta["sig_md5_pass%d" % i] = _md5_decompressed(sig)
+            with gzip.open(sig, "rt") as f:
+                lines = f.readlines()
+            meta["sig_rows_pass%d" % i] = len(lines) - 1
+            # a few verbatim output rows (head / middle / tail) as text known-answers
+            idx = sorted(set([0, 1, 2, 3, len(lines) // 2, len(lines) - 2, len(lines) - 1]))
+            meta["sig_sample_pass%d" % i] = {str(j): lines[j] for j in idx if 0 <= j < len(lines)}
+        fp = os.path.join(outdir, "%s.fithic_pass%d.res%d.txt" % (lib, i, res))
+        if os.path.exists(fp):
+            meta["fithic_pass%d_txt" % i] = open(fp).read()
+    log = os.path.join(outdir, lib + ".fithic.log")
+    if os.path.exists(log):
+        meta["log_txt"] = open(log).read()
+    return meta
+
+
+def save_case(name, argv_tail, files, passes, elapsed, outdir, lib, res, subsample=1):
+    """Write tests/golden/<name>.npz (+ .json).  Per-pair arrays are sub-sampled by `subsample`."""
+    arrays = {}
+    meta = {"name": name, "argv": argv_tail, "files": files, "n_passes": len(passes),
+            "reference_seconds_1core": round(elapsed, 2), "subsample": subsample}
+    for pi, P in enumerate(passes, start=1):
+        n = len(P["p"])
+        meta["n_rows"] = n
+        sel = np.arange(0, n, subsample)
+        for k, v in P.items():
+            if k in ("p", "q", "expcc", "b1", "b2"):
+                arrays["p%d_%s" % (pi, k)] = v[sel]
+            else:
+                arrays["p%d_%s" % (pi, k)] = v
+        q = P["q"]
+        meta["pass%d" % pi] = {
+            "n_q_lt_0.01": int(np.sum(q < 0.01)), "n_q_lt_0.05": int(np.sum(q < 0.05)),
+            "n_p_lt_1": int(np.sum(P["p"] < 1.0)), "n_nan_p": int(np.sum(np.isnan(P["p"]))),
+            "n_outlier_lines": int(P["n_outlier_lines"][0]),
+            "p_sha256": hashlib.sha256(P["p"].tobytes()).hexdigest(),
+            "q_sha256": hashlib.sha256(q.tobytes()).hexdigest(),
+        }
+    meta.update(_collect_outputs(outdir, lib, res, len(passes)))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
+    with open(os.path.join(HERE, name + ".json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("  wrote %s: %d passes, %d rows, reference took %.1f s" % (name, len(passes), meta.get("n_rows", -1), elapsed))
+
+
+def run_case(name, contacts, frags, bias, res, extra, subsample=1, npasses=1):
+    tmp = tempfile.mkdtemp(prefix="golden_")
+    lib = "G"
+    argv = ["-i", os.path.join(DATA, contacts), "-f", os.path.join(DATA, frags), "-o", tmp,
+            "-r", str(res), "-l", lib] + extra
+    if bias:
+        argv += ["-t", os.path.join(DATA, bias)]
+    passes, dt = run_reference(argv)
+    tail = ["-r", str(res)] + extra
+    save_case(name, tail, {"contacts": contacts, "frags": frags, "bias": bias}, passes, dt, tmp, lib, res, subsample)
+    shutil.rmtree(tmp)
+
+
+# ------------------------------------------------------------------------------------------------ F1
+def make_f1():
+    print("F1: bundled hESC chr1 40 kb")
+    base = ["-L", "50000", "-U", "5000000", "-b", "50"]
+    run_case("f1_nobias", "hESC_chr1_w40000.contacts.gz", "hESC_chr1_w40000.frags.gz", None, 40000,
+             base + ["-p", "1", "-x", "All"], subsample=29)
+    run_case("f1_bias", "hESC_chr1_w40000.contacts.gz", "hESC_chr1_w40000.frags.gz",
+             "hESC_chr1_w40000.bias.gz", 40000, base + ["-p", "2", "-x", "intraOnly"], subsample=29)
+
+
+# ------------------------------------------------------------------------------------------------ F2
+def _write_gz(path, text):
+    with open(path, "wb") as raw:
+        with gzip.GzipFile(fileobj=raw, mode="wb", mtime=0, filename="") as f:
+            f.write(text.encode())
+
+
+def synth_imr90_contacts(path, seed=20260928):
+    """Deterministic synthetic contacts over the bundled IMR90 1 Mb loci (24 chromosomes)."""
+    rng = np.random.default_rng(seed)
+    chrom_mids = {}
+    order = []
+    with gzip.open(os.path.join(DATA, "IMR90_w1Mb.frags.gz"), "rt") as f:
+        for line in f:
+            w = line.split()
+            if w[0] not in chrom_mids:
+                chrom_mids[w[0]] = []
+                order.append(w[0])
+            chrom_mids[w[0]].append(int(w[2]))
+    rows = []
+    for ch in order:
+        mids = chrom_mids[ch]
+        n = len(mids)
+        for i in range(n):
+            for j in range(i, min(n, i + 1 + 70)):
+                d = j - i
+                lam = 9.0 if d == 0 else 14.0 * d ** -1.05
+                if rng.random() < 0.55:
+                    continue
+                c = rng.poisson(lam * rng.lognormal(0.0, 0.35))
+                if c < 1:
+                    continue
+                if rng.random() < 0.01:
+                    c *= 5
+                rows.append((ch, mids[i], ch, mids[j], c))
+    ncis = len(rows)
+    allloci = [(ch, m) for ch in order for m in chrom_mids[ch]]
+    ntrans = 0
+    while ntrans < 7000:
+        a = allloci[rng.integers(len(allloci))]
+        b = allloci[rng.integers(len(allloci))]
+        if a[0] == b[0]:
+            continue
+        rows.append((a[0], a[1], b[0], b[1], 1 + rng.poisson(0.7)))
+        ntrans += 1
+    # interleave a little: shuffle blocks so that inter rows are not all at the end
+    perm = rng.permutation(len(rows))
+    rows = [rows[i] for i in perm]
+    # counts are written as floats with a fractional part now and then (int(float()) truncation, A4)
+    out = []
+    for k, (c1, m1, c2, m2, c) in enumerate(rows):
+        if k % 97 == 0:
+            out.append("%s\t%d\t%s\t%d\t%.1f\n" % (c1, m1, c2, m2, c + 0.7))
+        else:
+            out.append("%s\t%d\t%s\t%d\t%d\n" % (c1, m1, c2, m2, c))
+    _write_gz(path, "".join(out))
+    return ncis, ntrans
+
+
+def make_f2():
+    print("F2: synthetic multi-chromosome over IMR90 1 Mb loci")
+    contacts = "synth_IMR90_w1Mb.contacts.gz"
+    ncis, ntrans = synth_imr90_contacts(os.path.join(DATA, contacts))
+    print("  synthetic contacts: %d cis + %d trans rows" % (ncis, ntrans))
+    fr, bi = "IMR90_w1Mb.frags.gz", "IMR90_w1Mb.bias.gz"
+    run_case("f2_all", contacts, fr, bi, 1000000, ["-b", "20", "-p", "2", "-x", "All"])
+    run_case("f2_inter", contacts, fr, bi, 1000000, ["-b", "20", "-p", "2", "-x", "interOnly"])
+    run_case("f2_intra", contacts, fr, bi, 1000000,
+             ["-b", "20", "-p", "2", "-x", "intraOnly", "-L", "2000000", "-U", "50000000"])
+    run_case("f2_all_nobias", contacts, fr, None, 1000000,
+             ["-b", "15", "-p", "1", "-x", "All", "-L", "1000000", "-U", "60000000"])
+
+
+# ------------------------------------------------------------------------------------------------ F3
+def make_f3():
+    print("F3: bdtrc / betaln / log known answers")
+    rng = np.random.default_rng(7)
+    ks, ns, ps = [], [], []
+    # realistic Hi-C regimes: n = total in-range contacts, count small, expected around count
+    for n in (10 ** 5, 649_576, 6_495_767, 3_549_437, 10 ** 7, 123_456_789, 10 ** 9, 2_000_000_011):
+        for _ in range(1400):
+            count = int(min(1 + rng.geometric(0.08 if rng.random() < 0.8 else 0.004), 200000))
+            ratio = math.exp(rng.normal(0.0, 1.2))          # expected / observed
+            prior = min(max(count * ratio / n, 1e-12), 0.999)
+            ks.append(count - 1)
+            ns.append(n)
+            ps.append(prior)
+    # low-expected regime (pseries branch: bb*xx <= 1)
+    for n in (10 ** 5, 6_495_767, 10 ** 9):
+        for _ in range(400):
+            count = int(rng.integers(1, 12))
+            prior = rng.uniform(1e-3, 1.0) / n
+            ks.append(count - 1)
+            ns.append(n)
+            ps.append(prior)
+    # small n (a+b < MAXGAM: pow/beta path) and edge cases
+    for n in (5, 20, 60, 120, 169, 170, 171, 172, 400):
+        for _ in range(60):
+            k = int(rng.integers(0, n + 1))
+            ks.append(k - 1 if k > 0 else 0)
+            ns.append(n)
+            ps.append(float(rng.uniform(0, 1)))
+    edge = [(-1, 10, .5), (10, 10, .5), (3, 10, 0.0), (3, 10, 1.0), (0, 10, 0.005), (0, 10, 0.5),
+            (3, 10, -0.1), (3, 10, 1.1), (11, 10, .5), (0, 6495767, 1e-7), (0, 6495767, 0.02),
+            (4, 6495767, float("nan")), (2.7, 50, 0.3), (5, 6495767, -1e-9), (5, 6495767, 0.96),
+            (50, 1000, 0.97), (3, 100000, 0.999)]
+    for k, n, p in edge:
+        ks.append(k)
+        ns.append(n)
+        ps.append(p)
+    ks = np.array(ks, np.float64)
+    ns = np.array(ns, np.int64)
+    ps = np.array(ps, np.float64)
+    with np.errstate(all="ignore"):
+        vals = scsp.bdtrc(ks, ns, ps)
+    # lbeta / log at table arguments
+    lb_n = np.array([649_576, 6_495_767, 3_549_437, 123_456_789, 2_000_000_011, 150, 169], np.int64)
+    lb_c = np.array(list(range(1, 400)) + [500, 1000, 5000, 40000, 100000], np.int64)
+    lb = np.array([[scsp.betaln(float(c), float(n - c + 1)) if c <= n else np.nan for c in lb_c] for n in lb_n])
+    logs_x = np.concatenate([lb_n.astype(np.float64), lb_n + 1.0, np.arange(1, 300, dtype=np.float64),
+                             rng.uniform(1e-9, 1e-2, 300), 1.0 - rng.uniform(1e-9, 1e-2, 300)])
+    logs = np.array([math.log(v) for v in logs_x])
+    np.savez_compressed(os.path.join(HERE, "f3_bdtrc.npz"), k=ks, n=ns, p=ps, val=vals,
+                        lb_n=lb_n, lb_c=lb_c, lbeta=lb, log_x=logs_x, log_val=logs)
+    print("  %d bdtrc vectors (%d NaN), %d lbeta, %d log" % (len(ks), int(np.isnan(vals).sum()), lb.size, logs.size))
+
+
+# ------------------------------------------------------------------------------------------------ F4
+def make_f4():
+    print("F4: UnivariateSpline known answers")
+    g = np.load(os.path.join(HERE, "f1_nobias.npz"))
+    cases = []
+    xb, yb = g["p1_x"], g["p1_y"]
+    base = float(min(yb)) ** 2
+    for f in (1, 0.3, 0.1, 0.03, 0.01, 0.001, 0.0):
+        cases.append(("hESC_f%g" % f, xb, yb, base * f))
+    g2 = np.load(os.path.join(HERE, "f1_bias.npz"))
+    for pi in (1, 2):
+        xx, yy = g2["p%d_x_sorted" % pi], g2["p%d_y_sorted" % pi]
+        cases.append(("hESCbias_pass%d" % pi, xx, yy, float(min(yy)) ** 2))
+    rng = np.random.default_rng(11)
+    for m in (8, 9, 12, 20, 50, 100, 200):
+        x = np.cumsum(rng.uniform(0.5, 1.5, m)) * 20000.0 + 20000.0
+        y = 3e-3 * (x / 20000.0) ** -1.1 * np.exp(rng.normal(0, 0.05, m))
+        for f in (1, 0.1, 0.001):
+            cases.append(("synth_m%d_f%g" % (m, f), x, y, float(min(y)) ** 2 * f))
+    out = {}
+    names = []
+    for name, x, y, s in cases:
+        ius = UnivariateSpline(x, y, s=s)
+        t, c, k = ius._eval_args
+        n = len(t)
+        names.append(name)
+        out[name + "_x"] = np.asarray(x, np.float64)
+        out[name + "_y"] = np.asarray(y, np.float64)
+        out[name + "_t"] = np.asarray(t, np.float64)
+        out[name + "_c"] = np.asarray(c, np.float64)[:n - 4]
+        out[name + "_sfpier"] = np.array([s, ius._data[10], ius._data[-1]], np.float64)
+        xe = np.linspace(x[0], x[-1], 301)
+        out[name + "_xe"] = xe
+        out[name + "_ye"] = ius(xe)
+        nest0 = max(len(x) // 2, 8) if s > 0 else len(x) + 4
+        print("   %-22s m=%3d s=%.3e -> n=%3d ier=%d restart=%s" % (name, len(x), s, n, ius._data[-1], n > nest0))
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "f4_fitpack.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------------ F5
+def make_f5():
+    print("F5: benjamini_hochberg_correction known answers")
+    rng = np.random.default_rng(5)
+    out = {}
+    names = []
+
+    def add(name, p, N):
+        q = np.array(REF_STATS.benjamini_hochberg_correction(list(p), N), np.float64)
+        out[name + "_p"] = np.asarray(p, np.float64)
+        out[name + "_N"] = np.array([N], np.float64)
+        out[name + "_q"] = q
+        names.append(name)
+
+    add("uniform", rng.uniform(0, 1, 5000), 5000)
+    add("bigN", rng.uniform(0, 1, 5000) ** 6, 1529788)
+    p = rng.choice(np.concatenate([rng.uniform(0, 1, 40) ** 3, [1.0, 0.0]]), 4000)
+    add("ties", p, 9000)
+    p = rng.uniform(0, 1, 3000) ** 8
+    p[rng.integers(0, 3000, 300)] = 1.0
+    p[rng.integers(0, 3000, 50)] = np.nan
+    p[rng.integers(0, 3000, 20)] = 0.0
+    p[rng.integers(0, 3000, 20)] = 5e-324
+    p[rng.integers(0, 3000, 20)] = 1e-310
+    add("mixed_nan_one_zero_denormal", p, 123457)
+    add("all_ones", np.ones(17), 40)
+    add("single", np.array([0.03]), 10)
+    add("tiny", np.array([0.03, 0.4, 0.7, 0.01]), 10)
+    add("smallN", rng.uniform(0, 1, 200), 3)       # N < len(p): values exceed... min(.,1) saturates
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "f5_bh.npz"), **out)
+    print("  %d BH vectors" % len(names))
+
+
+# ------------------------------------------------------------------------------------------------ F6
+def make_f6():
+    print("F6: quirk probes")
+    res = 10000
+    # 3 chromosomes whose names sort differently as strings (chr1 < chr10 < chr2); chr10 has an
+    # unmappable tail (hits 0) so that npairs goes negative (A7); duplicate + missing bias rows (A11)
+    frag_lines, bias_lines = [], []
+    nloci = {"chr1": 60, "chr10": 45, "chr2": 52}
+    for ch in ("chr1", "chr2", "chr10"):
+        for i in range(nloci[ch]):
+            hits = 2 if i % 4 else 1
+            if ch == "chr10" and i in (3, 4, 20):
+                hits = 0
+            frag_lines.append("%s\t0\t%d\t%d\t1\n" % (ch, i * res + res // 2, hits))
+            b = 0.6 + ((i * 37) % 23) / 16.0
+            if i % 17 == 5:
+                b = 0.3
+            if i % 19 == 7:
+                b = 2.4
+            if i == 11:
+                bias_lines.append("%s\t%d\tnan\n" % (ch, i * res + res // 2))
+                continue
+            if ch == "chr2" and i in (30, 31):
+                continue                        # missing locus
+            bias_lines.append("%s\t%d\t%.6f\n" % (ch, i * res + res // 2, b))
+            if i == 8:
+                bias_lines.append("%s\t%d\t%.6f\n" % (ch, i * res + res // 2, 1.9))   # duplicate: first wins
+    _write_gz(os.path.join(DATA, "quirk.frags.gz"), "".join(frag_lines))
+    _write_gz(os.path.join(DATA, "quirk.bias.gz"), "".join(bias_lines))
+    rng = np.random.default_rng(3)
+    rows = []
+    for ch in ("chr1", "chr2", "chr10"):
+        n = nloci[ch]
+        for i in range(n):
+            for j in range(i, n):
+                d = j - i
+                if rng.random() < 0.5:
+                    continue
+                c = rng.poisson(30.0 / (1 + d) ** 0.9) + (1 if rng.random() < 0.3 else 0)
+                if c < 1:
+                    continue
+                rows.append("%s\t%d\t%s\t%d\t%d\n" % (ch, i * res + res // 2, ch, j * res + res // 2, c))
+    rows.append("chr1\t5000\tchr1\t45000\t0.4\n")          # count truncating to 0 (A4)
+    rows.append("chr1\t15000\tchr1\t55000\t3.9\n")
+    rows.append("chr3\t5000\tchr3\t45000\t7\n")            # chromosome absent from frags and bias
+    for _ in range(150):
+        a, b = rng.choice(["chr1", "chr2", "chr10"], 2, replace=False)
+        rows.append("%s\t%d\t%s\t%d\t%d\n" % (a, int(rng.integers(nloci[a])) * res + res // 2,
+                                             b, int(rng.integers(nloci[b])) * res + res // 2, 1 + rng.poisson(0.5)))
+    _write_gz(os.path.join(DATA, "quirk.contacts.gz"), "".join(rows))
+    c, f, b = "quirk.contacts.gz", "quirk.frags.gz", "quirk.bias.gz"
+    run_case("f6_quirk_all", c, f, b, res, ["-b", "12", "-p", "2", "-x", "All", "-L", "20000", "-U", "400000"])
+    run_case("f6_quirk_intra_nobounds", c, f, b, res, ["-b", "10", "-p", "1", "-x", "intraOnly"])
+    run_case("f6_quirk_zero_flags", c, f, None, res, ["-b", "0", "-p", "0", "-L", "0", "-U", "0", "-m", "0"])
+    run_case("f6_quirk_mapp2", c, f, b, res, ["-b", "8", "-p", "1", "-m", "2", "-x", "All", "-tL", "0.4", "-tU", "2.5"])
+
+
+if __name__ == "__main__":
+    which = [a.lower() for a in sys.argv[1:]] or ["f1", "f2", "f3", "f4", "f5", "f6"]
+    jobs = dict(f1=make_f1, f2=make_f2, f3=make_f3, f4=make_f4, f5=make_f5, f6=make_f6)
+    for w in which:
+        jobs[w]()
