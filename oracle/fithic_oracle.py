@@ -1,0 +1,572 @@
+"""oracle/fithic_oracle.py - TEST INFRASTRUCTURE ONLY.
+
+CPU restatement of the reference's hot path, stage by stage, on SoA numpy arrays:
+
+    read_interactions      <- /root/reference/fithic/fithic.py:389-454   (+ myUtils.py:112-148 getType)
+    make_bins              <- fithic.py:463-553
+    generate_frag_pairs    <- fithic.py:561-689, 779-793   (fixed-size branch only)
+    read_biases            <- fithic.py:798-837
+    calculate_probabilities<- fithic.py:843-918
+    fit_spline             <- fithic.py:925-1233  (spline fit :936-968, per-pair loop :1017-1124,
+                              BH dispatch :1126-1164, writer + outliers :1167-1220, FDR ticks :1235-1265)
+    benjamini_hochberg     <- myStats.py:24-48
+    run                    <- fithic.py:129-379 (main(), after argument parsing)
+
+Third-party numerics are the oracle's own restatements: cephes_oracle.c (scipy.special.bdtrc),
+fitpack_oracle.py (UnivariateSpline), `pava_decreasing` below (sklearn IsotonicRegression ->
+scipy.optimize.isotonic_regression, Busing 2022 PAVA).  Nothing here is imported by the product
+package `fithic_amd`; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
+
+Pinned by the golden fixtures under tests/golden/ (generated from the real reference by
+tests/golden/make_golden.py): per-stage intermediates, sub-sampled per-pair p/q/expCC/bias, sha256 of
+the full p and q arrays and md5 of the decompressed .significances.txt output.
+"""
+import os
+import gzip
+import math
+import bisect
+import ctypes
+import subprocess
+
+import numpy as np
+
+from . import fitpack_oracle
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+INTRA_ONLY, INTER_ONLY, ALL = "intraOnly", "interOnly", "All"
+
+
+def build(force=False):
+    """Compile cephes_oracle.c -> liboracle_cephes.so (no FMA contraction)."""
+    so = os.path.join(_HERE, "liboracle_cephes.so")
+    src = os.path.join(_HERE, "cephes_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
+                               "-o", so, src, "-lm"])
+    return so
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+    return _LIB
+
+
+def _dptr(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def bdtrc(k, n, p):
+    """Vectorised scipy.special.bdtrc(k, n, p) through the C restatement."""
+    k = np.ascontiguousarray(np.broadcast_to(np.asarray(k, np.float64), np.broadcast(k, n, p).shape))
+    n = np.ascontiguousarray(np.broadcast_to(np.asarray(n, np.float64), k.shape))
+    p = np.ascontiguousarray(np.broadcast_to(np.asarray(p, np.float64), k.shape))
+    out = np.empty(k.shape, np.float64)
+    _lib().fho_bdtrc_vec(_dptr(k), _dptr(n), _dptr(p), _dptr(out), ctypes.c_int64(k.size))
+    return out
+
+
+def bdtrc_stats(k, n, p):
+    k = np.ascontiguousarray(k, np.float64)
+    n = np.ascontiguousarray(np.broadcast_to(np.asarray(n, np.float64), k.shape))
+    p = np.ascontiguousarray(p, np.float64)
+    out = np.empty(k.shape, np.float64)
+    br = np.empty(k.shape, np.int32)
+    it = np.empty(k.shape, np.int32)
+    ip = ctypes.POINTER(ctypes.c_int32)
+    _lib().fho_bdtrc_vec_stats(_dptr(k), _dptr(n), _dptr(p), _dptr(out), br.ctypes.data_as(ip),
+                               it.ctypes.data_as(ip), ctypes.c_int64(k.size))
+    return out, br, it
+
+
+def lbeta(a, b):
+    a = np.ascontiguousarray(a, np.float64)
+    b = np.ascontiguousarray(b, np.float64)
+    out = np.empty(a.shape, np.float64)
+    _lib().fho_lbeta_vec(_dptr(a), _dptr(b), _dptr(out), ctypes.c_int64(a.size))
+    return out
+
+
+# ------------------------------------------------------------------------------------------ inputs
+class Pairs:
+    """Contact rows as SoA: chromosome ids (interned in order of first appearance), mids, counts."""
+
+    def __init__(self, chr1, mid1, chr2, mid2, count, names, raw_count=None):
+        self.chr1 = np.asarray(chr1, np.int32)
+        self.mid1 = np.asarray(mid1, np.int64)
+        self.chr2 = np.asarray(chr2, np.int32)
+        self.mid2 = np.asarray(mid2, np.int64)
+        self.count = np.asarray(count, np.int64)          # int(float(text)) - truncation toward 0
+        self.names = list(names)
+        self.raw_count = self.count.astype(np.float64) if raw_count is None else np.asarray(raw_count, np.float64)
+
+    def __len__(self):
+        return len(self.mid1)
+
+
+def _intern(cols, names=None):
+    names = [] if names is None else names
+    index = {n: i for i, n in enumerate(names)}
+    out = []
+    for col in cols:
+        ids = np.empty(len(col), np.int32)
+        for i, s in enumerate(col):
+            j = index.get(s)
+            if j is None:
+                j = index[s] = len(names)
+                names.append(s)
+            ids[i] = j
+        out.append(ids)
+    return out, names
+
+
+def read_contacts_file(path):
+    import pandas as pd
+    df = pd.read_csv(path, sep=r"\s+", header=None, names=["c1", "m1", "c2", "m2", "cc"],
+                     dtype={"c1": str, "m1": np.int64, "c2": str, "m2": np.int64, "cc": np.float64},
+                     compression="gzip", engine="c")
+    (i1, i2), names = _intern([df["c1"].values, df["c2"].values])
+    raw = df["cc"].values
+    return Pairs(i1, df["m1"].values, i2, df["m2"].values, np.trunc(raw).astype(np.int64), names, raw)
+
+
+def read_fragments_file(path):
+    """-> list of (chrom name, mid, hits) in file order."""
+    out = []
+    with gzip.open(path, "rt") as f:
+        for line in f:
+            w = line.split()
+            out.append((w[0], int(w[2]), int(w[3])))
+    return out
+
+
+def read_biases(path, tL, tU):
+    """fithic.py:798-837 -> {chrom: {mid: bias}}; out-of-range / NaN -> -1; first occurrence wins."""
+    dic = {}
+    with gzip.open(path, "rt") as f:
+        for line in f:
+            w = line.rstrip().split()
+            ch, mid, b = w[0], int(w[1]), float(w[2])
+            if b < tL or math.isnan(b):
+                b = -1
+            elif b > tU:
+                b = -1
+            d = dic.setdefault(ch, {})
+            if mid not in d:
+                d[mid] = b
+    return dic
+
+
+def gather_bias(pairs, bias_dic):
+    """fithic.py:1024-1056 - per-row bias1, bias2 (1.0 without a bias file, -1 when missing)."""
+    n = len(pairs)
+    if not bias_dic:
+        return np.ones(n), np.ones(n)
+    tables = []
+    for name in pairs.names:
+        t = bias_dic.get(name)
+        if t is None:
+            tables.append(None)
+        else:
+            mids = np.array(sorted(t), np.int64)
+            tables.append((mids, np.array([t[int(m)] for m in mids], np.float64)))
+    out = []
+    for ids, mids in ((pairs.chr1, pairs.mid1), (pairs.chr2, pairs.mid2)):
+        b = np.full(n, -1.0, np.float64)
+        for cid, tab in enumerate(tables):
+            if tab is None or len(tab[0]) == 0:
+                continue
+            sel = np.flatnonzero(ids == cid)
+            if len(sel) == 0:
+                continue
+            pos = np.minimum(np.searchsorted(tab[0], mids[sel]), len(tab[0]) - 1)
+            hit = tab[0][pos] == mids[sel]
+            b[sel[hit]] = tab[1][pos[hit]]
+        out.append(b)
+    return out[0], out[1]
+
+
+# ------------------------------------------------------------------------------------------ stages
+def in_range(d, L, U):
+    """myUtils.py:85-92 (L, U never equal -1 on this path: defaults are 0 / +inf, fithic.py:216-217)."""
+    return (d >= L) & (d <= U)
+
+
+def effective_skip_mask(n_rows, outlier_lines):
+    """fithic.py:408-412: walk the sorted outlier multiset with a forward-only cursor.  A duplicated
+    line number (passes >= 3) freezes the cursor: nothing after it is skipped."""
+    mask = np.zeros(n_rows, bool)
+    lines = sorted(int(v) for v in outlier_lines)
+    pos = 0
+    for line in range(n_rows):
+        if pos >= len(lines):
+            break
+        if line == lines[pos]:
+            mask[line] = True
+            pos += 1
+        elif lines[pos] < line:
+            break                                   # cursor is stuck behind a duplicate forever
+    return mask
+
+
+def read_interactions(pairs, L, U, skip_mask=None):
+    """fithic.py:389-454 -> (dist_keys, dist_sumcc, interCount, interSum, intraAllSum, inRangeSum)."""
+    keep = np.ones(len(pairs), bool) if skip_mask is None else ~skip_mask
+    inter = pairs.chr1 != pairs.chr2
+    d = np.abs(pairs.mid1 - pairs.mid2)
+    cc = pairs.count
+    m_inter = keep & inter
+    m_intra = keep & ~inter
+    m_rng = m_intra & in_range(d, L, U)
+    keys, inv = np.unique(d[m_rng], return_inverse=True)
+    sums = np.zeros(len(keys), np.int64)
+    np.add.at(sums, inv, cc[m_rng])
+    return (keys.astype(np.int64), sums, int(m_inter.sum()), int(cc[m_inter].sum()),
+            int(cc[m_intra].sum()), int(cc[m_rng].sum()))
+
+
+def make_bins(dist_keys, dist_sumcc, n_bins, in_range_sum, outlier_dists=None):
+    """fithic.py:463-553 -> list of bins [lb, ub, s1, s2, s3, s7, dists]."""
+    termination = 0
+    n = 0
+    so_far = 0
+    cur = []
+    desired = in_range_sum / n_bins
+    groups = []
+    for dist, cc in zip(dist_keys.tolist(), dist_sumcc.tolist()):
+        so_far += cc
+        full = False
+        if cc >= desired:
+            cur.append(dist)
+            termination = 0
+            full = True
+        elif termination + cc >= desired:
+            cur.append(dist)
+            termination = 0
+            full = True
+        else:
+            cur.append(dist)
+            termination += cc
+        if full:
+            n += 1
+            if n < n_bins:
+                desired = 1.0 * (in_range_sum - so_far) / (n_bins - n)
+            groups.append(cur)
+            termination = 0
+            cur = []
+    cc_of = dict(zip(dist_keys.tolist(), dist_sumcc.tolist()))
+    bins = []
+    for i, g in enumerate(groups):
+        lb = 0 if i == 0 else max(groups[i - 1]) + 1
+        bins.append(dict(lb=lb, ub=g[-1], s1=0, s2=sum(cc_of[v] for v in g), s3=0.0, s7=0, dists=g))
+    if outlier_dists is not None and len(bins):
+        tracker = 0
+        for dist in sorted(int(v) for v in outlier_dists):
+            while not (bins[tracker]["lb"] <= dist <= bins[tracker]["ub"]):
+                tracker += 1
+                if tracker >= len(bins):
+                    tracker -= 1
+                    break
+            bins[tracker]["s7"] -= 1
+            bins[tracker]["s1"] -= 1
+    return bins
+
+
+def generate_frag_pairs(frags, bins, resolution, L, U, mapp_thres, inter_count):
+    """fithic.py:561-689 (fixed-size branch).  Mutates bins; returns the scalars of :793."""
+    per_chr = {}
+    for ch, mid, hits in frags:
+        lst = per_chr.setdefault(ch, [])
+        if hits >= mapp_thres:
+            lst.append(mid)
+    n_frags = 0
+    max_frags = {}
+    max_possible = 0
+    for ch, lst in per_chr.items():
+        if not lst:
+            raise TypeError("chromosome %s has no mappable fragment (the reference raises here, fithic.py:600)" % ch)
+        max_frags[ch] = max(int(v) - resolution / 2 for v in lst)
+        n_frags += len(lst)
+        max_possible = max(max_possible, max_frags[ch])
+    poss_in_range = 0
+    poss_inter = 0
+    poss_intra_all = 0
+    for ch in sorted(per_chr):
+        n = len(per_chr[ch])
+        max_frag = max_frags[ch]
+        d = 0
+        tracker = 0
+        per = 0
+        for dist in range(0, int(max_frag + 1), resolution):
+            npairs = n - d
+            d += 1
+            if not (dist >= L and dist <= U):
+                continue
+            per += npairs
+            if bins:
+                while not (bins[tracker]["lb"] <= dist <= bins[tracker]["ub"]):
+                    tracker += 1
+                    if tracker >= len(bins):
+                        tracker -= 1
+                        break
+                b = bins[tracker]
+                b["s7"] += npairs
+                b["s1"] += npairs
+                b["s3"] += float(dist / 1000000.0) * npairs
+                per += npairs
+        poss_inter += n * (n_frags - n)
+        poss_intra_all += (n * (n + 1)) / 2
+        poss_in_range += per
+    poss_inter /= 2
+    inter_prob = 1.0 / inter_count if inter_count > 0 else 0
+    base_prob = 1.0 / poss_intra_all if poss_intra_all > 0 else 0
+    return dict(n_frags=n_frags, max_possible_dist=max_possible, poss_in_range=poss_in_range,
+                poss_inter=poss_inter, inter_prob=inter_prob, base_prob=base_prob)
+
+
+def calculate_probabilities(bins, in_range_sum):
+    """fithic.py:843-918 -> x, y, and the text of the .fithic_passN file."""
+    x, y = [], []
+    lines = ["avgGenomicDist\tcontactProbability\tstandardError\tnoOfLocusPairs\ttotalOfContactCounts\n"]
+    for b in bins:
+        if b["s1"] > 0 and in_range_sum > 0:
+            avg_cc = (1.0 * b["s2"] / b["s1"]) / in_range_sum
+        else:
+            avg_cc = 0
+        try:
+            avg_dist = 1000000.0 * (b["s3"] / b["s7"])
+        except ZeroDivisionError:
+            avg_dist = 0
+        x.append(avg_dist)
+        y.append(avg_cc)
+        lines.append("%d" % avg_dist + "\t" + "%.2e" % avg_cc + "\t" + "%.2e" % 0 + "\t" + "%d" % b["s1"] + "\t" + "%d" % b["s2"] + "\n")
+    return x, y, "".join(lines)
+
+
+def pava_decreasing(y):
+    """Antitonic regression with unit weights: scipy.optimize.isotonic_regression(increasing=False)
+    = Busing's PAVA (look-ahead + look-back pooling) on the reversed array."""
+    x = [float(v) for v in y][::-1]
+    n = len(x)
+    if n == 0:
+        return np.zeros(0)
+    w = [1.0] * n
+    r = [0] * (n + 1)
+    r[0], r[1] = 0, 1
+    b = 0
+    xb_prev, wb_prev = x[0], w[0]
+    i = 1
+    while i < n:
+        b += 1
+        xb, wb = x[i], w[i]
+        if xb_prev >= xb:
+            b -= 1
+            sb = wb_prev * xb_prev + wb * xb
+            wb += wb_prev
+            xb = sb / wb
+            while i < n - 1 and xb >= x[i + 1]:
+                i += 1
+                sb += w[i] * x[i]
+                wb += w[i]
+                xb = sb / wb
+            while b > 0 and x[b - 1] >= xb:
+                b -= 1
+                sb += w[b] * x[b]
+                wb += w[b]
+                xb = sb / wb
+        x[b] = xb_prev = xb
+        w[b] = wb_prev = wb
+        r[b + 1] = i + 1
+        i += 1
+    f = n - 1
+    for k in range(b, -1, -1):
+        t = r[k]
+        xk = x[k]
+        for j in range(f, t - 1, -1):
+            x[j] = xk
+        f = t - 1
+    return np.array(x[::-1], np.float64)
+
+
+def benjamini_hochberg(p, n_tests):
+    """myStats.py:24-48: ascending sort, min(p*N/rank, 1) (1.0 stays 1.0), forward running max, scatter."""
+    p = np.asarray(p, np.float64)
+    order = np.argsort(p)                      # NaN last, like the reference's ndarray.argsort()
+    sp = p[order]
+    rank = np.arange(1, len(p) + 1, dtype=np.float64)
+    with np.errstate(invalid="ignore", over="ignore"):
+        bh = sp * float(n_tests) / rank        # (p*N)/(i+1): same association as the reference
+        bh = np.where(sp == 1.0, 1.0, np.where(bh > 1.0, 1.0, bh))     # min(bh, 1): NaN stays NaN
+    # running max with Python max() semantics: max(bh, prev) keeps bh when the comparison is False (NaN)
+    out = np.empty_like(bh)
+    prev = 0.0
+    nan_at = np.flatnonzero(np.isnan(bh))
+    if len(nan_at) == 0:
+        out = np.maximum.accumulate(bh)
+    else:
+        first = nan_at[0]
+        out[:first] = np.maximum.accumulate(bh[:first]) if first else bh[:0]
+        prev = out[first - 1] if first else 0.0
+        for i in range(first, len(bh)):
+            v = bh[i]
+            # Python: max(v, prev) returns v unless prev > v
+            if prev > v:
+                v = prev
+            out[i] = v
+            prev = v
+    q = np.empty_like(out)
+    q[order] = out
+    return q
+
+
+def fdr_ticks(q):
+    """plot_qvalues (fithic.py:1235-1254): shifted cumulative counts over 0..0.05 step 0.001."""
+    ticks = np.arange(0.0, 0.05 + 0.001, 0.001)
+    counts = [0] * len(ticks)
+    qq = np.where(np.isnan(q), 1.0, q)
+    bins = np.floor(qq / 0.001).astype(np.int64)
+    for b, c in zip(*np.unique(bins[bins < len(ticks)], return_counts=True)):
+        counts[int(b)] += int(c)
+    for i in range(1, len(counts)):
+        counts[i] += counts[i - 1]
+    for i in range(1, len(counts)):
+        counts[-i] = counts[-i - 1]
+    counts[0] = 0
+    return counts
+
+
+class PassResult:
+    pass
+
+
+def fit_spline(pairs, dist_keys, x, y, b1, b2, mode, L, U, tL, tU, sums, frag, use_scipy=False):
+    """fithic.py:925-1233 minus file output.  sums = (interCount, interSum, intraAllSum, inRangeSum)."""
+    inter_count, inter_sum, _intra_all_sum, in_range_sum = sums
+    R = PassResult()
+    inter_only = mode == INTER_ONLY
+    all_reg = mode == ALL
+    n = len(pairs)
+    R.splineX = R.newSplineY = R.splineY = None
+    if not inter_only:
+        order = sorted(range(len(x)), key=lambda i: x[i])          # stable, like sorted(zip(x, y))
+        y = [y[i] for i in order]
+        x = sorted(x)
+        for i in range(1, len(x)):
+            if x[i] <= x[i - 1]:
+                raise SystemExit(2)
+        s = min(y) * min(y)
+        if use_scipy:
+            from scipy.interpolate import UnivariateSpline
+            ius = UnivariateSpline(x, y, s=s)
+            t, c, _k = ius._eval_args
+            t, c = list(t), list(c)[:len(t) - 4]
+            fp, ier = ius._data[10], ius._data[-1]
+        else:
+            t, c, fp, ier, _ = fitpack_oracle.univariate_spline(x, y, s)
+        lo, hi = min(x), max(x)
+        spline_x = [int(d) for d in dist_keys.tolist() if lo <= d <= hi]
+        spline_y = np.array(fitpack_oracle.splev(t, c, spline_x), np.float64)
+        if use_scipy:
+            from sklearn.isotonic import IsotonicRegression
+            new_y = IsotonicRegression(increasing=False).fit_transform(spline_x, spline_y)
+        else:
+            new_y = pava_decreasing(spline_y)
+        R.t, R.c, R.s, R.fp, R.ier = np.array(t), np.array(c), s, fp, ier
+        R.splineX, R.splineY, R.newSplineY = np.array(spline_x, np.int64), spline_y, new_y
+        R.x_sorted, R.y_sorted = np.array(x), np.array(y)
+        R.residual = float(np.sum([v * v for v in (np.array(y) - np.array(fitpack_oracle.splev(t, c, x)))]))
+    # ---- per-pair loop (fithic.py:1017-1124), vectorised by branch ------------------------------
+    inter = pairs.chr1 != pairs.chr2
+    d = np.abs(pairs.mid1 - pairs.mid2)
+    rng = ~inter & in_range(d, L, U)
+    p = np.ones(n, np.float64)
+    expcc = np.zeros(n, np.float64)
+    discard = ((b1 < 0) | (b2 < 0)) & ~inter                                     # branch 1
+    within = (b1 >= tL) & (b1 <= tU) & (b2 >= tL) & (b2 <= tU)
+    cnt = pairs.count.astype(np.float64)
+    if not inter_only:
+        sel = np.flatnonzero(~discard & rng)                                      # branch 2
+        if len(sel):
+            lo, hi = min(x), max(x)
+            # max(d, min(x)) -> min(., max(x)) -> min(bisect_left(splineX, .), len-1)   (fithic.py:1066-1068)
+            look = np.minimum(np.maximum(d[sel].astype(np.float64), lo), hi)
+            idx = np.minimum(np.searchsorted(R.splineX.astype(np.float64), look, side="left"), len(R.splineX) - 1)
+            prior = R.newSplineY[idx] * (b1[sel] * b2[sel])
+            p[sel] = bdtrc(cnt[sel] - 1, float(in_range_sum), prior)
+            expcc[sel] = np.where(within[sel], in_range_sum * prior, 0.0)
+        rest = ~discard & inter                      # branches 3, 4 keep p = 1; inter falls to 5/6
+    else:
+        rest = ~discard                              # interOnly: every non-discarded row is "inter"
+    if all_reg or inter_only:
+        sel = np.flatnonzero(rest)                                                # branch 5
+        if len(sel):
+            prior = frag["inter_prob"] * (b1[sel] * b2[sel])
+            p[sel] = bdtrc(cnt[sel] - 1, float(inter_sum), prior)
+            expcc[sel] = np.where(within[sel], inter_sum * prior, 0.0)
+    # ---- BH dispatch (fithic.py:1126-1164) ------------------------------------------------------
+    if all_reg:
+        N = frag["poss_in_range"] + inter_count
+    elif inter_only:
+        N = inter_count
+    else:
+        N = frag["poss_in_range"]
+    R.N = N
+    R.outlier_thres = 1.0 / N
+    R.p = p
+    R.q = benjamini_hochberg(p, N)
+    R.expcc = expcc
+    # ---- which rows the writer emits (fithic.py:1197-1213) and the outliers (:1215-1217) --------
+    R.emit = (inter & (all_reg or inter_only)) | (~inter & (all_reg or not inter_only) & in_range(d, L, U))
+    with np.errstate(invalid="ignore"):
+        out = p < R.outlier_thres
+    R.outlier_lines = np.flatnonzero(out)
+    R.outlier_dists = d[out]
+    R.fdr_y = fdr_ticks(R.q)
+    return R
+
+
+def format_significances(pairs, R, b1, b2):
+    """The decompressed text of <lib>.spline_passN.resR.significances.txt.gz (fithic.py:1178-1212)."""
+    out = ["chr1\tfragmentMid1\tchr2\tfragmentMid2\tcontactCount\tp-value\tq-value\tbias1\tbias2\tExpCC\n"]
+    names = pairs.names
+    for i in np.flatnonzero(R.emit).tolist():
+        out.append("%s\t%d\t%s\t%d\t%d\t%e\t%e\t%e\t%e\t%f\n" % (
+            names[pairs.chr1[i]], pairs.mid1[i], names[pairs.chr2[i]], pairs.mid2[i], pairs.raw_count[i],
+            R.p[i], R.q[i], b1[i], b2[i], R.expcc[i]))
+    return "".join(out)
+
+
+def run(contacts, frags, bias_path, resolution, n_bins=100, passes=1, mode=INTRA_ONLY, L=0, U=float("inf"),
+        mapp_thres=1, tL=0.5, tU=2, use_scipy=False, keep_text=False):
+    """main() of the reference after argument parsing (fithic.py:317-370). Returns a list of passes."""
+    pairs = read_contacts_file(contacts) if isinstance(contacts, str) else contacts
+    frag_rows = read_fragments_file(frags) if isinstance(frags, str) else frags
+    bias_dic = read_biases(bias_path, tL, tU) if bias_path else 0
+    b1, b2 = gather_bias(pairs, bias_dic)
+    results = []
+    outlier_lines, outlier_dists = [], []            # multisets (the reference never clears them)
+    for pass_no in range(1, passes + 1):
+        if pass_no > 1 and mode == INTER_ONLY:
+            break
+        skip = effective_skip_mask(len(pairs), outlier_lines) if pass_no > 1 else None
+        keys, sumcc, icnt, isum, intra_all, rng_sum = read_interactions(pairs, L, U, skip)
+        bins = make_bins(keys, sumcc, n_bins, rng_sum, outlier_dists if pass_no > 1 else None)
+        bins0 = [dict(b) for b in bins]
+        frag = generate_frag_pairs(frag_rows, bins, resolution, L, U, mapp_thres, icnt)
+        x, y, pass_txt = calculate_probabilities(bins, rng_sum)
+        R = fit_spline(pairs, keys, x, y, b1, b2, mode, L, U, tL, tU, (icnt, isum, intra_all, rng_sum), frag,
+                       use_scipy=use_scipy)
+        R.dist_keys, R.dist_sumcc = keys, sumcc
+        R.sums = (icnt, isum, intra_all, rng_sum)
+        R.bins0, R.bins, R.frag, R.x, R.y, R.pass_txt = bins0, bins, frag, x, y, pass_txt
+        R.b1, R.b2 = b1, b2
+        if keep_text:
+            R.sig_txt = format_significances(pairs, R, b1, b2)
+        outlier_lines.extend(R.outlier_lines.tolist())
+        outlier_dists.extend(R.outlier_dists.tolist())
+        R.n_outlier_lines_total = len(outlier_lines)
+        results.append(R)
+    return results
