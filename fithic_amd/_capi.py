@@ -1,0 +1,324 @@
+"""ctypes binding of libfithic_mi355x.so (the C ABI declared in include/fithic_mi355x.h).
+
+The product path has NO CPU fallback: if the shared library is missing this module raises at import of
+the symbols, and every kernel entry point fails loudly (FHX_ERR_NO_DEVICE) without a GPU.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libfithic_mi355x.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+FHX_OK = 0
+FHX_ERR_ARG, FHX_ERR_NO_DEVICE, FHX_ERR_HIP, FHX_ERR_UNSUPPORTED, FHX_ERR_REFERENCE_EXIT, FHX_ERR_NOMEM = -1, -2, -3, -4, -5, -6
+MODE_INTRA_ONLY, MODE_INTER_ONLY, MODE_ALL = 0, 1, 2
+INT64_MAX = (1 << 63) - 1
+
+# enum fhx_array
+(A_HIST_SUMCC, A_HIST_NPAIRS, A_BIN_LB, A_BIN_UB, A_BIN_POSS, A_BIN_SUMCC, A_BIN_SUMDIST, A_BIN_POSS7, A_X, A_Y,
+ A_KNOTS, A_COEFFS, A_TABLE_X, A_TABLE_Y0, A_TABLE_Y, A_OUTLIER_DIST_HIST, A_FDR_COUNTS, A_BIN_POSS0) = range(18)
+_ARRAY_DTYPE = {A_BIN_SUMDIST: np.float64, A_X: np.float64, A_Y: np.float64, A_KNOTS: np.float64,
+                A_COEFFS: np.float64, A_TABLE_Y0: np.float64, A_TABLE_Y: np.float64}
+
+
+class FhxParams(ctypes.Structure):
+    _fields_ = [("resolution", ctypes.c_int64), ("dist_low", ctypes.c_int64), ("dist_up", ctypes.c_int64),
+                ("n_bins", ctypes.c_int32), ("mapp_thres", ctypes.c_int32), ("mode", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("bias_low", ctypes.c_double), ("bias_up", ctypes.c_double)]
+
+
+class FhxStats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int64) for n in ("n_rows", "inter_count", "inter_sum", "intra_all_count", "intra_all_sum",
+                                              "in_range_count", "in_range_sum", "max_count", "n_dist", "n_skipped")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class FhxFitInfo(ctypes.Structure):
+    _fields_ = [("n_bins_made", ctypes.c_int32), ("n_knots", ctypes.c_int32), ("spline_ier", ctypes.c_int32),
+                ("spline_restarted", ctypes.c_int32), ("n_table", ctypes.c_int64), ("n_frags", ctypes.c_int64),
+                ("possible_intra_in_range", ctypes.c_int64), ("possible_inter_all", ctypes.c_double),
+                ("possible_intra_all", ctypes.c_double), ("max_possible_dist", ctypes.c_double),
+                ("inter_chr_prob", ctypes.c_double), ("baseline_intra_prob", ctypes.c_double),
+                ("spline_s", ctypes.c_double), ("spline_fp", ctypes.c_double), ("residual", ctypes.c_double),
+                ("bh_total_tests", ctypes.c_double), ("outlier_thres", ctypes.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# every symbol include/fithic_mi355x.h declares: name -> (restype, argtypes)
+_P = ctypes.c_void_p
+_I32P = ctypes.POINTER(ctypes.c_int32)
+_I64P = ctypes.POINTER(ctypes.c_int64)
+_F64P = ctypes.POINTER(ctypes.c_double)
+SYMBOLS = {
+    "fhx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_P)]),
+    "fhx_destroy": (None, [_P]),
+    "fhx_last_error": (ctypes.c_char_p, [_P]),
+    "fhx_version": (ctypes.c_char_p, []),
+    "fhx_set_params": (ctypes.c_int, [_P, ctypes.POINTER(FhxParams)]),
+    "fhx_load_fragments": (ctypes.c_int, [_P, _I32P, _I32P, _I32P, ctypes.c_int64, _I32P, ctypes.c_int32]),
+    "fhx_load_bias": (ctypes.c_int, [_P, _I32P, _I32P, _F64P, ctypes.c_int64]),
+    "fhx_load_pairs": (ctypes.c_int, [_P, _I32P, _I32P, _I32P, _I32P, _I32P, ctypes.c_int64]),
+    "fhx_load_pairs_device": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int64, _P]),
+    "fhx_pass_stats": (ctypes.c_int, [_P, ctypes.POINTER(FhxStats)]),
+    "fhx_set_global_stats": (ctypes.c_int, [_P, ctypes.POINTER(FhxStats), _I64P, _I64P, ctypes.c_int64]),
+    "fhx_set_outlier_dist_hist": (ctypes.c_int, [_P, _I64P, ctypes.c_int64]),
+    "fhx_fit": (ctypes.c_int, [_P, ctypes.POINTER(FhxFitInfo)]),
+    "fhx_pvalues": (ctypes.c_int, [_P]),
+    "fhx_bh": (ctypes.c_int, [_P, ctypes.c_double]),
+    "fhx_sync": (ctypes.c_int, [_P]),
+    "fhx_next_pass": (ctypes.c_int, [_P, _I64P]),
+    "fhx_fetch": (ctypes.c_int, [_P, _F64P, _F64P, _F64P, _F64P, _F64P]),
+    "fhx_get_array": (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_int64, _I64P]),
+    "fhx_device_ptr": (_P, [_P, ctypes.c_int]),
+    "fhx_n_sorted": (ctypes.c_int64, [_P]),
+    "fhx_kernel_seconds": (ctypes.c_int, [_P, _F64P, _F64P, _F64P]),
+    "fhx_bdtrc_array": (ctypes.c_int, [_P, ctypes.c_double, _I32P, _F64P, ctypes.c_int64, _F64P]),
+    "fhx_bh_array": (ctypes.c_int, [_P, _F64P, ctypes.c_int64, ctypes.c_double, _F64P]),
+    "fhx_bh_local_sort": (ctypes.c_int, [_P]),
+    "fhx_bh_apply_sorted": (ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, ctypes.c_double, _P, _F64P]),
+    "fhx_host_spline_fit": (ctypes.c_int, [_F64P, _F64P, ctypes.c_int32, ctypes.c_double, _F64P, _F64P, _I32P, _F64P, _I32P, _I32P]),
+    "fhx_host_spline_eval": (ctypes.c_int, [_F64P, _F64P, ctypes.c_int32, _F64P, ctypes.c_int64, _F64P]),
+    "fhx_host_pava_decreasing": (ctypes.c_int, [_F64P, ctypes.c_int64, _F64P]),
+    "fhx_host_lbeta_table": (ctypes.c_int, [ctypes.c_double, ctypes.c_int64, _F64P, _F64P]),
+}
+
+BUILD_CMD = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+             "-fno-fast-math", "-o", LIB_PATH, os.path.join(CSRC, "fhx_device.hip"), os.path.join(CSRC, "fhx_host.cpp")]
+
+
+def build(force=False):
+    """Compile the HIP kernels + host stages for gfx950 into the in-tree shared library."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(os.path.dirname(_PKG), "include", "fithic_mi355x.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    subprocess.check_call(BUILD_CMD)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises (loudly) when it has not been built - there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libfithic_mi355x.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; "
+                               "g.build()'` or fithic_amd._capi.build(); fithic_amd has no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)        # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class FhxError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("fhx error %d: %s" % (code, message))
+        self.code = code
+
+
+def _ptr(a, ctype):
+    return a.ctypes.data_as(ctypes.POINTER(ctype))
+
+
+def _i32(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype != np.int32:
+        if a.size and (a.min() < -(1 << 31) or a.max() >= (1 << 31)):
+            raise ValueError("value does not fit int32")
+        a = a.astype(np.int32)
+    return a
+
+
+class Context:
+    """One engine context = one GPU (device >= 0) or host-only (device = -1)."""
+
+    def __init__(self, device=0):
+        self._L = lib()
+        h = _P()
+        rc = self._L.fhx_create(int(device), ctypes.byref(h))
+        if rc != FHX_OK:
+            raise FhxError(rc, "fhx_create(device=%d) failed%s" % (device, " - no usable MI355X" if rc == FHX_ERR_NO_DEVICE else ""))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.fhx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != FHX_OK:
+            raise FhxError(rc, (self._L.fhx_last_error(self._h) or b"").decode())
+
+    # ---- setup ----
+    def set_params(self, resolution, dist_low=0, dist_up=None, n_bins=100, mapp_thres=1, mode=MODE_INTRA_ONLY,
+                   bias_low=0.5, bias_up=2.0):
+        up = INT64_MAX if dist_up is None or dist_up == float("inf") else int(dist_up)
+        p = FhxParams(int(resolution), int(dist_low), up, int(n_bins), int(mapp_thres), int(mode), 0, float(bias_low), float(bias_up))
+        self._check(self._L.fhx_set_params(self._h, ctypes.byref(p)))
+
+    def load_fragments(self, chr_ids, mids, hits, chr_sort_rank):
+        c, m, h, r = _i32(chr_ids), _i32(mids), _i32(hits), _i32(chr_sort_rank)
+        self._check(self._L.fhx_load_fragments(self._h, _ptr(c, ctypes.c_int32), _ptr(m, ctypes.c_int32), _ptr(h, ctypes.c_int32),
+                                               len(c), _ptr(r, ctypes.c_int32), len(r)))
+
+    def load_bias(self, chr_ids, mids, bias):
+        c, m = _i32(chr_ids), _i32(mids)
+        b = np.ascontiguousarray(bias, np.float64)
+        self._check(self._L.fhx_load_bias(self._h, _ptr(c, ctypes.c_int32), _ptr(m, ctypes.c_int32), _ptr(b, ctypes.c_double), len(c)))
+
+    def load_pairs(self, chr1, mid1, chr2, mid2, count):
+        a = [_i32(v) for v in (chr1, mid1, chr2, mid2, count)]
+        self._check(self._L.fhx_load_pairs(self._h, *[_ptr(v, ctypes.c_int32) for v in a], len(a[0])))
+
+    def load_pairs_device(self, ptrs, n, stream=None):
+        self._check(self._L.fhx_load_pairs_device(self._h, *[_P(int(p)) for p in ptrs], int(n), _P(stream or 0)))
+
+    # ---- one pass ----
+    def pass_stats(self):
+        st = FhxStats()
+        self._check(self._L.fhx_pass_stats(self._h, ctypes.byref(st)))
+        return st
+
+    def set_global_stats(self, stats, hist_sumcc, hist_npairs):
+        a = np.ascontiguousarray(hist_sumcc, np.int64)
+        b = np.ascontiguousarray(hist_npairs, np.int64)
+        self._check(self._L.fhx_set_global_stats(self._h, ctypes.byref(stats), _ptr(a, ctypes.c_int64), _ptr(b, ctypes.c_int64), len(a)))
+
+    def set_outlier_dist_hist(self, hist):
+        a = np.ascontiguousarray(hist, np.int64)
+        self._check(self._L.fhx_set_outlier_dist_hist(self._h, _ptr(a, ctypes.c_int64), len(a)))
+
+    def fit(self):
+        info = FhxFitInfo()
+        self._check(self._L.fhx_fit(self._h, ctypes.byref(info)))
+        return info
+
+    def pvalues(self):
+        self._check(self._L.fhx_pvalues(self._h))
+
+    def bh(self, n_total_tests):
+        self._check(self._L.fhx_bh(self._h, float(n_total_tests)))
+
+    def sync(self):
+        self._check(self._L.fhx_sync(self._h))
+
+    def next_pass(self):
+        n = ctypes.c_int64(0)
+        self._check(self._L.fhx_next_pass(self._h, ctypes.byref(n)))
+        return n.value
+
+    def fetch(self, n_rows, p=True, q=True, expcc=False, bias=False):
+        out = {}
+        bufs = []
+        for key, want in (("p", p), ("q", q), ("expcc", expcc), ("b1", bias), ("b2", bias)):
+            if want:
+                out[key] = np.empty(n_rows, np.float64)
+                bufs.append(_ptr(out[key], ctypes.c_double))
+            else:
+                bufs.append(None)
+        self._check(self._L.fhx_fetch(self._h, *bufs))
+        return out
+
+    def get_array(self, which):
+        n = ctypes.c_int64(0)
+        self._check(self._L.fhx_get_array(self._h, which, None, 0, ctypes.byref(n)))
+        a = np.empty(n.value, _ARRAY_DTYPE.get(which, np.int64))
+        self._check(self._L.fhx_get_array(self._h, which, a.ctypes.data_as(_P), n.value, ctypes.byref(n)))
+        return a
+
+    def kernel_seconds(self):
+        k = [ctypes.c_double(0) for _ in range(3)]
+        self._check(self._L.fhx_kernel_seconds(self._h, *[ctypes.byref(v) for v in k]))
+        return tuple(v.value for v in k)
+
+    def device_ptr(self, which):
+        return self._L.fhx_device_ptr(self._h, which)
+
+    def bdtrc_array(self, n_total, count, prior):
+        c = _i32(count)
+        pr = np.ascontiguousarray(prior, np.float64)
+        out = np.empty(len(c), np.float64)
+        self._check(self._L.fhx_bdtrc_array(self._h, float(n_total), _ptr(c, ctypes.c_int32), _ptr(pr, ctypes.c_double), len(c),
+                                            _ptr(out, ctypes.c_double)))
+        return out
+
+    def bh_array(self, p, n_total_tests):
+        p = np.ascontiguousarray(p, np.float64)
+        q = np.empty(len(p), np.float64)
+        self._check(self._L.fhx_bh_array(self._h, _ptr(p, ctypes.c_double), len(p), float(n_total_tests), _ptr(q, ctypes.c_double)))
+        return q
+
+    def bh_local_sort(self):
+        self._check(self._L.fhx_bh_local_sort(self._h))
+
+    def n_sorted(self):
+        return self._L.fhx_n_sorted(self._h)
+
+    def bh_apply_sorted(self, d_keys, n, rank0, carry_in, n_total_tests, d_q_sorted):
+        mx = ctypes.c_double(0)
+        self._check(self._L.fhx_bh_apply_sorted(self._h, _P(int(d_keys) if d_keys else 0), int(n), int(rank0), float(carry_in),
+                                                float(n_total_tests), _P(int(d_q_sorted) if d_q_sorted else 0), ctypes.byref(mx)))
+        return mx.value
+
+
+# ---- host numerics (no context needed) -------------------------------------------------------------
+def host_spline_fit(x, y, s):
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.ascontiguousarray(y, np.float64)
+    m = len(x)
+    t = np.empty(m + 8, np.float64)
+    c = np.empty(m + 8, np.float64)
+    n = ctypes.c_int32(0)
+    fp = ctypes.c_double(0)
+    ier = ctypes.c_int32(0)
+    rs = ctypes.c_int32(0)
+    rc = lib().fhx_host_spline_fit(_ptr(x, ctypes.c_double), _ptr(y, ctypes.c_double), m, float(s), _ptr(t, ctypes.c_double),
+                                   _ptr(c, ctypes.c_double), ctypes.byref(n), ctypes.byref(fp), ctypes.byref(ier), ctypes.byref(rs))
+    if rc != FHX_OK:
+        raise FhxError(rc, "fhx_host_spline_fit")
+    return t[:n.value].copy(), c[:n.value - 4].copy(), fp.value, ier.value, bool(rs.value)
+
+
+def host_spline_eval(t, c, xs):
+    t = np.ascontiguousarray(t, np.float64)
+    c = np.ascontiguousarray(c, np.float64)
+    xs = np.ascontiguousarray(xs, np.float64)
+    out = np.empty(len(xs), np.float64)
+    rc = lib().fhx_host_spline_eval(_ptr(t, ctypes.c_double), _ptr(c, ctypes.c_double), len(t), _ptr(xs, ctypes.c_double), len(xs),
+                                    _ptr(out, ctypes.c_double))
+    if rc != FHX_OK:
+        raise FhxError(rc, "fhx_host_spline_eval")
+    return out
+
+
+def host_pava_decreasing(y):
+    y = np.ascontiguousarray(y, np.float64)
+    out = np.empty(len(y), np.float64)
+    rc = lib().fhx_host_pava_decreasing(_ptr(y, ctypes.c_double), len(y), _ptr(out, ctypes.c_double))
+    if rc != FHX_OK:
+        raise FhxError(rc, "fhx_host_pava_decreasing")
+    return out
+
+
+def host_lbeta_table(n_total, max_count):
+    lb = np.empty(max_count + 1, np.float64)
+    ib = np.empty(max_count + 1, np.float64)
+    rc = lib().fhx_host_lbeta_table(float(n_total), int(max_count), _ptr(lb, ctypes.c_double), _ptr(ib, ctypes.c_double))
+    if rc != FHX_OK:
+        raise FhxError(rc, "fhx_host_lbeta_table")
+    return lb, ib

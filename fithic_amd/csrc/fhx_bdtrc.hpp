@@ -1,0 +1,246 @@
+// fhx_bdtrc.hpp - device-side binomial survival function, bit-faithful to Cephes bdtrc/incbet as shipped
+// in scipy.special (the reference calls scipy.special.bdtrc(count-1, n, prior) at fithic/fithic.py:1070,1101).
+//
+// Rules:
+//   * every recurrence is written as separate IEEE multiply / add / divide in Cephes' association and the
+//     translation unit is compiled with -ffp-contract=off, so hipcc cannot fuse a*b+c into v_fma_f64;
+//   * the continued fractions keep Cephes' 300-iteration cap and its big/biginv rescaling - in the
+//     "observed < expected" branch the fraction does NOT converge and the truncated value IS the answer;
+//   * lbeta(count, n-count+1) and 1/beta(...) come from host-built tables (glibc log, Cephes lgam): one ulp
+//     of lgam(n) is 1.5e-8 relative on every p-value, so they are never recomputed with the device's log;
+//   * `1.0 - xx` is a rounded subtraction followed by log(), exactly as Cephes does (no log1p "improvement").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace fhx {
+namespace dev {
+
+constexpr double kMachEp = 1.11022302462515654042E-16;
+constexpr double kMaxLog = 7.09782712893383996732E2;
+constexpr double kMinLog = -7.451332191019412076235E2;
+constexpr double kMaxGam = 171.624376956302725;
+constexpr double kBig = 4.503599627370496e15;
+constexpr double kBigInv = 2.22044604925031308085e-16;
+
+// per-(pass, n) constants of one binomial: n = total contacts, tables indexed by count
+struct BinomTables {
+    const double* lbeta;      // lbeta(count, n-count+1)
+    const double* inv_beta;   // 1/beta(count, n-count+1), used only when n + 1 < MAXGAM
+    double n;
+    int small_n;              // n + 1 < MAXGAM
+};
+
+// ---- Cephes unity.c log1p / expm1 (scipy's bdtrc uses these for k == 0) ---------------------------
+__device__ __forceinline__ double cephes_log1p(double x) {
+    double z = 1.0 + x;
+    if (z < 0.70710678118654752440 || z > 1.41421356237309504880) return log(z);
+    z = x * x;
+    double num = 4.5270000862445199635215E-5;
+    num = num * x + 4.9854102823193375972212E-1;
+    num = num * x + 6.5787325942061044846969E0;
+    num = num * x + 2.9911919328553073277375E1;
+    num = num * x + 6.0949667980987787057556E1;
+    num = num * x + 5.7112963590585538103336E1;
+    num = num * x + 2.0039553499201281259648E1;
+    double den = x + 1.5062909083469192043167E1;
+    den = den * x + 8.3047565967967209469434E1;
+    den = den * x + 2.2176239823732856465394E2;
+    den = den * x + 3.0909872225312059774938E2;
+    den = den * x + 2.1642788614495947685003E2;
+    den = den * x + 6.0118660497603843919306E1;
+    z = -0.5 * z + x * (z * num / den);
+    return x + z;
+}
+
+__device__ __forceinline__ double cephes_expm1(double x) {
+    if (!isfinite(x)) {
+        if (isnan(x) || x > 0) return x;
+        return -1.0;
+    }
+    if (x < -0.5 || x > 0.5) return exp(x) - 1.0;
+    const double xx = x * x;
+    double ep = 1.2617719307481059087798E-4;
+    ep = ep * xx + 3.0299440770744196129956E-2;
+    ep = ep * xx + 9.9999999999999999991025E-1;
+    double r = x * ep;
+    double eq = 3.0019850513866445504159E-6;
+    eq = eq * xx + 2.5244834034968410419224E-3;
+    eq = eq * xx + 2.2726554820815502876593E-1;
+    eq = eq * xx + 2.0000000000000000000897E0;
+    r = r / (eq - r);
+    return r + r;
+}
+
+// ---- power series for small b*x (incbet.c pseries) ------------------------------------------------
+__device__ __forceinline__ double pseries(double a, double b, double x, double lbeta_ab, double inv_beta_ab) {
+    const double ai = 1.0 / a;
+    double u = (1.0 - b) * x;
+    double v = u / (a + 1.0);
+    const double t1 = v;
+    double t = u;
+    double n = 2.0;
+    double s = 0.0;
+    const double z = kMachEp * ai;
+    while (fabs(v) > z) {
+        u = (n - b) * x / n;
+        t *= u;
+        v = t / (a + n);
+        s += v;
+        n += 1.0;
+    }
+    s += t1;
+    s += ai;
+    u = a * log(x);
+    if ((a + b) < kMaxGam && fabs(u) < kMaxLog) {
+        t = inv_beta_ab;
+        s = s * t * pow(x, a);
+    } else {
+        t = -lbeta_ab + u + log(s);
+        s = (t < kMinLog) ? 0.0 : exp(t);
+    }
+    return s;
+}
+
+// ---- continued fractions (incbet.c incbcf / incbd); kind 0 = incbcf, 1 = incbd ----------------------
+template <int KIND>
+__device__ __forceinline__ double contfrac(double a, double b, double x) {
+    double k1, k2, k3, k4, k5, k6, k7, k8, arg;
+    if (KIND == 0) {
+        arg = x;
+        k1 = a; k2 = a + b; k3 = a; k4 = a + 1.0; k5 = 1.0; k6 = b - 1.0; k7 = k4; k8 = a + 2.0;
+    } else {
+        arg = x / (1.0 - x);
+        k1 = a; k2 = b - 1.0; k3 = a; k4 = a + 1.0; k5 = 1.0; k6 = a + b; k7 = a + 1.0; k8 = a + 2.0;
+    }
+    double pkm2 = 0.0, qkm2 = 1.0, pkm1 = 1.0, qkm1 = 1.0, ans = 1.0, r = 1.0;
+    const double thresh = 3.0 * kMachEp;
+    int n = 0;
+    do {
+        double xk = -(arg * k1 * k2) / (k3 * k4);
+        double pk = pkm1 + pkm2 * xk;
+        double qk = qkm1 + qkm2 * xk;
+        pkm2 = pkm1; pkm1 = pk; qkm2 = qkm1; qkm1 = qk;
+
+        xk = (arg * k5 * k6) / (k7 * k8);
+        pk = pkm1 + pkm2 * xk;
+        qk = qkm1 + qkm2 * xk;
+        pkm2 = pkm1; pkm1 = pk; qkm2 = qkm1; qkm1 = qk;
+
+        double t;
+        if (qk != 0) r = pk / qk;
+        if (r != 0) {
+            t = fabs((ans - r) / r);
+            ans = r;
+        } else {
+            t = 1.0;
+        }
+        if (t < thresh) break;
+
+        k1 += 1.0;
+        k2 += (KIND == 0) ? 1.0 : -1.0;
+        k3 += 2.0;
+        k4 += 2.0;
+        k5 += 1.0;
+        k6 += (KIND == 0) ? -1.0 : 1.0;
+        k7 += 2.0;
+        k8 += 2.0;
+
+        if ((fabs(qk) + fabs(pk)) > kBig) {
+            pkm2 *= kBigInv; pkm1 *= kBigInv; qkm2 *= kBigInv; qkm1 *= kBigInv;
+        }
+        if ((fabs(qk) < kBigInv) || (fabs(pk) < kBigInv)) {
+            pkm2 *= kBig; pkm1 *= kBig; qkm2 *= kBig; qkm1 *= kBig;
+        }
+    } while (++n < 300);
+    return ans;
+}
+
+// branch classes of one incbet evaluation (used to run branch-homogeneous waves)
+enum BranchClass : int {
+    BC_TRIVIAL = 0,        // NaN / 0 / 1 / closed form k == 0: no loop at all
+    BC_PSERIES = 1,        // power series (either orientation)
+    BC_CF_SHORT = 2,       // incbcf / incbd, not swapped: converges in ~8 iterations
+    BC_CF_SWAPPED = 3      // swapped continued fraction: runs to (or near) the 300 cap
+};
+
+// incbet(aa, bb, xx) with aa = count, bb = n - count + 1 and the two table values for that count
+__device__ __forceinline__ double incbet(double aa, double bb, double xx, double lbeta_ab, double inv_beta_ab) {
+    if (xx <= 0.0 || xx >= 1.0) {
+        if (xx == 0.0) return 0.0;
+        if (xx == 1.0) return 1.0;
+        return __builtin_nan("");
+    }
+    if (bb * xx <= 1.0 && xx <= 0.95) return pseries(aa, bb, xx, lbeta_ab, inv_beta_ab);
+    double w = 1.0 - xx;
+    double a, b, x, xc, t, y;
+    int flag;
+    if (xx > aa / (aa + bb)) {
+        flag = 1; a = bb; b = aa; xc = xx; x = w;
+    } else {
+        flag = 0; a = aa; b = bb; xc = w; x = xx;
+    }
+    if (flag == 1 && b * x <= 1.0 && x <= 0.95) {
+        t = pseries(a, b, x, lbeta_ab, inv_beta_ab);
+    } else {
+        y = x * (a + b - 2.0) - (a - 1.0);
+        if (y < 0.0)
+            w = contfrac<0>(a, b, x);
+        else
+            w = contfrac<1>(a, b, x) / xc;
+        y = a * log(x);
+        t = b * log(xc);
+        if ((a + b) < kMaxGam && fabs(y) < kMaxLog && fabs(t) < kMaxLog) {
+            t = pow(xc, b);
+            t *= pow(x, a);
+            t /= a;
+            t *= w;
+            t *= inv_beta_ab;
+        } else {
+            y += t - lbeta_ab;
+            y += log(w / a);
+            t = (y < kMinLog) ? 0.0 : exp(y);
+        }
+    }
+    if (flag == 1) {
+        if (t <= kMachEp)
+            t = 1.0 - kMachEp;
+        else
+            t = 1.0 - t;
+    }
+    return t;
+}
+
+// scipy.special.bdtrc(count - 1, n, p) for an integer count
+__device__ __forceinline__ double bdtrc_count(int count, const BinomTables& T, double p) {
+    if (isnan(p)) return p;
+    const double fk = (double)count - 1.0;
+    if (p < 0.0 || p > 1.0 || T.n < fk) return __builtin_nan("");
+    if (fk < 0) return 1.0;
+    if (fk == T.n) return 0.0;
+    const double dn = T.n - fk;
+    if (count == 1) {
+        if (p < 0.01) return -cephes_expm1(dn * cephes_log1p(-p));
+        return 1.0 - pow(1.0 - p, dn);
+    }
+    return incbet(fk + 1.0, dn, p, T.lbeta[count], T.small_n ? T.inv_beta[count] : 0.0);
+}
+
+// cheap classification of which loop bdtrc_count(count, T, p) will run
+__device__ __forceinline__ int bdtrc_class(int count, double n_total, double p) {
+    if (isnan(p)) return BC_TRIVIAL;
+    const double fk = (double)count - 1.0;
+    if (p < 0.0 || p > 1.0 || n_total < fk || fk < 0 || fk == n_total || count == 1) return BC_TRIVIAL;
+    const double aa = fk + 1.0, bb = n_total - fk, xx = p;
+    if (xx <= 0.0 || xx >= 1.0) return BC_TRIVIAL;
+    if (bb * xx <= 1.0 && xx <= 0.95) return BC_PSERIES;
+    const double w = 1.0 - xx;
+    if (xx > aa / (aa + bb)) {
+        if (aa * w <= 1.0 && w <= 0.95) return BC_PSERIES;
+        return BC_CF_SWAPPED;
+    }
+    return BC_CF_SHORT;
+}
+
+}  // namespace dev
+}  // namespace fhx

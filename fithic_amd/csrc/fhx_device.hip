@@ -1,0 +1,1624 @@
+// fhx_device.hip - gfx950 kernels + the C-ABI context of libfithic_mi355x.so.
+//
+//   K0 ingest          raw (chr, mid) rows -> 12-byte SoA rows (slot1, slot2|inter-flag, count)
+//   K1 classify_hist   fithic.read_Interactions     (fithic/fithic.py:389-454)
+//   K2 pvalue          fithic.fit_Spline pair loop  (fithic/fithic.py:1017-1124) + Cephes bdtrc
+//   K3 bh_*            myStats.benjamini_hochberg_correction (fithic/myStats.py:24-48):
+//                      compact p < 1 -> LSD radix sort of the IEEE bit patterns -> min(p*N/rank,1) ->
+//                      inclusive max-scan -> scatter
+//
+// CDNA4 notes: wave64 everywhere (ballots are 64-bit); pair arrays are streamed with 16-byte-per-lane
+// coalesced loads; the distance histogram is privatised in LDS (int64 sums + int32 row counts) and flushed
+// with one global atomic per touched bin per workgroup; there is no dense contraction on this path, so no
+// MFMA; the whole TU is compiled with -ffp-contract=off (see fhx_bdtrc.hpp for why).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fithic_mi355x.h"
+#include "fhx_bdtrc.hpp"
+#include "fhx_host.hpp"
+
+namespace fhx {
+
+// ===================================================================================================
+// small device helpers
+// ===================================================================================================
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_down(v, off, 64));
+    return v;
+}
+
+// ===================================================================================================
+// K0: ingest.  Slot of a locus = chr_base[chr] + mid / res; a chromosome's loci must share mid % res
+// (that is what "fixed-size" data looks like: createFitHiCFragments-fixedsize.py writes mid = i*res + res/2).
+// ===================================================================================================
+struct ChrGrid {          // per chromosome id, device copy
+    int32_t base;         // first slot
+    int32_t off;          // mid % res shared by the chromosome's loci (-1: chromosome unseen)
+    int32_t nslots;
+    int32_t pad;
+};
+
+__global__ void k0_extent(const int32_t* __restrict__ chr, const int32_t* __restrict__ mid, int64_t n, int res,
+                          int n_chr, int32_t* __restrict__ max_idx, int32_t* __restrict__ min_off,
+                          int32_t* __restrict__ max_off, int32_t* __restrict__ bad) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int c = chr[i];
+        const int m = mid[i];
+        if (c < 0 || c >= n_chr || m < 0) {
+            atomicOr(bad, 1);
+            continue;
+        }
+        const int idx = m / res, off = m - idx * res;
+        if (idx > max_idx[c]) atomicMax(&max_idx[c], idx);
+        if (off < min_off[c]) atomicMin(&min_off[c], off);
+        if (off > max_off[c]) atomicMax(&max_off[c], off);
+    }
+}
+
+__global__ void k0_slots(const int32_t* __restrict__ chr1, const int32_t* __restrict__ mid1,
+                         const int32_t* __restrict__ chr2, const int32_t* __restrict__ mid2,
+                         const int32_t* __restrict__ cnt, int64_t n, int res, const ChrGrid* __restrict__ grid,
+                         int32_t* __restrict__ loc1, int32_t* __restrict__ loc2, int32_t* __restrict__ count) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int c1 = chr1[i], c2 = chr2[i];
+        const int s1 = grid[c1].base + mid1[i] / res;
+        const int s2 = grid[c2].base + mid2[i] / res;
+        loc1[i] = s1;
+        loc2[i] = (c1 == c2) ? s2 : ~s2;          // sign bit carries "inter-chromosomal"
+        count[i] = cnt[i];
+    }
+}
+
+// ===================================================================================================
+// K1: classification + sums + distance histogram
+// ===================================================================================================
+constexpr int K1_THREADS = 512;
+constexpr int K1_LDS_BINS = 6144;      // 6144 * (8 + 4) B = 72 KiB -> two workgroups per CU
+
+struct K1Sums {           // device accumulator block (int64 each)
+    long long inter_count, inter_sum, intra_all_count, intra_all_sum, in_range_count, in_range_sum, n_skipped;
+    int max_count, pad;
+};
+
+__global__ __launch_bounds__(K1_THREADS) void k1_classify_hist(
+    const int32_t* __restrict__ loc1, const int32_t* __restrict__ loc2, const int32_t* __restrict__ count,
+    const uint8_t* __restrict__ skip, int64_t n, int lo_idx, int hi_idx,
+    unsigned long long* __restrict__ hist_sumcc, unsigned long long* __restrict__ hist_npairs,
+    K1Sums* __restrict__ sums) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* lds_cc = reinterpret_cast<unsigned long long*>(smem);
+    unsigned int* lds_np = reinterpret_cast<unsigned int*>(smem + sizeof(unsigned long long) * K1_LDS_BINS);
+    for (int i = threadIdx.x; i < K1_LDS_BINS; i += K1_THREADS) {
+        lds_cc[i] = 0ull;
+        lds_np[i] = 0u;
+    }
+    __syncthreads();
+
+    long long inter_count = 0, inter_sum = 0, intra_cnt = 0, intra_sum = 0, rng_cnt = 0, rng_sum = 0, skipped = 0;
+    int max_count = 0;
+
+    auto one = [&](int l1, int l2, int c, int sk) {
+        max_count = max(max_count, c);
+        if (sk) {
+            ++skipped;
+            return;
+        }
+        if (l2 < 0) {
+            ++inter_count;
+            inter_sum += c;
+            return;
+        }
+        ++intra_cnt;
+        intra_sum += c;
+        const int d = abs(l1 - l2);
+        if (d >= lo_idx && d <= hi_idx) {
+            ++rng_cnt;
+            rng_sum += c;
+            const int b = d - lo_idx;
+            if (b < K1_LDS_BINS) {
+                atomicAdd(&lds_cc[b], (unsigned long long)(long long)c);
+                atomicAdd(&lds_np[b], 1u);
+            } else {
+                atomicAdd(&hist_sumcc[d], (unsigned long long)(long long)c);
+                atomicAdd(&hist_npairs[d], 1ull);
+            }
+        }
+    };
+
+    // 4 rows per lane per step: 16-byte coalesced loads of each of the three columns
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int4* a4 = reinterpret_cast<const int4*>(loc1);
+    const int4* b4 = reinterpret_cast<const int4*>(loc2);
+    const int4* c4 = reinterpret_cast<const int4*>(count);
+    const uchar4* s4 = reinterpret_cast<const uchar4*>(skip);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const int4 a = a4[i], b = b4[i], c = c4[i];
+        uchar4 s = make_uchar4(0, 0, 0, 0);
+        if (skip) s = s4[i];
+        one(a.x, b.x, c.x, s.x);
+        one(a.y, b.y, c.y, s.y);
+        one(a.z, b.z, c.z, s.z);
+        one(a.w, b.w, c.w, s.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        one(loc1[i], loc2[i], count[i], skip ? skip[i] : 0);
+    }
+
+    __syncthreads();
+    for (int i = threadIdx.x; i < K1_LDS_BINS; i += K1_THREADS) {
+        const unsigned int np = lds_np[i];
+        if (np) {
+            atomicAdd(&hist_sumcc[lo_idx + i], lds_cc[i]);
+            atomicAdd(&hist_npairs[lo_idx + i], (unsigned long long)np);
+        }
+    }
+    // sums: wave reduce, then one atomic per wave
+    inter_count = wave_sum_i64(inter_count);
+    inter_sum = wave_sum_i64(inter_sum);
+    intra_cnt = wave_sum_i64(intra_cnt);
+    intra_sum = wave_sum_i64(intra_sum);
+    rng_cnt = wave_sum_i64(rng_cnt);
+    rng_sum = wave_sum_i64(rng_sum);
+    skipped = wave_sum_i64(skipped);
+    max_count = wave_max_i32(max_count);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd((unsigned long long*)&sums->inter_count, (unsigned long long)inter_count);
+        atomicAdd((unsigned long long*)&sums->inter_sum, (unsigned long long)inter_sum);
+        atomicAdd((unsigned long long*)&sums->intra_all_count, (unsigned long long)intra_cnt);
+        atomicAdd((unsigned long long*)&sums->intra_all_sum, (unsigned long long)intra_sum);
+        atomicAdd((unsigned long long*)&sums->in_range_count, (unsigned long long)rng_cnt);
+        atomicAdd((unsigned long long*)&sums->in_range_sum, (unsigned long long)rng_sum);
+        atomicAdd((unsigned long long*)&sums->n_skipped, (unsigned long long)skipped);
+        atomicMax(&sums->max_count, max_count);
+    }
+}
+
+// ===================================================================================================
+// K2: per-pair prior + binomial survival p-value
+// ===================================================================================================
+struct K2Params {
+    const int32_t* loc1;
+    const int32_t* loc2;
+    const int32_t* count;
+    const double* slot_bias;      // -1 = discarded / missing; all 1.0 without a bias file
+    const double* prior_lut;      // newSplineY by distance index (clamp + bisect_left folded in)
+    dev::BinomTables intra, inter;
+    double inter_chr_prob;
+    double outlier_thres;         // 1/N
+    int lo_idx, hi_idx;
+    int mode;
+    int64_t n;
+    double* p;
+    uint8_t* outlier;             // p < 1/N, feeds the next pass
+};
+
+// prior and which binomial a row uses; returns false when the row's p-value is the constant 1.0
+__device__ __forceinline__ bool row_prior(const K2Params& P, int l1, int l2, double& prior, bool& is_inter) {
+    const bool inter = l2 < 0;
+    const int s2 = inter ? ~l2 : l2;
+    const double b1 = P.slot_bias[l1], b2 = P.slot_bias[s2];
+    if ((b1 < 0 || b2 < 0) && !inter) return false;                        // fithic.py:1057-1064
+    if (!inter && P.mode != FHX_MODE_INTER_ONLY) {
+        const int d = abs(l1 - s2);
+        if (d < P.lo_idx || d > P.hi_idx) return false;                   // intraShort / intraLong: p = 1
+        prior = P.prior_lut[d] * (b1 * b2);                               // fithic.py:1069
+        is_inter = false;
+        return true;
+    }
+    if (P.mode == FHX_MODE_INTRA_ONLY) return false;                      // inter row in intraOnly mode
+    prior = P.inter_chr_prob * (b1 * b2);                                 // fithic.py:1100 (also intra rows when interOnly)
+    is_inter = true;
+    return true;
+}
+
+constexpr int K2_THREADS = 256;
+
+__global__ __launch_bounds__(K2_THREADS) void k2_pvalue(K2Params P) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += stride) {
+        const int l1 = P.loc1[i], l2 = P.loc2[i], c = P.count[i];
+        double prior = 1.0, pv = 1.0;
+        bool is_inter = false;
+        if (row_prior(P, l1, l2, prior, is_inter)) pv = dev::bdtrc_count(c, is_inter ? P.inter : P.intra, prior);
+        P.p[i] = pv;
+        P.outlier[i] = (pv < P.outlier_thres) ? 1 : 0;
+    }
+}
+
+__global__ void k_bdtrc_array(dev::BinomTables T, const int32_t* __restrict__ count, const double* __restrict__ prior,
+                              int64_t n, double* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = dev::bdtrc_count(count[i], T, prior[i]);
+}
+
+// expected contact count and the two biases, recomputed on demand for the writer (fithic.py:1075-1078, :1105-1108)
+__global__ void k2_extras(K2Params P, double bias_low, double bias_up, double* __restrict__ expcc,
+                          double* __restrict__ ob1, double* __restrict__ ob2) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += stride) {
+        const int l1 = P.loc1[i], l2 = P.loc2[i];
+        const int s2 = l2 < 0 ? ~l2 : l2;
+        const double b1 = P.slot_bias[l1], b2 = P.slot_bias[s2];
+        double prior = 1.0, e = 0.0;
+        bool is_inter = false;
+        if (row_prior(P, l1, l2, prior, is_inter)) {
+            const bool within = b1 >= bias_low && b1 <= bias_up && b2 >= bias_low && b2 <= bias_up;
+            if (within) e = (is_inter ? P.inter.n : P.intra.n) * prior;
+        }
+        if (expcc) expcc[i] = e;
+        if (ob1) ob1[i] = b1;
+        if (ob2) ob2[i] = b2;
+    }
+}
+
+// outlier bookkeeping for the next pass: skip mask |= outlier, and the multiset of outlier distances
+__global__ void k_fold_outliers(const int32_t* __restrict__ loc1, const int32_t* __restrict__ loc2,
+                                const uint8_t* __restrict__ outlier, uint8_t* __restrict__ skip,
+                                uint8_t* __restrict__ seen_twice, int64_t n, int res, int n_dist,
+                                const int16_t* __restrict__ slot_chr, const ChrGrid* __restrict__ grid,
+                                unsigned long long* __restrict__ out_hist, unsigned long long* __restrict__ n_out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long mine = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (!outlier[i]) continue;
+        ++mine;
+        if (skip[i]) seen_twice[i] = 1;            // duplicated line number in the reference's SortedList (A17)
+        skip[i] = 1;
+        const int l1 = loc1[i], l2 = loc2[i];
+        long long idx;
+        if (l2 >= 0) {
+            idx = abs(l1 - l2);
+        } else {                                    // inter row: the reference still records abs(mid1 - mid2)
+            const int s2 = ~l2;
+            const ChrGrid g1 = grid[slot_chr[l1]], g2 = grid[slot_chr[s2]];
+            const long long m1 = (long long)(l1 - g1.base) * res + g1.off;
+            const long long m2 = (long long)(s2 - g2.base) * res + g2.off;
+            const long long d = m1 > m2 ? m1 - m2 : m2 - m1;
+            idx = (d + res - 1) / res;              // bins end on grid distances: rounding up keeps the bin
+        }
+        if (idx > n_dist - 1) idx = n_dist - 1;
+        atomicAdd(&out_hist[idx], 1ull);
+    }
+    mine = (unsigned long long)wave_sum_i64((long long)mine);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(n_out, mine);
+}
+
+// ===================================================================================================
+// K3: Benjamini-Hochberg as the reference defines it
+// ===================================================================================================
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_WAVES = SORT_THREADS / 64;
+constexpr int SORT_ITEMS = 16;                        // per thread
+constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 4096 keys per tile
+constexpr int SORT_BLOCKS = 1024;                     // persistent: 4 workgroups per CU
+constexpr int RADIX_BITS = 8;
+constexpr int RADIX = 1 << RADIX_BITS;
+
+// compaction: keys of the rows with p < 1 (IEEE bit pattern: all such p are >= 0, so unsigned order is
+// numeric order); rows with p == 1 get q = 1 and NaN rows get q = NaN right here.
+__global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restrict__ p, int64_t n,
+                                                           unsigned long long* __restrict__ keys,
+                                                           unsigned int* __restrict__ vals, double* __restrict__ q,
+                                                           unsigned long long* __restrict__ counter) {
+    __shared__ unsigned int wave_cnt[SORT_WAVES];
+    __shared__ unsigned long long block_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tiles = (n + SORT_THREADS - 1) / SORT_THREADS;
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int64_t i = t * SORT_THREADS + threadIdx.x;
+        double v = 1.0;
+        bool keep = false;
+        if (i < n) {
+            v = p[i];
+            keep = v < 1.0;                         // false for NaN
+            if (!keep) q[i] = (v == v) ? 1.0 : v;
+        }
+        const unsigned long long m = __ballot(keep);
+        const unsigned int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned int tot = 0;
+            for (int w = 0; w < SORT_WAVES; ++w) {
+                const unsigned int c = wave_cnt[w];
+                wave_cnt[w] = tot;
+                tot += c;
+            }
+            block_base = tot ? atomicAdd(counter, (unsigned long long)tot) : 0ull;
+        }
+        __syncthreads();
+        if (keep) {
+            const unsigned long long pos = block_base + wave_cnt[wave] + before;
+            unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+            if (bits == 0x8000000000000000ull) bits = 0ull;       // -0.0 sorts with +0.0
+            keys[pos] = bits;
+            vals[pos] = (unsigned int)i;
+        }
+        __syncthreads();
+    }
+}
+
+// per-workgroup digit counts for one radix pass; workgroup b owns the contiguous chunk [b*chunk, (b+1)*chunk)
+__global__ __launch_bounds__(SORT_THREADS) void rs_count(const unsigned long long* __restrict__ keys,
+                                                         const unsigned long long* __restrict__ n_ptr, int shift,
+                                                         unsigned int* __restrict__ block_hist) {
+    __shared__ unsigned int h[RADIX];
+    const int64_t n = (int64_t)*n_ptr;
+    const int64_t chunk = ((n + SORT_BLOCKS - 1) / SORT_BLOCKS + SORT_TILE - 1) / SORT_TILE * SORT_TILE;
+    const int64_t beg = (int64_t)blockIdx.x * chunk, end = min(n, beg + chunk);
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = beg + threadIdx.x; i < end; i += SORT_THREADS)
+        atomicAdd(&h[(keys[i] >> shift) & (RADIX - 1)], 1u);
+    __syncthreads();
+    block_hist[(size_t)threadIdx.x * SORT_BLOCKS + blockIdx.x] = h[threadIdx.x];      // digit-major
+}
+
+// exclusive scan of the digit-major (RADIX x SORT_BLOCKS) count matrix along the workgroup axis: one
+// workgroup per digit, one thread per sorting workgroup (coalesced row access); digit totals go to
+// digit_total[], their own exclusive scan is folded into rs_scatter's prologue.
+__global__ __launch_bounds__(SORT_BLOCKS) void rs_scan(unsigned int* __restrict__ block_hist,
+                                                       unsigned int* __restrict__ digit_total) {
+    __shared__ unsigned int wsum[SORT_BLOCKS / 64];
+    unsigned int* row = block_hist + (size_t)blockIdx.x * SORT_BLOCKS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned int mine = row[threadIdx.x];
+    unsigned int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int acc = 0;
+        for (int w = 0; w < SORT_BLOCKS / 64; ++w) {
+            const unsigned int c = wsum[w];
+            wsum[w] = acc;
+            acc += c;
+        }
+        digit_total[blockIdx.x] = acc;
+    }
+    __syncthreads();
+    row[threadIdx.x] = wsum[wave] + incl - mine;
+}
+
+// 256-entry exclusive scan held in LDS, done by the first wave (4 entries per lane)
+__device__ __forceinline__ void lds_exclusive_scan_256(unsigned int* a, int lane) {
+    unsigned int v0 = a[lane * 4], v1 = a[lane * 4 + 1], v2 = a[lane * 4 + 2], v3 = a[lane * 4 + 3];
+    const unsigned int mine = v0 + v1 + v2 + v3;
+    unsigned int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    unsigned int excl = incl - mine;
+    a[lane * 4] = excl;
+    excl += v0;
+    a[lane * 4 + 1] = excl;
+    excl += v1;
+    a[lane * 4 + 2] = excl;
+    excl += v2;
+    a[lane * 4 + 3] = excl;
+}
+
+// stable scatter of one radix pass.  Each wave owns a contiguous sub-range of the tile and ranks its keys
+// with wave-private LDS digit counters (no atomics: one leader lane per distinct digit); the tile is then
+// reordered through LDS so that the global writes of equal-digit runs are contiguous.
+__global__ __launch_bounds__(SORT_THREADS) void rs_scatter(const unsigned long long* __restrict__ keys_in,
+                                                           const unsigned int* __restrict__ vals_in,
+                                                           unsigned long long* __restrict__ keys_out,
+                                                           unsigned int* __restrict__ vals_out,
+                                                           const unsigned long long* __restrict__ n_ptr, int shift,
+                                                           const unsigned int* __restrict__ block_hist,
+                                                           const unsigned int* __restrict__ digit_total) {
+    __shared__ unsigned int wave_digit[SORT_WAVES][RADIX];     // per-wave digit counts -> exclusive offsets
+    __shared__ unsigned int tile_start[RADIX];                 // first tile-local slot of each digit
+    __shared__ unsigned int global_base[RADIX];                // running global offset of each digit
+    __shared__ unsigned long long s_keys[SORT_TILE];
+    __shared__ unsigned int s_vals[SORT_TILE];
+    const int64_t n = (int64_t)*n_ptr;
+    const int64_t chunk = ((n + SORT_BLOCKS - 1) / SORT_BLOCKS + SORT_TILE - 1) / SORT_TILE * SORT_TILE;
+    const int64_t beg = (int64_t)blockIdx.x * chunk, end = min(n, beg + chunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    tile_start[threadIdx.x] = digit_total[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < 64) lds_exclusive_scan_256(tile_start, lane);
+    __syncthreads();
+    global_base[threadIdx.x] = tile_start[threadIdx.x] + block_hist[(size_t)threadIdx.x * SORT_BLOCKS + blockIdx.x];
+    __syncthreads();
+    for (int64_t tile = beg; tile < end; tile += SORT_TILE) {
+        for (int w = 0; w < SORT_WAVES; ++w) wave_digit[w][threadIdx.x] = 0;
+        __syncthreads();
+        unsigned long long key[SORT_ITEMS];
+        unsigned int val[SORT_ITEMS];
+        unsigned int rank[SORT_ITEMS];
+        const int64_t wave_base = tile + (int64_t)wave * (64 * SORT_ITEMS);
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            const int64_t i = wave_base + r * 64 + lane;
+            const bool live = i < end;
+            key[r] = live ? keys_in[i] : ~0ull;
+            val[r] = live ? vals_in[i] : 0u;
+            const unsigned int digit = (unsigned int)(key[r] >> shift) & (RADIX - 1);
+            // lanes holding the same digit (dead lanes form their own group through bit 8)
+            unsigned long long same = ~0ull;
+            const unsigned int tag = digit | (live ? 0u : RADIX);
+#pragma unroll
+            for (int b = 0; b <= RADIX_BITS; ++b) {
+                const unsigned long long m = __ballot((tag >> b) & 1u);
+                same &= ((tag >> b) & 1u) ? m : ~m;
+            }
+            const unsigned int before = __popcll(same & lane_lt);
+            unsigned int old = 0;
+            if (live) {
+                old = wave_digit[wave][digit];      // every lane of the group reads the same counter ...
+            }
+            rank[r] = old + before;
+            __builtin_amdgcn_wave_barrier();
+            if (live && before == 0) wave_digit[wave][digit] = old + __popcll(same);   // ... its leader bumps it
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        // exclusive offsets: per digit across waves, then across digits (one digit per thread)
+        {
+            unsigned int acc = 0;
+            for (int w = 0; w < SORT_WAVES; ++w) {
+                const unsigned int c = wave_digit[w][threadIdx.x];
+                wave_digit[w][threadIdx.x] = acc;
+                acc += c;
+            }
+            tile_start[threadIdx.x] = acc;          // digit total for now
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) lds_exclusive_scan_256(tile_start, lane);
+        __syncthreads();
+        const int live_in_tile = (int)min<int64_t>(SORT_TILE, end - tile);
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            const int64_t i = wave_base + r * 64 + lane;
+            if (i < end) {
+                const unsigned int digit = (unsigned int)(key[r] >> shift) & (RADIX - 1);
+                const unsigned int slot = tile_start[digit] + wave_digit[wave][digit] + rank[r];
+                s_keys[slot] = key[r];
+                s_vals[slot] = val[r];
+            }
+        }
+        __syncthreads();
+        for (int s = threadIdx.x; s < live_in_tile; s += SORT_THREADS) {
+            const unsigned long long k = s_keys[s];
+            const unsigned int digit = (unsigned int)(k >> shift) & (RADIX - 1);
+            const unsigned int dst = global_base[digit] + (s - tile_start[digit]);
+            keys_out[dst] = k;
+            vals_out[dst] = s_vals[s];
+        }
+        __syncthreads();
+        // advance the running global offsets by this tile's digit totals
+        {
+            const unsigned int nxt = (threadIdx.x + 1 < RADIX) ? tile_start[threadIdx.x + 1] : (unsigned int)live_in_tile;
+            global_base[threadIdx.x] += nxt - tile_start[threadIdx.x];
+        }
+        __syncthreads();
+    }
+}
+
+// BH value of sorted position i (0-based, global rank = rank0 + i + 1): min(p*N/rank, 1), myStats.py:35-38
+__device__ __forceinline__ double bh_value(unsigned long long key_bits, double n_tests, double rank) {
+    const double pv = __longlong_as_double((long long)key_bits);
+    double v = pv * n_tests / rank;           // (p*N)/(i+1): mul then div, never fused
+    if (1.0 < v) v = 1.0;
+    return v;
+}
+
+constexpr int BH_THREADS = 256;
+constexpr int BH_ITEMS = 8;
+constexpr int BH_TILE = BH_THREADS * BH_ITEMS;
+
+__device__ __forceinline__ double wave_incl_max(double v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_up(v, off, 64);
+        if (lane >= off) v = fmax(v, o);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(BH_THREADS) void bh_tile_max(const unsigned long long* __restrict__ keys,
+                                                          const unsigned long long* __restrict__ n_ptr, int64_t n_fixed,
+                                                          double n_tests, double rank0, double* __restrict__ tile_max) {
+    __shared__ double wmax[BH_THREADS / 64];
+    const int64_t n = n_ptr ? (int64_t)*n_ptr : n_fixed;
+    const int64_t base = (int64_t)blockIdx.x * BH_TILE;
+    if (base >= n) return;
+    double m = 0.0;
+#pragma unroll
+    for (int r = 0; r < BH_ITEMS; ++r) {
+        const int64_t i = base + r * BH_THREADS + threadIdx.x;
+        if (i < n) m = fmax(m, bh_value(keys[i], n_tests, rank0 + (double)(i + 1)));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = wmax[0];
+        for (int w = 1; w < BH_THREADS / 64; ++w) t = fmax(t, wmax[w]);
+        tile_max[blockIdx.x] = t;
+    }
+}
+
+// exclusive running max over the tile maxima (carry-in of every tile); one workgroup
+__global__ __launch_bounds__(1024) void bh_scan_tiles(double* __restrict__ tile_max,
+                                                      const unsigned long long* __restrict__ n_ptr, int64_t n_fixed,
+                                                      double carry_in, double* __restrict__ total_max) {
+    __shared__ double part[1024];
+    const int64_t n = n_ptr ? (int64_t)*n_ptr : n_fixed;
+    const int64_t tiles = (n + BH_TILE - 1) / BH_TILE;
+    const int64_t per = (tiles + 1023) / 1024;
+    const int64_t beg = (int64_t)threadIdx.x * per, end = min(tiles, beg + per);
+    double m = 0.0;
+    for (int64_t t = beg; t < end; ++t) m = fmax(m, tile_max[t]);
+    part[threadIdx.x] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double run = carry_in;
+        for (int i = 0; i < 1024; ++i) {
+            const double c = part[i];
+            part[i] = run;
+            run = fmax(run, c);
+        }
+        if (total_max) *total_max = run;
+    }
+    __syncthreads();
+    double run = part[threadIdx.x];
+    for (int64_t t = beg; t < end; ++t) {
+        const double c = tile_max[t];
+        tile_max[t] = run;
+        run = fmax(run, c);
+    }
+}
+
+// q = inclusive running max of the BH values; written either scattered to row order (vals != null)
+// or in sorted order (distributed path)
+__global__ __launch_bounds__(BH_THREADS) void bh_apply(const unsigned long long* __restrict__ keys,
+                                                       const unsigned int* __restrict__ vals,
+                                                       const unsigned long long* __restrict__ n_ptr, int64_t n_fixed,
+                                                       double n_tests, double rank0, const double* __restrict__ tile_carry,
+                                                       double* __restrict__ q_out) {
+    __shared__ double wtot[BH_THREADS / 64];
+    const int64_t n = n_ptr ? (int64_t)*n_ptr : n_fixed;
+    const int64_t base = (int64_t)blockIdx.x * BH_TILE;
+    if (base >= n) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // blocked arrangement: thread t owns BH_ITEMS consecutive sorted positions
+    const int64_t first = base + (int64_t)threadIdx.x * BH_ITEMS;
+    double v[BH_ITEMS];
+    double run = 0.0;
+#pragma unroll
+    for (int r = 0; r < BH_ITEMS; ++r) {
+        const int64_t i = first + r;
+        const double b = (i < n) ? bh_value(keys[i], n_tests, rank0 + (double)(i + 1)) : 0.0;
+        run = fmax(run, b);
+        v[r] = run;
+    }
+    const double incl = wave_incl_max(run, lane);
+    double excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 0.0;
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    double carry = tile_carry[blockIdx.x];
+    for (int w = 0; w < wave; ++w) carry = fmax(carry, wtot[w]);
+    carry = fmax(carry, excl);
+#pragma unroll
+    for (int r = 0; r < BH_ITEMS; ++r) {
+        const int64_t i = first + r;
+        if (i < n) {
+            const double qv = fmax(v[r], carry);
+            if (vals)
+                q_out[vals[i]] = qv;
+            else
+                q_out[i] = qv;
+        }
+    }
+}
+
+// plot_qvalues' 51 buckets (fithic.py:1235-1254): counts of floor(q/0.001), NaN -> bucket of 1.0
+__global__ void k_fdr_hist(const double* __restrict__ q, int64_t n, unsigned long long* __restrict__ buckets) {
+    __shared__ unsigned int h[64];
+    if (threadIdx.x < 64) h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double v = q[i];
+        if (v != v) v = 1.0;
+        const double b = floor(v / 0.001);
+        if (b < 51.0) atomicAdd(&h[(int)b], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 51 && h[threadIdx.x]) atomicAdd(&buckets[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+}  // namespace fhx
+
+// =====================================================================================================
+// Context + C ABI
+// =====================================================================================================
+using namespace fhx;
+
+struct fhx_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid[3] = {false, false, false};
+    std::string err;
+    fhx_params prm{};
+    bool have_params = false;
+
+    // fragments
+    FragTable frags;
+    bool have_frags = false;
+    int n_chr = 0;
+
+    // bias rows as loaded (resolved onto the slot grid when pairs are known)
+    std::vector<int32_t> bias_chr, bias_mid;
+    std::vector<double> bias_val;
+    bool have_bias = false;
+
+    // pairs (device) + grid
+    int64_t n_rows = 0;
+    int32_t *d_loc1 = nullptr, *d_loc2 = nullptr, *d_count = nullptr;
+    std::vector<ChrGrid> grid;
+    ChrGrid* d_grid = nullptr;
+    int16_t* d_slot_chr = nullptr;
+    double* d_slot_bias = nullptr;
+    int64_t n_slots = 0;
+    int64_t n_dist = 0;
+    bool tables_dirty = true;
+
+    // pass state
+    int pass_no = 0;                  // passes completed so far
+    uint8_t *d_skip = nullptr, *d_outlier = nullptr, *d_seen_twice = nullptr;
+    bool skip_active = false;
+    unsigned long long *d_hist_cc = nullptr, *d_hist_np = nullptr, *d_out_hist = nullptr, *d_misc = nullptr;
+    K1Sums* d_sums = nullptr;
+    fhx_stats stats{};
+    bool have_stats = false;
+    std::vector<int64_t> h_hist_cc, h_hist_np, h_out_hist;
+    int64_t n_outliers_total = 0;
+    bool outlier_hist_nonempty = false;
+    PassFit fit;
+    bool have_fit = false;
+    double* d_lut = nullptr;
+    double *d_lbeta_intra = nullptr, *d_invb_intra = nullptr, *d_lbeta_inter = nullptr, *d_invb_inter = nullptr;
+    int64_t tab_cap = 0;
+    double *d_p = nullptr, *d_q = nullptr;
+    bool have_p = false, have_q = false;
+
+    // sort workspace
+    unsigned long long *d_keys[2] = {nullptr, nullptr};
+    unsigned int *d_vals[2] = {nullptr, nullptr};
+    unsigned int* d_block_hist = nullptr;
+    unsigned int* d_digit_total = nullptr;
+    double* d_tile_max = nullptr;
+    int sorted_buf = 0;
+    int64_t n_sorted = -1;
+    std::vector<int64_t> fdr_counts;
+};
+
+namespace {
+
+int fail(fhx_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define FHX_HIP(call)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            return fail(ctx, FHX_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+template <typename T>
+void dev_free(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+int grid_for(int64_t n, int threads, int max_blocks = 256 * 8) {
+    const int64_t b = (n + threads - 1) / threads;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(b, max_blocks));
+}
+
+K2Params make_k2_params(fhx_ctx* c) {
+    K2Params P{};
+    P.loc1 = c->d_loc1;
+    P.loc2 = c->d_loc2;
+    P.count = c->d_count;
+    P.slot_bias = c->d_slot_bias;
+    P.prior_lut = c->d_lut;
+    const double n_intra = (double)c->stats.in_range_sum, n_inter = (double)c->stats.inter_sum;
+    P.intra = dev::BinomTables{c->d_lbeta_intra, c->d_invb_intra, n_intra, (n_intra + 1.0) < dev::kMaxGam};
+    P.inter = dev::BinomTables{c->d_lbeta_inter, c->d_invb_inter, n_inter, (n_inter + 1.0) < dev::kMaxGam};
+    P.inter_chr_prob = c->fit.inter_chr_prob;
+    P.outlier_thres = 1.0 / c->fit.bh_total_tests;
+    const int64_t res = c->prm.resolution;
+    P.lo_idx = (int)std::min<int64_t>((c->prm.dist_low + res - 1) / res, INT32_MAX);
+    P.hi_idx = (int)std::min<int64_t>(c->prm.dist_up / res, INT32_MAX);
+    P.mode = c->prm.mode;
+    P.n = c->n_rows;
+    P.p = c->d_p;
+    P.outlier = c->d_outlier;
+    return P;
+}
+
+// bias rows -> per-slot table (first occurrence wins, bounds applied: fithic.py:818-832)
+int build_slot_tables(fhx_ctx* ctx) {
+    const int64_t res = ctx->prm.resolution;
+    std::vector<double> bias((size_t)std::max<int64_t>(ctx->n_slots, 1), ctx->have_bias ? -1.0 : 1.0);
+    std::vector<int16_t> slot_chr((size_t)std::max<int64_t>(ctx->n_slots, 1), 0);
+    for (size_t c = 0; c < ctx->grid.size(); ++c)
+        for (int32_t s = 0; s < ctx->grid[c].nslots; ++s) slot_chr[(size_t)ctx->grid[c].base + s] = (int16_t)c;
+    if (ctx->have_bias) {
+        std::vector<uint8_t> seen(bias.size(), 0);
+        for (size_t i = 0; i < ctx->bias_val.size(); ++i) {
+            const int32_t c = ctx->bias_chr[i], m = ctx->bias_mid[i];
+            if (c < 0 || c >= (int32_t)ctx->grid.size() || m < 0) continue;
+            const ChrGrid& g = ctx->grid[c];
+            if (g.off < 0) continue;                                  // chromosome has no contact rows
+            const int64_t idx = m / res;
+            if (m - idx * res != g.off || idx >= g.nslots) continue;  // no row can match this exact midpoint
+            const size_t s = (size_t)g.base + (size_t)idx;
+            if (seen[s]) continue;
+            seen[s] = 1;
+            double b = ctx->bias_val[i];
+            if (b < ctx->prm.bias_low || std::isnan(b))
+                b = -1;
+            else if (b > ctx->prm.bias_up)
+                b = -1;
+            bias[s] = b;
+        }
+    }
+    dev_free(ctx->d_slot_bias);
+    dev_free(ctx->d_slot_chr);
+    FHX_HIP(hipMalloc(&ctx->d_slot_bias, bias.size() * sizeof(double)));
+    FHX_HIP(hipMalloc(&ctx->d_slot_chr, slot_chr.size() * sizeof(int16_t)));
+    FHX_HIP(hipMemcpyAsync(ctx->d_slot_bias, bias.data(), bias.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    FHX_HIP(hipMemcpyAsync(ctx->d_slot_chr, slot_chr.data(), slot_chr.size() * sizeof(int16_t), hipMemcpyHostToDevice,
+                           ctx->stream));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->tables_dirty = false;
+    return FHX_OK;
+}
+
+int ingest_device_rows(fhx_ctx* ctx, const int32_t* c1, const int32_t* m1, const int32_t* c2, const int32_t* m2,
+                       const int32_t* cnt, int64_t n) {
+    if (!ctx->have_params) return fail(ctx, FHX_ERR_ARG, "fhx_set_params must be called before fhx_load_pairs");
+    if (n <= 0) return fail(ctx, FHX_ERR_ARG, "no rows");
+    if (n >= (1ll << 32)) return fail(ctx, FHX_ERR_UNSUPPORTED, "more than 2^32 rows per GPU: shard the contacts");
+    const int res = (int)ctx->prm.resolution;
+    int n_chr = std::max(ctx->n_chr, 1);
+    // the caller's chromosome id space may be larger than the fragments file's: scan for the maximum id is
+    // folded into the extent kernel by giving it a generous table
+    n_chr = std::max(n_chr, 4096);
+    int32_t *d_maxidx = nullptr, *d_minoff = nullptr, *d_maxoff = nullptr, *d_bad = nullptr;
+    FHX_HIP(hipMalloc(&d_maxidx, n_chr * sizeof(int32_t)));
+    FHX_HIP(hipMalloc(&d_minoff, n_chr * sizeof(int32_t)));
+    FHX_HIP(hipMalloc(&d_maxoff, n_chr * sizeof(int32_t)));
+    FHX_HIP(hipMalloc(&d_bad, sizeof(int32_t)));
+    FHX_HIP(hipMemsetAsync(d_maxidx, 0xFF, n_chr * sizeof(int32_t), ctx->stream));       // -1
+    FHX_HIP(hipMemsetAsync(d_minoff, 0x7F, n_chr * sizeof(int32_t), ctx->stream));       // large
+    FHX_HIP(hipMemsetAsync(d_maxoff, 0xFF, n_chr * sizeof(int32_t), ctx->stream));       // -1
+    FHX_HIP(hipMemsetAsync(d_bad, 0, sizeof(int32_t), ctx->stream));
+    const int blocks = grid_for(n, 256);
+    hipLaunchKernelGGL(k0_extent, dim3(blocks), dim3(256), 0, ctx->stream, c1, m1, n, res, n_chr, d_maxidx, d_minoff,
+                       d_maxoff, d_bad);
+    hipLaunchKernelGGL(k0_extent, dim3(blocks), dim3(256), 0, ctx->stream, c2, m2, n, res, n_chr, d_maxidx, d_minoff,
+                       d_maxoff, d_bad);
+    std::vector<int32_t> maxidx(n_chr), minoff(n_chr), maxoff(n_chr);
+    int32_t bad = 0;
+    FHX_HIP(hipMemcpyAsync(maxidx.data(), d_maxidx, n_chr * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    FHX_HIP(hipMemcpyAsync(minoff.data(), d_minoff, n_chr * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    FHX_HIP(hipMemcpyAsync(maxoff.data(), d_maxoff, n_chr * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    FHX_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    dev_free(d_maxidx);
+    dev_free(d_minoff);
+    dev_free(d_maxoff);
+    dev_free(d_bad);
+    if (bad) return fail(ctx, FHX_ERR_ARG, "contact rows hold a negative midpoint or a chromosome id outside [0, 4096)");
+    int used = 0;
+    for (int c = 0; c < n_chr; ++c)
+        if (maxidx[c] >= 0) used = c + 1;
+    used = std::max(used, ctx->n_chr);
+    ctx->grid.assign(used, ChrGrid{0, -1, 0, 0});
+    int64_t base = 0, n_dist = 1;
+    for (int c = 0; c < used; ++c) {
+        ctx->grid[c].base = (int32_t)base;
+        if (maxidx[c] >= 0) {
+            if (minoff[c] != maxoff[c])
+                return fail(ctx, FHX_ERR_UNSUPPORTED,
+                            "midpoints of one chromosome are not on one fixed-size grid (mid % resolution differs); "
+                            "the accelerated path needs fixed-size loci (reference fast path, fithic.py:592)");
+            ctx->grid[c].off = minoff[c];
+            ctx->grid[c].nslots = maxidx[c] + 1;
+            base += ctx->grid[c].nslots;
+            n_dist = std::max<int64_t>(n_dist, ctx->grid[c].nslots);
+        }
+    }
+    if (base >= (1ll << 31)) return fail(ctx, FHX_ERR_UNSUPPORTED, "more than 2^31 loci");
+    ctx->n_slots = base;
+    ctx->n_dist = n_dist;
+    dev_free(ctx->d_grid);
+    FHX_HIP(hipMalloc(&ctx->d_grid, std::max<size_t>(1, ctx->grid.size()) * sizeof(ChrGrid)));
+    FHX_HIP(hipMemcpyAsync(ctx->d_grid, ctx->grid.data(), ctx->grid.size() * sizeof(ChrGrid), hipMemcpyHostToDevice,
+                           ctx->stream));
+    // row arrays (padded to a multiple of 4 rows for the 16-byte loads)
+    const size_t cap = ((size_t)n + 3) / 4 * 4;
+    dev_free(ctx->d_loc1);
+    dev_free(ctx->d_loc2);
+    dev_free(ctx->d_count);
+    dev_free(ctx->d_skip);
+    dev_free(ctx->d_outlier);
+    dev_free(ctx->d_seen_twice);
+    dev_free(ctx->d_p);
+    dev_free(ctx->d_q);
+    FHX_HIP(hipMalloc(&ctx->d_loc1, cap * sizeof(int32_t)));
+    FHX_HIP(hipMalloc(&ctx->d_loc2, cap * sizeof(int32_t)));
+    FHX_HIP(hipMalloc(&ctx->d_count, cap * sizeof(int32_t)));
+    FHX_HIP(hipMalloc(&ctx->d_skip, cap));
+    FHX_HIP(hipMalloc(&ctx->d_outlier, cap));
+    FHX_HIP(hipMalloc(&ctx->d_seen_twice, cap));
+    FHX_HIP(hipMalloc(&ctx->d_p, cap * sizeof(double)));
+    FHX_HIP(hipMalloc(&ctx->d_q, cap * sizeof(double)));
+    FHX_HIP(hipMemsetAsync(ctx->d_skip, 0, cap, ctx->stream));
+    FHX_HIP(hipMemsetAsync(ctx->d_outlier, 0, cap, ctx->stream));
+    FHX_HIP(hipMemsetAsync(ctx->d_seen_twice, 0, cap, ctx->stream));
+    hipLaunchKernelGGL(k0_slots, dim3(blocks), dim3(256), 0, ctx->stream, c1, m1, c2, m2, cnt, n, res, ctx->d_grid,
+                       ctx->d_loc1, ctx->d_loc2, ctx->d_count);
+    // histograms
+    dev_free(ctx->d_hist_cc);
+    dev_free(ctx->d_hist_np);
+    dev_free(ctx->d_out_hist);
+    FHX_HIP(hipMalloc(&ctx->d_hist_cc, n_dist * sizeof(unsigned long long)));
+    FHX_HIP(hipMalloc(&ctx->d_hist_np, n_dist * sizeof(unsigned long long)));
+    FHX_HIP(hipMalloc(&ctx->d_out_hist, n_dist * sizeof(unsigned long long)));
+    FHX_HIP(hipMemsetAsync(ctx->d_out_hist, 0, n_dist * sizeof(unsigned long long), ctx->stream));
+    if (!ctx->d_sums) FHX_HIP(hipMalloc(&ctx->d_sums, sizeof(K1Sums)));
+    if (!ctx->d_misc) FHX_HIP(hipMalloc(&ctx->d_misc, 64 * sizeof(unsigned long long)));
+    // sort workspace
+    for (int b = 0; b < 2; ++b) {
+        dev_free(ctx->d_keys[b]);
+        dev_free(ctx->d_vals[b]);
+        FHX_HIP(hipMalloc(&ctx->d_keys[b], cap * sizeof(unsigned long long)));
+        FHX_HIP(hipMalloc(&ctx->d_vals[b], cap * sizeof(unsigned int)));
+    }
+    if (!ctx->d_block_hist) FHX_HIP(hipMalloc(&ctx->d_block_hist, (size_t)RADIX * SORT_BLOCKS * sizeof(unsigned int)));
+    if (!ctx->d_digit_total) FHX_HIP(hipMalloc(&ctx->d_digit_total, RADIX * sizeof(unsigned int)));
+    dev_free(ctx->d_tile_max);
+    FHX_HIP(hipMalloc(&ctx->d_tile_max, ((size_t)n / BH_TILE + 2) * sizeof(double)));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->n_rows = n;
+    ctx->pass_no = 0;
+    ctx->skip_active = false;
+    ctx->have_stats = ctx->have_fit = ctx->have_p = ctx->have_q = false;
+    ctx->n_outliers_total = 0;
+    ctx->outlier_hist_nonempty = false;
+    ctx->h_out_hist.assign((size_t)n_dist, 0);
+    ctx->tables_dirty = true;
+    ctx->n_sorted = -1;
+    return FHX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* fhx_version(void) { return "fithic-mi355x 0.1.0 (gfx950)"; }
+
+int fhx_create(int device, fhx_ctx** out) {
+    if (!out) return FHX_ERR_ARG;
+    *out = nullptr;
+    fhx_ctx* ctx = new (std::nothrow) fhx_ctx();
+    if (!ctx) return FHX_ERR_NOMEM;
+    ctx->device = device;
+    if (device >= 0) {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || device >= count) {
+            delete ctx;
+            return FHX_ERR_NO_DEVICE;
+        }
+        if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return FHX_ERR_HIP;
+        }
+        for (auto& e : ctx->ev)
+            if (hipEventCreate(&e) != hipSuccess) {
+                delete ctx;
+                return FHX_ERR_HIP;
+            }
+    }
+    *out = ctx;
+    return FHX_OK;
+}
+
+void fhx_destroy(fhx_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->device >= 0) {
+        (void)hipSetDevice(ctx->device);
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        dev_free(ctx->d_loc1);
+        dev_free(ctx->d_loc2);
+        dev_free(ctx->d_count);
+        dev_free(ctx->d_grid);
+        dev_free(ctx->d_slot_chr);
+        dev_free(ctx->d_slot_bias);
+        dev_free(ctx->d_skip);
+        dev_free(ctx->d_outlier);
+        dev_free(ctx->d_seen_twice);
+        dev_free(ctx->d_hist_cc);
+        dev_free(ctx->d_hist_np);
+        dev_free(ctx->d_out_hist);
+        dev_free(ctx->d_misc);
+        dev_free(ctx->d_sums);
+        dev_free(ctx->d_lut);
+        dev_free(ctx->d_lbeta_intra);
+        dev_free(ctx->d_invb_intra);
+        dev_free(ctx->d_lbeta_inter);
+        dev_free(ctx->d_invb_inter);
+        dev_free(ctx->d_p);
+        dev_free(ctx->d_q);
+        for (int b = 0; b < 2; ++b) {
+            dev_free(ctx->d_keys[b]);
+            dev_free(ctx->d_vals[b]);
+        }
+        dev_free(ctx->d_block_hist);
+        dev_free(ctx->d_digit_total);
+        dev_free(ctx->d_tile_max);
+        for (auto& e : ctx->ev)
+            if (e) (void)hipEventDestroy(e);
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+}
+
+const char* fhx_last_error(fhx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int fhx_set_params(fhx_ctx* ctx, const fhx_params* p) {
+    if (!ctx || !p) return FHX_ERR_ARG;
+    if (p->resolution <= 0)
+        return fail(ctx, FHX_ERR_UNSUPPORTED, "resolution must be > 0 (the -r 0 non-fixed-size mode is not accelerated)");
+    if (p->resolution > INT32_MAX) return fail(ctx, FHX_ERR_ARG, "resolution too large");
+    if (p->n_bins <= 0 || p->mapp_thres < 0 || p->mode < 0 || p->mode > 2) return fail(ctx, FHX_ERR_ARG, "bad parameter");
+    if (p->bias_low > p->bias_up)
+        return fail(ctx, FHX_ERR_REFERENCE_EXIT, "bias lower bound is greater than bias upper bound (fithic.py:261-263)");
+    ctx->prm = *p;
+    ctx->have_params = true;
+    ctx->tables_dirty = true;
+    return FHX_OK;
+}
+
+int fhx_load_fragments(fhx_ctx* ctx, const int32_t* chr, const int32_t* mid, const int32_t* hits, int64_t n,
+                       const int32_t* chr_sort_rank, int32_t n_chr) {
+    if (!ctx || !chr || !mid || !hits || !chr_sort_rank || n < 0 || n_chr <= 0) return FHX_ERR_ARG;
+    if (!ctx->have_params) return fail(ctx, FHX_ERR_ARG, "fhx_set_params must be called first");
+    std::vector<int64_t> cnt(n_chr, 0), mx(n_chr, -1);
+    std::vector<uint8_t> present(n_chr, 0);
+    for (int64_t i = 0; i < n; ++i) {
+        const int c = chr[i];
+        if (c < 0 || c >= n_chr) return fail(ctx, FHX_ERR_ARG, "fragment chromosome id out of range");
+        present[c] = 1;
+        if (hits[i] >= ctx->prm.mapp_thres) {
+            ++cnt[c];
+            mx[c] = std::max<int64_t>(mx[c], mid[i]);
+        }
+    }
+    std::vector<int> order;
+    for (int c = 0; c < n_chr; ++c)
+        if (present[c]) order.push_back(c);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return chr_sort_rank[a] < chr_sort_rank[b]; });
+    ctx->frags = FragTable();
+    for (int c : order) {
+        ctx->frags.chr_id.push_back(c);
+        ctx->frags.n_mappable.push_back(cnt[c]);
+        ctx->frags.max_mid.push_back(mx[c]);
+    }
+    ctx->n_chr = std::max(ctx->n_chr, n_chr);
+    ctx->have_frags = true;
+    return FHX_OK;
+}
+
+int fhx_load_bias(fhx_ctx* ctx, const int32_t* chr, const int32_t* mid, const double* bias, int64_t n) {
+    if (!ctx || n < 0 || (n > 0 && (!chr || !mid || !bias))) return FHX_ERR_ARG;
+    ctx->bias_chr.assign(chr, chr + n);
+    ctx->bias_mid.assign(mid, mid + n);
+    ctx->bias_val.assign(bias, bias + n);
+    ctx->have_bias = n > 0;                 // an empty bias dictionary is falsy in the reference (fithic.py:1026)
+    ctx->tables_dirty = true;
+    return FHX_OK;
+}
+
+int fhx_load_pairs_device(fhx_ctx* ctx, const void* c1, const void* m1, const void* c2, const void* m2, const void* cnt,
+                          int64_t n, void* stream) {
+    if (!ctx || !c1 || !m1 || !c2 || !m2 || !cnt) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    FHX_HIP(hipSetDevice(ctx->device));
+    if (stream) FHX_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return ingest_device_rows(ctx, (const int32_t*)c1, (const int32_t*)m1, (const int32_t*)c2, (const int32_t*)m2,
+                              (const int32_t*)cnt, n);
+}
+
+int fhx_load_pairs(fhx_ctx* ctx, const int32_t* chr1, const int32_t* mid1, const int32_t* chr2, const int32_t* mid2,
+                   const int32_t* count, int64_t n) {
+    if (!ctx || !chr1 || !mid1 || !chr2 || !mid2 || !count || n <= 0) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context cannot hold contact rows");
+    FHX_HIP(hipSetDevice(ctx->device));
+    int32_t* d[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const int32_t* h[5] = {chr1, mid1, chr2, mid2, count};
+    for (int k = 0; k < 5; ++k) {
+        FHX_HIP(hipMalloc(&d[k], (size_t)n * sizeof(int32_t)));
+        FHX_HIP(hipMemcpyAsync(d[k], h[k], (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    }
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    const int rc = ingest_device_rows(ctx, d[0], d[1], d[2], d[3], d[4], n);
+    for (int k = 0; k < 5; ++k) dev_free(d[k]);
+    return rc;
+}
+
+int fhx_pass_stats(fhx_ctx* ctx, fhx_stats* out) {
+    if (!ctx) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (ctx->n_rows <= 0) return fail(ctx, FHX_ERR_ARG, "no contact rows loaded");
+    FHX_HIP(hipSetDevice(ctx->device));
+    const int64_t res = ctx->prm.resolution;
+    const int64_t lo = (ctx->prm.dist_low + res - 1) / res;
+    const int64_t hi = std::min<int64_t>(ctx->prm.dist_up / res, ctx->n_dist - 1);
+    FHX_HIP(hipMemsetAsync(ctx->d_hist_cc, 0, ctx->n_dist * sizeof(unsigned long long), ctx->stream));
+    FHX_HIP(hipMemsetAsync(ctx->d_hist_np, 0, ctx->n_dist * sizeof(unsigned long long), ctx->stream));
+    FHX_HIP(hipMemsetAsync(ctx->d_sums, 0, sizeof(K1Sums), ctx->stream));
+    FHX_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    const size_t lds = (size_t)K1_LDS_BINS * (sizeof(unsigned long long) + sizeof(unsigned int));
+    const int blocks = grid_for((ctx->n_rows + 3) / 4, K1_THREADS, 512);
+    hipLaunchKernelGGL(k1_classify_hist, dim3(blocks), dim3(K1_THREADS), lds, ctx->stream, ctx->d_loc1, ctx->d_loc2,
+                       ctx->d_count, ctx->skip_active ? ctx->d_skip : (const uint8_t*)nullptr, ctx->n_rows,
+                       (int)std::min<int64_t>(lo, INT32_MAX), (int)hi, ctx->d_hist_cc, ctx->d_hist_np, ctx->d_sums);
+    FHX_HIP(hipGetLastError());
+    FHX_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    ctx->ev_valid[0] = true;
+    K1Sums s{};
+    ctx->h_hist_cc.assign((size_t)ctx->n_dist, 0);
+    ctx->h_hist_np.assign((size_t)ctx->n_dist, 0);
+    FHX_HIP(hipMemcpyAsync(&s, ctx->d_sums, sizeof(K1Sums), hipMemcpyDeviceToHost, ctx->stream));
+    FHX_HIP(hipMemcpyAsync(ctx->h_hist_cc.data(), ctx->d_hist_cc, ctx->n_dist * sizeof(int64_t), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    FHX_HIP(hipMemcpyAsync(ctx->h_hist_np.data(), ctx->d_hist_np, ctx->n_dist * sizeof(int64_t), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    fhx_stats& st = ctx->stats;
+    st.n_rows = ctx->n_rows;
+    st.inter_count = s.inter_count;
+    st.inter_sum = s.inter_sum;
+    st.intra_all_count = s.intra_all_count;
+    st.intra_all_sum = s.intra_all_sum;
+    st.in_range_count = s.in_range_count;
+    st.in_range_sum = s.in_range_sum;
+    st.max_count = s.max_count;
+    st.n_dist = ctx->n_dist;
+    st.n_skipped = s.n_skipped;
+    ctx->have_stats = true;
+    ctx->have_fit = ctx->have_p = ctx->have_q = false;
+    if (out) *out = st;
+    return FHX_OK;
+}
+
+int fhx_set_global_stats(fhx_ctx* ctx, const fhx_stats* g, const int64_t* hist_sumcc, const int64_t* hist_npairs,
+                         int64_t n_dist) {
+    if (!ctx || !g || !hist_sumcc || !hist_npairs || n_dist <= 0) return FHX_ERR_ARG;
+    const int64_t rows = ctx->n_rows;
+    ctx->stats = *g;
+    ctx->stats.n_rows = rows > 0 ? rows : g->n_rows;
+    ctx->stats.n_dist = n_dist;
+    ctx->n_dist = std::max(ctx->n_dist, n_dist);
+    ctx->h_hist_cc.assign(hist_sumcc, hist_sumcc + n_dist);
+    ctx->h_hist_np.assign(hist_npairs, hist_npairs + n_dist);
+    ctx->h_hist_cc.resize((size_t)ctx->n_dist, 0);
+    ctx->h_hist_np.resize((size_t)ctx->n_dist, 0);
+    ctx->have_stats = true;
+    ctx->have_fit = false;
+    return FHX_OK;
+}
+
+int fhx_set_outlier_dist_hist(fhx_ctx* ctx, const int64_t* hist, int64_t n_dist) {
+    if (!ctx || !hist || n_dist <= 0) return FHX_ERR_ARG;
+    ctx->h_out_hist.assign(hist, hist + n_dist);
+    if (ctx->pass_no < 1) ctx->pass_no = 1;          // an outlier multiset exists: this is pass >= 2
+    return FHX_OK;
+}
+
+int fhx_fit(fhx_ctx* ctx, fhx_fit_info* out) {
+    if (!ctx) return FHX_ERR_ARG;
+    if (!ctx->have_params || !ctx->have_frags) return fail(ctx, FHX_ERR_ARG, "parameters and fragments must be loaded");
+    if (!ctx->have_stats) return fail(ctx, FHX_ERR_ARG, "fhx_pass_stats (or fhx_set_global_stats) must run first");
+    PassInputs in;
+    in.resolution = ctx->prm.resolution;
+    in.dist_low = ctx->prm.dist_low;
+    in.dist_up = ctx->prm.dist_up;
+    in.n_bins = ctx->prm.n_bins;
+    in.mode = ctx->prm.mode;
+    in.hist_sumcc = ctx->h_hist_cc.data();
+    in.hist_npairs = ctx->h_hist_np.data();
+    in.n_dist = (int64_t)ctx->h_hist_cc.size();
+    in.in_range_sum = ctx->stats.in_range_sum;
+    in.inter_count = ctx->stats.inter_count;
+    in.inter_sum = ctx->stats.inter_sum;
+    if (ctx->h_out_hist.size() < ctx->h_hist_cc.size()) ctx->h_out_hist.resize(ctx->h_hist_cc.size(), 0);
+    in.outlier_dist_hist = ctx->pass_no > 0 ? ctx->h_out_hist.data() : nullptr;
+    std::string err;
+    const int rc = run_host_pass(in, ctx->frags, ctx->fit, err);
+    if (rc != FHX_OK) return fail(ctx, rc, err);
+    ctx->have_fit = true;
+    const PassFit& f = ctx->fit;
+    if (ctx->device >= 0) {
+        FHX_HIP(hipSetDevice(ctx->device));
+        if (ctx->tables_dirty) {
+            const int r2 = build_slot_tables(ctx);
+            if (r2 != FHX_OK) return r2;
+        }
+        // prior LUT + the two per-count tables
+        dev_free(ctx->d_lut);
+        FHX_HIP(hipMalloc(&ctx->d_lut, f.prior_lut.size() * sizeof(double)));
+        FHX_HIP(hipMemcpyAsync(ctx->d_lut, f.prior_lut.data(), f.prior_lut.size() * sizeof(double), hipMemcpyHostToDevice,
+                               ctx->stream));
+        const int64_t mc = std::max<int64_t>(ctx->stats.max_count, 1);
+        std::vector<double> lb_a, ib_a, lb_e, ib_e;
+        build_lbeta_table((double)ctx->stats.in_range_sum, mc, lb_a, ib_a);
+        build_lbeta_table((double)ctx->stats.inter_sum, mc, lb_e, ib_e);
+        if (mc + 1 > ctx->tab_cap) {
+            dev_free(ctx->d_lbeta_intra);
+            dev_free(ctx->d_invb_intra);
+            dev_free(ctx->d_lbeta_inter);
+            dev_free(ctx->d_invb_inter);
+            ctx->tab_cap = mc + 1;
+            FHX_HIP(hipMalloc(&ctx->d_lbeta_intra, ctx->tab_cap * sizeof(double)));
+            FHX_HIP(hipMalloc(&ctx->d_invb_intra, ctx->tab_cap * sizeof(double)));
+            FHX_HIP(hipMalloc(&ctx->d_lbeta_inter, ctx->tab_cap * sizeof(double)));
+            FHX_HIP(hipMalloc(&ctx->d_invb_inter, ctx->tab_cap * sizeof(double)));
+        }
+        const size_t bytes = (size_t)(mc + 1) * sizeof(double);
+        FHX_HIP(hipMemcpyAsync(ctx->d_lbeta_intra, lb_a.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+        FHX_HIP(hipMemcpyAsync(ctx->d_invb_intra, ib_a.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+        FHX_HIP(hipMemcpyAsync(ctx->d_lbeta_inter, lb_e.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+        FHX_HIP(hipMemcpyAsync(ctx->d_invb_inter, ib_e.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+        FHX_HIP(hipStreamSynchronize(ctx->stream));      // the host vectors go out of scope
+    }
+    if (out) {
+        std::memset(out, 0, sizeof(*out));
+        out->n_bins_made = (int32_t)f.bins.size();
+        out->n_knots = (int32_t)f.spline.t.size();
+        out->spline_ier = f.spline.ier;
+        out->spline_restarted = f.spline.restarted ? 1 : 0;
+        out->n_table = (int64_t)f.table_x.size();
+        out->n_frags = f.n_frags;
+        out->possible_intra_in_range = f.poss_intra_in_range;
+        out->possible_inter_all = f.poss_inter_all;
+        out->possible_intra_all = f.poss_intra_all;
+        out->max_possible_dist = f.max_possible_dist;
+        out->inter_chr_prob = f.inter_chr_prob;
+        out->baseline_intra_prob = f.baseline_intra_prob;
+        out->spline_s = f.spline_s;
+        out->spline_fp = f.spline.fp;
+        out->residual = f.residual;
+        out->bh_total_tests = f.bh_total_tests;
+        out->outlier_thres = 1.0 / f.bh_total_tests;
+    }
+    return FHX_OK;
+}
+
+int fhx_pvalues(fhx_ctx* ctx) {
+    if (!ctx) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (!ctx->have_fit) return fail(ctx, FHX_ERR_ARG, "fhx_fit must run first");
+    FHX_HIP(hipSetDevice(ctx->device));
+    const K2Params P = make_k2_params(ctx);
+    FHX_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    hipLaunchKernelGGL(k2_pvalue, dim3(grid_for(ctx->n_rows, K2_THREADS, 256 * 16)), dim3(K2_THREADS), 0, ctx->stream, P);
+    FHX_HIP(hipGetLastError());
+    FHX_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+    ctx->ev_valid[1] = true;
+    ctx->have_p = true;
+    ctx->have_q = false;
+    ctx->n_sorted = -1;
+    return FHX_OK;
+}
+
+// compact p < 1 and LSD-radix-sort (key, row); returns the index (0/1) of the buffer pair holding the result
+static int sort_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned long long* keys[2], unsigned int* vals[2],
+                        double* d_q, unsigned long long* counter, int* sorted_buf) {
+    FHX_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(k3_compact, dim3(grid_for(n, SORT_THREADS, 256 * 8)), dim3(SORT_THREADS), 0, ctx->stream, d_p, n,
+                       keys[0], vals[0], d_q, counter);
+    int src = 0;
+    // p < 1 means the IEEE exponent field is <= 1022: bits 62 and 63 are always clear, 62 bits to sort
+    for (int shift = 0; shift < 64; shift += RADIX_BITS) {
+        hipLaunchKernelGGL(rs_count, dim3(SORT_BLOCKS), dim3(SORT_THREADS), 0, ctx->stream, keys[src], counter, shift,
+                           ctx->d_block_hist);
+        hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3(SORT_BLOCKS), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total);
+        hipLaunchKernelGGL(rs_scatter, dim3(SORT_BLOCKS), dim3(SORT_THREADS), 0, ctx->stream, keys[src], vals[src],
+                           keys[1 - src], vals[1 - src], counter, shift, ctx->d_block_hist, ctx->d_digit_total);
+        src = 1 - src;
+    }
+    FHX_HIP(hipGetLastError());
+    *sorted_buf = src;
+    return FHX_OK;
+}
+
+static int bh_from_sorted(fhx_ctx* ctx, const unsigned long long* keys, const unsigned int* vals, int64_t n_rows,
+                          const unsigned long long* counter, double n_total_tests, double* tile_max, double* d_q) {
+    const int tiles = (int)((n_rows + BH_TILE - 1) / BH_TILE);
+    hipLaunchKernelGGL(bh_tile_max, dim3(tiles), dim3(BH_THREADS), 0, ctx->stream, keys, counter, (int64_t)0, n_total_tests,
+                       0.0, tile_max);
+    hipLaunchKernelGGL(bh_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, tile_max, counter, (int64_t)0, 0.0,
+                       (double*)nullptr);
+    hipLaunchKernelGGL(bh_apply, dim3(tiles), dim3(BH_THREADS), 0, ctx->stream, keys, vals, counter, (int64_t)0,
+                       n_total_tests, 0.0, tile_max, d_q);
+    FHX_HIP(hipGetLastError());
+    return FHX_OK;
+}
+
+static int ensure_sort_scratch(fhx_ctx* ctx) {
+    if (!ctx->d_block_hist) FHX_HIP(hipMalloc(&ctx->d_block_hist, (size_t)RADIX * SORT_BLOCKS * sizeof(unsigned int)));
+    if (!ctx->d_digit_total) FHX_HIP(hipMalloc(&ctx->d_digit_total, RADIX * sizeof(unsigned int)));
+    if (!ctx->d_misc) FHX_HIP(hipMalloc(&ctx->d_misc, 64 * sizeof(unsigned long long)));
+    return FHX_OK;
+}
+
+int fhx_bh_local_sort(fhx_ctx* ctx) {
+    if (!ctx) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (!ctx->have_p) return fail(ctx, FHX_ERR_ARG, "fhx_pvalues must run first");
+    FHX_HIP(hipSetDevice(ctx->device));
+    const int rc = sort_pvalues(ctx, ctx->d_p, ctx->n_rows, ctx->d_keys, ctx->d_vals, ctx->d_q, ctx->d_misc, &ctx->sorted_buf);
+    if (rc != FHX_OK) return rc;
+    ctx->n_sorted = -2;          // known on the device only until someone asks
+    return FHX_OK;
+}
+
+int fhx_bdtrc_array(fhx_ctx* ctx, double n_total, const int32_t* count, const double* prior, int64_t n, double* out) {
+    if (!ctx || !count || !prior || !out || n < 0) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (n == 0) return FHX_OK;
+    FHX_HIP(hipSetDevice(ctx->device));
+    int64_t mc = 1;
+    for (int64_t i = 0; i < n; ++i) mc = std::max<int64_t>(mc, count[i]);
+    std::vector<double> lb, ib;
+    build_lbeta_table(n_total, mc, lb, ib);
+    double *d_lb = nullptr, *d_ib = nullptr, *d_prior = nullptr, *d_out = nullptr;
+    int32_t* d_count = nullptr;
+    FHX_HIP(hipMalloc(&d_lb, lb.size() * sizeof(double)));
+    FHX_HIP(hipMalloc(&d_ib, ib.size() * sizeof(double)));
+    FHX_HIP(hipMalloc(&d_prior, (size_t)n * sizeof(double)));
+    FHX_HIP(hipMalloc(&d_out, (size_t)n * sizeof(double)));
+    FHX_HIP(hipMalloc(&d_count, (size_t)n * sizeof(int32_t)));
+    FHX_HIP(hipMemcpyAsync(d_lb, lb.data(), lb.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    FHX_HIP(hipMemcpyAsync(d_ib, ib.data(), ib.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    FHX_HIP(hipMemcpyAsync(d_prior, prior, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    FHX_HIP(hipMemcpyAsync(d_count, count, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    const dev::BinomTables T{d_lb, d_ib, n_total, (n_total + 1.0) < dev::kMaxGam};
+    hipLaunchKernelGGL(k_bdtrc_array, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, T, d_count, d_prior, n, d_out);
+    FHX_HIP(hipGetLastError());
+    FHX_HIP(hipMemcpyAsync(out, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    dev_free(d_lb);
+    dev_free(d_ib);
+    dev_free(d_prior);
+    dev_free(d_out);
+    dev_free(d_count);
+    return FHX_OK;
+}
+
+int fhx_bh_array(fhx_ctx* ctx, const double* p, int64_t n, double n_total_tests, double* q) {
+    if (!ctx || !p || !q || n < 0) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (n == 0) return FHX_OK;
+    if (n >= (1ll << 32)) return fail(ctx, FHX_ERR_UNSUPPORTED, "more than 2^32 p-values");
+    FHX_HIP(hipSetDevice(ctx->device));
+    int rc = ensure_sort_scratch(ctx);
+    if (rc != FHX_OK) return rc;
+    double *d_p = nullptr, *d_q = nullptr, *tile_max = nullptr;
+    unsigned long long* keys[2] = {nullptr, nullptr};
+    unsigned int* vals[2] = {nullptr, nullptr};
+    const size_t cap = (size_t)n;
+    FHX_HIP(hipMalloc(&d_p, cap * sizeof(double)));
+    FHX_HIP(hipMalloc(&d_q, cap * sizeof(double)));
+    FHX_HIP(hipMalloc(&tile_max, (cap / BH_TILE + 2) * sizeof(double)));
+    for (int b = 0; b < 2; ++b) {
+        FHX_HIP(hipMalloc(&keys[b], cap * sizeof(unsigned long long)));
+        FHX_HIP(hipMalloc(&vals[b], cap * sizeof(unsigned int)));
+    }
+    FHX_HIP(hipMemcpyAsync(d_p, p, cap * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    int buf = 0;
+    unsigned long long* counter = ctx->d_misc + 2;
+    rc = sort_pvalues(ctx, d_p, n, keys, vals, d_q, counter, &buf);
+    if (rc == FHX_OK) rc = bh_from_sorted(ctx, keys[buf], vals[buf], n, counter, n_total_tests, tile_max, d_q);
+    if (rc == FHX_OK) {
+        FHX_HIP(hipMemcpyAsync(q, d_q, cap * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        FHX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    dev_free(d_p);
+    dev_free(d_q);
+    dev_free(tile_max);
+    for (int b = 0; b < 2; ++b) {
+        dev_free(keys[b]);
+        dev_free(vals[b]);
+    }
+    return rc;
+}
+
+int fhx_bh(fhx_ctx* ctx, double n_total_tests) {
+    if (!ctx) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (!ctx->have_p) return fail(ctx, FHX_ERR_ARG, "fhx_pvalues must run first");
+    if (!(n_total_tests > 0)) return fail(ctx, FHX_ERR_ARG, "number of tests must be positive");
+    FHX_HIP(hipSetDevice(ctx->device));
+    FHX_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+    const int rc = fhx_bh_local_sort(ctx);
+    if (rc != FHX_OK) return rc;
+    const int s = ctx->sorted_buf;
+    const int rc2 = bh_from_sorted(ctx, ctx->d_keys[s], ctx->d_vals[s], ctx->n_rows, ctx->d_misc, n_total_tests,
+                                   ctx->d_tile_max, ctx->d_q);
+    if (rc2 != FHX_OK) return rc2;
+    FHX_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
+    ctx->ev_valid[2] = true;
+    ctx->have_q = true;
+    return FHX_OK;
+}
+
+int fhx_bh_apply_sorted(fhx_ctx* ctx, const void* d_sorted_keys, int64_t n, int64_t global_rank0, double carry_in,
+                        double n_total_tests, void* d_q_sorted, double* block_max_out) {
+    if (!ctx || n < 0) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    FHX_HIP(hipSetDevice(ctx->device));
+    if (n == 0) {
+        if (block_max_out) *block_max_out = carry_in;
+        return FHX_OK;
+    }
+    const int tiles = (int)((n + BH_TILE - 1) / BH_TILE);
+    double* tile_max = nullptr;
+    FHX_HIP(hipMalloc(&tile_max, ((size_t)tiles + 1) * sizeof(double)));
+    const unsigned long long* keys = (const unsigned long long*)d_sorted_keys;
+    hipLaunchKernelGGL(bh_tile_max, dim3(tiles), dim3(BH_THREADS), 0, ctx->stream, keys, (const unsigned long long*)nullptr, n,
+                       n_total_tests, (double)global_rank0, tile_max);
+    hipLaunchKernelGGL(bh_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, tile_max, (const unsigned long long*)nullptr, n,
+                       carry_in, tile_max + tiles);
+    if (d_q_sorted)
+        hipLaunchKernelGGL(bh_apply, dim3(tiles), dim3(BH_THREADS), 0, ctx->stream, keys, (const unsigned int*)nullptr,
+                           (const unsigned long long*)nullptr, n, n_total_tests, (double)global_rank0, tile_max,
+                           (double*)d_q_sorted);
+    double total = 0.0;
+    FHX_HIP(hipMemcpyAsync(&total, tile_max + tiles, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    dev_free(tile_max);
+    if (block_max_out) *block_max_out = total;
+    return FHX_OK;
+}
+
+int fhx_sync(fhx_ctx* ctx) {
+    if (!ctx) return FHX_ERR_ARG;
+    if (ctx->device < 0) return FHX_OK;
+    FHX_HIP(hipSetDevice(ctx->device));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    return FHX_OK;
+}
+
+int fhx_next_pass(fhx_ctx* ctx, int64_t* n_outliers_total) {
+    if (!ctx) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (!ctx->have_p) return fail(ctx, FHX_ERR_ARG, "fhx_pvalues must run first");
+    FHX_HIP(hipSetDevice(ctx->device));
+    unsigned long long* n_out = ctx->d_misc + 1;
+    FHX_HIP(hipMemsetAsync(n_out, 0, sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(k_fold_outliers, dim3(grid_for(ctx->n_rows, 256)), dim3(256), 0, ctx->stream, ctx->d_loc1, ctx->d_loc2,
+                       ctx->d_outlier, ctx->d_skip, ctx->d_seen_twice, ctx->n_rows, (int)ctx->prm.resolution, (int)ctx->n_dist,
+                       ctx->d_slot_chr, ctx->d_grid, ctx->d_out_hist, n_out);
+    FHX_HIP(hipGetLastError());
+    unsigned long long added = 0;
+    ctx->h_out_hist.assign((size_t)ctx->n_dist, 0);
+    FHX_HIP(hipMemcpyAsync(&added, n_out, sizeof(added), hipMemcpyDeviceToHost, ctx->stream));
+    FHX_HIP(hipMemcpyAsync(ctx->h_out_hist.data(), ctx->d_out_hist, ctx->n_dist * sizeof(int64_t), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->n_outliers_total += (int64_t)added;
+    ctx->skip_active = true;
+    ctx->pass_no += 1;
+    if (n_outliers_total) *n_outliers_total = ctx->n_outliers_total;
+    return FHX_OK;
+}
+
+int fhx_fetch(fhx_ctx* ctx, double* p, double* q, double* expcc, double* bias1, double* bias2) {
+    if (!ctx) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (!ctx->have_p) return fail(ctx, FHX_ERR_ARG, "no p-values yet");
+    if (q && !ctx->have_q) return fail(ctx, FHX_ERR_ARG, "no q-values yet");
+    FHX_HIP(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)ctx->n_rows * sizeof(double);
+    if (p) FHX_HIP(hipMemcpyAsync(p, ctx->d_p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (q) FHX_HIP(hipMemcpyAsync(q, ctx->d_q, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    double* d_tmp[3] = {nullptr, nullptr, nullptr};
+    double* host[3] = {expcc, bias1, bias2};
+    if (expcc || bias1 || bias2) {
+        for (int k = 0; k < 3; ++k)
+            if (host[k]) FHX_HIP(hipMalloc(&d_tmp[k], bytes));
+        const K2Params P = make_k2_params(ctx);
+        hipLaunchKernelGGL(k2_extras, dim3(grid_for(ctx->n_rows, 256)), dim3(256), 0, ctx->stream, P, ctx->prm.bias_low,
+                           ctx->prm.bias_up, d_tmp[0], d_tmp[1], d_tmp[2]);
+        FHX_HIP(hipGetLastError());
+        for (int k = 0; k < 3; ++k)
+            if (host[k]) FHX_HIP(hipMemcpyAsync(host[k], d_tmp[k], bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 3; ++k) dev_free(d_tmp[k]);
+    return FHX_OK;
+}
+
+int fhx_get_array(fhx_ctx* ctx, int which, void* dst, int64_t cap, int64_t* n_out) {
+    if (!ctx) return FHX_ERR_ARG;
+    const PassFit& f = ctx->fit;
+    auto put = [&](const void* src, size_t n, size_t elem) -> int {
+        if (n_out) *n_out = (int64_t)n;
+        if (!dst) return FHX_OK;
+        if ((int64_t)n > cap) return fail(ctx, FHX_ERR_ARG, "destination too small");
+        if (n) std::memcpy(dst, src, n * elem);
+        return FHX_OK;
+    };
+    auto bin_i64 = [&](int64_t Bin::*m) -> int {
+        std::vector<int64_t> v;
+        for (const auto& b : f.bins) v.push_back(b.*m);
+        return put(v.data(), v.size(), sizeof(int64_t));
+    };
+    switch (which) {
+        case FHX_A_HIST_SUMCC: return put(ctx->h_hist_cc.data(), ctx->h_hist_cc.size(), sizeof(int64_t));
+        case FHX_A_HIST_NPAIRS: return put(ctx->h_hist_np.data(), ctx->h_hist_np.size(), sizeof(int64_t));
+        case FHX_A_OUTLIER_DIST_HIST: return put(ctx->h_out_hist.data(), ctx->h_out_hist.size(), sizeof(int64_t));
+        default: break;
+    }
+    if (which == FHX_A_FDR_COUNTS) {
+        if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+        if (!ctx->have_q) return fail(ctx, FHX_ERR_ARG, "no q-values yet");
+        FHX_HIP(hipSetDevice(ctx->device));
+        unsigned long long* buckets = ctx->d_misc + 8;
+        FHX_HIP(hipMemsetAsync(buckets, 0, 51 * sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(k_fdr_hist, dim3(grid_for(ctx->n_rows, 256)), dim3(256), 0, ctx->stream, ctx->d_q, ctx->n_rows, buckets);
+        std::vector<int64_t> c(51, 0);
+        FHX_HIP(hipMemcpyAsync(c.data(), buckets, 51 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        FHX_HIP(hipStreamSynchronize(ctx->stream));
+        for (int i = 1; i < 51; ++i) c[i] += c[i - 1];       // cumulative ...
+        for (int i = 50; i >= 1; --i) c[i] = c[i - 1];       // ... shifted by one (fithic.py:1249-1254)
+        c[0] = 0;
+        return put(c.data(), c.size(), sizeof(int64_t));
+    }
+    if (!ctx->have_fit) return fail(ctx, FHX_ERR_ARG, "fhx_fit must run first");
+    switch (which) {
+        case FHX_A_BIN_LB: return bin_i64(&Bin::lb);
+        case FHX_A_BIN_UB: return bin_i64(&Bin::ub);
+        case FHX_A_BIN_POSS: return bin_i64(&Bin::poss);
+        case FHX_A_BIN_POSS0: return bin_i64(&Bin::poss0);
+        case FHX_A_BIN_SUMCC: return bin_i64(&Bin::sumcc);
+        case FHX_A_BIN_POSS7: return bin_i64(&Bin::poss7);
+        case FHX_A_BIN_SUMDIST: {
+            std::vector<double> v;
+            for (const auto& b : f.bins) v.push_back(b.sumdist);
+            return put(v.data(), v.size(), sizeof(double));
+        }
+        case FHX_A_X: return put(f.x.data(), f.x.size(), sizeof(double));
+        case FHX_A_Y: return put(f.y.data(), f.y.size(), sizeof(double));
+        case FHX_A_KNOTS: return put(f.spline.t.data(), f.spline.t.size(), sizeof(double));
+        case FHX_A_COEFFS: return put(f.spline.c.data(), f.spline.c.size(), sizeof(double));
+        case FHX_A_TABLE_X: return put(f.table_x.data(), f.table_x.size(), sizeof(int64_t));
+        case FHX_A_TABLE_Y0: return put(f.table_y0.data(), f.table_y0.size(), sizeof(double));
+        case FHX_A_TABLE_Y: return put(f.table_y.data(), f.table_y.size(), sizeof(double));
+        default: return fail(ctx, FHX_ERR_ARG, "unknown array id");
+    }
+}
+
+void* fhx_device_ptr(fhx_ctx* ctx, int which) {
+    if (!ctx || ctx->device < 0) return nullptr;
+    switch (which) {
+        case 0: return ctx->d_p;
+        case 1: return ctx->d_q;
+        case 2: return ctx->d_keys[ctx->sorted_buf];
+        case 3: return ctx->d_vals[ctx->sorted_buf];
+        default: return nullptr;
+    }
+}
+
+int64_t fhx_n_sorted(fhx_ctx* ctx) {
+    if (!ctx || ctx->device < 0 || ctx->n_sorted == -1) return -1;
+    if (ctx->n_sorted == -2) {
+        unsigned long long n = 0;
+        if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+        if (hipMemcpyAsync(&n, ctx->d_misc, sizeof(n), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return -1;
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
+        ctx->n_sorted = (int64_t)n;
+    }
+    return ctx->n_sorted;
+}
+
+int fhx_kernel_seconds(fhx_ctx* ctx, double* k1, double* k2, double* k3) {
+    if (!ctx) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    FHX_HIP(hipSetDevice(ctx->device));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    double* out[3] = {k1, k2, k3};
+    for (int k = 0; k < 3; ++k) {
+        if (!out[k]) continue;
+        *out[k] = 0.0;
+        if (!ctx->ev_valid[k]) continue;
+        float ms = 0.f;
+        FHX_HIP(hipEventElapsedTime(&ms, ctx->ev[2 * k], ctx->ev[2 * k + 1]));
+        *out[k] = ms * 1e-3;
+    }
+    return FHX_OK;
+}
+
+// ---- host numerics exported for tests / host-only callers ----------------------------------------------
+int fhx_host_spline_fit(const double* x, const double* y, int32_t m, double s, double* t, double* c, int32_t* n_knots,
+                        double* fp, int32_t* ier, int32_t* restarted) {
+    if (!x || !y || !t || !c || !n_knots) return FHX_ERR_ARG;
+    Spline sp;
+    const int rc = spline_fit(x, y, m, s, sp);
+    if (rc != FHX_OK) return rc;
+    *n_knots = (int32_t)sp.t.size();
+    std::memcpy(t, sp.t.data(), sp.t.size() * sizeof(double));
+    std::memcpy(c, sp.c.data(), sp.c.size() * sizeof(double));
+    if (fp) *fp = sp.fp;
+    if (ier) *ier = sp.ier;
+    if (restarted) *restarted = sp.restarted ? 1 : 0;
+    return FHX_OK;
+}
+
+int fhx_host_spline_eval(const double* t, const double* c, int32_t n_knots, const double* xs, int64_t nx, double* out) {
+    if (!t || !c || !xs || !out || n_knots < 8) return FHX_ERR_ARG;
+    Spline sp;
+    sp.t.assign(t, t + n_knots);
+    sp.c.assign(c, c + n_knots - 4);
+    spline_eval(sp, xs, nx, out);
+    return FHX_OK;
+}
+
+int fhx_host_pava_decreasing(const double* y, int64_t n, double* out) {
+    if (!y || !out || n < 0) return FHX_ERR_ARG;
+    pava_decreasing(y, n, out);
+    return FHX_OK;
+}
+
+int fhx_host_lbeta_table(double n_total, int64_t max_count, double* lbeta_out, double* inv_beta_out) {
+    if (!lbeta_out || max_count < 0) return FHX_ERR_ARG;
+    std::vector<double> lb, ib;
+    build_lbeta_table(n_total, max_count, lb, ib);
+    std::memcpy(lbeta_out, lb.data(), lb.size() * sizeof(double));
+    if (inv_beta_out) std::memcpy(inv_beta_out, ib.data(), ib.size() * sizeof(double));
+    return FHX_OK;
+}
+
+}  // extern "C"

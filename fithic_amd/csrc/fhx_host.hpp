@@ -1,0 +1,91 @@
+// fhx_host.hpp - host-side (O(#bins), O(#distances)) stages of the MI355X Fit-Hi-C engine.
+//
+// Everything here is order-sensitive double arithmetic that the reference does in Python / Cephes /
+// FITPACK; it is compiled with -ffp-contract=off so that no a*b+c is fused.
+// The O(#pairs) work lives in fhx_kernels.hip.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace fhx {
+
+// ---------------------------------------------------------------------------------------------------
+// Cephes log-gamma / log-beta / beta on the host: feeds the per-count tables K2 reads.
+// scipy.special.bdtrc -> incbet -> lbeta(a,b) / beta(a,b)   (call sites fithic/fithic.py:1070,1101)
+double cephes_lgam(double x);
+double cephes_lbeta(double a, double b);
+double cephes_beta(double a, double b);
+// table[c] = lbeta(c, n-c+1), inv_beta[c] = 1/beta(c, n-c+1) (only meaningful when n+1 < MAXGAM), c = 0..max_count
+void build_lbeta_table(double n_total, int64_t max_count, std::vector<double>& lbeta, std::vector<double>& inv_beta);
+
+// ---------------------------------------------------------------------------------------------------
+// Cubic smoothing spline exactly as scipy.interpolate.UnivariateSpline(x, y, s=s) builds it
+// (fithic/fithic.py:951): FITPACK fpcurf with nest = max(m/2, 8) and the iopt=1 continuation when
+// FITPACK reports "nest too small".
+struct Spline {
+    std::vector<double> t;     // knots (n)
+    std::vector<double> c;     // B-spline coefficients (n-4)
+    double fp = 0.0;
+    int ier = 0;
+    bool restarted = false;
+};
+int spline_fit(const double* x, const double* y, int m, double s, Spline& out);
+void spline_eval(const Spline& sp, const double* xs, int64_t nx, double* out);   // FITPACK splev, ext = 0
+
+// sklearn IsotonicRegression(increasing=False).fit_transform on distinct X (fithic/fithic.py:965-966)
+void pava_decreasing(const double* y, int64_t n, double* out);
+
+// ---------------------------------------------------------------------------------------------------
+// Stage logic.
+struct Bin {
+    int64_t lb = 0, ub = 0;    // binStats[b][0]
+    int64_t poss = 0;          // [1]
+    int64_t sumcc = 0;         // [2]
+    double sumdist = 0.0;      // [3]
+    int64_t poss7 = 0;         // [7]
+    int64_t poss0 = 0;         // [1] right after makeBinsFromInteractions (outlier decrements only)
+};
+
+struct FragTable {             // fragments file reduced to what generate_FragPairs needs
+    // one entry per chromosome that occurs in the file, in Python sorted() order of the names
+    std::vector<int64_t> n_mappable;      // len(allFragsDic[ch])
+    std::vector<int64_t> max_mid;         // max mappable mid (only valid when n_mappable > 0)
+    std::vector<int32_t> chr_id;
+};
+
+struct PassInputs {
+    int64_t resolution = 0, dist_low = 0, dist_up = INT64_MAX;
+    int32_t n_bins = 100;
+    int32_t mode = 0;
+    // genome-wide distance histogram: index i <-> distance i*resolution
+    const int64_t* hist_sumcc = nullptr;
+    const int64_t* hist_npairs = nullptr;
+    int64_t n_dist = 0;
+    int64_t in_range_sum = 0, inter_count = 0, inter_sum = 0;
+    // outlier-distance multiset of earlier passes (nullptr in pass 1): count per distance index
+    const int64_t* outlier_dist_hist = nullptr;
+};
+
+struct PassFit {
+    std::vector<Bin> bins;
+    std::vector<double> x, y;                    // calculateProbabilities, bin order
+    Spline spline;
+    double spline_s = 0.0, residual = 0.0;
+    std::vector<int64_t> table_x;                // splineX
+    std::vector<double> table_y0, table_y;       // splineY, newSplineY
+    double min_x = 0.0, max_x = 0.0;             // clamp limits of the per-pair lookup
+    // generate_FragPairs scalars
+    int64_t n_frags = 0, poss_intra_in_range = 0;
+    double poss_inter_all = 0.0, poss_intra_all = 0.0, max_possible_dist = 0.0;
+    double inter_chr_prob = 0.0, baseline_intra_prob = 0.0;
+    double bh_total_tests = 0.0;
+    // dense per-distance-index prior LUT for the kernel: lut[i] = newSplineY[min(bisect_left(splineX,
+    // clamp(i*res, min x, max x)), len-1)]   (fithic/fithic.py:1066-1069)
+    std::vector<double> prior_lut;
+};
+
+// returns 0, or FHX_ERR_REFERENCE_EXIT with `err` set where the reference would exit / raise
+int run_host_pass(const PassInputs& in, const FragTable& frags, PassFit& out, std::string& err);
+
+}  // namespace fhx

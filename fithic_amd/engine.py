@@ -1,0 +1,104 @@
+"""Host driver of one Fit-Hi-C run on one GPU: the body of the reference's main() after argument parsing
+(fithic/fithic.py:317-370) expressed over the C ABI of libfithic_mi355x.so.
+
+    pass_stats  (K1)   <- read_Interactions                       fithic/fithic.py:389-454
+    fit         (host) <- makeBinsFromInteractions, generate_FragPairs, calculateProbabilities,
+                          fit_Spline's spline + table             fithic/fithic.py:463-689, 843-918, 936-968
+    pvalues     (K2)   <- fit_Spline's per-pair loop + bdtrc      fithic/fithic.py:1017-1124
+    bh          (K3)   <- benjamini_hochberg_correction           fithic/myStats.py:24-48
+    next_pass          <- outlier collection                      fithic/fithic.py:1215-1217
+
+There is no CPU implementation behind this class: without the built library or without a GPU it raises.
+"""
+import numpy as np
+
+from . import _capi
+
+MODES = {"intraOnly": _capi.MODE_INTRA_ONLY, "interOnly": _capi.MODE_INTER_ONLY, "All": _capi.MODE_ALL}
+
+
+class PassOutput:
+    """Everything one spline pass produced (host copies of the small arrays; p/q stay on the GPU until fetched)."""
+
+    def __init__(self):
+        self.stats = None       # dict of fhx_stats
+        self.info = None        # dict of fhx_fit_info
+        self.arrays = {}
+
+
+class Engine:
+    def __init__(self, device=0):
+        self.ctx = _capi.Context(device)
+        self.device = device
+        self.n_rows = 0
+        self.mode = "intraOnly"
+        self.pass_no = 0
+
+    def close(self):
+        self.ctx.close()
+
+    def configure(self, resolution, dist_low=0, dist_up=float("inf"), n_bins=100, mapp_thres=1, mode="intraOnly",
+                  bias_low=0.5, bias_up=2.0):
+        if mode not in MODES:
+            raise ValueError("Invalid Option. Only options are 'All', 'interOnly', or 'intraOnly'")
+        self.mode = mode
+        self.resolution = int(resolution)
+        self.dist_low, self.dist_up = dist_low, dist_up
+        self.ctx.set_params(resolution, dist_low, dist_up, n_bins, mapp_thres, MODES[mode], bias_low, bias_up)
+
+    def load_fragments(self, chr_ids, mids, hits, chr_sort_rank):
+        self.ctx.load_fragments(chr_ids, mids, hits, chr_sort_rank)
+
+    def load_bias(self, chr_ids, mids, bias):
+        self.ctx.load_bias(chr_ids, mids, bias)
+
+    def load_contacts(self, chr1, mid1, chr2, mid2, count):
+        self.ctx.load_pairs(chr1, mid1, chr2, mid2, count)
+        self.n_rows = len(mid1)
+        self.pass_no = 0
+
+    def load_contacts_device(self, ptrs, n, stream=None):
+        self.ctx.load_pairs_device(ptrs, n, stream)
+        self.n_rows = int(n)
+        self.pass_no = 0
+
+    # ---- the four steps of a pass; run_pass() strings them together ----
+    def pass_stats(self):
+        return self.ctx.pass_stats()
+
+    def fit(self):
+        return self.ctx.fit()
+
+    def run_pass(self, collect=True):
+        """K1 -> host fit -> K2 -> K3, all on this context's stream.  Returns a PassOutput."""
+        out = PassOutput()
+        st = self.ctx.pass_stats()
+        info = self.ctx.fit()
+        self.ctx.pvalues()
+        self.ctx.bh(info.bh_total_tests)
+        out.stats, out.info = st.as_dict(), info.as_dict()
+        if collect:
+            self.ctx.sync()
+            A = _capi
+            names = dict(hist_sumcc=A.A_HIST_SUMCC, hist_npairs=A.A_HIST_NPAIRS, bin_lb=A.A_BIN_LB, bin_ub=A.A_BIN_UB,
+                         bin_poss=A.A_BIN_POSS, bin_poss0=A.A_BIN_POSS0, bin_sumcc=A.A_BIN_SUMCC, bin_sumdist=A.A_BIN_SUMDIST,
+                         bin_poss7=A.A_BIN_POSS7, x=A.A_X, y=A.A_Y)
+            if self.mode != "interOnly":
+                names.update(knots=A.A_KNOTS, coeffs=A.A_COEFFS, table_x=A.A_TABLE_X, table_y0=A.A_TABLE_Y0, table_y=A.A_TABLE_Y)
+            for k, w in names.items():
+                out.arrays[k] = self.ctx.get_array(w)
+        self.pass_no += 1
+        return out
+
+    def fetch(self, p=True, q=True, expcc=False, bias=False):
+        return self.ctx.fetch(self.n_rows, p=p, q=q, expcc=expcc, bias=bias)
+
+    def fdr_counts(self):
+        return self.ctx.get_array(_capi.A_FDR_COUNTS)
+
+    def next_pass(self):
+        """Fold this pass's outliers (p < 1/N) into the skip mask and the outlier-distance multiset."""
+        return self.ctx.next_pass()
+
+    def kernel_seconds(self):
+        return self.ctx.kernel_seconds()

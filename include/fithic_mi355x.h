@@ -1,0 +1,189 @@
+/*
+ * fithic_mi355x.h - C ABI of libfithic_mi355x.so, the MI355X-native Fit-Hi-C significance engine.
+ *
+ * The reference (ay-lab/fithic 2.0.7) is pure Python and has no FFI / plugin interface
+ * (SURVEY.md section 8b); the boundary this library honours is the set of Python call signatures on its
+ * hot path.  Each entry point below names the reference lines it replaces:
+ *
+ *   fhx_load_pairs / fhx_load_fragments / fhx_load_bias
+ *        the three tables the reference re-reads from gzip text in every stage
+ *        (fithic/fithic.py:406-417, :581-590, :805-832), handed over once as host SoA arrays
+ *   fhx_pass_stats      fithic.read_Interactions                      (fithic/fithic.py:389-454)      kernel K1
+ *   fhx_fit             fithic.makeBinsFromInteractions               (fithic/fithic.py:463-553)
+ *                       fithic.generate_FragPairs (fixed-size branch) (fithic/fithic.py:561-689)
+ *                       fithic.calculateProbabilities                 (fithic/fithic.py:843-918)
+ *                       fithic.fit_Spline, fit + table part           (fithic/fithic.py:936-968)      host C++
+ *   fhx_pvalues         fithic.fit_Spline, per-pair loop              (fithic/fithic.py:1017-1124)    kernel K2
+ *                       incl. scipy.special.bdtrc                     (call sites :1070, :1101)
+ *   fhx_bh              myStats.benjamini_hochberg_correction         (fithic/myStats.py:24-48)       kernels K3
+ *                       and its dispatch                              (fithic/fithic.py:1126-1164)
+ *   fhx_fetch           the value lists fit_Spline hands to its writer (fithic/fithic.py:1188-1194)
+ *   fhx_next_pass       outlier collection for pass >= 2              (fithic/fithic.py:1215-1217, :408-412, :528-548)
+ *
+ * Conventions: plain C, no exceptions cross the boundary; every function returns 0 (FHX_OK) or a negative
+ * error code; fhx_last_error(ctx) returns a message owned by the context.  One context per GPU (or per
+ * host thread for device = -1, host-only: everything except the kernels works).  A context is not
+ * thread-safe; different contexts are independent.  Host pointers passed in are copied before return.
+ */
+#ifndef FITHIC_MI355X_H
+#define FITHIC_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FHX_OK 0
+#define FHX_ERR_ARG (-1)           /* bad argument / call order */
+#define FHX_ERR_NO_DEVICE (-2)     /* kernel entry point called on a host-only context, or no GPU */
+#define FHX_ERR_HIP (-3)           /* a HIP runtime call failed */
+#define FHX_ERR_UNSUPPORTED (-4)   /* input outside the accelerated path (e.g. loci off the fixed-size grid) */
+#define FHX_ERR_REFERENCE_EXIT (-5)/* the reference would sys.exit(2) / raise here (message says where) */
+#define FHX_ERR_NOMEM (-6)
+
+#define FHX_MODE_INTRA_ONLY 0      /* -x intraOnly (default) */
+#define FHX_MODE_INTER_ONLY 1      /* -x interOnly */
+#define FHX_MODE_ALL 2             /* -x All */
+
+typedef struct fhx_ctx fhx_ctx;
+
+/* The reference's module globals (fithic/fithic.py:203-260) after its "zero means unset" rule. */
+typedef struct fhx_params {
+    int64_t resolution;            /* -r, > 0 (fixed-size mode only) */
+    int64_t dist_low;              /* -L, default 0 */
+    int64_t dist_up;               /* -U, INT64_MAX for +inf */
+    int32_t n_bins;                /* -b, default 100 */
+    int32_t mapp_thres;            /* -m, default 1 */
+    int32_t mode;                  /* FHX_MODE_* */
+    int32_t reserved;
+    double bias_low;               /* -tL, default 0.5 */
+    double bias_up;                /* -tU, default 2 */
+} fhx_params;
+
+/* What read_Interactions returns (fithic/fithic.py:454) plus the counters it logs (:447-449). */
+typedef struct fhx_stats {
+    int64_t n_rows;                /* rows on this context (shard) */
+    int64_t inter_count;           /* observedInterAllCount */
+    int64_t inter_sum;             /* observedInterAllSum */
+    int64_t intra_all_count;       /* observedIntraAllCount */
+    int64_t intra_all_sum;         /* observedIntraAllSum */
+    int64_t in_range_count;        /* observedIntraInRangeCount */
+    int64_t in_range_sum;          /* observedIntraInRangeSum */
+    int64_t max_count;             /* largest contact count seen (sizes the lbeta tables) */
+    int64_t n_dist;                /* length of the distance histogram: index i <-> distance i*resolution */
+    int64_t n_skipped;             /* rows skipped as outliers of earlier passes */
+} fhx_stats;
+
+/* Scalars of one fitted pass (generate_FragPairs' return tuple, fit_Spline's spline diagnostics). */
+typedef struct fhx_fit_info {
+    int32_t n_bins_made;           /* len(binStats) */
+    int32_t n_knots;               /* FITPACK n */
+    int32_t spline_ier;            /* FITPACK ier */
+    int32_t spline_restarted;      /* 1 if the nest-too-small continuation call ran */
+    int64_t n_table;               /* len(splineX) */
+    int64_t n_frags;               /* noOfFrags */
+    int64_t possible_intra_in_range; /* possibleIntraInRangeCount (double-counted as the reference does) */
+    double possible_inter_all;     /* possibleInterAllCount (float after /= 2) */
+    double possible_intra_all;     /* possibleIntraAllCount */
+    double max_possible_dist;      /* maxPossibleGenomicDist */
+    double inter_chr_prob;         /* interChrProb */
+    double baseline_intra_prob;    /* baselineIntraChrProb */
+    double spline_s;               /* min(y)^2 */
+    double spline_fp;              /* FITPACK fp */
+    double residual;               /* sum((y - ius(x))^2), numpy pairwise order */
+    double bh_total_tests;         /* N handed to benjamini_hochberg_correction for this mode */
+    double outlier_thres;          /* 1/N */
+} fhx_fit_info;
+
+/* Arrays a caller can copy out with fhx_get_array (all caller-allocated). */
+enum fhx_array {
+    FHX_A_HIST_SUMCC = 0,          /* int64[n_dist]   sum of counts per distance index (mainDic[d][1]) */
+    FHX_A_HIST_NPAIRS = 1,         /* int64[n_dist]   rows per distance index (key present iff > 0) */
+    FHX_A_BIN_LB = 2,              /* int64[n_bins_made] */
+    FHX_A_BIN_UB = 3,              /* int64[n_bins_made] */
+    FHX_A_BIN_POSS = 4,            /* int64   binStats[b][1] */
+    FHX_A_BIN_SUMCC = 5,           /* int64   binStats[b][2] */
+    FHX_A_BIN_SUMDIST = 6,         /* double  binStats[b][3] */
+    FHX_A_BIN_POSS7 = 7,           /* int64   binStats[b][7] */
+    FHX_A_X = 8,                   /* double[n_bins_made]  calculateProbabilities x (unsorted) */
+    FHX_A_Y = 9,                   /* double[n_bins_made] */
+    FHX_A_KNOTS = 10,              /* double[n_knots] */
+    FHX_A_COEFFS = 11,             /* double[n_knots-4] */
+    FHX_A_TABLE_X = 12,            /* int64[n_table]  splineX */
+    FHX_A_TABLE_Y0 = 13,           /* double[n_table] splineY (before isotonic regression) */
+    FHX_A_TABLE_Y = 14,            /* double[n_table] newSplineY */
+    FHX_A_OUTLIER_DIST_HIST = 15,  /* int64[n_dist]   multiset of outlier distances accumulated so far */
+    FHX_A_FDR_COUNTS = 16,         /* int64[51]       plot_qvalues' shifted cumulative counts */
+    FHX_A_BIN_POSS0 = 17           /* int64   binStats[b][1] right after makeBinsFromInteractions */
+};
+
+/* ---- life cycle --------------------------------------------------------------------------------- */
+int fhx_create(int device, fhx_ctx** out);      /* device >= 0: HIP device ordinal; -1: host-only */
+void fhx_destroy(fhx_ctx* ctx);
+const char* fhx_last_error(fhx_ctx* ctx);
+const char* fhx_version(void);
+int fhx_set_params(fhx_ctx* ctx, const fhx_params* p);
+
+/* ---- tables (host SoA in, copied) --------------------------------------------------------------- */
+/* Chromosome ids are small non-negative ints chosen by the caller, shared by all three tables.
+ * chr_sort_rank[id] = position of that chromosome NAME in Python's sorted() order: the reference walks
+ * chromosomes in that order (fithic.py:606) and its double accumulators depend on it. */
+int fhx_load_fragments(fhx_ctx* ctx, const int32_t* chr, const int32_t* mid, const int32_t* hits, int64_t n,
+                       const int32_t* chr_sort_rank, int32_t n_chr);
+int fhx_load_bias(fhx_ctx* ctx, const int32_t* chr, const int32_t* mid, const double* bias, int64_t n);
+int fhx_load_pairs(fhx_ctx* ctx, const int32_t* chr1, const int32_t* mid1, const int32_t* chr2,
+                   const int32_t* mid2, const int32_t* count, int64_t n);
+/* Same, but the five arrays already live in this GPU's memory (e.g. written by a generator kernel or
+ * received over xGMI); `stream` is a hipStream_t or NULL. */
+int fhx_load_pairs_device(fhx_ctx* ctx, const void* d_chr1, const void* d_mid1, const void* d_chr2,
+                          const void* d_mid2, const void* d_count, int64_t n, void* stream);
+
+/* ---- one spline pass ---------------------------------------------------------------------------- */
+int fhx_pass_stats(fhx_ctx* ctx, fhx_stats* out);                       /* K1, then waits for the sums */
+/* Distributed runs: replace the local histogram / sums by the all-reduced ones before fhx_fit. */
+int fhx_set_global_stats(fhx_ctx* ctx, const fhx_stats* global_stats, const int64_t* hist_sumcc,
+                         const int64_t* hist_npairs, int64_t n_dist);
+/* Distributed runs, pass >= 2: replace the local multiset of outlier distances (count per distance index,
+ * accumulated over all earlier passes) by the all-reduced one. */
+int fhx_set_outlier_dist_hist(fhx_ctx* ctx, const int64_t* hist, int64_t n_dist);
+int fhx_fit(fhx_ctx* ctx, fhx_fit_info* out);                           /* host; uploads the tables */
+int fhx_pvalues(fhx_ctx* ctx);                                          /* K2 (asynchronous) */
+int fhx_bh(fhx_ctx* ctx, double n_total_tests);                         /* K3 (asynchronous) */
+int fhx_sync(fhx_ctx* ctx);
+int fhx_next_pass(fhx_ctx* ctx, int64_t* n_outliers_total);             /* fold this pass's outliers in */
+
+/* ---- results ------------------------------------------------------------------------------------ */
+/* Any pointer may be NULL.  Arrays have n_rows entries in input row order. */
+int fhx_fetch(fhx_ctx* ctx, double* p, double* q, double* expcc, double* bias1, double* bias2);
+int fhx_get_array(fhx_ctx* ctx, int which, void* dst, int64_t capacity_elems, int64_t* n_out);
+/* Raw device pointers for plumbing (torch / RCCL exchange): 0 = p, 1 = q, 2 = sorted keys, 3 = sorted idx */
+void* fhx_device_ptr(fhx_ctx* ctx, int which);
+int64_t fhx_n_sorted(fhx_ctx* ctx);
+/* Seconds the kernels of the last pass took on the context's stream (HIP events): k1, k2, k3. */
+int fhx_kernel_seconds(fhx_ctx* ctx, double* k1, double* k2, double* k3);
+
+/* myStats.benjamini_hochberg_correction(p_values, num_total_tests) on an arbitrary host array (fithic/myStats.py:24-48):
+ * copies p to the GPU, runs the K3 kernels, copies q back (input order). */
+int fhx_bh_array(fhx_ctx* ctx, const double* p, int64_t n, double n_total_tests, double* q);
+
+/* scipy.special.bdtrc(count - 1, n_total, prior) element-wise on the GPU for integer counts (the only form the
+ * reference uses, fithic/fithic.py:1070,1101); host arrays in and out.  Known-answer testing of K2's arithmetic. */
+int fhx_bdtrc_array(fhx_ctx* ctx, double n_total, const int32_t* count, const double* prior, int64_t n, double* out);
+
+/* ---- distributed BH building blocks (section 8e): local sort, then rank/scan over a global segment -- */
+int fhx_bh_local_sort(fhx_ctx* ctx);                 /* compact p < 1, radix sort (key, row) on this GPU */
+int fhx_bh_apply_sorted(fhx_ctx* ctx, const void* d_sorted_keys, int64_t n, int64_t global_rank0,
+                        double carry_in, double n_total_tests, void* d_q_sorted, double* block_max_out);
+
+/* ---- host numerics, exported for tests and for callers that only need the host side ------------------ */
+int fhx_host_spline_fit(const double* x, const double* y, int32_t m, double s, double* t, double* c,
+                        int32_t* n_knots, double* fp, int32_t* ier, int32_t* restarted);
+int fhx_host_spline_eval(const double* t, const double* c, int32_t n_knots, const double* xs, int64_t nx, double* out);
+int fhx_host_pava_decreasing(const double* y, int64_t n, double* out);
+int fhx_host_lbeta_table(double n_total, int64_t max_count, double* lbeta_out, double* inv_beta_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FITHIC_MI355X_H */

@@ -1,0 +1,175 @@
+"""GPU parity tests (run with -m gpu on a real MI355X): the HIP path, called through the C ABI, against
+(a) the golden fixtures captured from the real reference and (b) the oracle on the same inputs.
+
+Bars (BASELINE.json north_star): distance-bin indices, pair counts, histograms and all integer results
+bit-exact; p- and q-values within 1e-10 absolute of scipy.special.bdtrc-based reference values (the tests
+also report how many values are bit-identical - in practice nearly all are).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_case, case_args, ALL_CASES, SMALL_CASES, bits_equal, max_abs_diff, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from fithic_amd import _capi
+    c = _capi.Context(0)          # raises if there is no GPU or the library is missing: no fallback
+    yield c
+    c.close()
+
+
+def test_extension_is_the_in_tree_hip_library(ctx):
+    from fithic_amd import _capi
+    assert os.path.exists(_capi.LIB_PATH)
+    with open("/proc/self/maps") as f:
+        assert "libfithic_mi355x.so" in f.read()
+    assert b"gfx950" in _capi.lib().fhx_version()
+
+
+def test_bdtrc_known_answers_on_gpu(ctx):
+    """K2's arithmetic against scipy.special.bdtrc bit patterns (F3), integer counts, every Cephes branch."""
+    g = np.load(os.path.join(GOLDEN, "f3_bdtrc.npz"))
+    k, n, p, ref = g["k"], g["n"], g["p"], g["val"]
+    integral = (k == np.floor(k))
+    worst, n_bits, total = 0.0, 0, 0
+    for nt in np.unique(n[integral]):
+        sel = integral & (n == nt)
+        out = ctx.bdtrc_array(float(nt), (k[sel] + 1).astype(np.int32), p[sel])
+        worst = max(worst, max_abs_diff(out, ref[sel]))
+        same = (out.view(np.int64) == ref[sel].view(np.int64)) | (np.isnan(out) & np.isnan(ref[sel]))
+        n_bits += int(same.sum())
+        total += int(sel.sum())
+    print("bdtrc KAT: %d/%d bit-identical, max |diff| %.3e" % (n_bits, total, worst))
+    assert worst <= TOL
+    assert n_bits >= 0.95 * total
+
+
+def test_bdtrc_against_oracle_random(ctx):
+    from oracle import fithic_oracle as fo
+    rng = np.random.default_rng(77)
+    for nt in (1234, 150, 6_495_767, 987_654_321):
+        cnt = np.minimum(rng.geometric(0.03, 20000), nt).astype(np.int32)
+        prior = np.clip(cnt * np.exp(rng.normal(0, 1.3, len(cnt))) / nt, 0, 1)
+        prior[::1000] = 0.0
+        prior[1::1000] = 1.0
+        prior[2::1000] = -0.25
+        prior[3::1000] = np.nan
+        out = ctx.bdtrc_array(float(nt), cnt, prior)
+        ref = fo.bdtrc(cnt.astype(np.float64) - 1, float(nt), prior)
+        assert max_abs_diff(out, ref) <= TOL, nt
+
+
+def test_bh_known_answers_on_gpu(ctx):
+    g = np.load(os.path.join(GOLDEN, "f5_bh.npz"))
+    for name in g["names"]:
+        q = ctx.bh_array(g[name + "_p"], g[name + "_N"][0])
+        assert bits_equal(q, g[name + "_q"]), name
+
+
+def test_bh_large_random_bit_exact_vs_oracle(ctx):
+    from oracle import fithic_oracle as fo
+    rng = np.random.default_rng(8)
+    n = 3_000_017                                   # several radix tiles per workgroup, ragged tail
+    p = rng.uniform(0, 1, n) ** rng.integers(1, 40, n)
+    p[rng.integers(0, n, n // 50)] = 1.0
+    p[rng.integers(0, n, 1000)] = np.nan
+    p[rng.integers(0, n, 1000)] = 0.0
+    p[rng.integers(0, n, n // 10)] = p[rng.integers(0, n, n // 10)]          # ties
+    q = ctx.bh_array(p, 7.5e9)
+    assert bits_equal(q, fo.benjamini_hochberg(p, 7.5e9))
+
+
+def _run_case(name, device=0):
+    from fithic_amd import tables
+    from fithic_amd.engine import Engine
+    meta, g = load_case(name)
+    kw = case_args(meta)
+    chroms = tables.ChromIndex()
+    con = tables.read_contacts(kw["contacts"], chroms)
+    fc, fm, fh = tables.read_fragments(kw["frags"], chroms)
+    eng = Engine(device)
+    eng.configure(kw["resolution"], kw["L"], kw["U"], kw["n_bins"], kw["mapp_thres"], kw["mode"], kw["tL"], kw["tU"])
+    eng.load_fragments(fc, fm, fh, chroms.sort_rank())
+    if kw["bias_path"]:
+        eng.load_bias(*tables.read_bias(kw["bias_path"], chroms))
+    eng.load_contacts(con.chr1, con.mid1, con.chr2, con.mid2, con.count)
+    passes = []
+    for pi in range(1, meta["n_passes"] + 1):
+        out = eng.run_pass()
+        out.values = eng.fetch(p=True, q=True, expcc=True, bias=True)
+        out.fdr = eng.fdr_counts()
+        out.n_outliers_total = eng.next_pass()
+        passes.append(out)
+    eng.close()
+    return meta, g, kw, passes
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_pipeline_matches_reference_goldens(name):
+    meta, g, kw, passes = _run_case(name)
+    res = kw["resolution"]
+    sub = meta["subsample"]
+    for pi, out in enumerate(passes, 1):
+        P = "p%d_" % pi
+        st = out.stats
+        # integer results: bit-exact
+        assert [st["inter_count"], st["inter_sum"], st["intra_all_sum"], st["in_range_sum"]] == [int(v) for v in g[P + "sums"]]
+        keys = np.flatnonzero(out.arrays["hist_npairs"] > 0) * res
+        assert np.array_equal(keys, g[P + "dist_keys"])
+        assert np.array_equal(out.arrays["hist_sumcc"][keys // res], g[P + "dist_sumcc"])
+        for k, mine in (("lb", "bin_lb"), ("ub", "bin_ub"), ("s1", "bin_poss"), ("s2", "bin_sumcc"), ("s7", "bin_poss7")):
+            assert np.array_equal(out.arrays[mine], g[P + "bins1_" + k]), k
+        assert bits_equal(out.arrays["x"], g[P + "x"]) and bits_equal(out.arrays["y"], g[P + "y"])
+        if P + "spl_t" in g:
+            assert bits_equal(out.arrays["knots"], g[P + "spl_t"])
+            assert np.array_equal(out.arrays["table_x"], g[P + "splineX"])
+            assert bits_equal(out.arrays["table_y"], g[P + "newSplineY"])
+        assert out.info["outlier_thres"] == g[P + "outlierThres"][0]
+        v = out.values
+        for key in ("b1", "b2"):
+            assert bits_equal(v[key][::sub], g[P + key]), key
+        dp = max_abs_diff(v["p"][::sub], g[P + "p"])
+        dq = max_abs_diff(v["q"][::sub], g[P + "q"])
+        de = max_abs_diff(v["expcc"][::sub], g[P + "expcc"])
+        same_p = np.mean((v["p"][::sub].view(np.int64) == g[P + "p"].view(np.int64)) | np.isnan(g[P + "p"]))
+        print("%s pass %d: max|dp| %.2e max|dq| %.2e max|dExpCC| %.2e, p bit-identical %.4f" % (name, pi, dp, dq, de, same_p))
+        assert dp <= TOL and dq <= TOL
+        assert bits_equal(v["expcc"][::sub], g[P + "expcc"])
+        assert out.n_outliers_total == g[P + "n_outlier_lines"][0]
+        assert np.array_equal(out.fdr, g[P + "fdr_y"])
+        m = meta["pass%d" % pi]
+        assert int(np.sum(v["q"] < 0.01)) == m["n_q_lt_0.01"] and int(np.sum(v["q"] < 0.05)) == m["n_q_lt_0.05"]
+        assert int(np.sum(v["p"] < 1.0)) == m["n_p_lt_1"] and int(np.isnan(v["p"]).sum()) == m["n_nan_p"]
+
+
+@pytest.mark.parametrize("name", SMALL_CASES + ["f1_bias"])
+def test_pipeline_matches_oracle_every_row(name):
+    """Full-length comparison (every row, every pass) with the oracle run on the same files."""
+    from oracle import fithic_oracle as fo
+    meta, g, kw, passes = _run_case(name)
+    ref = fo.run(**kw)
+    assert len(ref) == len(passes)
+    for out, r in zip(passes, ref):
+        v = out.values
+        assert max_abs_diff(v["p"], r.p) <= TOL
+        assert max_abs_diff(v["q"], r.q) <= TOL
+        assert bits_equal(v["expcc"], r.expcc) and bits_equal(v["b1"], r.b1) and bits_equal(v["b2"], r.b2)
+        # q is exactly BH of OUR p (the sort/scan path is bit-exact on its own input)
+        assert bits_equal(v["q"], fo.benjamini_hochberg(v["p"], out.info["bh_total_tests"]))
+
+
+def test_off_grid_loci_are_rejected_loudly():
+    from fithic_amd import _capi
+    c = _capi.Context(0)
+    c.set_params(10000)
+    with pytest.raises(_capi.FhxError) as e:
+        c.load_pairs([0, 0], [5000, 15001], [0, 0], [25000, 35000], [3, 4])
+    assert e.value.code == _capi.FHX_ERR_UNSUPPORTED
+    c.close()

@@ -1,0 +1,111 @@
+"""Host stages of libfithic_mi355x.so (binning, possible pairs, probabilities, FITPACK spline, PAVA, lbeta tables)
+against the golden fixtures - runs on CPU through a host-only context (device = -1)."""
+import os
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import load_case, case_args, ALL_CASES, bits_equal, GOLDEN
+from fithic_amd import _capi, tables
+from fithic_amd.engine import MODES
+
+
+def test_library_exports_every_declared_symbol():
+    import re
+    hdr = open(os.path.join(os.path.dirname(GOLDEN), "..", "include", "fithic_mi355x.h")).read()
+    declared = set(re.findall(r"\b(fhx_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"fhx_ctx", "fhx_params", "fhx_stats", "fhx_fit_info", "fhx_array"}
+    L = ctypes.CDLL(_capi.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(L, name), "libfithic_mi355x.so does not export %s" % name
+    assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
+
+
+def test_kernel_entry_points_fail_loudly_without_device():
+    ctx = _capi.Context(-1)
+    ctx.set_params(40000)
+    for call in (ctx.pass_stats, ctx.pvalues, lambda: ctx.bh(10.0), ctx.next_pass, lambda: ctx.bh_array([0.5], 3)):
+        with pytest.raises(_capi.FhxError) as e:
+            call()
+        assert e.value.code == _capi.FHX_ERR_NO_DEVICE
+
+
+def test_spline_fit_bit_exact_vs_scipy_fixtures():
+    g = np.load(os.path.join(GOLDEN, "f4_fitpack.npz"))
+    for name in g["names"]:
+        s, fp, ier = g[name + "_sfpier"]
+        t, c, fp2, ier2, _ = _capi.host_spline_fit(g[name + "_x"], g[name + "_y"], s)
+        assert bits_equal(t, g[name + "_t"]) and bits_equal(c, g[name + "_c"]), name
+        assert fp2 == fp and ier2 == int(ier), name
+        assert bits_equal(_capi.host_spline_eval(t, c, g[name + "_xe"]), g[name + "_ye"]), name
+
+
+def test_lbeta_table_bit_exact_vs_scipy_fixtures():
+    g = np.load(os.path.join(GOLDEN, "f3_bdtrc.npz"))
+    for i, n in enumerate(g["lb_n"]):
+        mc = int(min(g["lb_c"].max(), n))
+        lb, _ = _capi.host_lbeta_table(float(n), mc)
+        sel = g["lb_c"] <= mc
+        assert bits_equal(lb[g["lb_c"][sel]], g["lbeta"][i][sel]), n
+
+
+def test_pava_vs_live_scipy_if_present():
+    opt = pytest.importorskip("scipy.optimize")
+    rng = np.random.default_rng(4)
+    for n in (1, 2, 5, 100, 5000):
+        y = np.sort(rng.uniform(0, 1, n))[::-1] * np.exp(rng.normal(0, 0.4, n))
+        assert bits_equal(_capi.host_pava_decreasing(y), opt.isotonic_regression(y, increasing=False).x)
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_host_fit_matches_reference(name):
+    """fhx_fit fed with the reference's own distance histogram reproduces bins, x, y, knots, table bit for bit."""
+    meta, g = load_case(name)
+    kw = case_args(meta)
+    chroms = tables.ChromIndex()
+    fc, fm, fh = tables.read_fragments(kw["frags"], chroms)
+    res = kw["resolution"]
+    for pi in range(1, meta["n_passes"] + 1):
+        P = "p%d_" % pi
+        ctx = _capi.Context(-1)
+        ctx.set_params(res, kw["L"], kw["U"], kw["n_bins"], kw["mapp_thres"], MODES[kw["mode"]], kw["tL"], kw["tU"])
+        ctx.load_fragments(fc, fm, fh, chroms.sort_rank())
+        keys, sumcc = g[P + "dist_keys"], g[P + "dist_sumcc"]
+        n_dist = int(keys.max() // res + 1) if len(keys) else 1
+        if pi > 1:
+            od = g["p%d_outliersdist" % (pi - 1)]
+            n_dist = max(n_dist, int(-(-od.max() // res)) + 1)
+        hist_cc = np.zeros(n_dist, np.int64)
+        hist_np = np.zeros(n_dist, np.int64)
+        hist_cc[keys // res] = sumcc
+        hist_np[keys // res] = 1
+        st = _capi.FhxStats()
+        st.inter_count, st.inter_sum, st.intra_all_sum, st.in_range_sum = [int(v) for v in g[P + "sums"]]
+        ctx.set_global_stats(st, hist_cc, hist_np)
+        if pi > 1:
+            oh = np.zeros(n_dist, np.int64)
+            np.add.at(oh, -(-od // res), 1)          # ceil: bins end on grid distances
+            ctx.set_outlier_dist_hist(oh)
+        info = ctx.fit()
+        for k, w in (("lb", _capi.A_BIN_LB), ("ub", _capi.A_BIN_UB), ("s1", _capi.A_BIN_POSS), ("s2", _capi.A_BIN_SUMCC),
+                     ("s7", _capi.A_BIN_POSS7)):
+            assert np.array_equal(ctx.get_array(w), g[P + "bins1_" + k]), k
+        assert bits_equal(ctx.get_array(_capi.A_BIN_SUMDIST), g[P + "bins1_s3"])
+        assert np.array_equal(ctx.get_array(_capi.A_BIN_POSS0), g[P + "bins0_s1"])
+        fs = g[P + "frag_scalars"]
+        mine = np.array([info.n_frags, info.max_possible_dist, info.possible_intra_in_range, info.possible_inter_all,
+                         info.inter_chr_prob, info.baseline_intra_prob], np.float64)
+        assert bits_equal(mine, fs)
+        assert bits_equal(ctx.get_array(_capi.A_X), g[P + "x"]) and bits_equal(ctx.get_array(_capi.A_Y), g[P + "y"])
+        assert 1.0 / info.bh_total_tests == g[P + "outlierThres"][0]
+        if P + "spl_t" in g:
+            assert bits_equal(ctx.get_array(_capi.A_KNOTS), g[P + "spl_t"])
+            assert bits_equal(ctx.get_array(_capi.A_COEFFS), g[P + "spl_c"])
+            assert np.array_equal(ctx.get_array(_capi.A_TABLE_X), g[P + "splineX"])
+            assert bits_equal(ctx.get_array(_capi.A_TABLE_Y0), g[P + "splineY"])
+            assert bits_equal(ctx.get_array(_capi.A_TABLE_Y), g[P + "newSplineY"])
+            s, fp, ier = g[P + "spl_s_fp_ier"]
+            assert info.spline_s == s and info.spline_fp == fp and info.spline_ier == int(ier)
+            assert info.residual == g[P + "residual"][0]
+        ctx.close()
