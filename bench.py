@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py - contact-pairs/sec through one full spline pass (K1 classify+histogram -> host fit -> K2 p-values ->
+K3 Benjamini-Hochberg) on synthetic 5 kb human cis contacts, with the inputs resident in HBM.
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One JSON line on stdout (rank 0) with the driver's contract fields plus `roofline` (dominant kernel K2, HIP-event
+timed) and `cpu_baseline` (the oracle timed on this box's host cores on a bounded sample of the same rows).
+
+Workload (BASELINE.json configs[2], "C3"): 22 hg19 autosomes at 5 kb (576 216 loci), -L 20000 -U 2000000 (397
+distance values), ~1.5e8 observed cis pairs, ICE-like bias table, -b 100, 1 pass, intraOnly.  With N GPUs the default
+is weak scaling: the genome is replicated N times (chr1..chr22, chr1_r1.., N x 22 chromosomes), chromosomes are
+sharded over the ranks by size, the distance histogram is all-reduced and the BH ranking is global over all N x 1.5e8
+p-values (RCCL).  `--strong` keeps the single 22-chromosome genome and shards it instead (BASELINE configs[3]).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_K1, ALGO_BYTES_K2, ALGO_BYTES_K3 = 12, 20, 16          # per pair, SURVEY.md 8d (48 B in total)
+HBM_PEAK_GBS = 8000.0                                              # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--resolution", type=int, default=5000)
+    ap.add_argument("--keep", type=float, default=0.66, help="fraction of candidate cis pairs observed (sets the depth)")
+    ap.add_argument("--strong", action="store_true", help="shard one genome instead of replicating it per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-chroms", type=int, default=0, help="debug: use only the first k chromosomes")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from fithic_amd import synth, dist
+    from fithic_amd.engine import Engine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    comm = None
+    if world > 1:
+        import torch.distributed as td
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        td.init_process_group("nccl", device_id=device)          # nccl == RCCL on ROCm
+        comm = dist.Comm(td, device)
+
+    res = args.resolution
+    L, U = 4 * res, 400 * res
+    lo_idx, hi_idx = 4, 400
+    lengths = synth.HG19_AUTOSOMES[:args.max_chroms] if args.max_chroms else None
+    replicas = 1 if (args.strong or world == 1) else world
+    genome = synth.Genome(res, lengths, replicas=replicas)
+    amp = synth.solve_amplitude(args.keep, lo_idx, hi_idx)
+    owner = synth.assign_chromosomes(genome, world)
+    mine = [c for c in range(len(genome)) if owner[c] == rank]
+
+    t_gen = time.time()
+    parts = [synth.cis_contacts(genome, c, lo_idx, hi_idx, amp, device=device) for c in mine]
+    cols = [torch.cat([p[k] for p in parts]).contiguous() for k in range(5)]
+    n_local = int(cols[0].numel())
+    torch.cuda.synchronize()
+    log("[rank %d] generated %d rows on %d chromosomes in %.1f s" % (rank, n_local, len(mine), time.time() - t_gen))
+
+    eng = Engine(local_rank)
+    eng.configure(res, L, U, n_bins=100, mapp_thres=1, mode="intraOnly")
+    eng.load_fragments(*genome.fragments(), genome.sort_rank())
+    eng.load_bias(*genome.bias_table())
+    eng.load_contacts_device([t.data_ptr() for t in cols], n_local)
+    sample_cols = None
+    if rank == 0 and not args.no_cpu_baseline:
+        sample_chroms = [c for c in mine if genome.n_loci[c] <= 13000][-4:] or mine[-1:]
+        sample_cols = [[p[k].cpu().numpy() for k in range(5)] for c, p in zip(mine, parts) if c in sample_chroms]
+    del parts, cols
+    torch.cuda.empty_cache()
+
+    runner = dist.DistributedPass(eng, comm) if comm else None
+
+    def one_step():
+        if runner:
+            return runner.run()
+        eng.run_pass(collect=False)
+        return None
+
+    def barrier():
+        if comm:
+            comm.barrier()
+
+    for _ in range(args.warmup):
+        one_step()
+    kt = np.zeros(3)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+        kt += np.array(eng.kernel_seconds())          # HIP events on the engine's stream (syncs it)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if comm:
+        elapsed = comm.max_float(elapsed)
+        n_total = comm.sum_int(n_local)
+    else:
+        n_total = n_local
+    kt /= max(args.steps, 1)
+    k_all = comm.gather_floats(list(kt) + [float(n_local)]) if comm else [list(kt) + [float(n_local)]]
+
+    result = None
+    if rank == 0:
+        ms = 1000.0 * elapsed / args.steps
+        value = n_total * args.steps / elapsed
+        # dominant kernel = K2; slowest rank's launch
+        worst = max(k_all, key=lambda r: r[1])
+        k2_s, k2_rows = worst[1], worst[3]
+        achieved = ALGO_BYTES_K2 * k2_rows / k2_s / 1e9
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "k2_pmc_traffic.json")
+        if os.path.exists(prof):
+            try:
+                traffic = json.load(open(prof)).get("hbm_bytes_per_pair") * k2_rows
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "contact-pairs/sec through spline+p-value+BH pass (5 kb cis, whole node)",
+            "value": value, "unit": "contact-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if (args.strong and world > 1) else "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C3-synth: %d x hg19 22 autosomes @%d bp, -L %d -U %d, %d cis pairs, ICE-like bias, -b 100, "
+                                   "1 pass, intraOnly" % (replicas, res, L, U, n_total),
+                       "pairs": n_total, "resolution": res, "parallelism": "chromosome-sharded x%d" % world,
+                       "passes": 1},
+            "roofline": {"bound": "hbm", "kernel": "k2_pvalue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "note": "K2 is fp64-VALU bound (Cephes continued fractions, IEEE divides), not HBM bound; "
+                                 "algorithmic bytes = 20 B/pair (12 read + 8 written)",
+                         "launch_seconds": k2_s, "pairs_per_launch": k2_rows},
+            "kernels_ms": {"k1_classify_hist": 1e3 * worst[0], "k2_pvalue": 1e3 * worst[1], "k3_bh_sort_scan": 1e3 * worst[2]},
+            "whole_pass_hbm_frac": (ALGO_BYTES_K1 + ALGO_BYTES_K2 + ALGO_BYTES_K3) * value / (world * HBM_PEAK_GBS * 1e9),
+        }
+        if sample_cols:
+            result["cpu_baseline"] = cpu_baseline(genome, sample_cols, res, L, U)
+    if comm:
+        comm.barrier()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    eng.close()
+    if comm:
+        import torch.distributed as td
+        td.destroy_process_group()
+
+
+def cpu_baseline(genome, sample_cols, res, L, U):
+    """The oracle (plain C Cephes + numpy stage logic, 1 thread) on a bounded sample of the same rows."""
+    import numpy as np
+    from oracle import fithic_oracle as fo
+    chr_ids = sorted({int(c[0][0]) for c in sample_cols if len(c[0])})
+    names = {c: genome.names[c] for c in chr_ids}
+    local = {c: i for i, c in enumerate(chr_ids)}
+    cat = [np.concatenate([c[k] for c in sample_cols]) for k in range(5)]
+    remap = np.vectorize(local.get)(cat[0]).astype(np.int32)
+    pairs = fo.Pairs(remap, cat[1], remap, cat[3], cat[4], [names[c] for c in chr_ids])
+    frags, bias_dic = [], {}
+    for c in chr_ids:
+        mids = np.arange(genome.n_loci[c], dtype=np.int64) * res + res // 2
+        frags += [(names[c], int(m), 1) for m in mids]
+        b = genome.bias(c)
+        b = np.where((b < 0.5) | (b > 2.0), -1.0, b)
+        bias_dic[names[c]] = dict(zip(mids.tolist(), b.tolist()))
+    fo.build()
+    t0 = time.perf_counter()
+    fo.run(pairs, frags, None, res, n_bins=100, passes=1, mode="intraOnly", L=L, U=U, bias_dic=bias_dic)
+    dt = time.perf_counter() - t0
+    return {"value": len(pairs) / dt, "unit": "contact-pairs/s", "cores": 1, "kind": "port",
+            "sample": "%d rows of %s (same synthetic rows, own genome-wide fit on the sample), %.1f s" %
+                      (len(pairs), ",".join(names[c] for c in chr_ids), dt)}
+
+
+if __name__ == "__main__":
+    main()

@@ -84,6 +84,9 @@ SYMBOLS = {
     "fhx_bh_array": (ctypes.c_int, [_P, _F64P, ctypes.c_int64, ctypes.c_double, _F64P]),
     "fhx_bh_local_sort": (ctypes.c_int, [_P]),
     "fhx_bh_apply_sorted": (ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, ctypes.c_double, _P, _F64P]),
+    "fhx_sort_u64": (ctypes.c_int, [_P, _P, ctypes.c_int64, _P, _P]),
+    "fhx_bh_scatter": (ctypes.c_int, [_P, _P]),
+    "fhx_memcpy_d2d": (ctypes.c_int, [_P, _P, _P, ctypes.c_int64]),
     "fhx_host_spline_fit": (ctypes.c_int, [_F64P, _F64P, ctypes.c_int32, ctypes.c_double, _F64P, _F64P, _I32P, _F64P, _I32P, _I32P]),
     "fhx_host_spline_eval": (ctypes.c_int, [_F64P, _F64P, ctypes.c_int32, _F64P, ctypes.c_int64, _F64P]),
     "fhx_host_pava_decreasing": (ctypes.c_int, [_F64P, ctypes.c_int64, _F64P]),
@@ -274,6 +277,16 @@ class Context:
         self._check(self._L.fhx_bh_apply_sorted(self._h, _P(int(d_keys) if d_keys else 0), int(n), int(rank0), float(carry_in),
                                                 float(n_total_tests), _P(int(d_q_sorted) if d_q_sorted else 0), ctypes.byref(mx)))
         return mx.value
+
+
+    def sort_u64(self, d_keys_in, n, d_keys_out, d_perm_out):
+        self._check(self._L.fhx_sort_u64(self._h, _P(int(d_keys_in)), int(n), _P(int(d_keys_out)), _P(int(d_perm_out))))
+
+    def bh_scatter(self, d_q_sorted_local):
+        self._check(self._L.fhx_bh_scatter(self._h, _P(int(d_q_sorted_local))))
+
+    def memcpy_d2d(self, dst, src, nbytes):
+        self._check(self._L.fhx_memcpy_d2d(self._h, _P(int(dst)), _P(int(src)), int(nbytes)))
 
 
 # ---- host numerics (no context needed) -------------------------------------------------------------

@@ -643,6 +643,18 @@ __global__ __launch_bounds__(BH_THREADS) void bh_apply(const unsigned long long*
     }
 }
 
+__global__ void k_iota_u32(unsigned int* __restrict__ v, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) v[i] = (unsigned int)i;
+}
+
+__global__ void k_scatter_q(const unsigned int* __restrict__ rows, const double* __restrict__ q_sorted,
+                            const unsigned long long* __restrict__ n_ptr, double* __restrict__ q) {
+    const int64_t n = (int64_t)*n_ptr;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) q[rows[i]] = q_sorted[i];
+}
+
 // plot_qvalues' 51 buckets (fithic.py:1235-1254): counts of floor(q/0.001), NaN -> bucket of 1.0
 __global__ void k_fdr_hist(const double* __restrict__ q, int64_t n, unsigned long long* __restrict__ buckets) {
     __shared__ unsigned int h[64];
@@ -853,7 +865,7 @@ int ingest_device_rows(fhx_ctx* ctx, const int32_t* c1, const int32_t* m1, const
         if (maxidx[c] >= 0) used = c + 1;
     used = std::max(used, ctx->n_chr);
     ctx->grid.assign(used, ChrGrid{0, -1, 0, 0});
-    int64_t base = 0, n_dist = 1;
+    int64_t base = 0, n_dist = 1;          // histogram length = longest chromosome in slots + 1 spare index
     for (int c = 0; c < used; ++c) {
         ctx->grid[c].base = (int32_t)base;
         if (maxidx[c] >= 0) {
@@ -864,7 +876,7 @@ int ingest_device_rows(fhx_ctx* ctx, const int32_t* c1, const int32_t* m1, const
             ctx->grid[c].off = minoff[c];
             ctx->grid[c].nslots = maxidx[c] + 1;
             base += ctx->grid[c].nslots;
-            n_dist = std::max<int64_t>(n_dist, ctx->grid[c].nslots);
+            n_dist = std::max<int64_t>(n_dist, (int64_t)ctx->grid[c].nslots + 1);
         }
     }
     if (base >= (1ll << 31)) return fail(ctx, FHX_ERR_UNSUPPORTED, "more than 2^31 loci");
@@ -1138,12 +1150,12 @@ int fhx_set_global_stats(fhx_ctx* ctx, const fhx_stats* g, const int64_t* hist_s
     const int64_t rows = ctx->n_rows;
     ctx->stats = *g;
     ctx->stats.n_rows = rows > 0 ? rows : g->n_rows;
-    ctx->stats.n_dist = n_dist;
-    ctx->n_dist = std::max(ctx->n_dist, n_dist);
+    const int64_t len = std::max(ctx->n_dist, n_dist);      // the device histograms keep their local length
+    ctx->stats.n_dist = len;
     ctx->h_hist_cc.assign(hist_sumcc, hist_sumcc + n_dist);
     ctx->h_hist_np.assign(hist_npairs, hist_npairs + n_dist);
-    ctx->h_hist_cc.resize((size_t)ctx->n_dist, 0);
-    ctx->h_hist_np.resize((size_t)ctx->n_dist, 0);
+    ctx->h_hist_cc.resize((size_t)len, 0);
+    ctx->h_hist_np.resize((size_t)len, 0);
     ctx->have_stats = true;
     ctx->have_fit = false;
     return FHX_OK;
@@ -1420,6 +1432,62 @@ int fhx_bh_apply_sorted(fhx_ctx* ctx, const void* d_sorted_keys, int64_t n, int6
     FHX_HIP(hipStreamSynchronize(ctx->stream));
     dev_free(tile_max);
     if (block_max_out) *block_max_out = total;
+    return FHX_OK;
+}
+
+int fhx_sort_u64(fhx_ctx* ctx, const void* d_keys_in, int64_t n, void* d_keys_out, void* d_perm_out) {
+    if (!ctx || n < 0 || (n > 0 && (!d_keys_in || !d_keys_out || !d_perm_out))) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (n == 0) return FHX_OK;
+    if (n >= (1ll << 32)) return fail(ctx, FHX_ERR_UNSUPPORTED, "more than 2^32 keys");
+    FHX_HIP(hipSetDevice(ctx->device));
+    int rc = ensure_sort_scratch(ctx);
+    if (rc != FHX_OK) return rc;
+    unsigned long long* keys[2] = {nullptr, (unsigned long long*)d_keys_out};
+    unsigned int* vals[2] = {nullptr, (unsigned int*)d_perm_out};
+    FHX_HIP(hipMalloc(&keys[0], (size_t)n * sizeof(unsigned long long)));
+    FHX_HIP(hipMalloc(&vals[0], (size_t)n * sizeof(unsigned int)));
+    unsigned long long* counter = ctx->d_misc + 3;
+    const unsigned long long n_host = (unsigned long long)n;
+    FHX_HIP(hipMemcpyAsync(counter, &n_host, sizeof(n_host), hipMemcpyHostToDevice, ctx->stream));
+    // 8 passes ping-pong: start in the caller's output pair so that the result lands there
+    FHX_HIP(hipMemcpyAsync(keys[1], d_keys_in, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, vals[1], n);
+    int src = 1;
+    for (int shift = 0; shift < 64; shift += RADIX_BITS) {
+        hipLaunchKernelGGL(rs_count, dim3(SORT_BLOCKS), dim3(SORT_THREADS), 0, ctx->stream, keys[src], counter, shift,
+                           ctx->d_block_hist);
+        hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3(SORT_BLOCKS), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total);
+        hipLaunchKernelGGL(rs_scatter, dim3(SORT_BLOCKS), dim3(SORT_THREADS), 0, ctx->stream, keys[src], vals[src],
+                           keys[1 - src], vals[1 - src], counter, shift, ctx->d_block_hist, ctx->d_digit_total);
+        src = 1 - src;
+    }
+    FHX_HIP(hipGetLastError());
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    dev_free(keys[0]);
+    dev_free(vals[0]);
+    return FHX_OK;                                   // 8 passes: even number of swaps, result is in pair [1]
+}
+
+int fhx_bh_scatter(fhx_ctx* ctx, const void* d_q_sorted_local) {
+    if (!ctx || !d_q_sorted_local) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (ctx->n_sorted == -1) return fail(ctx, FHX_ERR_ARG, "fhx_bh_local_sort must run first");
+    FHX_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_scatter_q, dim3(grid_for(ctx->n_rows, 256)), dim3(256), 0, ctx->stream, ctx->d_vals[ctx->sorted_buf],
+                       (const double*)d_q_sorted_local, ctx->d_misc, ctx->d_q);
+    FHX_HIP(hipGetLastError());
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->have_q = true;
+    return FHX_OK;
+}
+
+int fhx_memcpy_d2d(fhx_ctx* ctx, void* dst, const void* src, int64_t bytes) {
+    if (!ctx || bytes < 0 || (bytes > 0 && (!dst || !src))) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    FHX_HIP(hipSetDevice(ctx->device));
+    if (bytes) FHX_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
     return FHX_OK;
 }
 

@@ -1,0 +1,219 @@
+"""Multi-GPU pass: one process per GPU, contacts sharded by chromosome, torch.distributed for the exchanges
+(backend "nccl" = RCCL over xGMI on the GPU box; "gloo" on CPU tensors in the tests).
+
+The reference is single-process; what has to be global is exactly what its data structures
+make global (section 8e):
+
+  exchange 1  mainDic and the five sums are genome-wide (fithic/fithic.py:434-440)
+              -> one all-reduce(SUM) of [sums | sumCC histogram | row-count histogram] (<= 2 x 50 k int64) and one
+                 all-reduce(MAX) of the largest count; every rank then runs the same deterministic host fit
+  exchange 2  benjamini_hochberg_correction ranks ALL p-values (fithic/myStats.py:27-46)
+              -> local radix sort, regular samples all-gathered, common splitters, all-to-all(v) of the keys so that
+                 rank r owns the r-th slice of the global order, local sort of the received runs, all-gather of the
+                 slice sizes (rank offsets) and of the slice maxima (carry of the running MAX), local BH + max-scan,
+                 all-to-all(v) of q back, scatter to row order
+  pass >= 2   the multiset of outlier distances is genome-wide (fithic/fithic.py:528-548) -> all-reduce(SUM)
+
+All per-GPU compute goes through `LocalOps` (the C ABI); the exchange logic itself is backend-agnostic so that the
+world_size-2 gloo tests exercise the same code with a checker-backed LocalOps.
+"""
+import numpy as np
+
+SAMPLES_PER_RANK = 1024
+
+
+class Comm:
+    """Thin wrapper over torch.distributed for tensors on `device`."""
+
+    def __init__(self, td, device):
+        import torch
+        self.td, self.torch, self.device = td, torch, device
+        self.rank, self.world = td.get_rank(), td.get_world_size()
+
+    def barrier(self):
+        self.td.barrier()
+
+    def all_reduce_i64(self, arr, op="sum"):
+        t = self.torch.as_tensor(np.ascontiguousarray(arr, np.int64)).to(self.device)
+        self.td.all_reduce(t, op=self.td.ReduceOp.SUM if op == "sum" else self.td.ReduceOp.MAX)
+        return t.cpu().numpy()
+
+    def all_gather_i64(self, t):
+        out = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.td.all_gather(out, t)
+        return out
+
+    def all_gather_f64_scalar(self, v):
+        t = self.torch.tensor([float(v)], dtype=self.torch.float64, device=self.device)
+        out = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.td.all_gather(out, t)
+        return [float(o.item()) for o in out]
+
+    def all_to_all_v(self, send, send_counts, dtype=None):
+        """send: 1-D tensor laid out rank-major; returns (recv tensor, recv_counts)."""
+        torch = self.torch
+        sc = torch.tensor(send_counts, dtype=torch.int64, device=self.device)
+        rc = torch.empty_like(sc)
+        self.td.all_to_all_single(rc, sc)
+        recv_counts = [int(v) for v in rc.cpu().tolist()]
+        recv = torch.empty(sum(recv_counts), dtype=send.dtype, device=self.device)
+        self.td.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=[int(v) for v in send_counts])
+        return recv, recv_counts
+
+    def max_float(self, v):
+        return max(self.all_gather_f64_scalar(v))
+
+    def sum_int(self, v):
+        return int(self.all_reduce_i64(np.array([int(v)]))[0])
+
+    def gather_floats(self, vals):
+        t = self.torch.tensor([float(v) for v in vals], dtype=self.torch.float64, device=self.device)
+        out = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.td.all_gather(out, t)
+        return [o.cpu().tolist() for o in out]
+
+
+class LocalOps:
+    """Per-GPU compute of a distributed pass, through the C ABI (fithic_amd._capi.Context)."""
+
+    def __init__(self, engine, torch, device):
+        self.eng, self.ctx, self.torch, self.device = engine, engine.ctx, torch, device
+
+    def local_stats(self):
+        from . import _capi
+        st = self.ctx.pass_stats()
+        return st, self.ctx.get_array(_capi.A_HIST_SUMCC), self.ctx.get_array(_capi.A_HIST_NPAIRS)
+
+    def set_global_and_fit(self, st, hist_cc, hist_np):
+        self.ctx.set_global_stats(st, hist_cc, hist_np)
+        return self.ctx.fit()
+
+    def pvalues(self):
+        self.ctx.pvalues()
+
+    def local_sorted_keys(self):
+        """int64 tensor (all keys < 2^62, so signed order = unsigned order) of this rank's sorted p < 1 bit patterns."""
+        self.ctx.bh_local_sort()
+        n = self.ctx.n_sorted()
+        t = self.torch.empty(n, dtype=self.torch.int64, device=self.device)
+        self.ctx.memcpy_d2d(t.data_ptr(), self.ctx.device_ptr(2), 8 * n)
+        return t
+
+    def sort_keys(self, keys):
+        out = self.torch.empty_like(keys)
+        perm = self.torch.empty(keys.numel(), dtype=self.torch.int32, device=self.device)
+        self.ctx.sort_u64(keys.data_ptr(), keys.numel(), out.data_ptr(), perm.data_ptr())
+        return out, perm
+
+    def bh_segment(self, sorted_keys, rank0, carry, n_tests, want_q):
+        q = self.torch.empty(sorted_keys.numel(), dtype=self.torch.float64, device=self.device) if want_q else None
+        mx = self.ctx.bh_apply_sorted(sorted_keys.data_ptr() if sorted_keys.numel() else 0, sorted_keys.numel(), rank0, carry,
+                                      n_tests, q.data_ptr() if (want_q and q.numel()) else 0)
+        return q, mx
+
+    def scatter_q(self, q_sorted_local):
+        if q_sorted_local.numel():
+            self.ctx.bh_scatter(q_sorted_local.data_ptr())
+        else:
+            self.ctx.sync()
+
+    def next_pass_local(self):
+        from . import _capi
+        n = self.ctx.next_pass()
+        return n, self.ctx.get_array(_capi.A_OUTLIER_DIST_HIST)
+
+    def set_outlier_hist(self, hist):
+        self.ctx.set_outlier_dist_hist(hist)
+
+
+def choose_splitters(torch, samples_sorted, world):
+    """world-1 splitters at regular positions of the sorted, gathered samples."""
+    n = samples_sorted.numel()
+    if n == 0 or world == 1:
+        return samples_sorted[:0]
+    pos = [min(n - 1, (r * n) // world) for r in range(1, world)]
+    return samples_sorted[torch.tensor(pos, dtype=torch.int64, device=samples_sorted.device)]
+
+
+def distributed_bh(comm, ops, n_tests):
+    """Global BH over the p-values of all ranks; leaves q in row order on every rank."""
+    torch = comm.torch
+    keys = ops.local_sorted_keys()
+    n = keys.numel()
+    # regular samples -> common splitters
+    s = SAMPLES_PER_RANK
+    if n:
+        idx = torch.clamp(((torch.arange(1, s + 1, device=keys.device, dtype=torch.int64) * n) // (s + 1)), max=n - 1)
+        samples = keys[idx]
+    else:
+        samples = torch.full((s,), (1 << 62), dtype=torch.int64, device=keys.device)      # sorts after every real key
+    gathered = torch.cat(comm.all_gather_i64(samples))
+    gathered = gathered[gathered < (1 << 62)]
+    splitters = choose_splitters(torch, torch.sort(gathered).values, comm.world)
+    # cut the local run at the splitters and exchange
+    if splitters.numel():
+        cuts = torch.searchsorted(keys, splitters, right=False).cpu().tolist()
+    else:
+        cuts = [n] * (comm.world - 1)
+    bounds = [0] + [int(c) for c in cuts] + [n]
+    send_counts = [bounds[r + 1] - bounds[r] for r in range(comm.world)]
+    recv, recv_counts = comm.all_to_all_v(keys, send_counts)
+    # my slice of the global order: sort the received runs, remember where each element came from
+    mine_sorted, perm = ops.sort_keys(recv)
+    m = mine_sorted.numel()
+    counts = [int(t.item()) for t in comm.all_gather_i64(torch.tensor([m], dtype=torch.int64, device=keys.device))]
+    rank0 = sum(counts[:comm.rank])
+    _, seg_max = ops.bh_segment(mine_sorted, rank0, 0.0, n_tests, want_q=False)
+    maxima = comm.all_gather_f64_scalar(seg_max)
+    carry = max([0.0] + maxima[:comm.rank])
+    q_sorted, _ = ops.bh_segment(mine_sorted, rank0, carry, n_tests, want_q=True)
+    # back to arrival order, then back to the owners (reverse all-to-all), then to row order
+    q_arrival = torch.empty_like(q_sorted)
+    if m:
+        q_arrival[perm.to(torch.int64)] = q_sorted
+    q_back, back_counts = comm.all_to_all_v(q_arrival, recv_counts)
+    assert back_counts == send_counts
+    ops.scatter_q(q_back)
+    return n, m
+
+
+class DistributedPass:
+    """K1 -> all-reduce -> fit -> K2 -> distributed BH, one call per spline pass."""
+
+    def __init__(self, engine, comm, ops=None):
+        self.comm = comm
+        self.ops = ops if ops is not None else LocalOps(engine, comm.torch, comm.device)
+        self.n_dist_global = None
+        self.info = None
+        self.stats = None
+
+    def run(self):
+        comm, ops = self.comm, self.ops
+        st, hist_cc, hist_np = ops.local_stats()
+        if self.n_dist_global is None:
+            self.n_dist_global = int(comm.all_reduce_i64(np.array([len(hist_cc)]), op="max")[0])
+        nd = self.n_dist_global
+        pack = np.zeros(8 + 2 * nd, np.int64)
+        pack[:8] = [st.inter_count, st.inter_sum, st.intra_all_count, st.intra_all_sum, st.in_range_count, st.in_range_sum,
+                    st.n_skipped, 0]
+        pack[8:8 + len(hist_cc)] = hist_cc
+        pack[8 + nd:8 + nd + len(hist_np)] = hist_np
+        pack = comm.all_reduce_i64(pack)
+        max_count = int(comm.all_reduce_i64(np.array([st.max_count]), op="max")[0])
+        (st.inter_count, st.inter_sum, st.intra_all_count, st.intra_all_sum, st.in_range_count, st.in_range_sum,
+         st.n_skipped) = [int(v) for v in pack[:7]]
+        st.max_count = max_count
+        info = ops.set_global_and_fit(st, pack[8:8 + nd], pack[8 + nd:8 + 2 * nd])
+        ops.pvalues()
+        distributed_bh(comm, ops, info.bh_total_tests)
+        self.info, self.stats = info, st
+        return info
+
+    def next_pass(self):
+        """Fold outliers locally, then make the outlier-distance multiset genome-wide."""
+        n_local, hist = self.ops.next_pass_local()
+        nd = max(self.n_dist_global or 0, int(self.comm.all_reduce_i64(np.array([len(hist)]), op="max")[0]))
+        buf = np.zeros(nd, np.int64)
+        buf[:len(hist)] = hist
+        self.ops.set_outlier_hist(self.comm.all_reduce_i64(buf))
+        return self.comm.sum_int(n_local)

@@ -175,6 +175,12 @@ int fhx_bdtrc_array(fhx_ctx* ctx, double n_total, const int32_t* count, const do
 int fhx_bh_local_sort(fhx_ctx* ctx);                 /* compact p < 1, radix sort (key, row) on this GPU */
 int fhx_bh_apply_sorted(fhx_ctx* ctx, const void* d_sorted_keys, int64_t n, int64_t global_rank0,
                         double carry_in, double n_total_tests, void* d_q_sorted, double* block_max_out);
+/* sort n 64-bit keys that live on this GPU (ascending, stable); d_perm_out[i] = original position of sorted element i */
+int fhx_sort_u64(fhx_ctx* ctx, const void* d_keys_in, int64_t n, void* d_keys_out, void* d_perm_out);
+/* q[row of local sorted element i] = d_q_sorted_local[i] for the fhx_n_sorted() elements of fhx_bh_local_sort */
+int fhx_bh_scatter(fhx_ctx* ctx, const void* d_q_sorted_local);
+/* device-to-device copy on the context's stream, then wait (plumbing between the library's buffers and torch's) */
+int fhx_memcpy_d2d(fhx_ctx* ctx, void* dst, const void* src, int64_t bytes);
 
 /* ---- host numerics, exported for tests and for callers that only need the host side ------------------ */
 int fhx_host_spline_fit(const double* x, const double* y, int32_t m, double s, double* t, double* c,

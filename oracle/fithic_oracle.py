@@ -540,11 +540,12 @@ def format_significances(pairs, R, b1, b2):
 
 
 def run(contacts, frags, bias_path, resolution, n_bins=100, passes=1, mode=INTRA_ONLY, L=0, U=float("inf"),
-        mapp_thres=1, tL=0.5, tU=2, use_scipy=False, keep_text=False):
+        mapp_thres=1, tL=0.5, tU=2, use_scipy=False, keep_text=False, bias_dic=None):
     """main() of the reference after argument parsing (fithic.py:317-370). Returns a list of passes."""
     pairs = read_contacts_file(contacts) if isinstance(contacts, str) else contacts
     frag_rows = read_fragments_file(frags) if isinstance(frags, str) else frags
-    bias_dic = read_biases(bias_path, tL, tU) if bias_path else 0
+    if bias_dic is None:
+        bias_dic = read_biases(bias_path, tL, tU) if bias_path else 0
     b1, b2 = gather_bias(pairs, bias_dic)
     results = []
     outlier_lines, outlier_dists = [], []            # multisets (the reference never clears them)
