@@ -70,12 +70,14 @@ SYMBOLS = {
     "fhx_pass_stats": (ctypes.c_int, [_P, ctypes.POINTER(FhxStats)]),
     "fhx_set_global_stats": (ctypes.c_int, [_P, ctypes.POINTER(FhxStats), _I64P, _I64P, ctypes.c_int64]),
     "fhx_set_outlier_dist_hist": (ctypes.c_int, [_P, _I64P, ctypes.c_int64]),
+    "fhx_make_bins": (ctypes.c_int, [_P, _I32P]),
     "fhx_fit": (ctypes.c_int, [_P, ctypes.POINTER(FhxFitInfo)]),
     "fhx_pvalues": (ctypes.c_int, [_P]),
     "fhx_bh": (ctypes.c_int, [_P, ctypes.c_double]),
     "fhx_sync": (ctypes.c_int, [_P]),
     "fhx_next_pass": (ctypes.c_int, [_P, _I64P]),
     "fhx_fetch": (ctypes.c_int, [_P, _F64P, _F64P, _F64P, _F64P, _F64P]),
+    "fhx_fetch_flags": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint8)]),
     "fhx_get_array": (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_int64, _I64P]),
     "fhx_device_ptr": (_P, [_P, ctypes.c_int]),
     "fhx_n_sorted": (ctypes.c_int64, [_P]),
@@ -206,6 +208,11 @@ class Context:
         a = np.ascontiguousarray(hist, np.int64)
         self._check(self._L.fhx_set_outlier_dist_hist(self._h, _ptr(a, ctypes.c_int64), len(a)))
 
+    def make_bins(self):
+        n = ctypes.c_int32(0)
+        self._check(self._L.fhx_make_bins(self._h, ctypes.byref(n)))
+        return n.value
+
     def fit(self):
         info = FhxFitInfo()
         self._check(self._L.fhx_fit(self._h, ctypes.byref(info)))
@@ -236,6 +243,13 @@ class Context:
                 bufs.append(None)
         self._check(self._L.fhx_fetch(self._h, *bufs))
         return out
+
+    def fetch_flags(self, n_rows, outlier=True, skip=False):
+        o = np.empty(n_rows, np.uint8) if outlier else None
+        k = np.empty(n_rows, np.uint8) if skip else None
+        self._check(self._L.fhx_fetch_flags(self._h, _ptr(o, ctypes.c_uint8) if outlier else None,
+                                            _ptr(k, ctypes.c_uint8) if skip else None))
+        return o, k
 
     def get_array(self, which):
         n = ctypes.c_int64(0)

@@ -97,7 +97,7 @@ struct K1Sums {           // device accumulator block (int64 each)
 
 __global__ __launch_bounds__(K1_THREADS) void k1_classify_hist(
     const int32_t* __restrict__ loc1, const int32_t* __restrict__ loc2, const int32_t* __restrict__ count,
-    const uint8_t* __restrict__ skip, int64_t n, int lo_idx, int hi_idx,
+    const uint8_t* __restrict__ skip, int64_t skip_limit, int64_t n, int lo_idx, int hi_idx,
     unsigned long long* __restrict__ hist_sumcc, unsigned long long* __restrict__ hist_npairs,
     K1Sums* __restrict__ sums) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -150,7 +150,14 @@ __global__ __launch_bounds__(K1_THREADS) void k1_classify_hist(
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         const int4 a = a4[i], b = b4[i], c = c4[i];
         uchar4 s = make_uchar4(0, 0, 0, 0);
-        if (skip) s = s4[i];
+        // rows after the first duplicated outlier line are not skipped any more (fithic.py:408-412)
+        if (skip && (i << 2) <= skip_limit) {
+            s = s4[i];
+            const int64_t r = i << 2;
+            if (r + 1 > skip_limit) s.y = 0;
+            if (r + 2 > skip_limit) s.z = 0;
+            if (r + 3 > skip_limit) s.w = 0;
+        }
         one(a.x, b.x, c.x, s.x);
         one(a.y, b.y, c.y, s.y);
         one(a.z, b.z, c.z, s.z);
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_classify_hist(
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const int64_t i = (n4 << 2) + threadIdx.x;
-        one(loc1[i], loc2[i], count[i], skip ? skip[i] : 0);
+        one(loc1[i], loc2[i], count[i], (skip && i <= skip_limit) ? skip[i] : 0);
     }
 
     __syncthreads();
@@ -274,13 +281,17 @@ __global__ void k_fold_outliers(const int32_t* __restrict__ loc1, const int32_t*
                                 const uint8_t* __restrict__ outlier, uint8_t* __restrict__ skip,
                                 uint8_t* __restrict__ seen_twice, int64_t n, int res, int n_dist,
                                 const int16_t* __restrict__ slot_chr, const ChrGrid* __restrict__ grid,
-                                unsigned long long* __restrict__ out_hist, unsigned long long* __restrict__ n_out) {
+                                unsigned long long* __restrict__ out_hist, unsigned long long* __restrict__ n_out,
+                                unsigned long long* __restrict__ first_dup) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     unsigned long long mine = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         if (!outlier[i]) continue;
         ++mine;
-        if (skip[i]) seen_twice[i] = 1;            // duplicated line number in the reference's SortedList (A17)
+        if (skip[i]) {                             // duplicated line number in the reference's SortedList (A17)
+            seen_twice[i] = 1;
+            atomicMin(first_dup, (unsigned long long)i);
+        }
         skip[i] = 1;
         const int l1 = loc1[i], l2 = loc2[i];
         long long idx;
@@ -718,9 +729,11 @@ struct fhx_ctx {
     bool have_stats = false;
     std::vector<int64_t> h_hist_cc, h_hist_np, h_out_hist;
     int64_t n_outliers_total = 0;
+    int64_t skip_limit = INT64_MAX;   // row of the first duplicated outlier line: later rows are no longer skipped
     bool outlier_hist_nonempty = false;
     PassFit fit;
     bool have_fit = false;
+    bool have_bins = false;
     double* d_lut = nullptr;
     double *d_lbeta_intra = nullptr, *d_invb_intra = nullptr, *d_lbeta_inter = nullptr, *d_invb_inter = nullptr;
     int64_t tab_cap = 0;
@@ -936,6 +949,7 @@ int ingest_device_rows(fhx_ctx* ctx, const int32_t* c1, const int32_t* m1, const
     ctx->skip_active = false;
     ctx->have_stats = ctx->have_fit = ctx->have_p = ctx->have_q = false;
     ctx->n_outliers_total = 0;
+    ctx->skip_limit = INT64_MAX;
     ctx->outlier_hist_nonempty = false;
     ctx->h_out_hist.assign((size_t)n_dist, 0);
     ctx->tables_dirty = true;
@@ -1025,6 +1039,8 @@ int fhx_set_params(fhx_ctx* ctx, const fhx_params* p) {
     if (p->n_bins <= 0 || p->mapp_thres < 0 || p->mode < 0 || p->mode > 2) return fail(ctx, FHX_ERR_ARG, "bad parameter");
     if (p->bias_low > p->bias_up)
         return fail(ctx, FHX_ERR_REFERENCE_EXIT, "bias lower bound is greater than bias upper bound (fithic.py:261-263)");
+    if (ctx->n_rows > 0 && ctx->have_params && p->resolution != ctx->prm.resolution)
+        return fail(ctx, FHX_ERR_ARG, "the resolution cannot change after the contact rows were loaded");
     ctx->prm = *p;
     ctx->have_params = true;
     ctx->tables_dirty = true;
@@ -1113,7 +1129,7 @@ int fhx_pass_stats(fhx_ctx* ctx, fhx_stats* out) {
     const size_t lds = (size_t)K1_LDS_BINS * (sizeof(unsigned long long) + sizeof(unsigned int));
     const int blocks = grid_for((ctx->n_rows + 3) / 4, K1_THREADS, 512);
     hipLaunchKernelGGL(k1_classify_hist, dim3(blocks), dim3(K1_THREADS), lds, ctx->stream, ctx->d_loc1, ctx->d_loc2,
-                       ctx->d_count, ctx->skip_active ? ctx->d_skip : (const uint8_t*)nullptr, ctx->n_rows,
+                       ctx->d_count, ctx->skip_active ? ctx->d_skip : (const uint8_t*)nullptr, ctx->skip_limit, ctx->n_rows,
                        (int)std::min<int64_t>(lo, INT32_MAX), (int)hi, ctx->d_hist_cc, ctx->d_hist_np, ctx->d_sums);
     FHX_HIP(hipGetLastError());
     FHX_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
@@ -1139,7 +1155,7 @@ int fhx_pass_stats(fhx_ctx* ctx, fhx_stats* out) {
     st.n_dist = ctx->n_dist;
     st.n_skipped = s.n_skipped;
     ctx->have_stats = true;
-    ctx->have_fit = ctx->have_p = ctx->have_q = false;
+    ctx->have_fit = ctx->have_bins = ctx->have_p = ctx->have_q = false;
     if (out) *out = st;
     return FHX_OK;
 }
@@ -1168,11 +1184,7 @@ int fhx_set_outlier_dist_hist(fhx_ctx* ctx, const int64_t* hist, int64_t n_dist)
     return FHX_OK;
 }
 
-int fhx_fit(fhx_ctx* ctx, fhx_fit_info* out) {
-    if (!ctx) return FHX_ERR_ARG;
-    if (!ctx->have_params || !ctx->have_frags) return fail(ctx, FHX_ERR_ARG, "parameters and fragments must be loaded");
-    if (!ctx->have_stats) return fail(ctx, FHX_ERR_ARG, "fhx_pass_stats (or fhx_set_global_stats) must run first");
-    PassInputs in;
+static void fill_pass_inputs(fhx_ctx* ctx, PassInputs& in) {
     in.resolution = ctx->prm.resolution;
     in.dist_low = ctx->prm.dist_low;
     in.dist_up = ctx->prm.dist_up;
@@ -1186,10 +1198,32 @@ int fhx_fit(fhx_ctx* ctx, fhx_fit_info* out) {
     in.inter_sum = ctx->stats.inter_sum;
     if (ctx->h_out_hist.size() < ctx->h_hist_cc.size()) ctx->h_out_hist.resize(ctx->h_hist_cc.size(), 0);
     in.outlier_dist_hist = ctx->pass_no > 0 ? ctx->h_out_hist.data() : nullptr;
+}
+
+int fhx_make_bins(fhx_ctx* ctx, int32_t* n_bins_made) {
+    if (!ctx) return FHX_ERR_ARG;
+    if (!ctx->have_params) return fail(ctx, FHX_ERR_ARG, "fhx_set_params must be called first");
+    if (!ctx->have_stats) return fail(ctx, FHX_ERR_ARG, "fhx_pass_stats (or fhx_set_global_stats) must run first");
+    PassInputs in;
+    fill_pass_inputs(ctx, in);
+    make_bins_stage(in, ctx->fit);
+    ctx->have_fit = false;                 // bins only: K2 still needs fhx_fit
+    ctx->have_bins = true;
+    if (n_bins_made) *n_bins_made = (int32_t)ctx->fit.bins.size();
+    return FHX_OK;
+}
+
+int fhx_fit(fhx_ctx* ctx, fhx_fit_info* out) {
+    if (!ctx) return FHX_ERR_ARG;
+    if (!ctx->have_params || !ctx->have_frags) return fail(ctx, FHX_ERR_ARG, "parameters and fragments must be loaded");
+    if (!ctx->have_stats) return fail(ctx, FHX_ERR_ARG, "fhx_pass_stats (or fhx_set_global_stats) must run first");
+    PassInputs in;
+    fill_pass_inputs(ctx, in);
     std::string err;
     const int rc = run_host_pass(in, ctx->frags, ctx->fit, err);
     if (rc != FHX_OK) return fail(ctx, rc, err);
     ctx->have_fit = true;
+    ctx->have_bins = true;
     const PassFit& f = ctx->fit;
     if (ctx->device >= 0) {
         FHX_HIP(hipSetDevice(ctx->device));
@@ -1252,6 +1286,10 @@ int fhx_pvalues(fhx_ctx* ctx) {
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
     if (!ctx->have_fit) return fail(ctx, FHX_ERR_ARG, "fhx_fit must run first");
     FHX_HIP(hipSetDevice(ctx->device));
+    if (ctx->tables_dirty) {               // e.g. the bias table arrived after the fit (the reference's call order)
+        const int r2 = build_slot_tables(ctx);
+        if (r2 != FHX_OK) return r2;
+    }
     const K2Params P = make_k2_params(ctx);
     FHX_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
     hipLaunchKernelGGL(k2_pvalue, dim3(grid_for(ctx->n_rows, K2_THREADS, 256 * 16)), dim3(K2_THREADS), 0, ctx->stream, P);
@@ -1505,18 +1543,22 @@ int fhx_next_pass(fhx_ctx* ctx, int64_t* n_outliers_total) {
     if (!ctx->have_p) return fail(ctx, FHX_ERR_ARG, "fhx_pvalues must run first");
     FHX_HIP(hipSetDevice(ctx->device));
     unsigned long long* n_out = ctx->d_misc + 1;
+    unsigned long long* first_dup = ctx->d_misc + 4;
     FHX_HIP(hipMemsetAsync(n_out, 0, sizeof(unsigned long long), ctx->stream));
+    FHX_HIP(hipMemsetAsync(first_dup, 0xFF, sizeof(unsigned long long), ctx->stream));
     hipLaunchKernelGGL(k_fold_outliers, dim3(grid_for(ctx->n_rows, 256)), dim3(256), 0, ctx->stream, ctx->d_loc1, ctx->d_loc2,
                        ctx->d_outlier, ctx->d_skip, ctx->d_seen_twice, ctx->n_rows, (int)ctx->prm.resolution, (int)ctx->n_dist,
-                       ctx->d_slot_chr, ctx->d_grid, ctx->d_out_hist, n_out);
+                       ctx->d_slot_chr, ctx->d_grid, ctx->d_out_hist, n_out, first_dup);
     FHX_HIP(hipGetLastError());
-    unsigned long long added = 0;
+    unsigned long long added = 0, dup = ~0ull;
+    FHX_HIP(hipMemcpyAsync(&dup, first_dup, sizeof(dup), hipMemcpyDeviceToHost, ctx->stream));
     ctx->h_out_hist.assign((size_t)ctx->n_dist, 0);
     FHX_HIP(hipMemcpyAsync(&added, n_out, sizeof(added), hipMemcpyDeviceToHost, ctx->stream));
     FHX_HIP(hipMemcpyAsync(ctx->h_out_hist.data(), ctx->d_out_hist, ctx->n_dist * sizeof(int64_t), hipMemcpyDeviceToHost,
                            ctx->stream));
     FHX_HIP(hipStreamSynchronize(ctx->stream));
     ctx->n_outliers_total += (int64_t)added;
+    if (dup != ~0ull) ctx->skip_limit = std::min<int64_t>(ctx->skip_limit, (int64_t)dup);
     ctx->skip_active = true;
     ctx->pass_no += 1;
     if (n_outliers_total) *n_outliers_total = ctx->n_outliers_total;
@@ -1546,6 +1588,18 @@ int fhx_fetch(fhx_ctx* ctx, double* p, double* q, double* expcc, double* bias1, 
     }
     FHX_HIP(hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < 3; ++k) dev_free(d_tmp[k]);
+    return FHX_OK;
+}
+
+int fhx_fetch_flags(fhx_ctx* ctx, uint8_t* outlier, uint8_t* skip) {
+    if (!ctx) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (ctx->n_rows <= 0) return fail(ctx, FHX_ERR_ARG, "no contact rows loaded");
+    if (outlier && !ctx->have_p) return fail(ctx, FHX_ERR_ARG, "no p-values yet");
+    FHX_HIP(hipSetDevice(ctx->device));
+    if (outlier) FHX_HIP(hipMemcpyAsync(outlier, ctx->d_outlier, (size_t)ctx->n_rows, hipMemcpyDeviceToHost, ctx->stream));
+    if (skip) FHX_HIP(hipMemcpyAsync(skip, ctx->d_skip, (size_t)ctx->n_rows, hipMemcpyDeviceToHost, ctx->stream));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
     return FHX_OK;
 }
 
@@ -1585,7 +1639,9 @@ int fhx_get_array(fhx_ctx* ctx, int which, void* dst, int64_t cap, int64_t* n_ou
         c[0] = 0;
         return put(c.data(), c.size(), sizeof(int64_t));
     }
-    if (!ctx->have_fit) return fail(ctx, FHX_ERR_ARG, "fhx_fit must run first");
+    if (!ctx->have_fit && !(ctx->have_bins && (which == FHX_A_BIN_LB || which == FHX_A_BIN_UB || which == FHX_A_BIN_SUMCC ||
+                                               which == FHX_A_BIN_POSS0)))
+        return fail(ctx, FHX_ERR_ARG, "fhx_fit must run first");
     switch (which) {
         case FHX_A_BIN_LB: return bin_i64(&Bin::lb);
         case FHX_A_BIN_UB: return bin_i64(&Bin::ub);

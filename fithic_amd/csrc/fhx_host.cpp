@@ -727,7 +727,7 @@ inline size_t advance_cursor(const std::vector<Bin>& bins, size_t cur, int64_t d
 
 }  // namespace
 
-int run_host_pass(const PassInputs& in, const FragTable& frags, PassFit& out, std::string& err) {
+void make_bins_stage(const PassInputs& in, PassFit& out) {
     out = PassFit();
     const int64_t res = in.resolution;
     // ---- makeBinsFromInteractions (fithic.py:463-553) --------------------------------------------
@@ -785,6 +785,11 @@ int run_host_pass(const PassInputs& in, const FragTable& frags, PassFit& out, st
         }
     }
     for (auto& b : out.bins) b.poss0 = b.poss;
+}
+
+int run_host_pass(const PassInputs& in, const FragTable& frags, PassFit& out, std::string& err) {
+    make_bins_stage(in, out);
+    const int64_t res = in.resolution;
 
     // ---- generate_FragPairs, fixed-size branch (fithic.py:592-689) ---------------------------------
     {

@@ -85,6 +85,8 @@ struct PassFit {
     std::vector<double> prior_lut;
 };
 
+// makeBinsFromInteractions alone (fithic.py:463-553): fills out.bins (lb, ub, sumcc, outlier decrements)
+void make_bins_stage(const PassInputs& in, PassFit& out);
 // returns 0, or FHX_ERR_REFERENCE_EXIT with `err` set where the reference would exit / raise
 int run_host_pass(const PassInputs& in, const FragTable& frags, PassFit& out, std::string& err);
 

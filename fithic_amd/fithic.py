@@ -1,0 +1,342 @@
+"""The reference's hot-path functions, same names / arguments / return values, running on the MI355X engine.
+
+Drop-in surface.  Like the reference, the functions communicate through module globals that
+main() assigns (fithic/fithic.py:203-308): distLowThres, distUpThres, mappThres, interOnly, allReg,
+biasLowerBound, biasUpperBound, logfile, visual - plus one global the reference does not need because it re-reads
+its files in every stage: `resolution` (the engine needs the fixed-size grid before the contacts go to the GPU).
+
+    read_Interactions(contactCountsFile, biasFile, outliers=None)              fithic/fithic.py:389
+    makeBinsFromInteractions(mainDic, noOfBins, observedIntraInRangeSum, outliersdist=None)        :463
+    generate_FragPairs(observedInterAllCount, observedInterAllSum, binStats, fragsfile, resolution) :561
+    read_biases(infilename)                                                                         :798
+    calculateProbabilities(mainDic, binStats, resolution, outfilename, observedIntraInRangeSum)     :843
+    fit_Spline(mainDic, x, y, yerr, infilename, outfilename, biasDic, outliersline, outliersdist, ...)  :925
+    benjamini_hochberg_correction(p_values, num_total_tests)                   fithic/myStats.py:24
+
+The per-pair and per-distance work runs in the HIP kernels behind the C ABI (no CPU implementation exists here);
+these wrappers only move tables in, shape results like the reference's Python objects, and write the two output
+files with the reference's exact formats.
+"""
+import gzip
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import _capi, tables
+from .engine import Engine, MODES
+
+# ---- the reference's module globals (defaults as in fithic/fithic.py:203-304) ------------------------
+mappThres = 1
+distLowThres = 0
+distUpThres = float("inf")
+visual = False
+interOnly = False
+allReg = False
+biasLowerBound = 0.5
+biasUpperBound = 2
+interChrProb = 0
+baselineIntraChrProb = 0
+distScaling = 1000000.0
+toKb, toMb, toProb = 10 ** -3, 10 ** -6, 10 ** 5
+logfile = None
+resolution = None          # engine-only global, see the module docstring
+device = 0                 # GPU ordinal the engine uses
+
+
+class _Session:
+    """What the reference keeps implicitly on disk and in globals between its stages."""
+
+    def __init__(self):
+        self.engine = None
+        self.chroms = tables.ChromIndex()
+        self.contacts = None
+        self.contacts_path = None
+        self.frags_path = None
+        self.bias_path = None
+        self.bias_loaded = False
+        self.n_bins = 100
+        self.stats = None
+        self.info = None
+        self.fit_done = False
+        self.arrays = {}
+        self.values = None
+        self.pass_started = 0
+
+    def mode(self):
+        return "All" if allReg else ("interOnly" if interOnly else "intraOnly")
+
+    def ensure_engine(self):
+        if self.engine is None:
+            self.engine = Engine(device)
+        return self.engine
+
+    def configure(self):
+        if resolution is None or resolution <= 0:
+            raise RuntimeError("fithic_amd.fithic.resolution must be set to the fixed-size resolution before "
+                               "read_Interactions (the accelerated path is the reference's fixed-size fast path)")
+        self.ensure_engine().configure(resolution, distLowThres, distUpThres, self.n_bins, mappThres, self.mode(),
+                                       biasLowerBound, biasUpperBound)
+
+    def ensure_fit(self):
+        if not self.fit_done:
+            self.configure()
+            info = self.engine.fit()
+            self.info = info.as_dict()
+            A = _capi
+            for k, w in dict(bin_lb=A.A_BIN_LB, bin_ub=A.A_BIN_UB, bin_poss=A.A_BIN_POSS, bin_poss0=A.A_BIN_POSS0,
+                             bin_sumcc=A.A_BIN_SUMCC, bin_sumdist=A.A_BIN_SUMDIST, bin_poss7=A.A_BIN_POSS7, x=A.A_X, y=A.A_Y).items():
+                self.arrays[k] = self.engine.ctx.get_array(w)
+            if not interOnly:
+                for k, w in dict(table_x=A.A_TABLE_X, table_y=A.A_TABLE_Y, knots=A.A_KNOTS, coeffs=A.A_COEFFS).items():
+                    self.arrays[k] = self.engine.ctx.get_array(w)
+            self.fit_done = True
+        return self.info
+
+
+_S = _Session()
+
+
+def reset_session():
+    """Forget the loaded tables (a new run in the same interpreter)."""
+    global _S
+    if _S.engine is not None:
+        _S.engine.close()
+    _S = _Session()
+
+
+def _log(text, mode="a"):
+    if logfile:
+        with open(logfile, mode) as f:
+            f.write(text)
+
+
+# ======================================================================================================
+def read_Interactions(contactCountsFile, biasFile, outliers=None):
+    """fithic/fithic.py:389-454.  Returns (mainDic, observedInterAllCount, observedInterAllSum,
+    observedIntraAllSum, observedIntraInRangeSum); mainDic = {distance: [0, sum of counts]}."""
+    print("Reading the contact counts file to generate bins...")
+    t0 = time.time()
+    S = _S
+    if S.contacts is None or S.contacts_path != contactCountsFile:
+        S.configure()
+        S.contacts = tables.read_contacts(contactCountsFile, S.chroms)
+        S.contacts_path = contactCountsFile
+        c = S.contacts
+        S.engine.load_contacts(c.chr1, c.mid1, c.chr2, c.mid2, c.count)
+        S.pass_started = 0
+    elif outliers is not None and S.pass_started >= 1 and S.values is not None:
+        S.engine.next_pass()                 # fold the previous pass's outliers into the skip mask (K1 skips them)
+    S.configure()
+    st = S.engine.pass_stats()
+    S.stats = st.as_dict()
+    S.fit_done = False
+    S.pass_started += 1
+    hist_cc = S.engine.ctx.get_array(_capi.A_HIST_SUMCC)
+    hist_np = S.engine.ctx.get_array(_capi.A_HIST_NPAIRS)
+    idx = np.flatnonzero(hist_np > 0)
+    mainDic = {int(i) * resolution: [0, int(hist_cc[i])] for i in idx}
+    print("Interactions file read. Time took %s" % (time.time() - t0))
+    lo = int(idx[0]) * resolution if len(idx) else float("inf")
+    hi = int(idx[-1]) * resolution if len(idx) else 0
+    _log("\n\nInteractions file read successfully\n"
+         "------------------------------------------------------------------------------------\n"
+         "Observed, Intra-chr in range: pairs= %s\t totalCount= %s\n"
+         "Observed, Intra-chr all: pairs= %s\t totalCount= %s\n"
+         "Observed, Inter-chr all: pairs= %s\t totalCount= %s\n"
+         "Range of observed genomic distances [%s %s]\n\n"
+         % (st.in_range_count, st.in_range_sum, st.intra_all_count, st.intra_all_sum, st.inter_count, st.inter_sum, lo, hi), "w")
+    return (mainDic, st.inter_count, st.inter_sum, st.intra_all_sum, st.in_range_sum)
+
+
+def _bin_stats(S, poss_key):
+    a = S.arrays
+    hist_np = S.engine.ctx.get_array(_capi.A_HIST_NPAIRS)
+    keys = np.flatnonzero(hist_np > 0) * resolution
+    out = {}
+    for b in range(len(a["bin_lb"])):
+        lb, ub = int(a["bin_lb"][b]), int(a["bin_ub"][b])
+        first = 0 if b == 0 else lb           # bin 0 starts at 0 but its first distance is the first key
+        dists = [int(d) for d in keys[(keys >= first) & (keys <= ub)]]
+        out[b] = [(lb, ub), int(a[poss_key][b]), int(a["bin_sumcc"][b]), 0, 0, 0, dists, int(a[poss_key][b])]
+    return out
+
+
+def makeBinsFromInteractions(mainDic, noOfBins, observedIntraInRangeSum, outliersdist=None):
+    """fithic/fithic.py:463-553.  Returns binStats = {bin: [(lb, ub), possPairs, sumCC, sumDist, avgCC, avgDist, [distances], possPairs]}."""
+    S = _S
+    S.n_bins = noOfBins
+    noPerBin = observedIntraInRangeSum / noOfBins
+    _log("Making equal occupancy bins\n"
+         "------------------------------------------------------------------------------------\n"
+         "Observed intra-chr read counts in range\t%r\nDesired number of contacts per bin\t%r,\nNumber of bins\t%r\n"
+         % (observedIntraInRangeSum, noPerBin, noOfBins))
+    S.fit_done = False
+    S.configure()
+    S.engine.ctx.make_bins()
+    A = _capi
+    for k, w in dict(bin_lb=A.A_BIN_LB, bin_ub=A.A_BIN_UB, bin_poss0=A.A_BIN_POSS0, bin_sumcc=A.A_BIN_SUMCC).items():
+        S.arrays[k] = S.engine.ctx.get_array(w)
+    _log("Equal occupancy bins generated\n\n")
+    return _bin_stats(S, "bin_poss0")
+
+
+def _load_fragments(S, fragsfile):
+    if S.frags_path != fragsfile:
+        fc, fm, fh = tables.read_fragments(fragsfile, S.chroms)
+        S.frag_table = (fc, fm, fh)
+        S.frags_path = fragsfile
+    S.configure()
+    fc, fm, fh = S.frag_table
+    S.engine.load_fragments(fc, fm, fh, S.chroms.sort_rank())
+
+
+def generate_FragPairs(observedInterAllCount, observedInterAllSum, binStats, fragsfile, resolution):
+    """fithic/fithic.py:561-793 (fixed-size branch).  Returns (binStats, noOfFrags, maxPossibleGenomicDist,
+    possibleIntraInRangeCount, possibleInterAllCount, interChrProb, baselineIntraChrProb)."""
+    global interChrProb, baselineIntraChrProb
+    if not resolution:
+        raise _capi.FhxError(_capi.FHX_ERR_UNSUPPORTED, "the non-fixed-size mode (-r 0) is not accelerated")
+    S = _S
+    t0 = time.time()
+    _log("Looping through all possible fragment pairs in-range\n"
+         "------------------------------------------------------------------------------------\n")
+    _load_fragments(S, fragsfile)
+    info = S.ensure_fit()
+    full = _bin_stats(S, "bin_poss")
+    for b, rec in full.items():
+        rec[3] = float(S.arrays["bin_sumdist"][b])
+        rec[7] = int(S.arrays["bin_poss7"][b])
+    binStats.clear()
+    binStats.update(full)
+    fc, fm, fh = S.frag_table
+    names = S.chroms.names
+    n_frags = info["n_frags"]
+    min_poss = float("inf")
+    for c in sorted(set(fc.tolist()), key=lambda i: names[i]):
+        sel = (fc == c) & (fh >= mappThres)
+        n = int(sel.sum())
+        stop = int(fm[sel].max() - resolution / 2 + 1)
+        d = np.arange(0, max(stop, 0), resolution)
+        npairs = n - np.arange(len(d))
+        rng = (d >= distLowThres) & (d <= distUpThres)
+        per = int(npairs[rng].sum()) * (2 if len(full) else 1)
+        if rng.any():
+            min_poss = min(min_poss, int(d[rng][0]))
+        _log("Chromosome %r,\t%s mappable fragments, \t%s possible intra-chr fragment pairs in range,\t%s possible inter-chr "
+             "fragment pairs\n" % (names[c], n, per, (n_frags - n) * n))
+    print("Fragments file read. Time took %s" % (time.time() - t0))
+    interChrProb = info["inter_chr_prob"] if info["inter_chr_prob"] else 0
+    baselineIntraChrProb = info["baseline_intra_prob"]
+    _log("Number of all fragments= %s\nPossible, Intra-chr in range: pairs= %s \nPossible, Intra-chr all: pairs= %s \n"
+         "Possible, Inter-chr all: pairs= %s \n" % (n_frags, info["possible_intra_in_range"], info["possible_intra_all"],
+                                                    info["possible_inter_all"]))
+    _log("Desired genomic distance range   [%d %s] \n" % (distLowThres, distUpThres))
+    try:
+        _log("Range of possible genomic distances  [%d  %d] \n" % (min_poss, info["max_possible_dist"]))
+    except (OverflowError, ValueError):
+        pass
+    _log("Baseline intrachromosomal probability is %s \nInterchromosomal probability is %s \n" % (baselineIntraChrProb, interChrProb))
+    return (binStats, n_frags, info["max_possible_dist"], info["possible_intra_in_range"], info["possible_inter_all"],
+            interChrProb, baselineIntraChrProb)
+
+
+class _BiasDic(dict):
+    """Truthiness and chromosome membership like the reference's nested dict; values are resolved on the GPU."""
+
+
+def read_biases(infilename):
+    """fithic/fithic.py:798-837.  Loads the bias table into the engine; returns {chrom: {mid: bias}} like the reference."""
+    t0 = time.time()
+    S = _S
+    bc, bm, bv = tables.read_bias(infilename, S.chroms)
+    S.configure()
+    S.engine.load_bias(bc, bm, bv)
+    S.bias_path, S.bias_loaded = infilename, True
+    bot, med, top = tables.bias_quantiles(bv)
+    _log("5th quantile of biases: %s\n50th quantile of biases: %s\n95th quantile of biases: %s\n" % (bot, med, top))
+    out = _BiasDic()
+    names = S.chroms.names
+    vals = np.where((bv < biasLowerBound) | np.isnan(bv) | (bv > biasUpperBound), -1.0, bv)
+    discard = int(((bv < biasLowerBound) | np.isnan(bv) | (bv > biasUpperBound)).sum())
+    for c, m, v in zip(bc.tolist(), bm.tolist(), vals.tolist()):
+        d = out.setdefault(names[c], {})
+        if m not in d:
+            d[m] = -1 if v == -1.0 else v
+    _log("Out of %s loci %s were discarded with biases not in range [%s-%s]\n\n" % (len(bv), discard, biasLowerBound, biasUpperBound))
+    print("Bias file read. Time took %s" % (time.time() - t0))
+    return out
+
+
+def calculateProbabilities(mainDic, binStats, resolution, outfilename, observedIntraInRangeSum):
+    """fithic/fithic.py:843-918.  Returns [x, y, yerr] and writes <outfilename>.res<R>.txt."""
+    S = _S
+    _log("\nCalculating probability means and standard deviations of contact counts\n"
+         "------------------------------------------------------------------------------------\n")
+    S.ensure_fit()
+    x = [float(v) for v in S.arrays["x"]]
+    y = [float(v) for v in S.arrays["y"]]
+    yerr = [0] * len(x)
+    name = outfilename + (".res" + str(resolution) if resolution else "") + ".txt"
+    print("Writing %s" % name)
+    with open(name, "w") as f:
+        f.write("avgGenomicDist\tcontactProbability\tstandardError\tnoOfLocusPairs\ttotalOfContactCounts\n")
+        for i in range(len(x)):
+            f.write("%d" % x[i] + "\t" + "%.2e" % y[i] + "\t" + "%.2e" % yerr[i] + "\t" + "%d" % S.arrays["bin_poss"][i] + "\t"
+                    + "%d" % S.arrays["bin_sumcc"][i] + "\n")
+            if i in binStats:
+                binStats[i][4], binStats[i][5] = y[i], x[i]
+    _log("Means and error written to %s\n\n" % name)
+    return [x, y, yerr]
+
+
+def fit_Spline(mainDic, x, y, yerr, infilename, outfilename, biasDic, outliersline, outliersdist, observedIntraInRangeSum,
+               possibleIntraInRangeCount, possibleInterAllCount, observedInterAllCount, observedIntraAllSum,
+               observedInterAllSum, biasLowerBound, biasUpperBound, resolution, passNo):
+    """fithic/fithic.py:925-1233.  Returns [splineX, newSplineY, residual, outliersline, outliersdist, FDRx, FDRy] and
+    writes <outfilename>.res<R>.significances.txt.gz."""
+    S = _S
+    _log("\nFitting a univariate spline to the probability means\n"
+         "------------------------------------------------------------------------------------\n")
+    info = S.ensure_fit()
+    splineX = newSplineY = residual = None
+    if not interOnly:
+        splineX = [int(v) for v in S.arrays["table_x"]]
+        newSplineY = np.array(S.arrays["table_y"])
+        residual = info["residual"]
+    eng = S.engine
+    eng.ctx.pvalues()                                   # K2
+    eng.ctx.bh(info["bh_total_tests"])                  # K3
+    print("Outlier threshold is... %s" % (info["outlier_thres"]))
+    v = eng.fetch(p=True, q=True, expcc=True, bias=True)
+    S.values = v
+    con = S.contacts
+    inter = con.chr1 != con.chr2
+    d = np.abs(con.mid1.astype(np.int64) - con.mid2.astype(np.int64))
+    in_rng = (d >= distLowThres) & (d <= distUpThres)
+    emit = (inter & (allReg or interOnly)) | (~inter & (allReg or not interOnly) & in_rng)
+    name = outfilename + (".res" + str(resolution) if resolution else "") + ".significances.txt.gz"
+    print("Writing p-values and q-values to file %s" % (outfilename + ".significances.txt"))
+    text = tables.format_significance_rows(S.chroms.names, con, emit, v["p"], v["q"], v["b1"], v["b2"], v["expcc"])
+    with gzip.open(name, "wt", compresslevel=6) as f:
+        f.write(text)
+    flags, _ = eng.ctx.fetch_flags(len(con), outlier=True, skip=False)
+    rows = np.flatnonzero(flags)
+    for r in rows.tolist():
+        outliersline.add(r) if hasattr(outliersline, "add") else outliersline.append(r)
+    for dist in d[rows].tolist():
+        outliersdist.add(dist) if hasattr(outliersdist, "add") else outliersdist.append(dist)
+    if not hasattr(outliersline, "add"):
+        outliersline.sort()
+        outliersdist.sort()
+    FDRx = np.arange(0.0, 0.05 + 0.001, 0.001)
+    FDRy = [int(c) for c in eng.fdr_counts()]
+    _log("Spline successfully fit\n\n\n")
+    return [splineX, newSplineY, residual, outliersline, outliersdist, FDRx, FDRy]
+
+
+def benjamini_hochberg_correction(p_values, num_total_tests):
+    """fithic/myStats.py:24-48 on the GPU (sort + scan kernels); returns a Python list like the reference."""
+    eng = _S.ensure_engine()
+    return eng.ctx.bh_array(np.asarray(p_values, np.float64), float(num_total_tests)).tolist()

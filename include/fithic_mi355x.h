@@ -147,6 +147,8 @@ int fhx_set_global_stats(fhx_ctx* ctx, const fhx_stats* global_stats, const int6
 /* Distributed runs, pass >= 2: replace the local multiset of outlier distances (count per distance index,
  * accumulated over all earlier passes) by the all-reduced one. */
 int fhx_set_outlier_dist_hist(fhx_ctx* ctx, const int64_t* hist, int64_t n_dist);
+/* makeBinsFromInteractions alone (host): bins are readable through fhx_get_array(FHX_A_BIN_LB/UB/SUMCC/POSS0). */
+int fhx_make_bins(fhx_ctx* ctx, int32_t* n_bins_made);
 int fhx_fit(fhx_ctx* ctx, fhx_fit_info* out);                           /* host; uploads the tables */
 int fhx_pvalues(fhx_ctx* ctx);                                          /* K2 (asynchronous) */
 int fhx_bh(fhx_ctx* ctx, double n_total_tests);                         /* K3 (asynchronous) */
@@ -156,6 +158,9 @@ int fhx_next_pass(fhx_ctx* ctx, int64_t* n_outliers_total);             /* fold 
 /* ---- results ------------------------------------------------------------------------------------ */
 /* Any pointer may be NULL.  Arrays have n_rows entries in input row order. */
 int fhx_fetch(fhx_ctx* ctx, double* p, double* q, double* expcc, double* bias1, double* bias2);
+/* Per-row byte flags: outlier[i] = (p_i < 1/N) of the last fhx_pvalues; skip[i] = row is skipped by fhx_pass_stats
+ * (outlier of an earlier pass, fithic/fithic.py:408-412).  Either pointer may be NULL. */
+int fhx_fetch_flags(fhx_ctx* ctx, uint8_t* outlier, uint8_t* skip);
 int fhx_get_array(fhx_ctx* ctx, int which, void* dst, int64_t capacity_elems, int64_t* n_out);
 /* Raw device pointers for plumbing (torch / RCCL exchange): 0 = p, 1 = q, 2 = sorted keys, 3 = sorted idx */
 void* fhx_device_ptr(fhx_ctx* ctx, int which);

@@ -173,3 +173,64 @@ def test_off_grid_loci_are_rejected_loudly():
         c.load_pairs([0, 0], [5000, 15001], [0, 0], [25000, 35000], [3, 4])
     assert e.value.code == _capi.FHX_ERR_UNSUPPORTED
     c.close()
+
+
+@pytest.mark.parametrize("name", ["f6_quirk_all", "f2_all"])
+def test_three_passes_match_oracle(name):
+    """-p 3: the reference's duplicated outlier line numbers stop the skipping after the first duplicate."""
+    from oracle import fithic_oracle as fo
+    from fithic_amd import tables
+    from fithic_amd.engine import Engine
+    meta, g = load_case(name)
+    kw = case_args(meta)
+    kw["passes"] = 3
+    ref = fo.run(**kw)
+    chroms = tables.ChromIndex()
+    con = tables.read_contacts(kw["contacts"], chroms)
+    eng = Engine(0)
+    eng.configure(kw["resolution"], kw["L"], kw["U"], kw["n_bins"], kw["mapp_thres"], kw["mode"], kw["tL"], kw["tU"])
+    eng.load_fragments(*tables.read_fragments(kw["frags"], chroms), chroms.sort_rank())
+    eng.load_bias(*tables.read_bias(kw["bias_path"], chroms))
+    eng.load_contacts(con.chr1, con.mid1, con.chr2, con.mid2, con.count)
+    for r in ref:
+        out = eng.run_pass()
+        v = eng.fetch()
+        assert [out.stats["inter_count"], out.stats["inter_sum"], out.stats["intra_all_sum"], out.stats["in_range_sum"]] == list(r.sums)
+        assert max_abs_diff(v["p"], r.p) <= TOL and max_abs_diff(v["q"], r.q) <= TOL
+        assert eng.next_pass() == r.n_outlier_lines_total
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["f1_nobias", "f1_bias", "f2_all", "f6_quirk_all"])
+def test_cli_writes_the_reference_files(name, tmp_path, capsys):
+    """The drop-in command line: decompressed .significances.txt and .fithic_passN.txt equal the reference's byte for byte."""
+    import gzip
+    import hashlib
+    from fithic_amd import cli
+    meta, g = load_case(name)
+    kw = case_args(meta)
+    argv = ["-i", kw["contacts"], "-f", kw["frags"], "-o", str(tmp_path), "-l", "G"] + meta["argv"]
+    if kw["bias_path"]:
+        argv += ["-t", kw["bias_path"]]
+    cli.main(argv)
+    res = kw["resolution"]
+    for pi in range(1, meta["n_passes"] + 1):
+        with gzip.open(os.path.join(str(tmp_path), "G.spline_pass%d.res%d.significances.txt.gz" % (pi, res)), "rb") as f:
+            text = f.read()
+        assert text.count(b"\n") - 1 == meta["sig_rows_pass%d" % pi]
+        assert hashlib.md5(text).hexdigest() == meta["sig_md5_pass%d" % pi]
+        with open(os.path.join(str(tmp_path), "G.fithic_pass%d.res%d.txt" % (pi, res))) as f:
+            assert f.read() == meta["fithic_pass%d_txt" % pi]
+    # the log keeps the reference's text (it is truncated by every read_Interactions, SURVEY A19); paths differ
+    with open(os.path.join(str(tmp_path), "G.fithic.log")) as f:
+        mine = [ln for ln in f.read().splitlines() if not ln.startswith("Means and error written")]
+    want = [ln for ln in meta["log_txt"].splitlines() if not ln.startswith("Means and error written")]
+    assert mine == want
+
+
+def test_mirror_benjamini_hochberg_signature():
+    from fithic_amd import fithic as F
+    q = F.benjamini_hochberg_correction([0.03, 0.4, 0.7, 0.01], 10)
+    g = np.load(os.path.join(GOLDEN, "f5_bh.npz"))
+    assert isinstance(q, list) and bits_equal(np.array(q), g["tiny_q"])
+    F.reset_session()
