@@ -75,6 +75,9 @@ SYMBOLS = {
     "fhx_pvalues": (ctypes.c_int, [_P]),
     "fhx_bh": (ctypes.c_int, [_P, ctypes.c_double]),
     "fhx_sync": (ctypes.c_int, [_P]),
+    "fhx_set_global_rows": (ctypes.c_int, [_P, _I64P, ctypes.c_int64]),
+    "fhx_get_skip_limit": (ctypes.c_int64, [_P]),
+    "fhx_set_skip_limit": (ctypes.c_int, [_P, ctypes.c_int64]),
     "fhx_next_pass": (ctypes.c_int, [_P, _I64P]),
     "fhx_fetch": (ctypes.c_int, [_P, _F64P, _F64P, _F64P, _F64P, _F64P]),
     "fhx_fetch_flags": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint8)]),
@@ -227,6 +230,16 @@ class Context:
     def sync(self):
         self._check(self._L.fhx_sync(self._h))
 
+    def set_global_rows(self, rows):
+        r = np.ascontiguousarray(rows, np.int64)
+        self._check(self._L.fhx_set_global_rows(self._h, _ptr(r, ctypes.c_int64), len(r)))
+
+    def get_skip_limit(self):
+        return self._L.fhx_get_skip_limit(self._h)
+
+    def set_skip_limit(self, limit):
+        self._check(self._L.fhx_set_skip_limit(self._h, int(limit)))
+
     def next_pass(self):
         n = ctypes.c_int64(0)
         self._check(self._L.fhx_next_pass(self._h, ctypes.byref(n)))
@@ -297,7 +310,7 @@ class Context:
         self._check(self._L.fhx_sort_u64(self._h, _P(int(d_keys_in)), int(n), _P(int(d_keys_out)), _P(int(d_perm_out))))
 
     def bh_scatter(self, d_q_sorted_local):
-        self._check(self._L.fhx_bh_scatter(self._h, _P(int(d_q_sorted_local))))
+        self._check(self._L.fhx_bh_scatter(self._h, _P(int(d_q_sorted_local)) if d_q_sorted_local else None))
 
     def memcpy_d2d(self, dst, src, nbytes):
         self._check(self._L.fhx_memcpy_d2d(self._h, _P(int(dst)), _P(int(src)), int(nbytes)))

@@ -97,7 +97,8 @@ struct K1Sums {           // device accumulator block (int64 each)
 
 __global__ __launch_bounds__(K1_THREADS) void k1_classify_hist(
     const int32_t* __restrict__ loc1, const int32_t* __restrict__ loc2, const int32_t* __restrict__ count,
-    const uint8_t* __restrict__ skip, int64_t skip_limit, int64_t n, int lo_idx, int hi_idx,
+    const uint8_t* __restrict__ skip, int64_t skip_limit, const long long* __restrict__ grow, int64_t n, int lo_idx,
+    int hi_idx,
     unsigned long long* __restrict__ hist_sumcc, unsigned long long* __restrict__ hist_npairs,
     K1Sums* __restrict__ sums) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -151,7 +152,14 @@ __global__ __launch_bounds__(K1_THREADS) void k1_classify_hist(
         const int4 a = a4[i], b = b4[i], c = c4[i];
         uchar4 s = make_uchar4(0, 0, 0, 0);
         // rows after the first duplicated outlier line are not skipped any more (fithic.py:408-412)
-        if (skip && (i << 2) <= skip_limit) {
+        if (skip && grow) {                       // shard: compare file positions, not local positions
+            s = s4[i];
+            const int64_t r = i << 2;
+            if (grow[r] > skip_limit) s.x = 0;
+            if (grow[r + 1] > skip_limit) s.y = 0;
+            if (grow[r + 2] > skip_limit) s.z = 0;
+            if (grow[r + 3] > skip_limit) s.w = 0;
+        } else if (skip && (i << 2) <= skip_limit) {
             s = s4[i];
             const int64_t r = i << 2;
             if (r + 1 > skip_limit) s.y = 0;
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_classify_hist(
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const int64_t i = (n4 << 2) + threadIdx.x;
-        one(loc1[i], loc2[i], count[i], (skip && i <= skip_limit) ? skip[i] : 0);
+        one(loc1[i], loc2[i], count[i], (skip && (grow ? grow[i] : i) <= skip_limit) ? skip[i] : 0);
     }
 
     __syncthreads();
@@ -282,7 +290,7 @@ __global__ void k_fold_outliers(const int32_t* __restrict__ loc1, const int32_t*
                                 uint8_t* __restrict__ seen_twice, int64_t n, int res, int n_dist,
                                 const int16_t* __restrict__ slot_chr, const ChrGrid* __restrict__ grid,
                                 unsigned long long* __restrict__ out_hist, unsigned long long* __restrict__ n_out,
-                                unsigned long long* __restrict__ first_dup) {
+                                unsigned long long* __restrict__ first_dup, const long long* __restrict__ grow) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     unsigned long long mine = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -290,7 +298,7 @@ __global__ void k_fold_outliers(const int32_t* __restrict__ loc1, const int32_t*
         ++mine;
         if (skip[i]) {                             // duplicated line number in the reference's SortedList (A17)
             seen_twice[i] = 1;
-            atomicMin(first_dup, (unsigned long long)i);
+            atomicMin(first_dup, (unsigned long long)(grow ? grow[i] : i));
         }
         skip[i] = 1;
         const int l1 = loc1[i], l2 = loc2[i];
@@ -729,6 +737,7 @@ struct fhx_ctx {
     bool have_stats = false;
     std::vector<int64_t> h_hist_cc, h_hist_np, h_out_hist;
     int64_t n_outliers_total = 0;
+    long long* d_grow = nullptr;      // file position of every local row (shards, -p >= 3 only)
     int64_t skip_limit = INT64_MAX;   // row of the first duplicated outlier line: later rows are no longer skipped
     bool outlier_hist_nonempty = false;
     PassFit fit;
@@ -840,7 +849,7 @@ int build_slot_tables(fhx_ctx* ctx) {
 int ingest_device_rows(fhx_ctx* ctx, const int32_t* c1, const int32_t* m1, const int32_t* c2, const int32_t* m2,
                        const int32_t* cnt, int64_t n) {
     if (!ctx->have_params) return fail(ctx, FHX_ERR_ARG, "fhx_set_params must be called before fhx_load_pairs");
-    if (n <= 0) return fail(ctx, FHX_ERR_ARG, "no rows");
+    if (n < 0) return fail(ctx, FHX_ERR_ARG, "negative row count");
     if (n >= (1ll << 32)) return fail(ctx, FHX_ERR_UNSUPPORTED, "more than 2^32 rows per GPU: shard the contacts");
     const int res = (int)ctx->prm.resolution;
     int n_chr = std::max(ctx->n_chr, 1);
@@ -900,7 +909,7 @@ int ingest_device_rows(fhx_ctx* ctx, const int32_t* c1, const int32_t* m1, const
     FHX_HIP(hipMemcpyAsync(ctx->d_grid, ctx->grid.data(), ctx->grid.size() * sizeof(ChrGrid), hipMemcpyHostToDevice,
                            ctx->stream));
     // row arrays (padded to a multiple of 4 rows for the 16-byte loads)
-    const size_t cap = ((size_t)n + 3) / 4 * 4;
+    const size_t cap = std::max<size_t>(4, ((size_t)n + 3) / 4 * 4);
     dev_free(ctx->d_loc1);
     dev_free(ctx->d_loc2);
     dev_free(ctx->d_count);
@@ -909,6 +918,7 @@ int ingest_device_rows(fhx_ctx* ctx, const int32_t* c1, const int32_t* m1, const
     dev_free(ctx->d_seen_twice);
     dev_free(ctx->d_p);
     dev_free(ctx->d_q);
+    dev_free(ctx->d_grow);
     FHX_HIP(hipMalloc(&ctx->d_loc1, cap * sizeof(int32_t)));
     FHX_HIP(hipMalloc(&ctx->d_loc2, cap * sizeof(int32_t)));
     FHX_HIP(hipMalloc(&ctx->d_count, cap * sizeof(int32_t)));
@@ -1003,6 +1013,7 @@ void fhx_destroy(fhx_ctx* ctx) {
         dev_free(ctx->d_skip);
         dev_free(ctx->d_outlier);
         dev_free(ctx->d_seen_twice);
+        dev_free(ctx->d_grow);
         dev_free(ctx->d_hist_cc);
         dev_free(ctx->d_hist_np);
         dev_free(ctx->d_out_hist);
@@ -1089,7 +1100,7 @@ int fhx_load_bias(fhx_ctx* ctx, const int32_t* chr, const int32_t* mid, const do
 
 int fhx_load_pairs_device(fhx_ctx* ctx, const void* c1, const void* m1, const void* c2, const void* m2, const void* cnt,
                           int64_t n, void* stream) {
-    if (!ctx || !c1 || !m1 || !c2 || !m2 || !cnt) return FHX_ERR_ARG;
+    if (!ctx || n < 0 || (n > 0 && (!c1 || !m1 || !c2 || !m2 || !cnt))) return FHX_ERR_ARG;
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
     FHX_HIP(hipSetDevice(ctx->device));
     if (stream) FHX_HIP(hipStreamSynchronize((hipStream_t)stream));
@@ -1099,14 +1110,14 @@ int fhx_load_pairs_device(fhx_ctx* ctx, const void* c1, const void* m1, const vo
 
 int fhx_load_pairs(fhx_ctx* ctx, const int32_t* chr1, const int32_t* mid1, const int32_t* chr2, const int32_t* mid2,
                    const int32_t* count, int64_t n) {
-    if (!ctx || !chr1 || !mid1 || !chr2 || !mid2 || !count || n <= 0) return FHX_ERR_ARG;
+    if (!ctx || n < 0 || (n > 0 && (!chr1 || !mid1 || !chr2 || !mid2 || !count))) return FHX_ERR_ARG;
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context cannot hold contact rows");
     FHX_HIP(hipSetDevice(ctx->device));
     int32_t* d[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     const int32_t* h[5] = {chr1, mid1, chr2, mid2, count};
     for (int k = 0; k < 5; ++k) {
-        FHX_HIP(hipMalloc(&d[k], (size_t)n * sizeof(int32_t)));
-        FHX_HIP(hipMemcpyAsync(d[k], h[k], (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        FHX_HIP(hipMalloc(&d[k], (size_t)std::max<int64_t>(n, 1) * sizeof(int32_t)));      // an empty shard is legal
+        if (n) FHX_HIP(hipMemcpyAsync(d[k], h[k], (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     }
     FHX_HIP(hipStreamSynchronize(ctx->stream));
     const int rc = ingest_device_rows(ctx, d[0], d[1], d[2], d[3], d[4], n);
@@ -1117,7 +1128,7 @@ int fhx_load_pairs(fhx_ctx* ctx, const int32_t* chr1, const int32_t* mid1, const
 int fhx_pass_stats(fhx_ctx* ctx, fhx_stats* out) {
     if (!ctx) return FHX_ERR_ARG;
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
-    if (ctx->n_rows <= 0) return fail(ctx, FHX_ERR_ARG, "no contact rows loaded");
+    if (!ctx->d_loc1) return fail(ctx, FHX_ERR_ARG, "no contact rows loaded");
     FHX_HIP(hipSetDevice(ctx->device));
     const int64_t res = ctx->prm.resolution;
     const int64_t lo = (ctx->prm.dist_low + res - 1) / res;
@@ -1129,7 +1140,8 @@ int fhx_pass_stats(fhx_ctx* ctx, fhx_stats* out) {
     const size_t lds = (size_t)K1_LDS_BINS * (sizeof(unsigned long long) + sizeof(unsigned int));
     const int blocks = grid_for((ctx->n_rows + 3) / 4, K1_THREADS, 512);
     hipLaunchKernelGGL(k1_classify_hist, dim3(blocks), dim3(K1_THREADS), lds, ctx->stream, ctx->d_loc1, ctx->d_loc2,
-                       ctx->d_count, ctx->skip_active ? ctx->d_skip : (const uint8_t*)nullptr, ctx->skip_limit, ctx->n_rows,
+                       ctx->d_count, ctx->skip_active ? ctx->d_skip : (const uint8_t*)nullptr, ctx->skip_limit,
+                       (ctx->skip_limit != INT64_MAX) ? (const long long*)ctx->d_grow : (const long long*)nullptr, ctx->n_rows,
                        (int)std::min<int64_t>(lo, INT32_MAX), (int)hi, ctx->d_hist_cc, ctx->d_hist_np, ctx->d_sums);
     FHX_HIP(hipGetLastError());
     FHX_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
@@ -1325,7 +1337,7 @@ static int sort_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned lon
 
 static int bh_from_sorted(fhx_ctx* ctx, const unsigned long long* keys, const unsigned int* vals, int64_t n_rows,
                           const unsigned long long* counter, double n_total_tests, double* tile_max, double* d_q) {
-    const int tiles = (int)((n_rows + BH_TILE - 1) / BH_TILE);
+    const int tiles = (int)std::max<int64_t>(1, (n_rows + BH_TILE - 1) / BH_TILE);
     hipLaunchKernelGGL(bh_tile_max, dim3(tiles), dim3(BH_THREADS), 0, ctx->stream, keys, counter, (int64_t)0, n_total_tests,
                        0.0, tile_max);
     hipLaunchKernelGGL(bh_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, tile_max, counter, (int64_t)0, 0.0,
@@ -1508,11 +1520,12 @@ int fhx_sort_u64(fhx_ctx* ctx, const void* d_keys_in, int64_t n, void* d_keys_ou
 }
 
 int fhx_bh_scatter(fhx_ctx* ctx, const void* d_q_sorted_local) {
-    if (!ctx || !d_q_sorted_local) return FHX_ERR_ARG;
+    if (!ctx) return FHX_ERR_ARG;
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
     if (ctx->n_sorted == -1) return fail(ctx, FHX_ERR_ARG, "fhx_bh_local_sort must run first");
     FHX_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_scatter_q, dim3(grid_for(ctx->n_rows, 256)), dim3(256), 0, ctx->stream, ctx->d_vals[ctx->sorted_buf],
+    if (d_q_sorted_local)                       // NULL is legal when this rank holds no p < 1 at all
+        hipLaunchKernelGGL(k_scatter_q, dim3(grid_for(ctx->n_rows, 256)), dim3(256), 0, ctx->stream, ctx->d_vals[ctx->sorted_buf],
                        (const double*)d_q_sorted_local, ctx->d_misc, ctx->d_q);
     FHX_HIP(hipGetLastError());
     FHX_HIP(hipStreamSynchronize(ctx->stream));
@@ -1537,6 +1550,28 @@ int fhx_sync(fhx_ctx* ctx) {
     return FHX_OK;
 }
 
+int fhx_set_global_rows(fhx_ctx* ctx, const int64_t* rows, int64_t n) {
+    if (!ctx || n < 0 || (n > 0 && !rows)) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (n != ctx->n_rows) return fail(ctx, FHX_ERR_ARG, "one file position per loaded contact row is required");
+    FHX_HIP(hipSetDevice(ctx->device));
+    dev_free(ctx->d_grow);
+    const size_t cap = std::max<size_t>(4, ((size_t)n + 3) / 4 * 4);
+    FHX_HIP(hipMalloc(&ctx->d_grow, cap * sizeof(long long)));
+    FHX_HIP(hipMemsetAsync(ctx->d_grow, 0, cap * sizeof(long long), ctx->stream));
+    if (n) FHX_HIP(hipMemcpyAsync(ctx->d_grow, rows, (size_t)n * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    return FHX_OK;
+}
+
+int64_t fhx_get_skip_limit(fhx_ctx* ctx) { return ctx ? ctx->skip_limit : INT64_MAX; }
+
+int fhx_set_skip_limit(fhx_ctx* ctx, int64_t limit) {
+    if (!ctx) return FHX_ERR_ARG;
+    ctx->skip_limit = limit;
+    return FHX_OK;
+}
+
 int fhx_next_pass(fhx_ctx* ctx, int64_t* n_outliers_total) {
     if (!ctx) return FHX_ERR_ARG;
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
@@ -1548,7 +1583,7 @@ int fhx_next_pass(fhx_ctx* ctx, int64_t* n_outliers_total) {
     FHX_HIP(hipMemsetAsync(first_dup, 0xFF, sizeof(unsigned long long), ctx->stream));
     hipLaunchKernelGGL(k_fold_outliers, dim3(grid_for(ctx->n_rows, 256)), dim3(256), 0, ctx->stream, ctx->d_loc1, ctx->d_loc2,
                        ctx->d_outlier, ctx->d_skip, ctx->d_seen_twice, ctx->n_rows, (int)ctx->prm.resolution, (int)ctx->n_dist,
-                       ctx->d_slot_chr, ctx->d_grid, ctx->d_out_hist, n_out, first_dup);
+                       ctx->d_slot_chr, ctx->d_grid, ctx->d_out_hist, n_out, first_dup, (const long long*)ctx->d_grow);
     FHX_HIP(hipGetLastError());
     unsigned long long added = 0, dup = ~0ull;
     FHX_HIP(hipMemcpyAsync(&dup, first_dup, sizeof(dup), hipMemcpyDeviceToHost, ctx->stream));
@@ -1594,7 +1629,7 @@ int fhx_fetch(fhx_ctx* ctx, double* p, double* q, double* expcc, double* bias1, 
 int fhx_fetch_flags(fhx_ctx* ctx, uint8_t* outlier, uint8_t* skip) {
     if (!ctx) return FHX_ERR_ARG;
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
-    if (ctx->n_rows <= 0) return fail(ctx, FHX_ERR_ARG, "no contact rows loaded");
+    if (!ctx->d_loc1) return fail(ctx, FHX_ERR_ARG, "no contact rows loaded");
     if (outlier && !ctx->have_p) return fail(ctx, FHX_ERR_ARG, "no p-values yet");
     FHX_HIP(hipSetDevice(ctx->device));
     if (outlier) FHX_HIP(hipMemcpyAsync(outlier, ctx->d_outlier, (size_t)ctx->n_rows, hipMemcpyDeviceToHost, ctx->stream));

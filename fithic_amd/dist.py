@@ -25,9 +25,13 @@ SAMPLES_PER_RANK = 1024
 class Comm:
     """Thin wrapper over torch.distributed for tensors on `device`."""
 
-    def __init__(self, td, device):
+    def __init__(self, td, device, compute_device=None):
+        """`device`: where the collectives run (cuda for RCCL, cpu for gloo); `compute_device`: where LocalOps keeps
+        its tensors (defaults to `device`; a cuda compute device with a cpu/gloo transport stages through host memory,
+        which lets two ranks share one GPU in the tests)."""
         import torch
         self.td, self.torch, self.device = td, torch, device
+        self.compute_device = compute_device if compute_device is not None else device
         self.rank, self.world = td.get_rank(), td.get_world_size()
 
     def barrier(self):
@@ -39,9 +43,10 @@ class Comm:
         return t.cpu().numpy()
 
     def all_gather_i64(self, t):
+        t = t.to(self.device)
         out = [self.torch.empty_like(t) for _ in range(self.world)]
         self.td.all_gather(out, t)
-        return out
+        return [o.to(self.compute_device) for o in out]
 
     def all_gather_f64_scalar(self, v):
         t = self.torch.tensor([float(v)], dtype=self.torch.float64, device=self.device)
@@ -56,9 +61,10 @@ class Comm:
         rc = torch.empty_like(sc)
         self.td.all_to_all_single(rc, sc)
         recv_counts = [int(v) for v in rc.cpu().tolist()]
+        send = send.to(self.device).contiguous()
         recv = torch.empty(sum(recv_counts), dtype=send.dtype, device=self.device)
         self.td.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=[int(v) for v in send_counts])
-        return recv, recv_counts
+        return recv.to(self.compute_device), recv_counts
 
     def max_float(self, v):
         return max(self.all_gather_f64_scalar(v))
@@ -112,10 +118,7 @@ class LocalOps:
         return q, mx
 
     def scatter_q(self, q_sorted_local):
-        if q_sorted_local.numel():
-            self.ctx.bh_scatter(q_sorted_local.data_ptr())
-        else:
-            self.ctx.sync()
+        self.ctx.bh_scatter(q_sorted_local.data_ptr() if q_sorted_local.numel() else 0)
 
     def next_pass_local(self):
         from . import _capi
@@ -124,6 +127,12 @@ class LocalOps:
 
     def set_outlier_hist(self, hist):
         self.ctx.set_outlier_dist_hist(hist)
+
+    def get_skip_limit(self):
+        return self.ctx.get_skip_limit()
+
+    def set_skip_limit(self, limit):
+        self.ctx.set_skip_limit(limit)
 
 
 def choose_splitters(torch, samples_sorted, world):
@@ -161,7 +170,7 @@ def distributed_bh(comm, ops, n_tests):
     # my slice of the global order: sort the received runs, remember where each element came from
     mine_sorted, perm = ops.sort_keys(recv)
     m = mine_sorted.numel()
-    counts = [int(t.item()) for t in comm.all_gather_i64(torch.tensor([m], dtype=torch.int64, device=keys.device))]
+    counts = [int(t.item()) for t in comm.all_gather_i64(torch.tensor([m], dtype=torch.int64))]
     rank0 = sum(counts[:comm.rank])
     _, seg_max = ops.bh_segment(mine_sorted, rank0, 0.0, n_tests, want_q=False)
     maxima = comm.all_gather_f64_scalar(seg_max)
@@ -182,7 +191,7 @@ class DistributedPass:
 
     def __init__(self, engine, comm, ops=None):
         self.comm = comm
-        self.ops = ops if ops is not None else LocalOps(engine, comm.torch, comm.device)
+        self.ops = ops if ops is not None else LocalOps(engine, comm.torch, comm.compute_device)
         self.n_dist_global = None
         self.info = None
         self.stats = None
@@ -216,4 +225,7 @@ class DistributedPass:
         buf = np.zeros(nd, np.int64)
         buf[:len(hist)] = hist
         self.ops.set_outlier_hist(self.comm.all_reduce_i64(buf))
+        # first duplicated outlier LINE of the whole file (-p >= 3 semantics): min over ranks, in file positions
+        limit = -int(self.comm.all_reduce_i64(np.array([-min(self.ops.get_skip_limit(), (1 << 62))]), op="max")[0])
+        self.ops.set_skip_limit(limit if limit < (1 << 62) else (1 << 63) - 1)
         return self.comm.sum_int(n_local)

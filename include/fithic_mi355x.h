@@ -153,6 +153,14 @@ int fhx_fit(fhx_ctx* ctx, fhx_fit_info* out);                           /* host;
 int fhx_pvalues(fhx_ctx* ctx);                                          /* K2 (asynchronous) */
 int fhx_bh(fhx_ctx* ctx, double n_total_tests);                         /* K3 (asynchronous) */
 int fhx_sync(fhx_ctx* ctx);
+/* Sharded runs with -p >= 3 only.  The reference stops skipping outlier lines after the first line number that
+ * is an outlier in two passes (fithic/fithic.py:408-412 on a SortedList with duplicates); that is a
+ * statement about positions in the ONE input file, so a shard must know its rows' file positions
+ * (fhx_set_global_rows, ascending not required) and the ranks must agree on the limit (min over ranks of
+ * fhx_get_skip_limit, handed back with fhx_set_skip_limit; INT64_MAX = no duplicate yet). */
+int fhx_set_global_rows(fhx_ctx* ctx, const int64_t* file_row_of_local_row, int64_t n);
+int64_t fhx_get_skip_limit(fhx_ctx* ctx);
+int fhx_set_skip_limit(fhx_ctx* ctx, int64_t limit);
 int fhx_next_pass(fhx_ctx* ctx, int64_t* n_outliers_total);             /* fold this pass's outliers in */
 
 /* ---- results ------------------------------------------------------------------------------------ */

@@ -1,0 +1,194 @@
+"""world_size-2 test of the multi-GPU exchange logic (fithic_amd/dist.py) on CPU tensors over gloo.
+
+The per-GPU compute of a distributed pass goes through `LocalOps`; here it is replaced by a checker-backed
+implementation (oracle + numpy) so that what is exercised is exactly the product's exchange code: the packed
+all-reduce of sums + distance histograms, the replicated host fit (the product's C++ host pass through a host-only
+context), the sample-sort all-to-all of the BH keys, the rank offsets, the running-max carry and the way back.
+Result: every rank's q-values equal the single-process reference values (golden fixture) bit for bit.
+"""
+import os
+import sys
+import socket
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, passes, result_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as td
+    from conftest import load_case, case_args
+    from fithic_amd import dist, _capi, tables
+    from fithic_amd.engine import MODES
+    from oracle import fithic_oracle as fo
+
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    comm = dist.Comm(td, torch.device("cpu"))
+    meta, g = load_case(case)
+    kw = case_args(meta)
+    kw["passes"] = passes
+    res = kw["resolution"]
+    pairs = fo.read_contacts_file(kw["contacts"])
+    ref = fo.run(pairs, kw["frags"], kw["bias_path"], res, kw["n_bins"], passes, kw["mode"], kw["L"], kw["U"], kw["mapp_thres"],
+                 kw["tL"], kw["tU"])
+    # shard rows by the chromosome of the first locus (round-robin over chromosome ids)
+    mine = np.flatnonzero(pairs.chr1 % world == rank)
+    local = fo.Pairs(pairs.chr1[mine], pairs.mid1[mine], pairs.chr2[mine], pairs.mid2[mine], pairs.count[mine], pairs.names)
+    chroms = tables.ChromIndex()
+    frag_tab = tables.read_fragments(kw["frags"], chroms)
+    host = _capi.Context(-1)                  # the product's host stages, no GPU needed
+    host.set_params(res, kw["L"], kw["U"], kw["n_bins"], kw["mapp_thres"], MODES[kw["mode"]], kw["tL"], kw["tU"])
+    host.load_fragments(*frag_tab, chroms.sort_rank())
+
+    class CheckerOps:
+        """LocalOps with the compute done by the oracle / numpy (test double)."""
+
+        def __init__(self):
+            self.pass_idx = 0
+            self.skip = np.zeros(len(local), bool)
+            self.q = None
+            self.out_hist = None
+            self.n_out = 0
+
+        def local_stats(self):
+            keys, sumcc, icnt, isum, intra_all, rng_sum = fo.read_interactions(local, kw["L"], kw["U"], self.skip if self.pass_idx else None)
+            n_dist = int(max(np.abs(local.mid1 - local.mid2).max() // res + 2, 2))
+            hcc = np.zeros(n_dist, np.int64)
+            hnp = np.zeros(n_dist, np.int64)
+            d = np.abs(local.mid1 - local.mid2)
+            keep = ~self.skip if self.pass_idx else np.ones(len(local), bool)
+            m = keep & (local.chr1 == local.chr2) & (d >= kw["L"]) & (d <= kw["U"])
+            np.add.at(hcc, d[m] // res, local.count[m])
+            np.add.at(hnp, d[m] // res, 1)
+            st = _capi.FhxStats()
+            st.n_rows, st.inter_count, st.inter_sum, st.intra_all_sum, st.in_range_sum = len(local), icnt, isum, intra_all, rng_sum
+            st.in_range_count = int(m.sum())
+            st.max_count = int(local.count.max())
+            return st, hcc, hnp
+
+        def set_global_and_fit(self, st, hist_cc, hist_np):
+            self.global_sums = (st.inter_count, st.inter_sum, st.intra_all_sum, st.in_range_sum)
+            host.set_global_stats(st, hist_cc, hist_np)
+            if self.out_hist is not None:
+                host.set_outlier_dist_hist(self.out_hist)
+            return host.fit()
+
+        def pvalues(self):
+            self.p = ref[self.pass_idx].p[mine]          # reference p of my rows (K2 itself is covered by the GPU tests)
+
+        def local_sorted_keys(self):
+            keep = self.p < 1.0
+            self.rows = np.flatnonzero(keep)
+            bits = self.p[keep].view(np.int64)
+            order = np.argsort(bits, kind="stable")
+            self.rows = self.rows[order]
+            self.q = np.where(np.isnan(self.p), np.nan, 1.0)
+            return torch.from_numpy(bits[order].copy())
+
+        def sort_keys(self, keys):
+            k = keys.numpy()
+            order = np.argsort(k, kind="stable")
+            return torch.from_numpy(k[order].copy()), torch.from_numpy(order.astype(np.int32))
+
+        def bh_segment(self, sorted_keys, rank0, carry, n_tests, want_q):
+            pv = sorted_keys.numpy().view(np.float64)
+            rank_ = rank0 + np.arange(1, len(pv) + 1, dtype=np.float64)
+            bh = pv * float(n_tests) / rank_
+            bh = np.where(bh > 1.0, 1.0, bh)
+            run = np.maximum.accumulate(np.concatenate([[carry], bh]))[1:] if len(bh) else bh
+            mx = float(run[-1]) if len(run) else float(carry)
+            return (torch.from_numpy(run.copy()) if want_q else None), mx
+
+        def scatter_q(self, q_sorted_local):
+            self.q[self.rows] = q_sorted_local.numpy()
+
+        def next_pass_local(self):
+            r = ref[self.pass_idx]
+            thr = r.outlier_thres
+            with np.errstate(invalid="ignore"):
+                out = self.p < thr
+            self.skip |= out
+            d = np.abs(local.mid1 - local.mid2)[out]
+            n_dist = int(max(np.abs(local.mid1 - local.mid2).max() // res + 2, 2))
+            if self.out_hist_local is None:
+                self.out_hist_local = np.zeros(n_dist, np.int64)
+            np.add.at(self.out_hist_local, -(-d // res), 1)
+            self.n_out += int(out.sum())
+            self.pass_idx += 1
+            return self.n_out, self.out_hist_local
+
+        out_hist_local = None
+
+        def set_outlier_hist(self, hist):
+            self.out_hist = np.asarray(hist, np.int64)
+
+        def get_skip_limit(self):
+            return (1 << 63) - 1
+
+        def set_skip_limit(self, limit):
+            pass
+
+    ops = CheckerOps()
+    runner = dist.DistributedPass(None, comm, ops=ops)
+    ok = True
+    msgs = []
+    for pi in range(passes):
+        info = runner.run()
+        r = ref[pi]
+        if tuple(ops.global_sums) != tuple(r.sums):
+            ok = False
+            msgs.append("sums differ pass %d: %s vs %s" % (pi, ops.global_sums, r.sums))
+        if info.bh_total_tests != r.N:
+            ok = False
+            msgs.append("N differs")
+        want = r.q[mine]
+        same = (ops.q.view(np.int64) == want.view(np.int64)) | (np.isnan(ops.q) & np.isnan(want))
+        if not same.all():
+            ok = False
+            msgs.append("q differs on %d of %d rows in pass %d" % ((~same).sum(), len(same), pi))
+        if pi + 1 < passes:
+            total = runner.next_pass()
+            if total != r.n_outlier_lines_total:
+                ok = False
+                msgs.append("outlier count %d vs %d" % (total, r.n_outlier_lines_total))
+    with open(os.path.join(result_dir, "rank%d.txt" % rank), "w") as f:
+        f.write("OK" if ok else "FAIL: " + "; ".join(msgs))
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize("case,passes", [("f2_all", 2), ("f6_quirk_all", 2), ("f2_inter", 1)])
+def test_distributed_pass_world2_gloo(case, passes, tmp_path):
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, case, passes, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        with open(os.path.join(str(tmp_path), "rank%d.txt" % r)) as f:
+            assert f.read() == "OK"
+
+
+def test_splitters_and_chromosome_assignment():
+    torch = pytest.importorskip("torch")
+    from fithic_amd import dist, synth
+    s = torch.arange(0, 1000, dtype=torch.int64)
+    sp = dist.choose_splitters(torch, s, 4)
+    assert sp.tolist() == [250, 500, 750]
+    assert dist.choose_splitters(torch, s[:0], 4).numel() == 0
+    g = synth.Genome(5000)
+    owner = synth.assign_chromosomes(g, 8)
+    load = [sum(g.n_loci[c] for c in range(len(g)) if owner[c] == r) for r in range(8)]
+    assert len(set(owner)) == 8 and max(load) / (sum(load) / 8) < 1.15          # greedy balance within 15 %
