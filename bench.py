@@ -59,7 +59,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     comm = None
-    if world > 1:
+    if world > 1 or os.environ.get("FHX_FORCE_DIST"):      # FHX_FORCE_DIST=1: run the RCCL path with a single rank
         import torch.distributed as td
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         td.init_process_group("nccl", device_id=device)          # nccl == RCCL on ROCm
