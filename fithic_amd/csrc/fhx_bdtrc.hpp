@@ -159,9 +159,11 @@ __device__ __forceinline__ double contfrac(double a, double b, double x) {
 // branch classes of one incbet evaluation (used to run branch-homogeneous waves)
 enum BranchClass : int {
     BC_TRIVIAL = 0,        // NaN / 0 / 1 / closed form k == 0: no loop at all
-    BC_PSERIES = 1,        // power series (either orientation)
-    BC_CF_SHORT = 2,       // incbcf / incbd, not swapped: converges in ~8 iterations
-    BC_CF_SWAPPED = 3      // swapped continued fraction: runs to (or near) the 300 cap
+    BC_PSERIES = 1,        // power series (either orientation): ~15 iterations
+    BC_CF_BCF = 2,         // incbcf, not swapped: converges in ~9 iterations
+    BC_CF_BD = 3,          // incbd (either orientation): converges in ~9 iterations
+    BC_CF_SWAPPED = 4,     // swapped incbcf ("observed < expected"): runs to (or near) the 300 cap
+    BC_COUNT = 5
 };
 
 // incbet(aa, bb, xx) with aa = count, bb = n - count + 1 and the two table values for that count
@@ -226,7 +228,7 @@ __device__ __forceinline__ double bdtrc_count(int count, const BinomTables& T, d
     return incbet(fk + 1.0, dn, p, T.lbeta[count], T.small_n ? T.inv_beta[count] : 0.0);
 }
 
-// cheap classification of which loop bdtrc_count(count, T, p) will run
+// cheap classification of which loop bdtrc_count(count, T, p) will run (same predicates as incbet, same rounding)
 __device__ __forceinline__ int bdtrc_class(int count, double n_total, double p) {
     if (isnan(p)) return BC_TRIVIAL;
     const double fk = (double)count - 1.0;
@@ -235,11 +237,17 @@ __device__ __forceinline__ int bdtrc_class(int count, double n_total, double p) 
     if (xx <= 0.0 || xx >= 1.0) return BC_TRIVIAL;
     if (bb * xx <= 1.0 && xx <= 0.95) return BC_PSERIES;
     const double w = 1.0 - xx;
+    double a, b, x;
+    bool swapped;
     if (xx > aa / (aa + bb)) {
-        if (aa * w <= 1.0 && w <= 0.95) return BC_PSERIES;
-        return BC_CF_SWAPPED;
+        swapped = true; a = bb; b = aa; x = w;
+        if (b * x <= 1.0 && x <= 0.95) return BC_PSERIES;
+    } else {
+        swapped = false; a = aa; b = bb; x = xx;
     }
-    return BC_CF_SHORT;
+    const double y = x * (a + b - 2.0) - (a - 1.0);
+    if (y < 0.0) return swapped ? BC_CF_SWAPPED : BC_CF_BCF;
+    return BC_CF_BD;
 }
 
 }  // namespace dev

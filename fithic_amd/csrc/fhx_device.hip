@@ -245,13 +245,91 @@ __device__ __forceinline__ bool row_prior(const K2Params& P, int l1, int l2, dou
 
 constexpr int K2_THREADS = 256;
 
-__global__ __launch_bounds__(K2_THREADS) void k2_pvalue(K2Params P) {
+// K2 runs as one classification launch plus one launch per branch class so that waves are branch-homogeneous
+// (SURVEY appendix C / F): the iteration count of Cephes' incbet is multi-modal - none for the closed form, ~15 for the
+// power series, ~9 for the converging continued fractions and (practically always) the full 300 for the swapped
+// continued fraction ("observed < expected").  k2_classify finishes the loop-free class in place and appends every
+// other row to the queue of its class (wave-aggregated: one atomic per wave and class); k2_queue then runs one
+// class at a time with every lane on the same code path and nearly the same trip count.
+constexpr int K2_QUEUES = dev::BC_COUNT - 1;        // classes 1..4
+
+struct K2Queues {
+    unsigned int* rows[K2_QUEUES];
+    unsigned long long* count;                      // K2_QUEUES counters
+};
+
+constexpr int K2_CL_ITEMS = 8;
+constexpr int K2_CL_TILE = K2_THREADS * K2_CL_ITEMS;     // 2048 rows per workgroup step
+constexpr int K2_COUNT_STRIDE = 16;                      // queue counters 128 B apart: one L2 line each
+
+__global__ __launch_bounds__(K2_THREADS) void k2_classify(K2Params P, K2Queues Q) {
+    // rows of one tile are staged per class in LDS (wave-aggregated LDS atomics), then each class takes ONE global
+    // atomic per tile and is flushed with coalesced stores: a same-address global atomic per wave would cap the
+    // kernel at ~88 M atomics/s (MI355X_MICROARCH.md "dequeue"), i.e. slower than the arithmetic it feeds.
+    __shared__ unsigned int stage[K2_QUEUES][K2_CL_TILE];
+    __shared__ unsigned int cnt[K2_QUEUES];
+    __shared__ unsigned long long gbase[K2_QUEUES];
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    const int64_t tiles = (P.n + K2_CL_TILE - 1) / K2_CL_TILE;
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        if (threadIdx.x < K2_QUEUES) cnt[threadIdx.x] = 0;
+        __syncthreads();
+#pragma unroll 1
+        for (int r = 0; r < K2_CL_ITEMS; ++r) {
+            const int64_t i = t * K2_CL_TILE + r * K2_THREADS + threadIdx.x;
+            int cls = -1;                                              // -1: no row, 0: done here, 1..4: queued
+            if (i < P.n) {
+                const int l1 = P.loc1[i], l2 = P.loc2[i], c = P.count[i];
+                double prior = 1.0, pv = 1.0;
+                bool is_inter = false;
+                cls = 0;
+                if (row_prior(P, l1, l2, prior, is_inter)) {
+                    const dev::BinomTables& T = is_inter ? P.inter : P.intra;
+                    cls = dev::bdtrc_class(c, T.n, prior);
+                    if (cls == dev::BC_TRIVIAL) pv = dev::bdtrc_count(c, T, prior);
+                }
+                if (cls == 0) {
+                    P.p[i] = pv;
+                    P.outlier[i] = (pv < P.outlier_thres) ? 1 : 0;
+                }
+            }
+#pragma unroll
+            for (int k = 1; k <= K2_QUEUES; ++k) {
+                const unsigned long long m = __ballot(cls == k);
+                if (m) {
+                    unsigned int base = 0;
+                    if (lane == 0) base = atomicAdd(&cnt[k - 1], (unsigned int)__popcll(m));
+                    base = __shfl(base, 0, 64);
+                    if (cls == k) stage[k - 1][base + __popcll(m & lane_lt)] = (unsigned int)i;
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < K2_QUEUES)
+            gbase[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&Q.count[threadIdx.x * K2_COUNT_STRIDE], (unsigned long long)cnt[threadIdx.x]) : 0ull;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K2_QUEUES; ++k) {
+            const unsigned int c = cnt[k];
+            const unsigned long long b = gbase[k];
+            for (unsigned int j = threadIdx.x; j < c; j += K2_THREADS) Q.rows[k][b + j] = stage[k][j];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(K2_THREADS) void k2_queue(K2Params P, const unsigned int* __restrict__ rows,
+                                                       const unsigned long long* __restrict__ count) {
+    const int64_t n = (int64_t)*count;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += stride) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const int64_t i = rows[j];
         const int l1 = P.loc1[i], l2 = P.loc2[i], c = P.count[i];
-        double prior = 1.0, pv = 1.0;
+        double prior = 1.0;
         bool is_inter = false;
-        if (row_prior(P, l1, l2, prior, is_inter)) pv = dev::bdtrc_count(c, is_inter ? P.inter : P.intra, prior);
+        row_prior(P, l1, l2, prior, is_inter);
+        const double pv = dev::bdtrc_count(c, is_inter ? P.inter : P.intra, prior);
         P.p[i] = pv;
         P.outlier[i] = (pv < P.outlier_thres) ? 1 : 0;
     }
@@ -941,7 +1019,7 @@ int ingest_device_rows(fhx_ctx* ctx, const int32_t* c1, const int32_t* m1, const
     FHX_HIP(hipMalloc(&ctx->d_out_hist, n_dist * sizeof(unsigned long long)));
     FHX_HIP(hipMemsetAsync(ctx->d_out_hist, 0, n_dist * sizeof(unsigned long long), ctx->stream));
     if (!ctx->d_sums) FHX_HIP(hipMalloc(&ctx->d_sums, sizeof(K1Sums)));
-    if (!ctx->d_misc) FHX_HIP(hipMalloc(&ctx->d_misc, 64 * sizeof(unsigned long long)));
+    if (!ctx->d_misc) FHX_HIP(hipMalloc(&ctx->d_misc, 128 * sizeof(unsigned long long)));
     // sort workspace
     for (int b = 0; b < 2; ++b) {
         dev_free(ctx->d_keys[b]);
@@ -1304,7 +1382,18 @@ int fhx_pvalues(fhx_ctx* ctx) {
     }
     const K2Params P = make_k2_params(ctx);
     FHX_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
-    hipLaunchKernelGGL(k2_pvalue, dim3(grid_for(ctx->n_rows, K2_THREADS, 256 * 16)), dim3(K2_THREADS), 0, ctx->stream, P);
+    // queues live in the sort workspace, which is idle until K3: 2 x u32[n] + 2 x u64[n]
+    K2Queues Q;
+    Q.rows[0] = ctx->d_vals[0];
+    Q.rows[1] = ctx->d_vals[1];
+    Q.rows[2] = reinterpret_cast<unsigned int*>(ctx->d_keys[0]);
+    Q.rows[3] = reinterpret_cast<unsigned int*>(ctx->d_keys[1]);
+    Q.count = ctx->d_misc + 64;
+    FHX_HIP(hipMemsetAsync(Q.count, 0, K2_QUEUES * K2_COUNT_STRIDE * sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(k2_classify, dim3(grid_for(ctx->n_rows, K2_CL_TILE, 256 * 8)), dim3(K2_THREADS), 0, ctx->stream, P, Q);
+    for (int k = K2_QUEUES - 1; k >= 0; --k)          // longest-running class first
+        hipLaunchKernelGGL(k2_queue, dim3(256 * 8), dim3(K2_THREADS), 0, ctx->stream, P, (const unsigned int*)Q.rows[k],
+                           (const unsigned long long*)(Q.count + k * K2_COUNT_STRIDE));
     FHX_HIP(hipGetLastError());
     FHX_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
     ctx->ev_valid[1] = true;
@@ -1351,7 +1440,7 @@ static int bh_from_sorted(fhx_ctx* ctx, const unsigned long long* keys, const un
 static int ensure_sort_scratch(fhx_ctx* ctx) {
     if (!ctx->d_block_hist) FHX_HIP(hipMalloc(&ctx->d_block_hist, (size_t)RADIX * SORT_BLOCKS * sizeof(unsigned int)));
     if (!ctx->d_digit_total) FHX_HIP(hipMalloc(&ctx->d_digit_total, RADIX * sizeof(unsigned int)));
-    if (!ctx->d_misc) FHX_HIP(hipMalloc(&ctx->d_misc, 64 * sizeof(unsigned long long)));
+    if (!ctx->d_misc) FHX_HIP(hipMalloc(&ctx->d_misc, 128 * sizeof(unsigned long long)));
     return FHX_OK;
 }
 
