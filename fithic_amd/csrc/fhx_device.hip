@@ -406,8 +406,9 @@ constexpr int SORT_WAVES = SORT_THREADS / 64;
 constexpr int SORT_ITEMS = 16;                        // per thread
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 4096 keys per tile
 constexpr int SORT_BLOCKS = 1024;                     // persistent: 4 workgroups per CU
-constexpr int RADIX_BITS = 8;
+constexpr int RADIX_BITS = 11;                       // 6 passes cover 66 >= 64 key bits
 constexpr int RADIX = 1 << RADIX_BITS;
+constexpr int SORT_PASSES = 6;                        // even: the result lands in the buffer pair it started in
 
 // compaction: keys of the rows with p < 1 (IEEE bit pattern: all such p are >= 0, so unsigned order is
 // numeric order); rows with p == 1 get q = 1 and NaN rows get q = NaN right here.
@@ -415,22 +416,34 @@ __global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restr
                                                            unsigned long long* __restrict__ keys,
                                                            unsigned int* __restrict__ vals, double* __restrict__ q,
                                                            unsigned long long* __restrict__ counter) {
+    // one global atomic per 4096-row tile (a same-address atomic per 256 rows capped this kernel at ~88 M atomics/s)
     __shared__ unsigned int wave_cnt[SORT_WAVES];
     __shared__ unsigned long long block_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t tiles = (n + SORT_THREADS - 1) / SORT_THREADS;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    const int64_t tiles = (n + SORT_TILE - 1) / SORT_TILE;
     for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
-        const int64_t i = t * SORT_THREADS + threadIdx.x;
-        double v = 1.0;
-        bool keep = false;
-        if (i < n) {
-            v = p[i];
-            keep = v < 1.0;                         // false for NaN
-            if (!keep) q[i] = (v == v) ? 1.0 : v;
+        const int64_t wave_base = t * SORT_TILE + (int64_t)wave * (64 * SORT_ITEMS);
+        double v[SORT_ITEMS];
+        unsigned int before[SORT_ITEMS];
+        unsigned long long keepmask = 0;          // bit r: this lane keeps item r
+        unsigned int run = 0;
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            const int64_t i = wave_base + r * 64 + lane;
+            bool keep = false;
+            v[r] = 1.0;
+            if (i < n) {
+                v[r] = p[i];
+                keep = v[r] < 1.0;                  // false for NaN
+                if (!keep) q[i] = (v[r] == v[r]) ? 1.0 : v[r];
+            }
+            const unsigned long long m = __ballot(keep);
+            before[r] = run + __popcll(m & lane_lt);
+            run += __popcll(m);
+            if (keep) keepmask |= (1ull << r);
         }
-        const unsigned long long m = __ballot(keep);
-        const unsigned int before = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        if (lane == 0) wave_cnt[wave] = run;
         __syncthreads();
         if (threadIdx.x == 0) {
             unsigned int tot = 0;
@@ -442,12 +455,15 @@ __global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restr
             block_base = tot ? atomicAdd(counter, (unsigned long long)tot) : 0ull;
         }
         __syncthreads();
-        if (keep) {
-            const unsigned long long pos = block_base + wave_cnt[wave] + before;
-            unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-            if (bits == 0x8000000000000000ull) bits = 0ull;       // -0.0 sorts with +0.0
-            keys[pos] = bits;
-            vals[pos] = (unsigned int)i;
+        const unsigned long long base = block_base + wave_cnt[wave];
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            if ((keepmask >> r) & 1ull) {
+                unsigned long long bits = (unsigned long long)__double_as_longlong(v[r]);
+                if (bits == 0x8000000000000000ull) bits = 0ull;       // -0.0 sorts with +0.0
+                keys[base + before[r]] = bits;
+                vals[base + before[r]] = (unsigned int)(wave_base + r * 64 + lane);
+            }
         }
         __syncthreads();
     }
@@ -461,12 +477,20 @@ __global__ __launch_bounds__(SORT_THREADS) void rs_count(const unsigned long lon
     const int64_t n = (int64_t)*n_ptr;
     const int64_t chunk = ((n + SORT_BLOCKS - 1) / SORT_BLOCKS + SORT_TILE - 1) / SORT_TILE * SORT_TILE;
     const int64_t beg = (int64_t)blockIdx.x * chunk, end = min(n, beg + chunk);
-    h[threadIdx.x] = 0;
+    for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) h[d] = 0;
     __syncthreads();
-    for (int64_t i = beg + threadIdx.x; i < end; i += SORT_THREADS)
-        atomicAdd(&h[(keys[i] >> shift) & (RADIX - 1)], 1u);
+    // two keys per lane per step (16-byte loads); chunk starts are multiples of SORT_TILE, so they are aligned
+    const int64_t len = end > beg ? end - beg : 0;           // workgroups past the end own nothing
+    const int64_t n2 = len >> 1;
+    const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(keys + beg);
+    for (int64_t i = threadIdx.x; i < n2; i += SORT_THREADS) {
+        const ulonglong2 k = k2[i];
+        atomicAdd(&h[(k.x >> shift) & (RADIX - 1)], 1u);
+        atomicAdd(&h[(k.y >> shift) & (RADIX - 1)], 1u);
+    }
+    if (threadIdx.x == 0 && (len & 1)) atomicAdd(&h[(keys[end - 1] >> shift) & (RADIX - 1)], 1u);
     __syncthreads();
-    block_hist[(size_t)threadIdx.x * SORT_BLOCKS + blockIdx.x] = h[threadIdx.x];      // digit-major
+    for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) block_hist[(size_t)d * SORT_BLOCKS + blockIdx.x] = h[d];   // digit-major
 }
 
 // exclusive scan of the digit-major (RADIX x SORT_BLOCKS) count matrix along the workgroup axis: one
@@ -499,29 +523,39 @@ __global__ __launch_bounds__(SORT_BLOCKS) void rs_scan(unsigned int* __restrict_
     row[threadIdx.x] = wsum[wave] + incl - mine;
 }
 
-// 256-entry exclusive scan held in LDS, done by the first wave (4 entries per lane)
-__device__ __forceinline__ void lds_exclusive_scan_256(unsigned int* a, int lane) {
-    unsigned int v0 = a[lane * 4], v1 = a[lane * 4 + 1], v2 = a[lane * 4 + 2], v3 = a[lane * 4 + 3];
-    const unsigned int mine = v0 + v1 + v2 + v3;
+// RADIX-entry exclusive scan held in LDS by the whole workgroup (RADIX / SORT_THREADS consecutive entries per thread);
+// returns the total through *total_out (LDS) when given
+__device__ __forceinline__ void block_exclusive_scan_radix(unsigned int* a, unsigned int* wave_tmp) {
+    constexpr int PER = RADIX / SORT_THREADS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned int v[PER];
+    unsigned int mine = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        v[k] = a[threadIdx.x * PER + k];
+        mine += v[k];
+    }
     unsigned int incl = mine;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const unsigned int o = __shfl_up(incl, off, 64);
         if (lane >= off) incl += o;
     }
+    if (lane == 63) wave_tmp[wave] = incl;
+    __syncthreads();
     unsigned int excl = incl - mine;
-    a[lane * 4] = excl;
-    excl += v0;
-    a[lane * 4 + 1] = excl;
-    excl += v1;
-    a[lane * 4 + 2] = excl;
-    excl += v2;
-    a[lane * 4 + 3] = excl;
+    for (int w = 0; w < wave; ++w) excl += wave_tmp[w];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        a[threadIdx.x * PER + k] = excl;
+        excl += v[k];
+    }
+    __syncthreads();
 }
 
 // stable scatter of one radix pass.  Each wave owns a contiguous sub-range of the tile and ranks its keys
-// with wave-private LDS digit counters (no atomics: one leader lane per distinct digit); the tile is then
-// reordered through LDS so that the global writes of equal-digit runs are contiguous.
+// with wave-private LDS digit counters (no atomics: one leader lane per distinct digit, found with RADIX_BITS+1
+// ballots); the tile is then reordered through LDS so that the global writes of equal-digit runs are contiguous.
 __global__ __launch_bounds__(SORT_THREADS) void rs_scatter(const unsigned long long* __restrict__ keys_in,
                                                            const unsigned int* __restrict__ vals_in,
                                                            unsigned long long* __restrict__ keys_out,
@@ -529,28 +563,34 @@ __global__ __launch_bounds__(SORT_THREADS) void rs_scatter(const unsigned long l
                                                            const unsigned long long* __restrict__ n_ptr, int shift,
                                                            const unsigned int* __restrict__ block_hist,
                                                            const unsigned int* __restrict__ digit_total) {
-    __shared__ unsigned int wave_digit[SORT_WAVES][RADIX];     // per-wave digit counts -> exclusive offsets
+    __shared__ unsigned short wave_digit[SORT_WAVES][RADIX];   // per-wave digit counts (<= 1024) -> exclusive offsets
     __shared__ unsigned int tile_start[RADIX];                 // first tile-local slot of each digit
     __shared__ unsigned int global_base[RADIX];                // running global offset of each digit
+    __shared__ unsigned int wave_tmp[SORT_WAVES];
     __shared__ unsigned long long s_keys[SORT_TILE];
     __shared__ unsigned int s_vals[SORT_TILE];
+    constexpr int PER = RADIX / SORT_THREADS;
     const int64_t n = (int64_t)*n_ptr;
     const int64_t chunk = ((n + SORT_BLOCKS - 1) / SORT_BLOCKS + SORT_TILE - 1) / SORT_TILE * SORT_TILE;
     const int64_t beg = (int64_t)blockIdx.x * chunk, end = min(n, beg + chunk);
+    if (beg >= end) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
-    tile_start[threadIdx.x] = digit_total[threadIdx.x];
+    for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) tile_start[d] = digit_total[d];
     __syncthreads();
-    if (threadIdx.x < 64) lds_exclusive_scan_256(tile_start, lane);
-    __syncthreads();
-    global_base[threadIdx.x] = tile_start[threadIdx.x] + block_hist[(size_t)threadIdx.x * SORT_BLOCKS + blockIdx.x];
+    block_exclusive_scan_radix(tile_start, wave_tmp);
+    for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS)
+        global_base[d] = tile_start[d] + block_hist[(size_t)d * SORT_BLOCKS + blockIdx.x];
     __syncthreads();
     for (int64_t tile = beg; tile < end; tile += SORT_TILE) {
-        for (int w = 0; w < SORT_WAVES; ++w) wave_digit[w][threadIdx.x] = 0;
+        for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) {
+#pragma unroll
+            for (int w = 0; w < SORT_WAVES; ++w) wave_digit[w][d] = 0;
+        }
         __syncthreads();
         unsigned long long key[SORT_ITEMS];
         unsigned int val[SORT_ITEMS];
-        unsigned int rank[SORT_ITEMS];
+        unsigned short rank[SORT_ITEMS];
         const int64_t wave_base = tile + (int64_t)wave * (64 * SORT_ITEMS);
 #pragma unroll
         for (int r = 0; r < SORT_ITEMS; ++r) {
@@ -558,8 +598,12 @@ __global__ __launch_bounds__(SORT_THREADS) void rs_scatter(const unsigned long l
             const bool live = i < end;
             key[r] = live ? keys_in[i] : ~0ull;
             val[r] = live ? vals_in[i] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            const bool live = (wave_base + r * 64 + lane) < end;
             const unsigned int digit = (unsigned int)(key[r] >> shift) & (RADIX - 1);
-            // lanes holding the same digit (dead lanes form their own group through bit 8)
+            // lanes holding the same digit (dead lanes form their own group through the extra bit)
             unsigned long long same = ~0ull;
             const unsigned int tag = digit | (live ? 0u : RADIX);
 #pragma unroll
@@ -569,28 +613,26 @@ __global__ __launch_bounds__(SORT_THREADS) void rs_scatter(const unsigned long l
             }
             const unsigned int before = __popcll(same & lane_lt);
             unsigned int old = 0;
-            if (live) {
-                old = wave_digit[wave][digit];      // every lane of the group reads the same counter ...
-            }
-            rank[r] = old + before;
+            if (live) old = wave_digit[wave][digit];          // every lane of the group reads the same counter ...
+            rank[r] = (unsigned short)(old + before);
             __builtin_amdgcn_wave_barrier();
-            if (live && before == 0) wave_digit[wave][digit] = old + __popcll(same);   // ... its leader bumps it
+            if (live && before == 0) wave_digit[wave][digit] = (unsigned short)(old + __popcll(same));   // ... its leader bumps it
             __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
-        // exclusive offsets: per digit across waves, then across digits (one digit per thread)
-        {
+        // exclusive offsets: per digit across waves, then across digits
+        for (int d = threadIdx.x * PER; d < (threadIdx.x + 1) * PER; ++d) {
             unsigned int acc = 0;
+#pragma unroll
             for (int w = 0; w < SORT_WAVES; ++w) {
-                const unsigned int c = wave_digit[w][threadIdx.x];
-                wave_digit[w][threadIdx.x] = acc;
+                const unsigned int c = wave_digit[w][d];
+                wave_digit[w][d] = (unsigned short)acc;
                 acc += c;
             }
-            tile_start[threadIdx.x] = acc;          // digit total for now
+            tile_start[d] = acc;                              // digit total for now
         }
         __syncthreads();
-        if (threadIdx.x < 64) lds_exclusive_scan_256(tile_start, lane);
-        __syncthreads();
+        block_exclusive_scan_radix(tile_start, wave_tmp);
         const int live_in_tile = (int)min<int64_t>(SORT_TILE, end - tile);
 #pragma unroll
         for (int r = 0; r < SORT_ITEMS; ++r) {
@@ -612,9 +654,9 @@ __global__ __launch_bounds__(SORT_THREADS) void rs_scatter(const unsigned long l
         }
         __syncthreads();
         // advance the running global offsets by this tile's digit totals
-        {
-            const unsigned int nxt = (threadIdx.x + 1 < RADIX) ? tile_start[threadIdx.x + 1] : (unsigned int)live_in_tile;
-            global_base[threadIdx.x] += nxt - tile_start[threadIdx.x];
+        for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) {
+            const unsigned int nxt = (d + 1 < RADIX) ? tile_start[d + 1] : (unsigned int)live_in_tile;
+            global_base[d] += nxt - tile_start[d];
         }
         __syncthreads();
     }
@@ -1407,11 +1449,12 @@ int fhx_pvalues(fhx_ctx* ctx) {
 static int sort_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned long long* keys[2], unsigned int* vals[2],
                         double* d_q, unsigned long long* counter, int* sorted_buf) {
     FHX_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL(k3_compact, dim3(grid_for(n, SORT_THREADS, 256 * 8)), dim3(SORT_THREADS), 0, ctx->stream, d_p, n,
+    hipLaunchKernelGGL(k3_compact, dim3(grid_for(n, SORT_TILE, 256 * 8)), dim3(SORT_THREADS), 0, ctx->stream, d_p, n,
                        keys[0], vals[0], d_q, counter);
     int src = 0;
     // p < 1 means the IEEE exponent field is <= 1022: bits 62 and 63 are always clear, 62 bits to sort
-    for (int shift = 0; shift < 64; shift += RADIX_BITS) {
+    for (int pass = 0; pass < SORT_PASSES; ++pass) {
+        const int shift = pass * RADIX_BITS;
         hipLaunchKernelGGL(rs_count, dim3(SORT_BLOCKS), dim3(SORT_THREADS), 0, ctx->stream, keys[src], counter, shift,
                            ctx->d_block_hist);
         hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3(SORT_BLOCKS), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total);
@@ -1589,11 +1632,12 @@ int fhx_sort_u64(fhx_ctx* ctx, const void* d_keys_in, int64_t n, void* d_keys_ou
     unsigned long long* counter = ctx->d_misc + 3;
     const unsigned long long n_host = (unsigned long long)n;
     FHX_HIP(hipMemcpyAsync(counter, &n_host, sizeof(n_host), hipMemcpyHostToDevice, ctx->stream));
-    // 8 passes ping-pong: start in the caller's output pair so that the result lands there
+    // an even number of ping-pong passes: start in the caller's output pair so that the result lands there
     FHX_HIP(hipMemcpyAsync(keys[1], d_keys_in, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, vals[1], n);
     int src = 1;
-    for (int shift = 0; shift < 64; shift += RADIX_BITS) {
+    for (int pass = 0; pass < SORT_PASSES; ++pass) {
+        const int shift = pass * RADIX_BITS;
         hipLaunchKernelGGL(rs_count, dim3(SORT_BLOCKS), dim3(SORT_THREADS), 0, ctx->stream, keys[src], counter, shift,
                            ctx->d_block_hist);
         hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3(SORT_BLOCKS), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total);
@@ -1605,7 +1649,7 @@ int fhx_sort_u64(fhx_ctx* ctx, const void* d_keys_in, int64_t n, void* d_keys_ou
     FHX_HIP(hipStreamSynchronize(ctx->stream));
     dev_free(keys[0]);
     dev_free(vals[0]);
-    return FHX_OK;                                   // 8 passes: even number of swaps, result is in pair [1]
+    return FHX_OK;                                   // even number of swaps: the result is in pair [1]
 }
 
 int fhx_bh_scatter(fhx_ctx* ctx, const void* d_q_sorted_local) {

@@ -86,6 +86,20 @@ def test_bh_large_random_bit_exact_vs_oracle(ctx):
     assert bits_equal(q, fo.benjamini_hochberg(p, 7.5e9))
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 255, 4095, 4096, 4097, 8191, 12289, 100001, 1048577])
+def test_bh_ragged_sizes_bit_exact(ctx, n):
+    """Tile / chunk boundaries of the compaction, radix sort and scan kernels (ragged tails, odd lengths)."""
+    from oracle import fithic_oracle as fo
+    rng = np.random.default_rng(n)
+    p = rng.uniform(0, 1, n) ** rng.integers(1, 30, n)
+    p[rng.integers(0, n, max(1, n // 7))] = 1.0
+    if n > 10:
+        p[rng.integers(0, n, 3)] = np.nan
+    assert bits_equal(ctx.bh_array(p, 3.0 * n + 1), fo.benjamini_hochberg(p, 3.0 * n + 1))
+    allone = np.ones(n)
+    assert bits_equal(ctx.bh_array(allone, 5.0), allone)          # nothing to sort at all
+
+
 def _run_case(name, device=0):
     from fithic_amd import tables
     from fithic_amd.engine import Engine
