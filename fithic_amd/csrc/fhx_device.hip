@@ -289,10 +289,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_classify(K2Params P, K2Queues Q
                     cls = dev::bdtrc_class(c, T.n, prior);
                     if (cls == dev::BC_TRIVIAL) pv = dev::bdtrc_count(c, T, prior);
                 }
-                if (cls == 0) {
-                    P.p[i] = pv;
-                    P.outlier[i] = (pv < P.outlier_thres) ? 1 : 0;
-                }
+                if (cls == 0) P.p[i] = pv;
             }
 #pragma unroll
             for (int k = 1; k <= K2_QUEUES; ++k) {
@@ -319,6 +316,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_classify(K2Params P, K2Queues Q
     }
 }
 
+template <int CLS>
 __global__ __launch_bounds__(K2_THREADS) void k2_queue(K2Params P, const unsigned int* __restrict__ rows,
                                                        const unsigned long long* __restrict__ count) {
     const int64_t n = (int64_t)*count;
@@ -329,10 +327,14 @@ __global__ __launch_bounds__(K2_THREADS) void k2_queue(K2Params P, const unsigne
         double prior = 1.0;
         bool is_inter = false;
         row_prior(P, l1, l2, prior, is_inter);
-        const double pv = dev::bdtrc_count(c, is_inter ? P.inter : P.intra, prior);
-        P.p[i] = pv;
-        P.outlier[i] = (pv < P.outlier_thres) ? 1 : 0;
+        P.p[i] = dev::bdtrc_count_class<CLS>(c, is_inter ? P.inter : P.intra, prior);
     }
+}
+
+// outlier flags (p < 1/N, fithic.py:1215) are derived from p when somebody asks: K2 never writes per-row bytes
+__global__ void k_outlier_flags(const double* __restrict__ p, double thres, int64_t n, uint8_t* __restrict__ flags) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) flags[i] = (p[i] < thres) ? 1 : 0;
 }
 
 __global__ void k_bdtrc_array(dev::BinomTables T, const int32_t* __restrict__ count, const double* __restrict__ prior,
@@ -340,6 +342,14 @@ __global__ void k_bdtrc_array(dev::BinomTables T, const int32_t* __restrict__ co
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
         out[i] = dev::bdtrc_count(count[i], T, prior[i]);
+}
+
+template <int KIND, int LAZY>
+__global__ void k_debug_contfrac(const double* __restrict__ a, const double* __restrict__ b, const double* __restrict__ x,
+                                 int64_t n, double* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = LAZY ? dev::contfrac_lazy<KIND>(a[i], b[i], x[i]) : dev::contfrac<KIND>(a[i], b[i], x[i]);
 }
 
 // expected contact count and the two biases, recomputed on demand for the writer (fithic.py:1075-1078, :1105-1108)
@@ -364,7 +374,7 @@ __global__ void k2_extras(K2Params P, double bias_low, double bias_up, double* _
 
 // outlier bookkeeping for the next pass: skip mask |= outlier, and the multiset of outlier distances
 __global__ void k_fold_outliers(const int32_t* __restrict__ loc1, const int32_t* __restrict__ loc2,
-                                const uint8_t* __restrict__ outlier, uint8_t* __restrict__ skip,
+                                const double* __restrict__ pvals, double thres, uint8_t* __restrict__ skip,
                                 uint8_t* __restrict__ seen_twice, int64_t n, int res, int n_dist,
                                 const int16_t* __restrict__ slot_chr, const ChrGrid* __restrict__ grid,
                                 unsigned long long* __restrict__ out_hist, unsigned long long* __restrict__ n_out,
@@ -372,7 +382,7 @@ __global__ void k_fold_outliers(const int32_t* __restrict__ loc1, const int32_t*
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     unsigned long long mine = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        if (!outlier[i]) continue;
+        if (!(pvals[i] < thres)) continue;             // NaN is not an outlier (p_val < outlierThres is False)
         ++mine;
         if (skip[i]) {                             // duplicated line number in the reference's SortedList (A17)
             seen_twice[i] = 1;
@@ -1433,9 +1443,15 @@ int fhx_pvalues(fhx_ctx* ctx) {
     Q.count = ctx->d_misc + 64;
     FHX_HIP(hipMemsetAsync(Q.count, 0, K2_QUEUES * K2_COUNT_STRIDE * sizeof(unsigned long long), ctx->stream));
     hipLaunchKernelGGL(k2_classify, dim3(grid_for(ctx->n_rows, K2_CL_TILE, 256 * 8)), dim3(K2_THREADS), 0, ctx->stream, P, Q);
-    for (int k = K2_QUEUES - 1; k >= 0; --k)          // longest-running class first
-        hipLaunchKernelGGL(k2_queue, dim3(256 * 8), dim3(K2_THREADS), 0, ctx->stream, P, (const unsigned int*)Q.rows[k],
-                           (const unsigned long long*)(Q.count + k * K2_COUNT_STRIDE));
+    const dim3 qgrid(256 * 8), qblock(K2_THREADS);
+#define FHX_LAUNCH_QUEUE(CLS)                                                                                          \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue<CLS>), qgrid, qblock, 0, ctx->stream, P,                               \
+                       (const unsigned int*)Q.rows[(CLS) - 1], (const unsigned long long*)(Q.count + ((CLS) - 1) * K2_COUNT_STRIDE))
+    FHX_LAUNCH_QUEUE(dev::BC_CF_SWAPPED);            // longest-running class first
+    FHX_LAUNCH_QUEUE(dev::BC_CF_BD);
+    FHX_LAUNCH_QUEUE(dev::BC_CF_BCF);
+    FHX_LAUNCH_QUEUE(dev::BC_PSERIES);
+#undef FHX_LAUNCH_QUEUE
     FHX_HIP(hipGetLastError());
     FHX_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
     ctx->ev_valid[1] = true;
@@ -1528,6 +1544,29 @@ int fhx_bdtrc_array(fhx_ctx* ctx, double n_total, const int32_t* count, const do
     dev_free(d_prior);
     dev_free(d_out);
     dev_free(d_count);
+    return FHX_OK;
+}
+
+int fhx_debug_contfrac(fhx_ctx* ctx, int kind, int lazy, const double* a, const double* b, const double* x, int64_t n,
+                       double* out) {
+    if (!ctx || !a || !b || !x || !out || n < 0 || kind < 0 || kind > 1) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (n == 0) return FHX_OK;
+    FHX_HIP(hipSetDevice(ctx->device));
+    double* d[4] = {nullptr, nullptr, nullptr, nullptr};
+    const double* h[3] = {a, b, x};
+    const size_t bytes = (size_t)n * sizeof(double);
+    for (int k = 0; k < 4; ++k) FHX_HIP(hipMalloc(&d[k], bytes));
+    for (int k = 0; k < 3; ++k) FHX_HIP(hipMemcpyAsync(d[k], h[k], bytes, hipMemcpyHostToDevice, ctx->stream));
+    const dim3 g(grid_for(n, 256)), t(256);
+    if (kind == 0 && !lazy) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_debug_contfrac<0, 0>), g, t, 0, ctx->stream, d[0], d[1], d[2], n, d[3]);
+    if (kind == 0 && lazy) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_debug_contfrac<0, 1>), g, t, 0, ctx->stream, d[0], d[1], d[2], n, d[3]);
+    if (kind == 1 && !lazy) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_debug_contfrac<1, 0>), g, t, 0, ctx->stream, d[0], d[1], d[2], n, d[3]);
+    if (kind == 1 && lazy) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_debug_contfrac<1, 1>), g, t, 0, ctx->stream, d[0], d[1], d[2], n, d[3]);
+    FHX_HIP(hipGetLastError());
+    FHX_HIP(hipMemcpyAsync(out, d[3], bytes, hipMemcpyDeviceToHost, ctx->stream));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 4; ++k) dev_free(d[k]);
     return FHX_OK;
 }
 
@@ -1715,7 +1754,7 @@ int fhx_next_pass(fhx_ctx* ctx, int64_t* n_outliers_total) {
     FHX_HIP(hipMemsetAsync(n_out, 0, sizeof(unsigned long long), ctx->stream));
     FHX_HIP(hipMemsetAsync(first_dup, 0xFF, sizeof(unsigned long long), ctx->stream));
     hipLaunchKernelGGL(k_fold_outliers, dim3(grid_for(ctx->n_rows, 256)), dim3(256), 0, ctx->stream, ctx->d_loc1, ctx->d_loc2,
-                       ctx->d_outlier, ctx->d_skip, ctx->d_seen_twice, ctx->n_rows, (int)ctx->prm.resolution, (int)ctx->n_dist,
+                       ctx->d_p, 1.0 / ctx->fit.bh_total_tests, ctx->d_skip, ctx->d_seen_twice, ctx->n_rows, (int)ctx->prm.resolution, (int)ctx->n_dist,
                        ctx->d_slot_chr, ctx->d_grid, ctx->d_out_hist, n_out, first_dup, (const long long*)ctx->d_grow);
     FHX_HIP(hipGetLastError());
     unsigned long long added = 0, dup = ~0ull;
@@ -1765,6 +1804,11 @@ int fhx_fetch_flags(fhx_ctx* ctx, uint8_t* outlier, uint8_t* skip) {
     if (!ctx->d_loc1) return fail(ctx, FHX_ERR_ARG, "no contact rows loaded");
     if (outlier && !ctx->have_p) return fail(ctx, FHX_ERR_ARG, "no p-values yet");
     FHX_HIP(hipSetDevice(ctx->device));
+    if (outlier) {
+        hipLaunchKernelGGL(k_outlier_flags, dim3(grid_for(ctx->n_rows, 256)), dim3(256), 0, ctx->stream, ctx->d_p,
+                           1.0 / ctx->fit.bh_total_tests, ctx->n_rows, ctx->d_outlier);
+        FHX_HIP(hipGetLastError());
+    }
     if (outlier) FHX_HIP(hipMemcpyAsync(outlier, ctx->d_outlier, (size_t)ctx->n_rows, hipMemcpyDeviceToHost, ctx->stream));
     if (skip) FHX_HIP(hipMemcpyAsync(skip, ctx->d_skip, (size_t)ctx->n_rows, hipMemcpyDeviceToHost, ctx->stream));
     FHX_HIP(hipStreamSynchronize(ctx->stream));

@@ -184,6 +184,12 @@ int fhx_bh_array(fhx_ctx* ctx, const double* p, int64_t n, double n_total_tests,
  * reference uses, fithic/fithic.py:1070,1101); host arrays in and out.  Known-answer testing of K2's arithmetic. */
 int fhx_bdtrc_array(fhx_ctx* ctx, double n_total, const int32_t* count, const double* prior, int64_t n, double* out);
 
+/* Test hook: the raw Cephes continued fraction (kind 0 = incbcf, 1 = incbd) of K2 evaluated element-wise on the GPU,
+ * either with Cephes' literal convergence test (lazy = 0) or with the division-free test K2 uses (lazy = 1); the two
+ * must agree bit for bit.  Host arrays in and out. */
+int fhx_debug_contfrac(fhx_ctx* ctx, int kind, int lazy, const double* a, const double* b, const double* x, int64_t n,
+                       double* out);
+
 /* ---- distributed BH building blocks (section 8e): local sort, then rank/scan over a global segment -- */
 int fhx_bh_local_sort(fhx_ctx* ctx);                 /* compact p < 1, radix sort (key, row) on this GPU */
 int fhx_bh_apply_sorted(fhx_ctx* ctx, const void* d_sorted_keys, int64_t n, int64_t global_rank0,

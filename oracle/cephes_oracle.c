@@ -488,6 +488,12 @@ void fho_bdtrc_vec_stats(const double *k, const double *n, const double *p, doub
     }
 }
 
+void fho_contfrac_vec(int which, const double *a, const double *b, const double *x, double *out, int64_t len)
+{
+    for (int64_t i = 0; i < len; ++i)
+        out[i] = continued_fraction(a[i], b[i], x[i], which);
+}
+
 void fho_lbeta_vec(const double *a, const double *b, double *out, int64_t len)
 {
     for (int64_t i = 0; i < len; ++i)

@@ -82,6 +82,14 @@ def bdtrc_stats(k, n, p):
     return out, br, it
 
 
+def contfrac(which, a, b, x):
+    """Cephes incbcf (which = 0) / incbd (which = 1) element-wise."""
+    a, b, x = (np.ascontiguousarray(v, np.float64) for v in (a, b, x))
+    out = np.empty(a.shape, np.float64)
+    _lib().fho_contfrac_vec(ctypes.c_int(which), _dptr(a), _dptr(b), _dptr(x), _dptr(out), ctypes.c_int64(a.size))
+    return out
+
+
 def lbeta(a, b):
     a = np.ascontiguousarray(a, np.float64)
     b = np.ascontiguousarray(b, np.float64)

@@ -7,8 +7,10 @@ import sys
 
 
 def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"<\(fhx::dev::BranchClass\)(\d+)>", r"<class \1>", name)   # k2_queue<class 1..4>: pseries, bcf, bd, swapped
     name = re.sub(r"\(.*", "", name)                       # drop the argument list
-    name = re.sub(r"<.*", "<...>", name)
+    name = re.sub(r"<(?!class).*", "<...>", name)
     return name[-70:]
 
 

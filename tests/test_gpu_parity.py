@@ -66,6 +66,30 @@ def test_bdtrc_against_oracle_random(ctx):
         assert max_abs_diff(out, ref) <= TOL, nt
 
 
+@pytest.mark.parametrize("kind", [0, 1])
+def test_continued_fraction_bit_exact(ctx, kind):
+    """The raw Cephes continued fractions on the GPU - literal test and division-free test - against the oracle's C,
+    bit for bit (this is the part of bdtrc whose truncated, non-converged value is the answer: SURVEY fact 4)."""
+    from oracle import fithic_oracle as fo
+    rng = np.random.default_rng(100 + kind)
+    n = 60000
+    ntot = rng.choice([3.0e5, 6.495767e6, 2.2294127e7, 1.5e9], n)
+    cnt = rng.geometric(0.1, n).astype(np.float64) + 1
+    ratio = np.exp(rng.normal(0.3 if kind == 0 else -0.2, 0.8, n))
+    prior = np.clip(cnt * ratio / ntot, 1e-12, 0.6)
+    swapped = rng.random(n) < 0.6
+    a = np.where(swapped, ntot - cnt + 1, cnt)
+    b = np.where(swapped, cnt, ntot - cnt + 1)
+    x = np.where(swapped, 1.0 - prior, prior)
+    # a few degenerate inputs: tiny / huge ratios, x = 0
+    a[:5], b[:5], x[:5] = [1, 2, 5, 1e7, 3], [1, 1, 2, 2, 1e7], [0.0, 0.5, 1e-300, 0.999999, 1e-9]
+    ref = fo.contfrac(kind, a, b, x)
+    plain = ctx.debug_contfrac(kind, 0, a, b, x)
+    lazy = ctx.debug_contfrac(kind, 1, a, b, x)
+    assert bits_equal(plain, ref)
+    assert bits_equal(lazy, ref)
+
+
 def test_bh_known_answers_on_gpu(ctx):
     g = np.load(os.path.join(GOLDEN, "f5_bh.npz"))
     for name in g["names"]:
