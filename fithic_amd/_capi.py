@@ -87,6 +87,7 @@ SYMBOLS = {
     "fhx_kernel_seconds": (ctypes.c_int, [_P, _F64P, _F64P, _F64P]),
     "fhx_bdtrc_array": (ctypes.c_int, [_P, ctypes.c_double, _I32P, _F64P, ctypes.c_int64, _F64P]),
     "fhx_debug_contfrac": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _F64P, _F64P, _F64P, ctypes.c_int64, _F64P]),
+    "fhx_debug_lean_div": (ctypes.c_int, [_P, _F64P, _F64P, ctypes.c_int64, _F64P]),
     "fhx_bh_array": (ctypes.c_int, [_P, _F64P, ctypes.c_int64, ctypes.c_double, _F64P]),
     "fhx_bh_local_sort": (ctypes.c_int, [_P]),
     "fhx_bh_apply_sorted": (ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, ctypes.c_double, _P, _F64P]),
@@ -293,6 +294,12 @@ class Context:
         out = np.empty(len(a), np.float64)
         self._check(self._L.fhx_debug_contfrac(self._h, int(kind), int(lazy), _ptr(a, ctypes.c_double), _ptr(b, ctypes.c_double),
                                                _ptr(x, ctypes.c_double), len(a), _ptr(out, ctypes.c_double)))
+        return out
+
+    def debug_lean_div(self, n, d):
+        n, d = (np.ascontiguousarray(v, np.float64) for v in (n, d))
+        out = np.empty(len(n), np.float64)
+        self._check(self._L.fhx_debug_lean_div(self._h, _ptr(n, ctypes.c_double), _ptr(d, ctypes.c_double), len(n), _ptr(out, ctypes.c_double)))
         return out
 
     def bh_array(self, p, n_total_tests):

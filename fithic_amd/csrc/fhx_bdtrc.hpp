@@ -166,30 +166,50 @@ __device__ __forceinline__ double contfrac(double a, double b, double x) {
 // inconclusive (and on every unusual input: zero / tiny / huge pk or qk) the pending quotient is materialised with a
 // real IEEE division and Cephes' statements run literally.  On Hi-C data the swapped fraction sits on a rounding-noise
 // plateau of t ~ 1e-11 for all 300 iterations, so ~99.9 % of iterations take the cheap path.
-template <int KIND>
-__device__ __forceinline__ double contfrac_lazy(double a, double b, double x) {
-    double k1, k2, k3, k4, k5, k6, k7, k8, arg;
+// IEEE-754 division for operands that cannot overflow / underflow on the way: the reciprocal refinement and the final
+// residual correction that hipcc's own expansion of `/` performs (v_rcp_f64, two Newton steps, quotient, one fused
+// residual step), without the v_div_scale / v_div_fmas / v_div_fixup scaffolding that only matters for extreme
+// exponents and non-finite inputs.  Bit-identical to `n / d` for finite d with 1e-200 < |d| < 1e200 and |n| = 0 or in the
+// same window (checked on 10^8 random operand pairs by tests/test_gpu_parity.py::test_lean_division_matches_ieee);
+// the sign of a zero quotient may differ, which no caller below can observe.
+__device__ __forceinline__ double lean_div(double n, double d) {
+    const double y0 = __builtin_amdgcn_rcp(d);
+    const double e0 = __builtin_fma(-d, y0, 1.0);
+    const double y1 = __builtin_fma(y0, e0, y0);
+    const double e1 = __builtin_fma(-d, y1, 1.0);
+    const double y2 = __builtin_fma(y1, e1, y1);
+    const double q0 = n * y2;
+    const double r0 = __builtin_fma(-d, q0, n);
+    return __builtin_fma(r0, y2, q0);
+}
+
+template <bool LEAN>
+__device__ __forceinline__ double cf_div(double n, double d) {
+    return LEAN ? lean_div(n, d) : n / d;
+}
+
+template <int KIND, bool LEAN>
+__device__ __forceinline__ double contfrac_lazy_impl(double a, double b, double arg) {
+    double k1, k2, k3, k4, k5, k6, k8;
     if (KIND == 0) {
-        arg = x;
-        k1 = a; k2 = a + b; k3 = a; k4 = a + 1.0; k5 = 1.0; k6 = b - 1.0; k7 = k4; k8 = a + 2.0;
+        k1 = a; k2 = a + b; k3 = a; k4 = a + 1.0; k5 = 1.0; k6 = b - 1.0; k8 = a + 2.0;
     } else {
-        arg = x / (1.0 - x);
-        k1 = a; k2 = b - 1.0; k3 = a; k4 = a + 1.0; k5 = 1.0; k6 = a + b; k7 = a + 1.0; k8 = a + 2.0;
+        k1 = a; k2 = b - 1.0; k3 = a; k4 = a + 1.0; k5 = 1.0; k6 = a + b; k8 = a + 2.0;
     }
+    // k7 == k4 in both fractions (a + 1 + 2n): one variable serves both
     double pkm2 = 0.0, qkm2 = 1.0, pkm1 = 1.0, qkm1 = 1.0;
-    double ans = 1.0, r = 1.0;          // Cephes' variables, valid when !pending
-    double rp = 1.0, rq = 1.0;          // pending: ans == r == rp/rq, division not performed yet
-    bool pending = false;
-    bool fast_ok = true;                // invariant "ans == r" (broken only if some r was exactly 0)
+    double rp = 1.0, rq = 1.0;          // Cephes' ans (== r while fast_ok) as an unevaluated ratio; exact when rq == 1
+    double ans = 1.0, r = 1.0;          // only used once the invariant ans == r is broken (some r was exactly 0)
+    bool fast_ok = true;
     const double thresh = 3.0 * kMachEp;
     int n = 0;
     do {
-        double xk = -(arg * k1 * k2) / (k3 * k4);
+        double xk = -cf_div<LEAN>(arg * k1 * k2, k3 * k4);
         double pk = pkm1 + pkm2 * xk;
         double qk = qkm1 + qkm2 * xk;
         pkm2 = pkm1; pkm1 = pk; qkm2 = qkm1; qkm1 = qk;
 
-        xk = (arg * k5 * k6) / (k7 * k8);
+        xk = cf_div<LEAN>(arg * k5 * k6, k4 * k8);
         pk = pkm1 + pkm2 * xk;
         qk = qkm1 + qkm2 * xk;
         pkm2 = pkm1; pkm1 = pk; qkm2 = qkm1; qkm1 = qk;
@@ -199,20 +219,18 @@ __device__ __forceinline__ double contfrac_lazy(double a, double b, double x) {
         const double mag_min = fmin(apk, aqk);
         bool exact = true;
         if (fast_ok && mag_min > 1e-100 && mag_sum < 1e100) {
-            const double c1 = (pending ? rp : ans) * qk;
-            const double c2 = pk * (pending ? rq : 1.0);
+            const double c1 = rp * qk;
+            const double c2 = pk * rq;
             if (fabs(c1 - c2) > 1e-13 * fabs(c2)) {        // certainly t > thresh: Cephes would set ans = r = pk/qk and go on
                 rp = pk;
                 rq = qk;
-                pending = true;
                 exact = false;
             }
         }
         if (exact) {
-            if (pending) {
-                ans = rp / rq;
+            if (fast_ok) {
+                ans = rp / rq;                               // materialise the pending quotient (x / 1.0 is exact)
                 r = ans;
-                pending = false;
             }
             double t;
             if (qk != 0) r = pk / qk;
@@ -223,6 +241,8 @@ __device__ __forceinline__ double contfrac_lazy(double a, double b, double x) {
                 t = 1.0;
             }
             if (ans != r) fast_ok = false;
+            rp = ans;
+            rq = 1.0;
             if (t < thresh) break;
         }
 
@@ -232,7 +252,6 @@ __device__ __forceinline__ double contfrac_lazy(double a, double b, double x) {
         k4 += 2.0;
         k5 += 1.0;
         k6 += (KIND == 0) ? -1.0 : 1.0;
-        k7 += 2.0;
         k8 += 2.0;
 
         if (mag_sum > kBig) {
@@ -242,8 +261,17 @@ __device__ __forceinline__ double contfrac_lazy(double a, double b, double x) {
             pkm2 *= kBig; pkm1 *= kBig; qkm2 *= kBig; qkm1 *= kBig;
         }
     } while (++n < 300);
-    if (pending) ans = rp / rq;
-    return ans;
+    return fast_ok ? rp / rq : ans;
+}
+
+template <int KIND>
+__device__ __forceinline__ double contfrac_lazy(double a, double b, double x) {
+    const double arg = (KIND == 0) ? x : x / (1.0 - x);
+    // operand window of lean_div: denominators are (a+2n)(a+2n+1) with 1 <= a < 2^53 (exact integers), numerators are
+    // arg * k * k' with |k k'| < 1e20, so |arg| in [1e-150, 1e150] keeps every operand inside [1e-200, 1e200] or exactly 0
+    const double aa = fabs(arg);
+    if (aa > 1e-150 && aa < 1e150 && a >= 1.0 && a < 4.5e15 && b < 4.5e15) return contfrac_lazy_impl<KIND, true>(a, b, arg);
+    return contfrac_lazy_impl<KIND, false>(a, b, arg);
 }
 
 // branch classes of one incbet evaluation (used to run branch-homogeneous waves)

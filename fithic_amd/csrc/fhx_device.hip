@@ -352,6 +352,11 @@ __global__ void k_debug_contfrac(const double* __restrict__ a, const double* __r
         out[i] = LAZY ? dev::contfrac_lazy<KIND>(a[i], b[i], x[i]) : dev::contfrac<KIND>(a[i], b[i], x[i]);
 }
 
+__global__ void k_debug_lean_div(const double* __restrict__ n, const double* __restrict__ d, int64_t len, double* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) out[i] = dev::lean_div(n[i], d[i]);
+}
+
 // expected contact count and the two biases, recomputed on demand for the writer (fithic.py:1075-1078, :1105-1108)
 __global__ void k2_extras(K2Params P, double bias_low, double bias_up, double* __restrict__ expcc,
                           double* __restrict__ ob1, double* __restrict__ ob2) {
@@ -1567,6 +1572,24 @@ int fhx_debug_contfrac(fhx_ctx* ctx, int kind, int lazy, const double* a, const 
     FHX_HIP(hipMemcpyAsync(out, d[3], bytes, hipMemcpyDeviceToHost, ctx->stream));
     FHX_HIP(hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < 4; ++k) dev_free(d[k]);
+    return FHX_OK;
+}
+
+int fhx_debug_lean_div(fhx_ctx* ctx, const double* n, const double* d, int64_t len, double* out) {
+    if (!ctx || !n || !d || !out || len < 0) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (len == 0) return FHX_OK;
+    FHX_HIP(hipSetDevice(ctx->device));
+    double* dv[3] = {nullptr, nullptr, nullptr};
+    const size_t bytes = (size_t)len * sizeof(double);
+    for (int k = 0; k < 3; ++k) FHX_HIP(hipMalloc(&dv[k], bytes));
+    FHX_HIP(hipMemcpyAsync(dv[0], n, bytes, hipMemcpyHostToDevice, ctx->stream));
+    FHX_HIP(hipMemcpyAsync(dv[1], d, bytes, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_debug_lean_div, dim3(grid_for(len, 256)), dim3(256), 0, ctx->stream, dv[0], dv[1], len, dv[2]);
+    FHX_HIP(hipGetLastError());
+    FHX_HIP(hipMemcpyAsync(out, dv[2], bytes, hipMemcpyDeviceToHost, ctx->stream));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 3; ++k) dev_free(dv[k]);
     return FHX_OK;
 }
 

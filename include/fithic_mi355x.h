@@ -190,6 +190,9 @@ int fhx_bdtrc_array(fhx_ctx* ctx, double n_total, const int32_t* count, const do
 int fhx_debug_contfrac(fhx_ctx* ctx, int kind, int lazy, const double* a, const double* b, const double* x, int64_t n,
                        double* out);
 
+/* Test hook: out[i] = K2's lean division of n[i] / d[i] (must equal IEEE n/d inside the operand window it is used in). */
+int fhx_debug_lean_div(fhx_ctx* ctx, const double* n, const double* d, int64_t len, double* out);
+
 /* ---- distributed BH building blocks (section 8e): local sort, then rank/scan over a global segment -- */
 int fhx_bh_local_sort(fhx_ctx* ctx);                 /* compact p < 1, radix sort (key, row) on this GPU */
 int fhx_bh_apply_sorted(fhx_ctx* ctx, const void* d_sorted_keys, int64_t n, int64_t global_rank0,

@@ -90,6 +90,31 @@ def test_continued_fraction_bit_exact(ctx, kind):
     assert bits_equal(lazy, ref)
 
 
+def test_lean_division_matches_ieee(ctx):
+    """K2 divides with the core of hipcc's own f64 division expansion (no scaling scaffolding): must equal IEEE n/d
+    bit for bit on the operand window it is used in - numerators 0 or arg*k*k', denominators (a+2n)(a+2n+1)."""
+    rng = np.random.default_rng(2024)
+    total = 0
+    for rep in range(25):
+        m = 4_000_000
+        a = np.floor(10 ** rng.uniform(0, 9.3, m))
+        k = rng.integers(0, 300, m).astype(np.float64)
+        d = (a + 2 * k) * (a + 2 * k + 1)
+        arg = np.where(rng.random(m) < 0.5, 1.0 - 10 ** rng.uniform(-12, -0.3, m), 10 ** rng.uniform(-14, 2, m))
+        nmr = arg * (a + k) * (a + rng.integers(1, 2000, m) + k)
+        nmr[::1000] = 0.0
+        nmr[1::3] *= -1.0
+        if rep % 5 == 0:                 # edges of the window
+            nmr *= 10 ** rng.uniform(-180, 150, m)
+        got = ctx.debug_lean_div(nmr, d)
+        want = nmr / d
+        nz = want != 0
+        assert np.array_equal(got[nz].view(np.int64), want[nz].view(np.int64))
+        assert np.all(got[~nz] == 0)
+        total += m
+    assert total == 100_000_000
+
+
 def test_bh_known_answers_on_gpu(ctx):
     g = np.load(os.path.join(GOLDEN, "f5_bh.npz"))
     for name in g["names"]:
