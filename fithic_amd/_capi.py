@@ -89,6 +89,8 @@ SYMBOLS = {
     "fhx_debug_contfrac": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _F64P, _F64P, _F64P, ctypes.c_int64, _F64P]),
     "fhx_debug_lean_div": (ctypes.c_int, [_P, _F64P, _F64P, ctypes.c_int64, _F64P]),
     "fhx_bh_array": (ctypes.c_int, [_P, _F64P, ctypes.c_int64, ctypes.c_double, _F64P]),
+    "fhx_bh_top_hist": (ctypes.c_int, [_P, _I64P, ctypes.c_int64]),
+    "fhx_bh_set_cutoff": (ctypes.c_int, [_P, _I64P, ctypes.c_int64, ctypes.c_double]),
     "fhx_bh_local_sort": (ctypes.c_int, [_P]),
     "fhx_bh_apply_sorted": (ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, ctypes.c_double, _P, _F64P]),
     "fhx_sort_u64": (ctypes.c_int, [_P, _P, ctypes.c_int64, _P, _P]),
@@ -307,6 +309,15 @@ class Context:
         q = np.empty(len(p), np.float64)
         self._check(self._L.fhx_bh_array(self._h, _ptr(p, ctypes.c_double), len(p), float(n_total_tests), _ptr(q, ctypes.c_double)))
         return q
+
+    def bh_top_hist(self):
+        h = np.zeros(8192, np.int64)
+        self._check(self._L.fhx_bh_top_hist(self._h, _ptr(h, ctypes.c_int64), len(h)))
+        return h
+
+    def bh_set_cutoff(self, global_hist, n_total_tests):
+        h = np.ascontiguousarray(global_hist, np.int64)
+        self._check(self._L.fhx_bh_set_cutoff(self._h, _ptr(h, ctypes.c_int64), len(h), float(n_total_tests)))
 
     def bh_local_sort(self):
         self._check(self._L.fhx_bh_local_sort(self._h))

@@ -425,18 +425,101 @@ constexpr int RADIX_BITS = 11;                       // 6 passes cover 66 >= 64 
 constexpr int RADIX = 1 << RADIX_BITS;
 constexpr int SORT_PASSES = 6;                        // even: the result lands in the buffer pair it started in
 
+// ---- early cutoff -----------------------------------------------------------------------------------------------
+// The reference's monotonisation is a FORWARD running max of min(p*N/rank, 1) over ascending p (fithic/myStats.py:31-46):
+// once one element reaches 1 every later element has q = 1.  An element with p >= t whose rank is at most C certainly has
+// fl(fl(p*N)/rank) >= fl(fl(t*N)/C) (rounding is monotone), so from a coarse histogram of the keys (top 14 bits: sign,
+// exponent, 2 mantissa bits) we can name a key T* such that every element >= T* has q = 1 exactly - those rows are not
+// sorted at all.  On Hi-C data N (possible pairs) exceeds the number of observed rows, so only the enriched small-p tail
+// (typically 10-20 % of the rows) survives the cutoff.  The result is bit-identical to sorting everything.
+constexpr int TOP_SHIFT = 50;
+constexpr int TOP_BINS = 8192;                         // keys of p < 1 are < 2^62, so key >> 50 < 4096 (kept at 8192 for slack)
+
+__device__ __forceinline__ unsigned long long pvalue_key(double v) {
+    unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    if (bits == 0x8000000000000000ull) bits = 0ull;    // -0.0 sorts with +0.0
+    return bits;
+}
+
+__global__ __launch_bounds__(512) void k3_top_hist(const double* __restrict__ p, int64_t n, unsigned long long* __restrict__ hist) {
+    __shared__ unsigned int h[TOP_BINS];
+    for (int i = threadIdx.x; i < TOP_BINS; i += 512) h[i] = 0;
+    __syncthreads();
+    const int64_t n2 = n >> 1;
+    const double2* p2 = reinterpret_cast<const double2*>(p);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        const double2 v = p2[i];
+        if (v.x < 1.0) atomicAdd(&h[pvalue_key(v.x) >> TOP_SHIFT], 1u);
+        if (v.y < 1.0) atomicAdd(&h[pvalue_key(v.y) >> TOP_SHIFT], 1u);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) {
+        const double v = p[n - 1];
+        if (v < 1.0) atomicAdd(&h[pvalue_key(v) >> TOP_SHIFT], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TOP_BINS; i += 512)
+        if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+}
+
+// smallest bin b (non-empty) with fl(fl(lower_edge(b) * N) / (#keys in bins 0..b)) >= 1 -> cutoff key = b << TOP_SHIFT
+__host__ __device__ inline bool bin_saturates(int b, unsigned long long cum_incl, double n_tests) {
+    const unsigned long long edge_bits = (unsigned long long)b << TOP_SHIFT;
+    double edge;
+    memcpy(&edge, &edge_bits, sizeof(edge));
+    const double v = edge * n_tests / (double)cum_incl;
+    return v >= 1.0;
+}
+
+__global__ __launch_bounds__(1024) void k3_cutoff(const unsigned long long* __restrict__ hist, double n_tests,
+                                                  unsigned long long* __restrict__ cutoff_key) {
+    __shared__ unsigned long long part[1024];
+    __shared__ unsigned int best;
+    constexpr int PER = TOP_BINS / 1024;
+    unsigned long long local[PER];
+    unsigned long long sum = 0;
+    for (int k = 0; k < PER; ++k) {
+        local[k] = hist[threadIdx.x * PER + k];
+        sum += local[k];
+    }
+    part[threadIdx.x] = sum;
+    if (threadIdx.x == 0) best = TOP_BINS;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long acc = 0;
+        for (int i = 0; i < 1024; ++i) {
+            const unsigned long long c = part[i];
+            part[i] = acc;
+            acc += c;
+        }
+    }
+    __syncthreads();
+    unsigned long long cum = part[threadIdx.x];
+    for (int k = 0; k < PER; ++k) {
+        cum += local[k];
+        const int b = threadIdx.x * PER + k;
+        if (local[k] && bin_saturates(b, cum, n_tests)) atomicMin(&best, (unsigned int)b);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        *cutoff_key = (best < (unsigned int)TOP_BINS) ? ((unsigned long long)best << TOP_SHIFT) : 0x3FF0000000000000ull;
+}
+
 // compaction: keys of the rows with p < 1 (IEEE bit pattern: all such p are >= 0, so unsigned order is
 // numeric order); rows with p == 1 get q = 1 and NaN rows get q = NaN right here.
 __global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restrict__ p, int64_t n,
                                                            unsigned long long* __restrict__ keys,
                                                            unsigned int* __restrict__ vals, double* __restrict__ q,
-                                                           unsigned long long* __restrict__ counter) {
+                                                           unsigned long long* __restrict__ counter,
+                                                           const unsigned long long* __restrict__ cutoff_key) {
+    // rows at or above the cutoff key (see above) have q = 1 and are not sorted; NaN rows get q = NaN.
     // one global atomic per 4096-row tile (a same-address atomic per 256 rows capped this kernel at ~88 M atomics/s)
     __shared__ unsigned int wave_cnt[SORT_WAVES];
     __shared__ unsigned long long block_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     const int64_t tiles = (n + SORT_TILE - 1) / SORT_TILE;
+    const unsigned long long cutoff = *cutoff_key;
     for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
         const int64_t wave_base = t * SORT_TILE + (int64_t)wave * (64 * SORT_ITEMS);
         double v[SORT_ITEMS];
@@ -450,7 +533,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restr
             v[r] = 1.0;
             if (i < n) {
                 v[r] = p[i];
-                keep = v[r] < 1.0;                  // false for NaN
+                keep = (v[r] < 1.0) && (pvalue_key(v[r]) < cutoff);          // false for NaN
                 if (!keep) q[i] = (v[r] == v[r]) ? 1.0 : v[r];
             }
             const unsigned long long m = __ballot(keep);
@@ -474,9 +557,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restr
 #pragma unroll
         for (int r = 0; r < SORT_ITEMS; ++r) {
             if ((keepmask >> r) & 1ull) {
-                unsigned long long bits = (unsigned long long)__double_as_longlong(v[r]);
-                if (bits == 0x8000000000000000ull) bits = 0ull;       // -0.0 sorts with +0.0
-                keys[base + before[r]] = bits;
+                keys[base + before[r]] = pvalue_key(v[r]);
                 vals[base + before[r]] = (unsigned int)(wave_base + r * 64 + lane);
             }
         }
@@ -889,6 +970,7 @@ struct fhx_ctx {
     unsigned int *d_vals[2] = {nullptr, nullptr};
     unsigned int* d_block_hist = nullptr;
     unsigned int* d_digit_total = nullptr;
+    unsigned long long* d_top_hist = nullptr;
     double* d_tile_max = nullptr;
     int sorted_buf = 0;
     int64_t n_sorted = -1;
@@ -1086,6 +1168,7 @@ int ingest_device_rows(fhx_ctx* ctx, const int32_t* c1, const int32_t* m1, const
     }
     if (!ctx->d_block_hist) FHX_HIP(hipMalloc(&ctx->d_block_hist, (size_t)RADIX * SORT_BLOCKS * sizeof(unsigned int)));
     if (!ctx->d_digit_total) FHX_HIP(hipMalloc(&ctx->d_digit_total, RADIX * sizeof(unsigned int)));
+    if (!ctx->d_top_hist) FHX_HIP(hipMalloc(&ctx->d_top_hist, TOP_BINS * sizeof(unsigned long long)));
     dev_free(ctx->d_tile_max);
     FHX_HIP(hipMalloc(&ctx->d_tile_max, ((size_t)n / BH_TILE + 2) * sizeof(double)));
     FHX_HIP(hipStreamSynchronize(ctx->stream));
@@ -1167,6 +1250,7 @@ void fhx_destroy(fhx_ctx* ctx) {
         }
         dev_free(ctx->d_block_hist);
         dev_free(ctx->d_digit_total);
+        dev_free(ctx->d_top_hist);
         dev_free(ctx->d_tile_max);
         for (auto& e : ctx->ev)
             if (e) (void)hipEventDestroy(e);
@@ -1463,15 +1547,29 @@ int fhx_pvalues(fhx_ctx* ctx) {
     ctx->have_p = true;
     ctx->have_q = false;
     ctx->n_sorted = -1;
+    {
+        const unsigned long long one = 0x3FF0000000000000ull;      // until a cutoff is computed: keep every p < 1
+        FHX_HIP(hipMemcpyAsync(ctx->d_misc + 6, &one, sizeof(one), hipMemcpyHostToDevice, ctx->stream));
+    }
     return FHX_OK;
 }
 
 // compact p < 1 and LSD-radix-sort (key, row); returns the index (0/1) of the buffer pair holding the result
+// cutoff key from a device-local histogram of the p-values (single-GPU path; sharded runs all-reduce the histogram)
+static int auto_cutoff(fhx_ctx* ctx, const double* d_p, int64_t n, double n_total_tests, unsigned long long* d_cutoff) {
+    FHX_HIP(hipMemsetAsync(ctx->d_top_hist, 0, TOP_BINS * sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(k3_top_hist, dim3(grid_for((n + 1) / 2, 512, 256 * 4)), dim3(512), 0, ctx->stream, d_p, n, ctx->d_top_hist);
+    hipLaunchKernelGGL(k3_cutoff, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long*)ctx->d_top_hist, n_total_tests,
+                       d_cutoff);
+    FHX_HIP(hipGetLastError());
+    return FHX_OK;
+}
+
 static int sort_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned long long* keys[2], unsigned int* vals[2],
-                        double* d_q, unsigned long long* counter, int* sorted_buf) {
+                        double* d_q, unsigned long long* counter, const unsigned long long* d_cutoff, int* sorted_buf) {
     FHX_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
     hipLaunchKernelGGL(k3_compact, dim3(grid_for(n, SORT_TILE, 256 * 8)), dim3(SORT_THREADS), 0, ctx->stream, d_p, n,
-                       keys[0], vals[0], d_q, counter);
+                       keys[0], vals[0], d_q, counter, d_cutoff);
     int src = 0;
     // p < 1 means the IEEE exponent field is <= 1022: bits 62 and 63 are always clear, 62 bits to sort
     for (int pass = 0; pass < SORT_PASSES; ++pass) {
@@ -1505,6 +1603,38 @@ static int ensure_sort_scratch(fhx_ctx* ctx) {
     if (!ctx->d_block_hist) FHX_HIP(hipMalloc(&ctx->d_block_hist, (size_t)RADIX * SORT_BLOCKS * sizeof(unsigned int)));
     if (!ctx->d_digit_total) FHX_HIP(hipMalloc(&ctx->d_digit_total, RADIX * sizeof(unsigned int)));
     if (!ctx->d_misc) FHX_HIP(hipMalloc(&ctx->d_misc, 128 * sizeof(unsigned long long)));
+    if (!ctx->d_top_hist) FHX_HIP(hipMalloc(&ctx->d_top_hist, TOP_BINS * sizeof(unsigned long long)));
+    return FHX_OK;
+}
+
+int fhx_bh_top_hist(fhx_ctx* ctx, int64_t* hist_out, int64_t capacity) {
+    if (!ctx || !hist_out || capacity < TOP_BINS) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (!ctx->have_p) return fail(ctx, FHX_ERR_ARG, "fhx_pvalues must run first");
+    FHX_HIP(hipSetDevice(ctx->device));
+    FHX_HIP(hipMemsetAsync(ctx->d_top_hist, 0, TOP_BINS * sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(k3_top_hist, dim3(grid_for((ctx->n_rows + 1) / 2, 512, 256 * 4)), dim3(512), 0, ctx->stream, ctx->d_p,
+                       ctx->n_rows, ctx->d_top_hist);
+    FHX_HIP(hipGetLastError());
+    FHX_HIP(hipMemcpyAsync(hist_out, ctx->d_top_hist, TOP_BINS * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    return FHX_OK;
+}
+
+int fhx_bh_set_cutoff(fhx_ctx* ctx, const int64_t* global_hist, int64_t n_bins, double n_total_tests) {
+    if (!ctx || !global_hist || n_bins != TOP_BINS || !(n_total_tests > 0)) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    FHX_HIP(hipSetDevice(ctx->device));
+    unsigned long long cutoff = 0x3FF0000000000000ull, cum = 0;
+    for (int b = 0; b < TOP_BINS; ++b) {
+        cum += (unsigned long long)global_hist[b];
+        if (global_hist[b] > 0 && bin_saturates(b, cum, n_total_tests)) {
+            cutoff = (unsigned long long)b << TOP_SHIFT;
+            break;
+        }
+    }
+    FHX_HIP(hipMemcpyAsync(ctx->d_misc + 6, &cutoff, sizeof(cutoff), hipMemcpyHostToDevice, ctx->stream));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
     return FHX_OK;
 }
 
@@ -1513,7 +1643,8 @@ int fhx_bh_local_sort(fhx_ctx* ctx) {
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
     if (!ctx->have_p) return fail(ctx, FHX_ERR_ARG, "fhx_pvalues must run first");
     FHX_HIP(hipSetDevice(ctx->device));
-    const int rc = sort_pvalues(ctx, ctx->d_p, ctx->n_rows, ctx->d_keys, ctx->d_vals, ctx->d_q, ctx->d_misc, &ctx->sorted_buf);
+    const int rc = sort_pvalues(ctx, ctx->d_p, ctx->n_rows, ctx->d_keys, ctx->d_vals, ctx->d_q, ctx->d_misc, ctx->d_misc + 6,
+                                &ctx->sorted_buf);
     if (rc != FHX_OK) return rc;
     ctx->n_sorted = -2;          // known on the device only until someone asks
     return FHX_OK;
@@ -1615,7 +1746,9 @@ int fhx_bh_array(fhx_ctx* ctx, const double* p, int64_t n, double n_total_tests,
     FHX_HIP(hipMemcpyAsync(d_p, p, cap * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     int buf = 0;
     unsigned long long* counter = ctx->d_misc + 2;
-    rc = sort_pvalues(ctx, d_p, n, keys, vals, d_q, counter, &buf);
+    unsigned long long* cutoff = ctx->d_misc + 7;
+    rc = auto_cutoff(ctx, d_p, n, n_total_tests, cutoff);
+    if (rc == FHX_OK) rc = sort_pvalues(ctx, d_p, n, keys, vals, d_q, counter, cutoff, &buf);
     if (rc == FHX_OK) rc = bh_from_sorted(ctx, keys[buf], vals[buf], n, counter, n_total_tests, tile_max, d_q);
     if (rc == FHX_OK) {
         FHX_HIP(hipMemcpyAsync(q, d_q, cap * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1638,7 +1771,9 @@ int fhx_bh(fhx_ctx* ctx, double n_total_tests) {
     if (!(n_total_tests > 0)) return fail(ctx, FHX_ERR_ARG, "number of tests must be positive");
     FHX_HIP(hipSetDevice(ctx->device));
     FHX_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
-    const int rc = fhx_bh_local_sort(ctx);
+    int rc = auto_cutoff(ctx, ctx->d_p, ctx->n_rows, n_total_tests, ctx->d_misc + 6);
+    if (rc != FHX_OK) return rc;
+    rc = fhx_bh_local_sort(ctx);
     if (rc != FHX_OK) return rc;
     const int s = ctx->sorted_buf;
     const int rc2 = bh_from_sorted(ctx, ctx->d_keys[s], ctx->d_vals[s], ctx->n_rows, ctx->d_misc, n_total_tests,

@@ -97,6 +97,12 @@ class LocalOps:
     def pvalues(self):
         self.ctx.pvalues()
 
+    def top_hist(self):
+        return self.ctx.bh_top_hist()
+
+    def set_cutoff(self, global_hist, n_tests):
+        self.ctx.bh_set_cutoff(global_hist, n_tests)
+
     def local_sorted_keys(self):
         """int64 tensor (all keys < 2^62, so signed order = unsigned order) of this rank's sorted p < 1 bit patterns."""
         self.ctx.bh_local_sort()
@@ -147,6 +153,8 @@ def choose_splitters(torch, samples_sorted, world):
 def distributed_bh(comm, ops, n_tests):
     """Global BH over the p-values of all ranks; leaves q in row order on every rank."""
     torch = comm.torch
+    # exact early cutoff: rows whose q is provably 1 are neither sorted nor exchanged (needs the GLOBAL key histogram)
+    ops.set_cutoff(comm.all_reduce_i64(ops.top_hist()), n_tests)
     keys = ops.local_sorted_keys()
     n = keys.numel()
     # regular samples -> common splitters

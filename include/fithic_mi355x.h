@@ -194,7 +194,13 @@ int fhx_debug_contfrac(fhx_ctx* ctx, int kind, int lazy, const double* a, const 
 int fhx_debug_lean_div(fhx_ctx* ctx, const double* n, const double* d, int64_t len, double* out);
 
 /* ---- distributed BH building blocks (section 8e): local sort, then rank/scan over a global segment -- */
-int fhx_bh_local_sort(fhx_ctx* ctx);                 /* compact p < 1, radix sort (key, row) on this GPU */
+/* Early cutoff (exact): the reference's q is a FORWARD running max of min(p*N/rank, 1), so every p at or above the first
+ * key whose value*N/rank bound reaches 1 has q = 1 and need not be sorted.  fhx_bh computes that key from a coarse
+ * histogram of its own p-values; sharded runs all-reduce the 8192-bin histograms (fhx_bh_top_hist) and hand the sum
+ * back (fhx_bh_set_cutoff) before fhx_bh_local_sort.  Without either call every p < 1 is sorted. */
+int fhx_bh_top_hist(fhx_ctx* ctx, int64_t* hist_out, int64_t capacity);
+int fhx_bh_set_cutoff(fhx_ctx* ctx, const int64_t* global_hist, int64_t n_bins, double n_total_tests);
+int fhx_bh_local_sort(fhx_ctx* ctx);                 /* compact p below the cutoff, radix sort (key, row) on this GPU */
 int fhx_bh_apply_sorted(fhx_ctx* ctx, const void* d_sorted_keys, int64_t n, int64_t global_rank0,
                         double carry_in, double n_total_tests, void* d_q_sorted, double* block_max_out);
 /* sort n 64-bit keys that live on this GPU (ascending, stable); d_perm_out[i] = original position of sorted element i */

@@ -90,8 +90,25 @@ def _worker(rank, world, port, case, passes, result_dir):
         def pvalues(self):
             self.p = ref[self.pass_idx].p[mine]          # reference p of my rows (K2 itself is covered by the GPU tests)
 
-        def local_sorted_keys(self):
+        cutoff_bits = None
+
+        def top_hist(self):
+            h = np.zeros(8192, np.int64)
             keep = self.p < 1.0
+            np.add.at(h, (np.abs(self.p[keep]).view(np.int64) >> 50), 1)
+            return h
+
+        def set_cutoff(self, global_hist, n_tests):
+            cum = np.cumsum(global_hist)
+            self.cutoff_bits = np.int64(0x3FF0000000000000)
+            for b in np.flatnonzero(global_hist > 0):
+                edge = np.array([int(b) << 50], np.int64).view(np.float64)[0]
+                if edge * float(n_tests) / float(cum[b]) >= 1.0:
+                    self.cutoff_bits = np.int64(int(b) << 50)
+                    break
+
+        def local_sorted_keys(self):
+            keep = (self.p < 1.0) & (np.abs(np.nan_to_num(self.p, nan=2.0)).view(np.int64) < self.cutoff_bits)
             self.rows = np.flatnonzero(keep)
             bits = self.p[keep].view(np.int64)
             order = np.argsort(bits, kind="stable")
