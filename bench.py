@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--resolution", type=int, default=5000)
     ap.add_argument("--keep", type=float, default=0.66, help="fraction of candidate cis pairs observed (sets the depth)")
     ap.add_argument("--strong", action="store_true", help="shard one genome instead of replicating it per GPU")
+    ap.add_argument("--overdispersion", type=float, default=0.0,
+                    help="0 = synth-v1 (Poisson around the model); s > 0 adds lognormal rate noise: heavier small-p tail, like real maps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-chroms", type=int, default=0, help="debug: use only the first k chromosomes")
     args = ap.parse_args()
@@ -76,7 +78,7 @@ def main():
     mine = [c for c in range(len(genome)) if owner[c] == rank]
 
     t_gen = time.time()
-    parts = [synth.cis_contacts(genome, c, lo_idx, hi_idx, amp, device=device) for c in mine]
+    parts = [synth.cis_contacts(genome, c, lo_idx, hi_idx, amp, device=device, overdispersion=args.overdispersion) for c in mine]
     cols = [torch.cat([p[k] for p in parts]).contiguous() for k in range(5)]
     n_local = int(cols[0].numel())
     torch.cuda.synchronize()
@@ -148,7 +150,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C3-synth: %d x hg19 22 autosomes @%d bp, -L %d -U %d, %d cis pairs, ICE-like bias, -b 100, "
                                    "1 pass, intraOnly" % (replicas, res, L, U, n_total),
-                       "pairs": n_total, "resolution": res, "parallelism": "chromosome-sharded x%d" % world,
+                       "pairs": n_total, "resolution": res, "generator": "synth-v1" if args.overdispersion == 0 else
+                       "synth-v1 + lognormal rate noise s=%g" % args.overdispersion, "parallelism": "chromosome-sharded x%d" % world,
                        "passes": 1},
             "roofline": {"bound": "hbm", "kernel": "k2_pvalue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

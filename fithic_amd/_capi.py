@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libfithic_mi355x.so")
+LIB_PATH = os.environ.get("FHX_LIB") or os.path.join(_PKG, "libfithic_mi355x.so")   # FHX_LIB: A/B experiments only
 CSRC = os.path.join(_PKG, "csrc")
 
 FHX_OK = 0

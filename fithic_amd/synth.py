@@ -79,8 +79,10 @@ def solve_amplitude(keep_fraction, lo_idx, hi_idx):
     return math.sqrt(lo * hi)
 
 
-def cis_contacts(genome, chrom, lo_idx, hi_idx, amplitude, device="cpu", max_window=None):
-    """Contact rows of one chromosome as torch int32 tensors (chr1, mid1, chr2, mid2, count) on `device`."""
+def cis_contacts(genome, chrom, lo_idx, hi_idx, amplitude, device="cpu", max_window=None, overdispersion=0.0):
+    """Contact rows of one chromosome as torch int32 tensors (chr1, mid1, chr2, mid2, count) on `device`.
+    overdispersion = 0 is synth-v1 (pure Poisson around the model); s > 0 multiplies every pair's rate by
+    exp(s*z - s^2/2), z ~ N(0,1) (gamma-Poisson-like counts, the heavier small-p tail real Hi-C maps show)."""
     import torch
     n = genome.n_loci[chrom]
     hi = min(hi_idx, n - 1)
@@ -104,6 +106,9 @@ def cis_contacts(genome, chrom, lo_idx, hi_idx, amplitude, device="cpu", max_win
         ok = j < n
         jj = torch.where(ok, j, torch.zeros_like(j))
         lam = (b[i][:, None] * b[jj]) * decay[None, :]
+        if overdispersion > 0:
+            z = torch.randn(lam.shape, device=device, generator=gen, dtype=torch.float32)
+            lam = lam * torch.exp(overdispersion * z - 0.5 * overdispersion * overdispersion).to(lam.dtype)
         cnt = torch.poisson(lam.to(torch.float32), generator=gen).to(torch.int32)
         boost = torch.rand(cnt.shape, device=device, generator=gen) < 0.001
         cnt = torch.where(boost, cnt * 4, cnt)
