@@ -85,6 +85,7 @@ SYMBOLS = {
     "fhx_device_ptr": (_P, [_P, ctypes.c_int]),
     "fhx_n_sorted": (ctypes.c_int64, [_P]),
     "fhx_kernel_seconds": (ctypes.c_int, [_P, _F64P, _F64P, _F64P]),
+    "fhx_k2_heavy_launch": (ctypes.c_int, [_P, _F64P, _I64P]),
     "fhx_bdtrc_array": (ctypes.c_int, [_P, ctypes.c_double, _I32P, _F64P, ctypes.c_int64, _F64P]),
     "fhx_debug_contfrac": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _F64P, _F64P, _F64P, ctypes.c_int64, _F64P]),
     "fhx_debug_lean_div": (ctypes.c_int, [_P, _F64P, _F64P, ctypes.c_int64, _F64P]),
@@ -279,6 +280,11 @@ class Context:
         k = [ctypes.c_double(0) for _ in range(3)]
         self._check(self._L.fhx_kernel_seconds(self._h, *[ctypes.byref(v) for v in k]))
         return tuple(v.value for v in k)
+
+    def k2_heavy_launch(self):
+        sec, rows = ctypes.c_double(0), ctypes.c_int64(0)
+        self._check(self._L.fhx_k2_heavy_launch(self._h, ctypes.byref(sec), ctypes.byref(rows)))
+        return sec.value, rows.value
 
     def device_ptr(self, which):
         return self._L.fhx_device_ptr(self._h, which)

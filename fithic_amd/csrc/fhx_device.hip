@@ -916,7 +916,8 @@ using namespace fhx;
 struct fhx_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [6],[7]: around the heavy K2 launch
+    long long n_heavy_last = 0;
     bool ev_valid[3] = {false, false, false};
     std::string err;
     fhx_params prm{};
@@ -1536,7 +1537,9 @@ int fhx_pvalues(fhx_ctx* ctx) {
 #define FHX_LAUNCH_QUEUE(CLS)                                                                                          \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue<CLS>), qgrid, qblock, 0, ctx->stream, P,                               \
                        (const unsigned int*)Q.rows[(CLS) - 1], (const unsigned long long*)(Q.count + ((CLS) - 1) * K2_COUNT_STRIDE))
+    FHX_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
     FHX_LAUNCH_QUEUE(dev::BC_CF_SWAPPED);            // longest-running class first
+    FHX_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
     FHX_LAUNCH_QUEUE(dev::BC_CF_BD);
     FHX_LAUNCH_QUEUE(dev::BC_CF_BCF);
     FHX_LAUNCH_QUEUE(dev::BC_PSERIES);
@@ -2056,6 +2059,21 @@ int64_t fhx_n_sorted(fhx_ctx* ctx) {
         ctx->n_sorted = (int64_t)n;
     }
     return ctx->n_sorted;
+}
+
+int fhx_k2_heavy_launch(fhx_ctx* ctx, double* seconds, int64_t* rows) {
+    if (!ctx) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (!ctx->ev_valid[1]) return fail(ctx, FHX_ERR_ARG, "fhx_pvalues has not run");
+    FHX_HIP(hipSetDevice(ctx->device));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    FHX_HIP(hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]));
+    unsigned long long n = 0;
+    FHX_HIP(hipMemcpy(&n, ctx->d_misc + 64 + (dev::BC_CF_SWAPPED - 1) * K2_COUNT_STRIDE, sizeof(n), hipMemcpyDeviceToHost));
+    if (seconds) *seconds = ms * 1e-3;
+    if (rows) *rows = (int64_t)n;
+    return FHX_OK;
 }
 
 int fhx_kernel_seconds(fhx_ctx* ctx, double* k1, double* k2, double* k3) {

@@ -175,6 +175,9 @@ void* fhx_device_ptr(fhx_ctx* ctx, int which);
 int64_t fhx_n_sorted(fhx_ctx* ctx);
 /* Seconds the kernels of the last pass took on the context's stream (HIP events): k1, k2, k3. */
 int fhx_kernel_seconds(fhx_ctx* ctx, double* k1, double* k2, double* k3);
+/* Duration (HIP events on the context's stream) and row count of the dominant launch of the last fhx_pvalues: the queue
+ * of rows whose continued fraction runs to Cephes' 300-iteration cap (k2_queue<BC_CF_SWAPPED>). */
+int fhx_k2_heavy_launch(fhx_ctx* ctx, double* seconds, int64_t* rows);
 
 /* myStats.benjamini_hochberg_correction(p_values, num_total_tests) on an arbitrary host array (fithic/myStats.py:24-48):
  * copies p to the GPU, runs the K3 kernels, copies q back (input order). */

@@ -7,11 +7,23 @@ import sys
 
 
 def short(name):
+    """kernel name without its parameter list; short template arguments are kept (k2_queue<...4> -> k2_queue<4>)"""
     name = re.sub(r"^void ", "", name)
-    name = re.sub(r"<\(fhx::dev::BranchClass\)(\d+)>", r"<class \1>", name)   # k2_queue<class 1..4>: pseries, bcf, bd, swapped
-    name = re.sub(r"\(.*", "", name)                       # drop the argument list
-    name = re.sub(r"<(?!class).*", "<...>", name)
-    return name[-70:]
+    depth, cut = 0, len(name)
+    for i in range(len(name) - 1, -1, -1):          # drop the trailing "(...)" parameter list
+        if name[i] == ")":
+            depth += 1
+        elif name[i] == "(":
+            depth -= 1
+            if depth == 0:
+                cut = i
+                break
+    name = name[:cut]
+    m = re.search(r"<(.*)>$", name)
+    if m:
+        arg = re.sub(r"\(fhx::dev::BranchClass\)", "", m.group(1))
+        name = name[:m.start()] + ("<" + arg + ">" if len(arg) <= 24 else "<...>")
+    return name[-44:]
 
 
 def main(path):
