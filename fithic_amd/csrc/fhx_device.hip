@@ -253,20 +253,29 @@ constexpr int K2_THREADS = 256;
 // class at a time with every lane on the same code path and nearly the same trip count.
 constexpr int K2_QUEUES = dev::BC_COUNT - 1;        // classes 1..4
 
-struct K2Queues {
-    unsigned int* rows[K2_QUEUES];
-    unsigned long long* count;                      // K2_QUEUES counters
+// one queued row: everything the per-class kernel needs, so that it streams 16 B/row instead of re-gathering the
+// three pair columns, two biases and the prior LUT through a row index (measured 66 B/row of HBM traffic that way)
+struct QEntry {
+    unsigned int row;
+    int count;                  // negative: the row uses the inter-chromosomal binomial (n = observedInterAllSum)
+    double prior;
 };
 
-constexpr int K2_CL_ITEMS = 8;
-constexpr int K2_CL_TILE = K2_THREADS * K2_CL_ITEMS;     // 2048 rows per workgroup step
+struct K2Queues {
+    QEntry* base[K2_QUEUES];    // two queues share one buffer of n_rows entries: one grows up from its start,
+    int dir[K2_QUEUES];         // the other grows down from its end (+1 / -1)
+    unsigned long long* count;  // K2_QUEUES counters, K2_COUNT_STRIDE apart
+};
+
+constexpr int K2_CL_ITEMS = 4;
+constexpr int K2_CL_TILE = K2_THREADS * K2_CL_ITEMS;     // 1024 rows per workgroup step (8 items/thread costs 189 VGPRs -> 2 waves/SIMD and is slower)
 constexpr int K2_COUNT_STRIDE = 16;                      // queue counters 128 B apart: one L2 line each
 
 __global__ __launch_bounds__(K2_THREADS) void k2_classify(K2Params P, K2Queues Q) {
-    // rows of one tile are staged per class in LDS (wave-aggregated LDS atomics), then each class takes ONE global
-    // atomic per tile and is flushed with coalesced stores: a same-address global atomic per wave would cap the
-    // kernel at ~88 M atomics/s (MI355X_MICROARCH.md "dequeue"), i.e. slower than the arithmetic it feeds.
-    __shared__ unsigned int stage[K2_QUEUES][K2_CL_TILE];
+    // Per tile: every wave reserves slots per class with ballots + ONE LDS atomic per (wave, class, item), then each
+    // class takes ONE global atomic per tile (a same-address global atomic per wave would cap the kernel at ~88 M
+    // atomics/s - MI355X_MICROARCH.md "dequeue" - i.e. slower than the arithmetic it feeds), then the lanes write
+    // their own 16-byte entries at base + slot (lanes of one class hold consecutive slots).
     __shared__ unsigned int cnt[K2_QUEUES];
     __shared__ unsigned long long gbase[K2_QUEUES];
     const int lane = threadIdx.x & 63;
@@ -275,22 +284,31 @@ __global__ __launch_bounds__(K2_THREADS) void k2_classify(K2Params P, K2Queues Q
     for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
         if (threadIdx.x < K2_QUEUES) cnt[threadIdx.x] = 0;
         __syncthreads();
-#pragma unroll 1
+        int cls_of[K2_CL_ITEMS];
+        unsigned int slot_of[K2_CL_ITEMS];
+        int count_of[K2_CL_ITEMS];
+        double prior_of[K2_CL_ITEMS];
+#pragma unroll
         for (int r = 0; r < K2_CL_ITEMS; ++r) {
             const int64_t i = t * K2_CL_TILE + r * K2_THREADS + threadIdx.x;
             int cls = -1;                                              // -1: no row, 0: done here, 1..4: queued
+            double prior = 1.0;
+            int c = 0;
             if (i < P.n) {
-                const int l1 = P.loc1[i], l2 = P.loc2[i], c = P.count[i];
-                double prior = 1.0, pv = 1.0;
+                const int l1 = P.loc1[i], l2 = P.loc2[i];
+                c = P.count[i];
+                double pv = 1.0;
                 bool is_inter = false;
                 cls = 0;
                 if (row_prior(P, l1, l2, prior, is_inter)) {
                     const dev::BinomTables& T = is_inter ? P.inter : P.intra;
                     cls = dev::bdtrc_class(c, T.n, prior);
                     if (cls == dev::BC_TRIVIAL) pv = dev::bdtrc_count(c, T, prior);
+                    if (is_inter) c = -c;
                 }
                 if (cls == 0) P.p[i] = pv;
             }
+            unsigned int slot = 0;
 #pragma unroll
             for (int k = 1; k <= K2_QUEUES; ++k) {
                 const unsigned long long m = __ballot(cls == k);
@@ -298,36 +316,44 @@ __global__ __launch_bounds__(K2_THREADS) void k2_classify(K2Params P, K2Queues Q
                     unsigned int base = 0;
                     if (lane == 0) base = atomicAdd(&cnt[k - 1], (unsigned int)__popcll(m));
                     base = __shfl(base, 0, 64);
-                    if (cls == k) stage[k - 1][base + __popcll(m & lane_lt)] = (unsigned int)i;
+                    if (cls == k) slot = base + __popcll(m & lane_lt);
                 }
             }
+            cls_of[r] = cls;
+            slot_of[r] = slot;
+            count_of[r] = c;
+            prior_of[r] = prior;
         }
         __syncthreads();
         if (threadIdx.x < K2_QUEUES)
             gbase[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&Q.count[threadIdx.x * K2_COUNT_STRIDE], (unsigned long long)cnt[threadIdx.x]) : 0ull;
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < K2_QUEUES; ++k) {
-            const unsigned int c = cnt[k];
-            const unsigned long long b = gbase[k];
-            for (unsigned int j = threadIdx.x; j < c; j += K2_THREADS) Q.rows[k][b + j] = stage[k][j];
+        for (int r = 0; r < K2_CL_ITEMS; ++r) {
+            const int k = cls_of[r] - 1;
+            if (k >= 0) {
+                QEntry e;
+                e.row = (unsigned int)(t * K2_CL_TILE + r * K2_THREADS + threadIdx.x);
+                e.count = count_of[r];
+                e.prior = prior_of[r];
+                const long long pos = (long long)(gbase[k] + slot_of[r]);
+                Q.base[k][Q.dir[k] * pos] = e;
+            }
         }
         __syncthreads();
     }
 }
 
 template <int CLS>
-__global__ __launch_bounds__(K2_THREADS) void k2_queue(K2Params P, const unsigned int* __restrict__ rows,
+__global__ __launch_bounds__(K2_THREADS) void k2_queue(K2Params P, const QEntry* __restrict__ base, int dir,
                                                        const unsigned long long* __restrict__ count) {
     const int64_t n = (int64_t)*count;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
-        const int64_t i = rows[j];
-        const int l1 = P.loc1[i], l2 = P.loc2[i], c = P.count[i];
-        double prior = 1.0;
-        bool is_inter = false;
-        row_prior(P, l1, l2, prior, is_inter);
-        P.p[i] = dev::bdtrc_count_class<CLS>(c, is_inter ? P.inter : P.intra, prior);
+        const QEntry e = base[dir * j];
+        const bool is_inter = e.count < 0;
+        const int c = is_inter ? -e.count : e.count;
+        P.p[e.row] = dev::bdtrc_count_class<CLS>(c, is_inter ? P.inter : P.intra, e.prior);
     }
 }
 
@@ -972,6 +998,7 @@ struct fhx_ctx {
     unsigned int* d_block_hist = nullptr;
     unsigned int* d_digit_total = nullptr;
     unsigned long long* d_top_hist = nullptr;
+    QEntry* d_queue[2] = {nullptr, nullptr};          // K2's per-class row queues
     double* d_tile_max = nullptr;
     int sorted_buf = 0;
     int64_t n_sorted = -1;
@@ -1170,6 +1197,10 @@ int ingest_device_rows(fhx_ctx* ctx, const int32_t* c1, const int32_t* m1, const
     if (!ctx->d_block_hist) FHX_HIP(hipMalloc(&ctx->d_block_hist, (size_t)RADIX * SORT_BLOCKS * sizeof(unsigned int)));
     if (!ctx->d_digit_total) FHX_HIP(hipMalloc(&ctx->d_digit_total, RADIX * sizeof(unsigned int)));
     if (!ctx->d_top_hist) FHX_HIP(hipMalloc(&ctx->d_top_hist, TOP_BINS * sizeof(unsigned long long)));
+    for (int b = 0; b < 2; ++b) {
+        dev_free(ctx->d_queue[b]);
+        FHX_HIP(hipMalloc(&ctx->d_queue[b], cap * sizeof(QEntry)));
+    }
     dev_free(ctx->d_tile_max);
     FHX_HIP(hipMalloc(&ctx->d_tile_max, ((size_t)n / BH_TILE + 2) * sizeof(double)));
     FHX_HIP(hipStreamSynchronize(ctx->stream));
@@ -1252,6 +1283,8 @@ void fhx_destroy(fhx_ctx* ctx) {
         dev_free(ctx->d_block_hist);
         dev_free(ctx->d_digit_total);
         dev_free(ctx->d_top_hist);
+        dev_free(ctx->d_queue[0]);
+        dev_free(ctx->d_queue[1]);
         dev_free(ctx->d_tile_max);
         for (auto& e : ctx->ev)
             if (e) (void)hipEventDestroy(e);
@@ -1525,18 +1558,24 @@ int fhx_pvalues(fhx_ctx* ctx) {
     const K2Params P = make_k2_params(ctx);
     FHX_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
     // queues live in the sort workspace, which is idle until K3: 2 x u32[n] + 2 x u64[n]
+    // two entry buffers of n_rows each: [swapped CF up | power series down] and [incbcf up | incbd down]
     K2Queues Q;
-    Q.rows[0] = ctx->d_vals[0];
-    Q.rows[1] = ctx->d_vals[1];
-    Q.rows[2] = reinterpret_cast<unsigned int*>(ctx->d_keys[0]);
-    Q.rows[3] = reinterpret_cast<unsigned int*>(ctx->d_keys[1]);
+    const long long last = (long long)std::max<int64_t>(ctx->n_rows, 1) - 1;
+    Q.base[dev::BC_CF_SWAPPED - 1] = ctx->d_queue[0];
+    Q.dir[dev::BC_CF_SWAPPED - 1] = 1;
+    Q.base[dev::BC_PSERIES - 1] = ctx->d_queue[0] + last;
+    Q.dir[dev::BC_PSERIES - 1] = -1;
+    Q.base[dev::BC_CF_BCF - 1] = ctx->d_queue[1];
+    Q.dir[dev::BC_CF_BCF - 1] = 1;
+    Q.base[dev::BC_CF_BD - 1] = ctx->d_queue[1] + last;
+    Q.dir[dev::BC_CF_BD - 1] = -1;
     Q.count = ctx->d_misc + 64;
     FHX_HIP(hipMemsetAsync(Q.count, 0, K2_QUEUES * K2_COUNT_STRIDE * sizeof(unsigned long long), ctx->stream));
     hipLaunchKernelGGL(k2_classify, dim3(grid_for(ctx->n_rows, K2_CL_TILE, 256 * 8)), dim3(K2_THREADS), 0, ctx->stream, P, Q);
     const dim3 qgrid(256 * 8), qblock(K2_THREADS);
 #define FHX_LAUNCH_QUEUE(CLS)                                                                                          \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue<CLS>), qgrid, qblock, 0, ctx->stream, P,                               \
-                       (const unsigned int*)Q.rows[(CLS) - 1], (const unsigned long long*)(Q.count + ((CLS) - 1) * K2_COUNT_STRIDE))
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue<CLS>), qgrid, qblock, 0, ctx->stream, P, (const QEntry*)Q.base[(CLS) - 1], \
+                       Q.dir[(CLS) - 1], (const unsigned long long*)(Q.count + ((CLS) - 1) * K2_COUNT_STRIDE))
     FHX_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
     FHX_LAUNCH_QUEUE(dev::BC_CF_SWAPPED);            // longest-running class first
     FHX_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
