@@ -183,12 +183,25 @@ __device__ __forceinline__ double lean_div(double n, double d) {
     return __builtin_fma(r0, y2, q0);
 }
 
-template <bool LEAN>
-__device__ __forceinline__ double cf_div(double n, double d) {
-    return LEAN ? lean_div(n, d) : n / d;
+// Division modes of the continued-fraction loop: 0 = hipcc's `/`, 1 = lean_div, 2 = lean_div whose reciprocal seed is
+// the previous denominator's refined reciprocal instead of v_rcp_f64.  The denominators of both fractions form ONE
+// sequence D_m = (a+m)(a+m+1), m = 0, 1, 2, ... (k3*k4 is D_2n, k7*k8 is D_2n+1), so 1/D_m is within 2/(a+m) of 1/D_m-1;
+// for a >= 1e6 two Newton steps from that seed land on the same reciprocal quality as v_rcp_f64 + two steps
+// (error e -> e^2: 2e-6 -> 4e-12 -> 2e-23, i.e. rounding-limited), and the final fused residual step is identical.
+template <int MODE>
+__device__ __forceinline__ double cf_div(double n, double d, double& y) {
+    if (MODE == 0) return n / d;
+    if (MODE == 1) return lean_div(n, d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    const double q0 = n * y;
+    const double r0 = __builtin_fma(-d, q0, n);
+    return __builtin_fma(r0, y, q0);
 }
 
-template <int KIND, bool LEAN>
+template <int KIND, int MODE>
 __device__ __forceinline__ double contfrac_lazy_impl(double a, double b, double arg) {
     double k1, k2, k3, k4, k5, k6, k8;
     if (KIND == 0) {
@@ -202,14 +215,21 @@ __device__ __forceinline__ double contfrac_lazy_impl(double a, double b, double 
     double ans = 1.0, r = 1.0;          // only used once the invariant ans == r is broken (some r was exactly 0)
     bool fast_ok = true;
     const double thresh = 3.0 * kMachEp;
+    double yrec = 0.0;                  // running reciprocal of the denominator sequence (MODE 2 only)
+    if (MODE == 2) {
+        const double d0 = k3 * k4;
+        yrec = __builtin_amdgcn_rcp(d0);
+        const double e0 = __builtin_fma(-d0, yrec, 1.0);
+        yrec = __builtin_fma(yrec, e0, yrec);
+    }
     int n = 0;
     do {
-        double xk = -cf_div<LEAN>(arg * k1 * k2, k3 * k4);
+        double xk = -cf_div<MODE>(arg * k1 * k2, k3 * k4, yrec);
         double pk = pkm1 + pkm2 * xk;
         double qk = qkm1 + qkm2 * xk;
         pkm2 = pkm1; pkm1 = pk; qkm2 = qkm1; qkm1 = qk;
 
-        xk = cf_div<LEAN>(arg * k5 * k6, k4 * k8);
+        xk = cf_div<MODE>(arg * k5 * k6, k4 * k8, yrec);
         pk = pkm1 + pkm2 * xk;
         qk = qkm1 + qkm2 * xk;
         pkm2 = pkm1; pkm1 = pk; qkm2 = qkm1; qkm1 = qk;
@@ -270,8 +290,11 @@ __device__ __forceinline__ double contfrac_lazy(double a, double b, double x) {
     // operand window of lean_div: denominators are (a+2n)(a+2n+1) with 1 <= a < 2^53 (exact integers), numerators are
     // arg * k * k' with |k k'| < 1e20, so |arg| in [1e-150, 1e150] keeps every operand inside [1e-200, 1e200] or exactly 0
     const double aa = fabs(arg);
-    if (aa > 1e-150 && aa < 1e150 && a >= 1.0 && a < 4.5e15 && b < 4.5e15) return contfrac_lazy_impl<KIND, true>(a, b, arg);
-    return contfrac_lazy_impl<KIND, false>(a, b, arg);
+    if (aa > 1e-150 && aa < 1e150 && a >= 1.0 && a < 4.5e15 && b < 4.5e15) {
+        if (a >= 1e6) return contfrac_lazy_impl<KIND, 2>(a, b, arg);
+        return contfrac_lazy_impl<KIND, 1>(a, b, arg);
+    }
+    return contfrac_lazy_impl<KIND, 0>(a, b, arg);
 }
 
 // branch classes of one incbet evaluation (used to run branch-homogeneous waves)

@@ -72,8 +72,8 @@ def test_continued_fraction_bit_exact(ctx, kind):
     bit for bit (this is the part of bdtrc whose truncated, non-converged value is the answer: SURVEY fact 4)."""
     from oracle import fithic_oracle as fo
     rng = np.random.default_rng(100 + kind)
-    n = 60000
-    ntot = rng.choice([3.0e5, 6.495767e6, 2.2294127e7, 1.5e9], n)
+    n = 400000               # ~1e8 divisions through each of the three division modes (plain, lean, tracked reciprocal)
+    ntot = rng.choice([3.0e5, 1.2e6, 6.495767e6, 2.2294127e7, 2.1e8, 1.5e9], n)
     cnt = rng.geometric(0.1, n).astype(np.float64) + 1
     ratio = np.exp(rng.normal(0.3 if kind == 0 else -0.2, 0.8, n))
     prior = np.clip(cnt * ratio / ntot, 1e-12, 0.6)
