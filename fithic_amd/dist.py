@@ -37,6 +37,12 @@ class Comm:
     def barrier(self):
         self.td.barrier()
 
+    def _done(self):
+        """torch.distributed ops only order against torch's CURRENT stream; the engine launches on its own stream, so a
+        tensor handed to the C ABI right after a collective must be complete on the host's view first."""
+        if self.device.type == "cuda":
+            self.torch.cuda.current_stream(self.device).synchronize()
+
     def all_reduce_i64(self, arr, op="sum"):
         t = self.torch.as_tensor(np.ascontiguousarray(arr, np.int64)).to(self.device)
         self.td.all_reduce(t, op=self.td.ReduceOp.SUM if op == "sum" else self.td.ReduceOp.MAX)
@@ -46,6 +52,7 @@ class Comm:
         t = t.to(self.device)
         out = [self.torch.empty_like(t) for _ in range(self.world)]
         self.td.all_gather(out, t)
+        self._done()
         return [o.to(self.compute_device) for o in out]
 
     def all_gather_f64_scalar(self, v):
@@ -64,6 +71,7 @@ class Comm:
         send = send.to(self.device).contiguous()
         recv = torch.empty(sum(recv_counts), dtype=send.dtype, device=self.device)
         self.td.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=[int(v) for v in send_counts])
+        self._done()
         return recv.to(self.compute_device), recv_counts
 
     def max_float(self, v):
