@@ -97,6 +97,16 @@ SYMBOLS = {
     "fhx_sort_u64": (ctypes.c_int, [_P, _P, ctypes.c_int64, _P, _P]),
     "fhx_bh_scatter": (ctypes.c_int, [_P, _P]),
     "fhx_memcpy_d2d": (ctypes.c_int, [_P, _P, _P, ctypes.c_int64]),
+    "fhx_host_read_table": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_P)]),
+    "fhx_table_rows": (ctypes.c_int64, [_P]),
+    "fhx_table_n_names": (ctypes.c_int32, [_P]),
+    "fhx_table_name": (ctypes.c_char_p, [_P, ctypes.c_int32]),
+    "fhx_table_error": (ctypes.c_char_p, [_P]),
+    "fhx_table_copy": (ctypes.c_int, [_P, ctypes.c_int32, _P]),
+    "fhx_table_free": (None, [_P]),
+    "fhx_host_write_significances": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int32, _I32P, _I32P, _I32P,
+                                                    _I32P, _I32P, _F64P, _F64P, _F64P, _F64P, _F64P, ctypes.c_int64, ctypes.c_int32,
+                                                    ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _I64P]),
     "fhx_host_spline_fit": (ctypes.c_int, [_F64P, _F64P, ctypes.c_int32, ctypes.c_double, _F64P, _F64P, _I32P, _F64P, _I32P, _I32P]),
     "fhx_host_spline_eval": (ctypes.c_int, [_F64P, _F64P, ctypes.c_int32, _F64P, ctypes.c_int64, _F64P]),
     "fhx_host_pava_decreasing": (ctypes.c_int, [_F64P, ctypes.c_int64, _F64P]),
@@ -104,7 +114,8 @@ SYMBOLS = {
 }
 
 BUILD_CMD = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-             "-fno-fast-math", "-o", LIB_PATH, os.path.join(CSRC, "fhx_device.hip"), os.path.join(CSRC, "fhx_host.cpp")]
+             "-fno-fast-math", "-pthread", "-o", os.path.join(_PKG, "libfithic_mi355x.so"), os.path.join(CSRC, "fhx_device.hip"),
+             os.path.join(CSRC, "fhx_host.cpp"), os.path.join(CSRC, "fhx_io.cpp"), "-lz"]
 
 
 def build(force=False):
@@ -346,6 +357,48 @@ class Context:
 
     def memcpy_d2d(self, dst, src, nbytes):
         self._check(self._L.fhx_memcpy_d2d(self._h, _P(int(dst)), _P(int(src)), int(nbytes)))
+
+
+# ---- native text I/O (no context needed) ---------------------------------------------------------------
+def host_read_table(path, kind, threads=0):
+    """-> (names, int32 columns dict, float64 column or None).  kind: 0 contacts, 1 fragments, 2 bias."""
+    L = lib()
+    h = _P()
+    rc = L.fhx_host_read_table(os.fsencode(path), int(kind), int(threads), ctypes.byref(h))
+    try:
+        if rc != FHX_OK:
+            raise FhxError(rc, (L.fhx_table_error(h) or b"").decode() if h else "fhx_host_read_table")
+        n = L.fhx_table_rows(h)
+        names = [L.fhx_table_name(h, i).decode() for i in range(L.fhx_table_n_names(h))]
+        cols = {}
+        want = {0: (0, 1, 2, 3, 4), 1: (0, 1, 4), 2: (0, 1)}[kind]
+        for c in want:
+            a = np.empty(n, np.int32)
+            L.fhx_table_copy(h, c, a.ctypes.data_as(_P))
+            cols[c] = a
+        dv = None
+        if kind in (0, 2):
+            dv = np.empty(n, np.float64)
+            L.fhx_table_copy(h, 5, dv.ctypes.data_as(_P))
+        return names, cols, dv
+    finally:
+        if h:
+            L.fhx_table_free(h)
+
+
+def host_write_significances(path, names, chr1, mid1, chr2, mid2, count, p, q, b1, b2, expcc, mode, dist_low, dist_up,
+                             gzip_level=6, threads=0):
+    arr_names = (ctypes.c_char_p * len(names))(*[n.encode() for n in names])
+    i32 = [_i32(v) for v in (chr1, mid1, chr2, mid2, count)]
+    f64 = [np.ascontiguousarray(v, np.float64) for v in (p, q, b1, b2, expcc)]
+    up = INT64_MAX if dist_up is None or dist_up == float("inf") else int(dist_up)
+    written = ctypes.c_int64(0)
+    rc = lib().fhx_host_write_significances(os.fsencode(path), arr_names, len(names), *[_ptr(v, ctypes.c_int32) for v in i32],
+                                            *[_ptr(v, ctypes.c_double) for v in f64], len(i32[0]), int(mode), int(dist_low), up,
+                                            int(gzip_level), int(threads), ctypes.byref(written))
+    if rc != FHX_OK:
+        raise FhxError(rc, "fhx_host_write_significances(%s)" % path)
+    return written.value
 
 
 # ---- host numerics (no context needed) -------------------------------------------------------------

@@ -318,9 +318,9 @@ def fit_Spline(mainDic, x, y, yerr, infilename, outfilename, biasDic, outliersli
     emit = (inter & (allReg or interOnly)) | (~inter & (allReg or not interOnly) & in_rng)
     name = outfilename + (".res" + str(resolution) if resolution else "") + ".significances.txt.gz"
     print("Writing p-values and q-values to file %s" % (outfilename + ".significances.txt"))
-    text = tables.format_significance_rows(S.chroms.names, con, emit, v["p"], v["q"], v["b1"], v["b2"], v["expcc"])
-    with gzip.open(name, "wt", compresslevel=6) as f:
-        f.write(text)
+    mode_id = MODES["All" if allReg else ("interOnly" if interOnly else "intraOnly")]
+    _capi.host_write_significances(name, S.chroms.names, con.chr1, con.mid1, con.chr2, con.mid2, con.count, v["p"], v["q"],
+                                   v["b1"], v["b2"], v["expcc"], mode_id, distLowThres, distUpThres)
     flags, _ = eng.ctx.fetch_flags(len(con), outlier=True, skip=False)
     rows = np.flatnonzero(flags)
     for r in rows.tolist():

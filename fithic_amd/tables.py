@@ -1,4 +1,4 @@
-"""Input tables of Fit-Hi-C as SoA numpy arrays + the output writer.
+"""Input tables of Fit-Hi-C as SoA numpy arrays (parsed by the native reader in libfithic_mi355x.so).
 
 File formats are the reference's (README.md:139-208 of ay-lab/fithic):
   contacts   gz text, whitespace separated  chr1 mid1 chr2 mid2 count      (fithic/fithic.py:413-417)
@@ -7,9 +7,6 @@ File formats are the reference's (README.md:139-208 of ay-lab/fithic):
 Chromosome names of all three files are interned into one id space (`ChromIndex`); the reference iterates
 chromosomes in Python's sorted() string order (fithic/fithic.py:606), which `sort_rank()` hands to the engine.
 """
-import gzip
-import io
-
 import numpy as np
 
 
@@ -20,20 +17,6 @@ class ChromIndex:
         self.names = []
         self._ids = {}
 
-    def intern_column(self, col):
-        """ids (int32) of an object / str column; new names get new ids in order of first appearance."""
-        import pandas as pd
-        codes, uniques = pd.factorize(col, sort=False)
-        remap = np.empty(len(uniques), np.int32)
-        for k, name in enumerate(uniques):
-            name = str(name)
-            j = self._ids.get(name)
-            if j is None:
-                j = self._ids[name] = len(self.names)
-                self.names.append(name)
-            remap[k] = j
-        return remap[codes]
-
     def sort_rank(self):
         order = sorted(range(len(self.names)), key=lambda i: self.names[i])
         rank = np.empty(len(self.names), np.int32)
@@ -43,14 +26,6 @@ class ChromIndex:
 
     def __len__(self):
         return len(self.names)
-
-
-def _read_table(path, ncols_min):
-    import pandas as pd
-    opener = gzip.open
-    with opener(path, "rb") as f:
-        raw = f.read()
-    return pd.read_csv(io.BytesIO(raw), sep=r"\s+", header=None, engine="c", dtype=str if ncols_min == 0 else None)
 
 
 class Contacts:
@@ -67,30 +42,41 @@ class Contacts:
         return Contacts(self.chr1[sel], self.mid1[sel], self.chr2[sel], self.mid2[sel], self.count[sel], self.raw_count[sel])
 
 
-def read_contacts(path, chroms):
-    import pandas as pd
-    df = pd.read_csv(path, sep=r"\s+", header=None, names=["c1", "m1", "c2", "m2", "cc"], compression="gzip", engine="c",
-                     dtype={"c1": str, "m1": np.int64, "c2": str, "m2": np.int64, "cc": np.float64})
-    raw = df["cc"].values.astype(np.float64)
-    both = chroms.intern_column(np.concatenate([df["c1"].values, df["c2"].values]))
-    n = len(df)
-    return Contacts(both[:n].copy(), df["m1"].values.astype(np.int32), both[n:].copy(), df["m2"].values.astype(np.int32),
-                    np.trunc(raw).astype(np.int32), raw)
+def _intern_native(names, ids, chroms):
+    """file-local chromosome ids (order of first appearance in the file) -> the run's shared id space"""
+    remap = np.empty(max(len(names), 1), np.int32)
+    for k, name in enumerate(names):
+        j = chroms._ids.get(name)
+        if j is None:
+            j = chroms._ids[name] = len(chroms.names)
+            chroms.names.append(name)
+        remap[k] = j
+    return remap[ids] if len(ids) else ids.astype(np.int32)
 
 
-def read_fragments(path, chroms):
+def read_contacts(path, chroms, threads=0):
+    """Native multi-threaded parser (libfithic_mi355x.so: fhx_host_read_table).  Same semantics as the reference's loop:
+    whitespace split, exactly five fields, int(mid), count = int(float(text)); a malformed line raises like the reference."""
+    from . import _capi
+    names, cols, raw = _capi.host_read_table(path, 0, threads)
+    # both loci share the file's name table; intern in the reference's order of appearance (row by row, chr1 then chr2)
+    c1 = _intern_native(names, cols[0], chroms)
+    c2 = _intern_native(names, cols[2], chroms)
+    return Contacts(c1, cols[1], c2, cols[3], cols[4], raw)
+
+
+def read_fragments(path, chroms, threads=0):
     """-> (chr ids, mids, hits) as int32 arrays in file order."""
-    import pandas as pd
-    df = pd.read_csv(path, sep=r"\s+", header=None, compression="gzip", engine="c", dtype={0: str})
-    return chroms.intern_column(df[0].values), df[2].values.astype(np.int32), df[3].values.astype(np.int32)
+    from . import _capi
+    names, cols, _ = _capi.host_read_table(path, 1, threads)
+    return _intern_native(names, cols[0], chroms), cols[1], cols[4]
 
 
-def read_bias(path, chroms):
+def read_bias(path, chroms, threads=0):
     """-> (chr ids, mids, raw bias values); bounds / NaN / first-occurrence rules are applied by the engine."""
-    import pandas as pd
-    df = pd.read_csv(path, sep=r"\s+", header=None, names=["c", "m", "b"], compression="gzip", engine="c",
-                     dtype={"c": str, "m": np.int64, "b": np.float64})
-    return chroms.intern_column(df["c"].values), df["m"].values.astype(np.int32), df["b"].values.astype(np.float64)
+    from . import _capi
+    names, cols, bias = _capi.host_read_table(path, 2, threads)
+    return _intern_native(names, cols[0], chroms), cols[1], bias
 
 
 def bias_quantiles(bias):
@@ -109,14 +95,3 @@ def bias_quantiles(bias):
         gamma = min(max(aleph - k, 0.0), 1.0)
         out.append((1.0 - gamma) * v[k - 1] + gamma * v[min(k, n - 1)])
     return out
-
-
-def format_significance_rows(names, contacts, emit, p, q, b1, b2, expcc):
-    """Text of the .significances.txt file (header + the rows the reference's writer emits,
-    fithic/fithic.py:1178-1212): "%s\\t%d\\t%s\\t%d\\t%d\\t%e\\t%e\\t%e\\t%e\\t%f"."""
-    out = ["chr1\tfragmentMid1\tchr2\tfragmentMid2\tcontactCount\tp-value\tq-value\tbias1\tbias2\tExpCC\n"]
-    c1, m1, c2, m2, rc = contacts.chr1, contacts.mid1, contacts.chr2, contacts.mid2, contacts.raw_count
-    fmt = "%s\t%d\t%s\t%d\t%d\t%e\t%e\t%e\t%e\t%f\n"
-    for i in np.flatnonzero(emit).tolist():
-        out.append(fmt % (names[c1[i]], m1[i], names[c2[i]], m2[i], rc[i], p[i], q[i], b1[i], b2[i], expcc[i]))
-    return "".join(out)

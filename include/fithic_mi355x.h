@@ -220,6 +220,30 @@ int fhx_host_spline_eval(const double* t, const double* c, int32_t n_knots, cons
 int fhx_host_pava_decreasing(const double* y, int64_t n, double* out);
 int fhx_host_lbeta_table(double n_total, int64_t max_count, double* lbeta_out, double* inv_beta_out);
 
+/* ---- native text I/O (host only) -------------------------------------------------------------------
+ * Reader for the three gzip text tables (fithic/fithic.py:406-417 contacts, :581-590 fragments, :805-808 bias):
+ * kind 0 = contacts (chr1 mid1 chr2 mid2 count), 1 = fragments (uses columns 0, 2, 3), 2 = bias (chr mid bias).
+ * Chromosome names are interned in order of first appearance.  Columns for fhx_table_copy: 0 chr1, 1 mid1, 2 chr2, 3 mid2,
+ * 4 count = int(float(text)) or hits (int32 each); 5 = the float itself / the bias (double).  A malformed line returns
+ * FHX_ERR_REFERENCE_EXIT (the reference raises ValueError there); fhx_table_error gives the line number. */
+typedef struct fhx_table fhx_table;
+int fhx_host_read_table(const char* path, int32_t kind, int32_t n_threads, fhx_table** out);
+int64_t fhx_table_rows(const fhx_table* t);
+int32_t fhx_table_n_names(const fhx_table* t);
+const char* fhx_table_name(const fhx_table* t, int32_t i);
+const char* fhx_table_error(const fhx_table* t);
+int fhx_table_copy(const fhx_table* t, int32_t column, void* dst);
+void fhx_table_free(fhx_table* t);
+/* Writer of <lib>.spline_passN.resR.significances.txt.gz (fithic/fithic.py:1167-1213): header + one
+ * "%s\t%d\t%s\t%d\t%d\t%e\t%e\t%e\t%e\t%f" row per emitted contact (inter rows in All / interOnly mode, in-range intra
+ * rows in All / intraOnly mode).  Rows are formatted and deflated in parallel, one gzip member per 65 536 rows; the
+ * decompressed bytes equal the reference's.  n_threads <= 0: all host cores. */
+int fhx_host_write_significances(const char* path, const char* const* chr_names, int32_t n_names, const int32_t* chr1,
+                                 const int32_t* mid1, const int32_t* chr2, const int32_t* mid2, const int32_t* count,
+                                 const double* p, const double* q, const double* bias1, const double* bias2,
+                                 const double* expcc, int64_t n_rows, int32_t mode, int64_t dist_low, int64_t dist_up,
+                                 int32_t gzip_level, int32_t n_threads, int64_t* rows_written);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,77 @@
+"""Native text I/O of libfithic_mi355x.so, CPU only: the reader against an independent pandas parse of
+every fixture file, the writer against the md5 of the reference's own decompressed output."""
+import gzip
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_case, case_args, DATA, ALL_CASES
+from fithic_amd import _capi, tables
+
+
+@pytest.mark.parametrize("fname,kind", [("hESC_chr1_w40000.contacts.gz", 0), ("synth_IMR90_w1Mb.contacts.gz", 0),
+                                        ("quirk.contacts.gz", 0), ("IMR90_w1Mb.frags.gz", 1), ("quirk.frags.gz", 1),
+                                        ("hESC_chr1_w40000.frags.gz", 1), ("IMR90_w1Mb.bias.gz", 2), ("quirk.bias.gz", 2)])
+@pytest.mark.parametrize("threads", [1, 5])
+def test_reader_matches_an_independent_parse(fname, kind, threads):
+    path = os.path.join(DATA, fname)
+    names, cols, dv = _capi.host_read_table(path, kind, threads)
+    rows = [ln.split() for ln in gzip.open(path, "rt")]
+    assert len(rows) == len(cols[0])
+    mine_chr = [names[i] for i in cols[0]]
+    assert mine_chr == [r[0] for r in rows]
+    seen = []
+    for r in rows:                                   # order of first appearance (chr1 then chr2 per row for contacts)
+        for name in ([r[0], r[2]] if kind == 0 else [r[0]]):
+            if name not in seen:
+                seen.append(name)
+    assert names == seen
+    if kind == 0:
+        assert np.array_equal(cols[1], [int(r[1]) for r in rows]) and np.array_equal(cols[3], [int(r[3]) for r in rows])
+        assert [names[i] for i in cols[2]] == [r[2] for r in rows]
+        assert np.array_equal(cols[4], [int(float(r[4])) for r in rows])
+        assert np.array_equal(dv, [float(r[4]) for r in rows])
+    elif kind == 1:
+        assert np.array_equal(cols[1], [int(r[2]) for r in rows]) and np.array_equal(cols[4], [int(r[3]) for r in rows])
+    else:
+        want = np.array([float(r[2]) for r in rows])
+        assert np.array_equal(cols[1], [int(r[1]) for r in rows])
+        assert np.array_equal(np.isnan(dv), np.isnan(want)) and np.array_equal(dv[~np.isnan(dv)], want[~np.isnan(want)])
+
+
+def test_reader_rejects_what_the_reference_rejects(tmp_path):
+    bad = tmp_path / "bad.gz"
+    with gzip.open(bad, "wt") as f:
+        f.write("chr1\t5000\tchr1\t15000\t3\nchr1\t5000\tchr1\t25000\n")        # 4 fields: ValueError in the reference
+    with pytest.raises(_capi.FhxError) as e:
+        _capi.host_read_table(str(bad), 0)
+    assert e.value.code == _capi.FHX_ERR_REFERENCE_EXIT and "line 2" in str(e.value)
+    with gzip.open(bad, "wt") as f:
+        f.write("chr1\t5000\tchr1\t1.5e4\t3\n")                                  # int('1.5e4') raises
+    with pytest.raises(_capi.FhxError):
+        _capi.host_read_table(str(bad), 0)
+    with pytest.raises(_capi.FhxError):
+        _capi.host_read_table(str(tmp_path / "missing.gz"), 0)
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_writer_reproduces_the_reference_file(name, tmp_path):
+    """Values from the checker (bit-identical to the reference, see test_oracle_golden) through the PRODUCT's writer:
+    the decompressed bytes must hash to the md5 of the reference's own output file."""
+    from oracle import fithic_oracle as fo
+    from fithic_amd.engine import MODES
+    meta, g = load_case(name)
+    kw = case_args(meta)
+    chroms = tables.ChromIndex()
+    con = tables.read_contacts(kw["contacts"], chroms)
+    ref = fo.run(**kw)
+    for pi, r in enumerate(ref, 1):
+        out = str(tmp_path / ("p%d.gz" % pi))
+        n = _capi.host_write_significances(out, chroms.names, con.chr1, con.mid1, con.chr2, con.mid2, con.count, r.p, r.q,
+                                           r.b1, r.b2, r.expcc, MODES[kw["mode"]], kw["L"], kw["U"], threads=3)
+        with gzip.open(out, "rb") as f:
+            text = f.read()
+        assert n == meta["sig_rows_pass%d" % pi] == text.count(b"\n") - 1
+        assert hashlib.md5(text).hexdigest() == meta["sig_md5_pass%d" % pi]
