@@ -20,7 +20,8 @@ INT64_MAX = (1 << 63) - 1
 
 # enum fhx_array
 (A_HIST_SUMCC, A_HIST_NPAIRS, A_BIN_LB, A_BIN_UB, A_BIN_POSS, A_BIN_SUMCC, A_BIN_SUMDIST, A_BIN_POSS7, A_X, A_Y,
- A_KNOTS, A_COEFFS, A_TABLE_X, A_TABLE_Y0, A_TABLE_Y, A_OUTLIER_DIST_HIST, A_FDR_COUNTS, A_BIN_POSS0) = range(18)
+ A_KNOTS, A_COEFFS, A_TABLE_X, A_TABLE_Y0, A_TABLE_Y, A_OUTLIER_DIST_HIST, A_FDR_COUNTS, A_BIN_POSS0, A_DIST_KEYS,
+ A_OUTLIER_DISTS) = range(20)
 _ARRAY_DTYPE = {A_BIN_SUMDIST: np.float64, A_X: np.float64, A_Y: np.float64, A_KNOTS: np.float64,
                 A_COEFFS: np.float64, A_TABLE_Y0: np.float64, A_TABLE_Y: np.float64}
 
@@ -69,6 +70,8 @@ SYMBOLS = {
     "fhx_load_pairs_device": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int64, _P]),
     "fhx_pass_stats": (ctypes.c_int, [_P, ctypes.POINTER(FhxStats)]),
     "fhx_set_global_stats": (ctypes.c_int, [_P, ctypes.POINTER(FhxStats), _I64P, _I64P, ctypes.c_int64]),
+    "fhx_set_dist_keys": (ctypes.c_int, [_P, _I64P, ctypes.c_int64]),
+    "fhx_set_outlier_dists": (ctypes.c_int, [_P, _I64P, ctypes.c_int64]),
     "fhx_set_outlier_dist_hist": (ctypes.c_int, [_P, _I64P, ctypes.c_int64]),
     "fhx_make_bins": (ctypes.c_int, [_P, _I32P]),
     "fhx_fit": (ctypes.c_int, [_P, ctypes.POINTER(FhxFitInfo)]),
@@ -222,6 +225,14 @@ class Context:
         a = np.ascontiguousarray(hist_sumcc, np.int64)
         b = np.ascontiguousarray(hist_npairs, np.int64)
         self._check(self._L.fhx_set_global_stats(self._h, ctypes.byref(stats), _ptr(a, ctypes.c_int64), _ptr(b, ctypes.c_int64), len(a)))
+
+    def set_dist_keys(self, keys):
+        a = np.ascontiguousarray(keys, np.int64)
+        self._check(self._L.fhx_set_dist_keys(self._h, _ptr(a, ctypes.c_int64), len(a)))
+
+    def set_outlier_dists(self, dists):
+        a = np.ascontiguousarray(dists, np.int64)
+        self._check(self._L.fhx_set_outlier_dists(self._h, _ptr(a, ctypes.c_int64), len(a)))
 
     def set_outlier_dist_hist(self, hist):
         a = np.ascontiguousarray(hist, np.int64)

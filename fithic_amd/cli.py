@@ -20,7 +20,7 @@ def parse_args(argv=None):
                         help="REQUIRED: midpoints (or start indices) of the fragments are read from FRAGSFILE")
     parser.add_argument("-o", "--outdir", dest="outdir", required=True, help="REQUIRED: where the output files will be written")
     parser.add_argument("-r", "--resolution", dest="resolution", type=int, required=True,
-                        help="REQUIRED: resolution of the fixed-size dataset (0 = non-fixed-size data: not accelerated)")
+                        help="REQUIRED: resolution of the fixed-size dataset; 0 if the data is not fixed size")
     parser.add_argument("-t", "--biases", dest="biasfile", required=False,
                         help="RECOMMENDED: biases calculated by ICE or KR norm for each locus are read from BIASFILE")
     parser.add_argument("-p", "--passes", dest="noOfPasses", type=int, required=False, help="OPTIONAL: number of spline passes. Default is 1")
@@ -83,8 +83,6 @@ def main(argv=None):
     resolution = args.resolution
     if resolution == 0:
         print("Fixed size data not being used.")
-        print("fithic-mi355x accelerates the fixed-size path only (-r > 0); use the reference for -r 0")
-        sys.exit(2)
     elif resolution > 0:
         print("Fixed size option detected... Fast version of FitHiC will be used")
         print("Resolution is %s kb" % (resolution / 1000))

@@ -222,7 +222,31 @@ struct K2Params {
     int64_t n;
     double* p;
     uint8_t* outlier;             // p < 1/N, feeds the next pass
+    // non-fixed-size mode (-r 0): loci are ranks into the sorted distinct (chr, mid) list, distances come from slot_mid,
+    // and the prior is found by bisect_left over the spline table (fithic.py:1066-1069) instead of a dense LUT
+    int nonfixed;
+    const int32_t* slot_mid;
+    const double* table_x;
+    const double* table_y;
+    int n_table;
+    double min_x, max_x;
+    long long dist_low, dist_up;
 };
+
+__device__ __forceinline__ double prior_by_search(const K2Params& P, long long dist) {
+    double look = (double)dist;
+    if (look < P.min_x) look = P.min_x;                                   // max(d, min(x))
+    if (look > P.max_x) look = P.max_x;                                   // min(., max(x))
+    int lo = 0, hi = P.n_table;                                           // bisect_left
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (P.table_x[mid] < look)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return P.table_y[min(lo, P.n_table - 1)];
+}
 
 // prior and which binomial a row uses; returns false when the row's p-value is the constant 1.0
 __device__ __forceinline__ bool row_prior(const K2Params& P, int l1, int l2, double& prior, bool& is_inter) {
@@ -231,6 +255,13 @@ __device__ __forceinline__ bool row_prior(const K2Params& P, int l1, int l2, dou
     const double b1 = P.slot_bias[l1], b2 = P.slot_bias[s2];
     if ((b1 < 0 || b2 < 0) && !inter) return false;                        // fithic.py:1057-1064
     if (!inter && P.mode != FHX_MODE_INTER_ONLY) {
+        if (P.nonfixed) {
+            const long long dist = llabs((long long)P.slot_mid[l1] - (long long)P.slot_mid[s2]);
+            if (dist < P.dist_low || dist > P.dist_up) return false;
+            prior = prior_by_search(P, dist) * (b1 * b2);
+            is_inter = false;
+            return true;
+        }
         const int d = abs(l1 - s2);
         if (d < P.lo_idx || d > P.hi_idx) return false;                   // intraShort / intraLong: p = 1
         prior = P.prior_lut[d] * (b1 * b2);                               // fithic.py:1069
@@ -904,6 +935,266 @@ __global__ __launch_bounds__(BH_THREADS) void bh_apply(const unsigned long long*
     }
 }
 
+// ===================================================================================================
+// non-fixed-size mode (-r 0): loci and distances are arbitrary integers, so the dense index arithmetic of the
+// fixed-size path is replaced by sort + run detection (reusing the radix sort above)
+// ===================================================================================================
+constexpr int SEG_THREADS = 256;
+constexpr int SEG_ITEMS = 16;
+constexpr int SEG_TILE = SEG_THREADS * SEG_ITEMS;
+
+// locus keys (chr << 32 | mid) of both ends of every row: element i = locus 1 of row i, element n + i = locus 2
+__global__ void nf_locus_keys(const int32_t* __restrict__ c1, const int32_t* __restrict__ m1, const int32_t* __restrict__ c2,
+                              const int32_t* __restrict__ m2, int64_t n, unsigned long long* __restrict__ keys,
+                              unsigned int* __restrict__ vals, int* __restrict__ bad) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (c1[i] < 0 || c2[i] < 0 || m1[i] < 0 || m2[i] < 0) atomicOr(bad, 1);
+        keys[i] = ((unsigned long long)(unsigned int)c1[i] << 32) | (unsigned int)m1[i];
+        keys[n + i] = ((unsigned long long)(unsigned int)c2[i] << 32) | (unsigned int)m2[i];
+        vals[i] = (unsigned int)i;
+        vals[n + i] = (unsigned int)(n + i);
+    }
+}
+
+// run heads of a sorted key array: per-tile head counts, then (after the scan of the tile counts) the run id of every element
+__global__ __launch_bounds__(SEG_THREADS) void seg_count_heads(const unsigned long long* __restrict__ keys, int64_t n,
+                                                               unsigned int* __restrict__ tile_heads) {
+    __shared__ unsigned int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * SEG_TILE;
+    unsigned int mine = 0;
+    for (int r = 0; r < SEG_ITEMS; ++r) {
+        const int64_t i = base + r * SEG_THREADS + threadIdx.x;
+        if (i < n && (i == 0 || keys[i] != keys[i - 1])) ++mine;
+    }
+    mine = (unsigned int)wave_sum_i64((long long)mine);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) tile_heads[blockIdx.x] = cnt;
+}
+
+__global__ __launch_bounds__(1024) void seg_scan_tiles(unsigned int* __restrict__ tile_heads, int64_t tiles,
+                                                       unsigned long long* __restrict__ total) {
+    __shared__ unsigned int part[1024];
+    const int64_t per = (tiles + 1023) / 1024;
+    const int64_t beg = (int64_t)threadIdx.x * per, end = min(tiles, beg + per);
+    unsigned int sum = 0;
+    for (int64_t t = beg; t < end; ++t) sum += tile_heads[t];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int acc = 0;
+        for (int i = 0; i < 1024; ++i) {
+            const unsigned int c = part[i];
+            part[i] = acc;
+            acc += c;
+        }
+        *total = acc;
+    }
+    __syncthreads();
+    unsigned int run = part[threadIdx.x];
+    for (int64_t t = beg; t < end; ++t) {
+        const unsigned int c = tile_heads[t];
+        tile_heads[t] = run;
+        run += c;
+    }
+}
+
+// run id of every sorted element (0-based), blocked arrangement: thread t owns SEG_ITEMS consecutive elements
+__global__ __launch_bounds__(SEG_THREADS) void seg_ids(const unsigned long long* __restrict__ keys, int64_t n,
+                                                       const unsigned int* __restrict__ tile_base,
+                                                       unsigned int* __restrict__ ids) {
+    __shared__ unsigned int wtot[SEG_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t first = (int64_t)blockIdx.x * SEG_TILE + (int64_t)threadIdx.x * SEG_ITEMS;
+    unsigned int heads = 0;
+    unsigned int flag[SEG_ITEMS];
+#pragma unroll
+    for (int r = 0; r < SEG_ITEMS; ++r) {
+        const int64_t i = first + r;
+        flag[r] = (i < n && (i == 0 || keys[i] != keys[i - 1])) ? 1u : 0u;
+        heads += flag[r];
+    }
+    unsigned int incl = heads;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    unsigned int before = tile_base[blockIdx.x] + incl - heads;
+    for (int w = 0; w < wave; ++w) before += wtot[w];
+#pragma unroll
+    for (int r = 0; r < SEG_ITEMS; ++r) {
+        const int64_t i = first + r;
+        before += flag[r];
+        if (i < n) ids[i] = before - 1;                  // heads so far, including this element's own head
+    }
+}
+
+// locus slots: element -> run id; the run's key goes to the slot table
+__global__ void nf_assign_slots(const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ vals,
+                                const unsigned int* __restrict__ ids, int64_t n2, int32_t* __restrict__ loc,
+                                unsigned long long* __restrict__ slot_key) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        loc[vals[i]] = (int32_t)ids[i];
+        if (i == 0 || keys[i] != keys[i - 1]) slot_key[ids[i]] = keys[i];
+    }
+}
+
+// rows: (loc1, loc2) with the inter flag in the sign of loc2, plus the slot tables
+__global__ void nf_finish_rows(const int32_t* __restrict__ c1, const int32_t* __restrict__ c2, const int32_t* __restrict__ cnt,
+                               const int32_t* __restrict__ loc, int64_t n, int32_t* __restrict__ loc1,
+                               int32_t* __restrict__ loc2, int32_t* __restrict__ count) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        loc1[i] = loc[i];
+        loc2[i] = (c1[i] == c2[i]) ? loc[n + i] : ~loc[n + i];
+        count[i] = cnt[i];
+    }
+}
+
+__global__ void nf_slot_tables(const unsigned long long* __restrict__ slot_key, int64_t n_slots, int32_t* __restrict__ slot_mid,
+                               int16_t* __restrict__ slot_chr) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += stride) {
+        slot_mid[i] = (int32_t)(slot_key[i] & 0xFFFFFFFFull);
+        slot_chr[i] = (int16_t)(slot_key[i] >> 32);
+    }
+}
+
+// K1 for -r 0: the same classification and sums as k1_classify_hist; in-range rows emit (distance, count) for the sort
+__global__ __launch_bounds__(SORT_THREADS) void nf_k1_classify(
+    const int32_t* __restrict__ loc1, const int32_t* __restrict__ loc2, const int32_t* __restrict__ count,
+    const uint8_t* __restrict__ skip, int64_t skip_limit, const long long* __restrict__ grow, int64_t n,
+    const int32_t* __restrict__ slot_mid, long long dist_low, long long dist_up, unsigned long long* __restrict__ keys,
+    unsigned int* __restrict__ vals, unsigned long long* __restrict__ counter, K1Sums* __restrict__ sums) {
+    __shared__ unsigned int wave_cnt[SORT_WAVES];
+    __shared__ unsigned long long block_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    long long inter_count = 0, inter_sum = 0, intra_cnt = 0, intra_sum = 0, rng_cnt = 0, rng_sum = 0, skipped = 0;
+    int max_count = 0;
+    const int64_t tiles = (n + SORT_TILE - 1) / SORT_TILE;
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int64_t wave_base = t * SORT_TILE + (int64_t)wave * (64 * SORT_ITEMS);
+        unsigned long long d_of[SORT_ITEMS];
+        unsigned int c_of[SORT_ITEMS], before[SORT_ITEMS];
+        unsigned long long keepmask = 0;
+        unsigned int run = 0;
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            const int64_t i = wave_base + r * 64 + lane;
+            bool keep = false;
+            d_of[r] = 0;
+            c_of[r] = 0;
+            if (i < n) {
+                const int l1 = loc1[i], l2 = loc2[i], c = count[i];
+                max_count = max(max_count, c);
+                const bool sk = skip && skip[i] && ((grow ? grow[i] : i) <= skip_limit);
+                if (sk) {
+                    ++skipped;
+                } else if (l2 < 0) {
+                    ++inter_count;
+                    inter_sum += c;
+                } else {
+                    ++intra_cnt;
+                    intra_sum += c;
+                    const long long dist = llabs((long long)slot_mid[l1] - (long long)slot_mid[l2]);
+                    if (dist >= dist_low && dist <= dist_up) {
+                        ++rng_cnt;
+                        rng_sum += c;
+                        keep = true;
+                        d_of[r] = (unsigned long long)dist;
+                        c_of[r] = (unsigned int)c;
+                    }
+                }
+            }
+            const unsigned long long m = __ballot(keep);
+            before[r] = run + __popcll(m & lane_lt);
+            run += __popcll(m);
+            if (keep) keepmask |= (1ull << r);
+        }
+        if (lane == 0) wave_cnt[wave] = run;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned int tot = 0;
+            for (int w = 0; w < SORT_WAVES; ++w) {
+                const unsigned int c = wave_cnt[w];
+                wave_cnt[w] = tot;
+                tot += c;
+            }
+            block_base = tot ? atomicAdd(counter, (unsigned long long)tot) : 0ull;
+        }
+        __syncthreads();
+        const unsigned long long base = block_base + wave_cnt[wave];
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            if ((keepmask >> r) & 1ull) {
+                keys[base + before[r]] = d_of[r];
+                vals[base + before[r]] = c_of[r];
+            }
+        }
+        __syncthreads();
+    }
+    inter_count = wave_sum_i64(inter_count);
+    inter_sum = wave_sum_i64(inter_sum);
+    intra_cnt = wave_sum_i64(intra_cnt);
+    intra_sum = wave_sum_i64(intra_sum);
+    rng_cnt = wave_sum_i64(rng_cnt);
+    rng_sum = wave_sum_i64(rng_sum);
+    skipped = wave_sum_i64(skipped);
+    max_count = wave_max_i32(max_count);
+    if (lane == 0) {
+        atomicAdd((unsigned long long*)&sums->inter_count, (unsigned long long)inter_count);
+        atomicAdd((unsigned long long*)&sums->inter_sum, (unsigned long long)inter_sum);
+        atomicAdd((unsigned long long*)&sums->intra_all_count, (unsigned long long)intra_cnt);
+        atomicAdd((unsigned long long*)&sums->intra_all_sum, (unsigned long long)intra_sum);
+        atomicAdd((unsigned long long*)&sums->in_range_count, (unsigned long long)rng_cnt);
+        atomicAdd((unsigned long long*)&sums->in_range_sum, (unsigned long long)rng_sum);
+        atomicAdd((unsigned long long*)&sums->n_skipped, (unsigned long long)skipped);
+        atomicMax(&sums->max_count, max_count);
+    }
+}
+
+// distinct distances: key, sum of counts and number of rows per run of the sorted (distance, count) array
+__global__ void nf_accumulate_runs(const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ vals,
+                                   const unsigned int* __restrict__ ids, int64_t n, unsigned long long* __restrict__ out_key,
+                                   unsigned long long* __restrict__ out_sum, unsigned long long* __restrict__ out_cnt) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const unsigned int s = ids[i];
+        if (i == 0 || keys[i] != keys[i - 1]) out_key[s] = keys[i];
+        atomicAdd(&out_sum[s], (unsigned long long)vals[i]);
+        atomicAdd(&out_cnt[s], 1ull);
+    }
+}
+
+// outliers of a -r 0 pass: skip mask + the list of their distances (the reference's SortedList outliersdist)
+__global__ void nf_fold_outliers(const int32_t* __restrict__ loc1, const int32_t* __restrict__ loc2,
+                                 const double* __restrict__ pvals, double thres, uint8_t* __restrict__ skip,
+                                 uint8_t* __restrict__ seen_twice, int64_t n, const int32_t* __restrict__ slot_mid,
+                                 unsigned long long* __restrict__ dist_list, unsigned long long* __restrict__ n_out,
+                                 unsigned long long* __restrict__ first_dup, const long long* __restrict__ grow) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (!(pvals[i] < thres)) continue;
+        if (skip[i]) {
+            seen_twice[i] = 1;
+            atomicMin(first_dup, (unsigned long long)(grow ? grow[i] : i));
+        }
+        skip[i] = 1;
+        const int l1 = loc1[i], l2 = loc2[i];
+        const int s2 = l2 < 0 ? ~l2 : l2;
+        const long long dist = llabs((long long)slot_mid[l1] - (long long)slot_mid[s2]);   // also for inter rows (fithic.py:1217)
+        dist_list[atomicAdd(n_out, 1ull)] = (unsigned long long)dist;
+    }
+}
+
 __global__ void k_iota_u32(unsigned int* __restrict__ v, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) v[i] = (unsigned int)i;
@@ -999,6 +1290,15 @@ struct fhx_ctx {
     unsigned int* d_digit_total = nullptr;
     unsigned long long* d_top_hist = nullptr;
     QEntry* d_queue[2] = {nullptr, nullptr};          // K2's per-class row queues
+    // non-fixed-size mode (-r 0)
+    bool nonfixed = false;
+    int32_t* d_slot_mid = nullptr;
+    std::vector<unsigned long long> h_slot_keys;      // sorted distinct (chr << 32 | mid) of every locus the rows touch
+    std::vector<int64_t> h_dist_keys;                 // distinct in-range distances of the current pass, ascending
+    std::vector<int64_t> h_outlier_dists;             // outlier distances of all earlier passes, ascending (a multiset)
+    double *d_table_x = nullptr, *d_table_y = nullptr;
+    unsigned int* d_seg_ids = nullptr;                // run ids / tile counts scratch
+    unsigned int* d_seg_tiles = nullptr;
     double* d_tile_max = nullptr;
     int sorted_buf = 0;
     int64_t n_sorted = -1;
@@ -1042,18 +1342,59 @@ K2Params make_k2_params(fhx_ctx* c) {
     P.inter = dev::BinomTables{c->d_lbeta_inter, c->d_invb_inter, n_inter, (n_inter + 1.0) < dev::kMaxGam};
     P.inter_chr_prob = c->fit.inter_chr_prob;
     P.outlier_thres = 1.0 / c->fit.bh_total_tests;
-    const int64_t res = c->prm.resolution;
+    const int64_t res = std::max<int64_t>(c->prm.resolution, 1);          // -r 0 does not use the index window
     P.lo_idx = (int)std::min<int64_t>((c->prm.dist_low + res - 1) / res, INT32_MAX);
     P.hi_idx = (int)std::min<int64_t>(c->prm.dist_up / res, INT32_MAX);
     P.mode = c->prm.mode;
     P.n = c->n_rows;
     P.p = c->d_p;
     P.outlier = c->d_outlier;
+    P.nonfixed = c->nonfixed ? 1 : 0;
+    P.slot_mid = c->d_slot_mid;
+    P.table_x = c->d_table_x;
+    P.table_y = c->d_table_y;
+    P.n_table = (int)c->fit.table_x.size();
+    P.min_x = c->fit.min_x;
+    P.max_x = c->fit.max_x;
+    P.dist_low = c->prm.dist_low;
+    P.dist_up = c->prm.dist_up;
     return P;
 }
 
 // bias rows -> per-slot table (first occurrence wins, bounds applied: fithic.py:818-832)
+int build_slot_tables_nonfixed(fhx_ctx* ctx) {
+    // exact (chr, mid) match against the sorted distinct loci of the rows; first occurrence wins (fithic.py:829-832)
+    std::vector<double> bias((size_t)std::max<int64_t>(ctx->n_slots, 1), ctx->have_bias ? -1.0 : 1.0);
+    if (ctx->have_bias) {
+        std::vector<uint8_t> seen(bias.size(), 0);
+        const auto& keys = ctx->h_slot_keys;
+        for (size_t i = 0; i < ctx->bias_val.size(); ++i) {
+            const int32_t c = ctx->bias_chr[i], m = ctx->bias_mid[i];
+            if (c < 0 || m < 0) continue;
+            const unsigned long long k = ((unsigned long long)(unsigned int)c << 32) | (unsigned int)m;
+            const auto it = std::lower_bound(keys.begin(), keys.end(), k);
+            if (it == keys.end() || *it != k) continue;
+            const size_t s = (size_t)(it - keys.begin());
+            if (seen[s]) continue;
+            seen[s] = 1;
+            double b = ctx->bias_val[i];
+            if (b < ctx->prm.bias_low || std::isnan(b))
+                b = -1;
+            else if (b > ctx->prm.bias_up)
+                b = -1;
+            bias[s] = b;
+        }
+    }
+    dev_free(ctx->d_slot_bias);
+    FHX_HIP(hipMalloc(&ctx->d_slot_bias, bias.size() * sizeof(double)));
+    FHX_HIP(hipMemcpyAsync(ctx->d_slot_bias, bias.data(), bias.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->tables_dirty = false;
+    return FHX_OK;
+}
+
 int build_slot_tables(fhx_ctx* ctx) {
+    if (ctx->nonfixed) return build_slot_tables_nonfixed(ctx);
     const int64_t res = ctx->prm.resolution;
     std::vector<double> bias((size_t)std::max<int64_t>(ctx->n_slots, 1), ctx->have_bias ? -1.0 : 1.0);
     std::vector<int16_t> slot_chr((size_t)std::max<int64_t>(ctx->n_slots, 1), 0);
@@ -1089,6 +1430,137 @@ int build_slot_tables(fhx_ctx* ctx) {
     FHX_HIP(hipStreamSynchronize(ctx->stream));
     ctx->tables_dirty = false;
     return FHX_OK;
+}
+
+int ensure_sort_scratch_early(fhx_ctx* ctx) {
+    if (!ctx->d_block_hist) FHX_HIP(hipMalloc(&ctx->d_block_hist, (size_t)RADIX * SORT_BLOCKS * sizeof(unsigned int)));
+    if (!ctx->d_digit_total) FHX_HIP(hipMalloc(&ctx->d_digit_total, RADIX * sizeof(unsigned int)));
+    if (!ctx->d_misc) FHX_HIP(hipMalloc(&ctx->d_misc, 128 * sizeof(unsigned long long)));
+    if (!ctx->d_top_hist) FHX_HIP(hipMalloc(&ctx->d_top_hist, TOP_BINS * sizeof(unsigned long long)));
+    return FHX_OK;
+}
+
+// LSD radix sort of (u64 key, u32 payload) pairs over the low `passes`*11 key bits; n lives in *counter (device)
+int radix_sort_pairs(fhx_ctx* ctx, unsigned long long* keys[2], unsigned int* vals[2], const unsigned long long* counter,
+                     int passes, int* result_buf) {
+    int src = 0;
+    for (int pass = 0; pass < passes; ++pass) {
+        const int shift = pass * RADIX_BITS;
+        hipLaunchKernelGGL(rs_count, dim3(SORT_BLOCKS), dim3(SORT_THREADS), 0, ctx->stream, keys[src], counter, shift,
+                           ctx->d_block_hist);
+        hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3(SORT_BLOCKS), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total);
+        hipLaunchKernelGGL(rs_scatter, dim3(SORT_BLOCKS), dim3(SORT_THREADS), 0, ctx->stream, keys[src], vals[src],
+                           keys[1 - src], vals[1 - src], counter, shift, ctx->d_block_hist, ctx->d_digit_total);
+        src = 1 - src;
+    }
+    FHX_HIP(hipGetLastError());
+    *result_buf = src;
+    return FHX_OK;
+}
+
+// run ids of a sorted key array of n elements (n known on the host); returns the number of runs
+int run_ids(fhx_ctx* ctx, const unsigned long long* keys, int64_t n, unsigned int* ids, unsigned int* tile_scratch,
+            int64_t* n_runs) {
+    *n_runs = 0;
+    if (n == 0) return FHX_OK;
+    const int tiles = (int)((n + SEG_TILE - 1) / SEG_TILE);
+    unsigned long long* total = ctx->d_misc + 9;
+    hipLaunchKernelGGL(seg_count_heads, dim3(tiles), dim3(SEG_THREADS), 0, ctx->stream, keys, n, tile_scratch);
+    hipLaunchKernelGGL(seg_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, tile_scratch, (int64_t)tiles, total);
+    hipLaunchKernelGGL(seg_ids, dim3(tiles), dim3(SEG_THREADS), 0, ctx->stream, keys, n, (const unsigned int*)tile_scratch, ids);
+    FHX_HIP(hipGetLastError());
+    unsigned long long t = 0;
+    FHX_HIP(hipMemcpyAsync(&t, total, sizeof(t), hipMemcpyDeviceToHost, ctx->stream));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    *n_runs = (int64_t)t;
+    return FHX_OK;
+}
+
+int alloc_row_arrays(fhx_ctx* ctx, int64_t n, int64_t n_dist);
+
+// -r 0: loci are arbitrary (chr, mid) pairs.  Slot = rank of the locus among the sorted distinct loci of the rows.
+int ingest_device_rows_nonfixed(fhx_ctx* ctx, const int32_t* c1, const int32_t* m1, const int32_t* c2, const int32_t* m2,
+                                const int32_t* cnt, int64_t n) {
+    if (!ctx->have_params) return fail(ctx, FHX_ERR_ARG, "fhx_set_params must be called before fhx_load_pairs");
+    if (n < 0) return fail(ctx, FHX_ERR_ARG, "negative row count");
+    if (2 * n >= (1ll << 32)) return fail(ctx, FHX_ERR_UNSUPPORTED, "more than 2^31 rows per GPU: shard the contacts");
+    int rc = ensure_sort_scratch_early(ctx);
+    if (rc != FHX_OK) return rc;
+    const int64_t n2 = 2 * n;
+    const size_t cap2 = std::max<size_t>(4, (size_t)n2);
+    unsigned long long* keys[2] = {nullptr, nullptr};
+    unsigned int* vals[2] = {nullptr, nullptr};
+    unsigned int *ids = nullptr, *tiles = nullptr;
+    int32_t* loc = nullptr;
+    unsigned long long* slot_key = nullptr;
+    int* bad = nullptr;
+    for (int b = 0; b < 2; ++b) {
+        FHX_HIP(hipMalloc(&keys[b], cap2 * sizeof(unsigned long long)));
+        FHX_HIP(hipMalloc(&vals[b], cap2 * sizeof(unsigned int)));
+    }
+    FHX_HIP(hipMalloc(&ids, cap2 * sizeof(unsigned int)));
+    FHX_HIP(hipMalloc(&tiles, (cap2 / SEG_TILE + 2) * sizeof(unsigned int)));
+    FHX_HIP(hipMalloc(&loc, cap2 * sizeof(int32_t)));
+    FHX_HIP(hipMalloc(&slot_key, cap2 * sizeof(unsigned long long)));
+    FHX_HIP(hipMalloc(&bad, sizeof(int)));
+    FHX_HIP(hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(nf_locus_keys, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, c1, m1, c2, m2, n, keys[0], vals[0], bad);
+    unsigned long long* counter = ctx->d_misc + 3;
+    const unsigned long long n2u = (unsigned long long)n2;
+    FHX_HIP(hipMemcpyAsync(counter, &n2u, sizeof(n2u), hipMemcpyHostToDevice, ctx->stream));
+    int buf = 0;
+    rc = radix_sort_pairs(ctx, keys, vals, counter, SORT_PASSES, &buf);
+    int64_t n_slots = 0;
+    if (rc == FHX_OK) rc = run_ids(ctx, keys[buf], n2, ids, tiles, &n_slots);
+    int h_bad = 0;
+    if (rc == FHX_OK) {
+        hipLaunchKernelGGL(nf_assign_slots, dim3(grid_for(n2, 256)), dim3(256), 0, ctx->stream, keys[buf], vals[buf],
+                           (const unsigned int*)ids, n2, loc, slot_key);
+        FHX_HIP(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        FHX_HIP(hipStreamSynchronize(ctx->stream));
+        if (h_bad) rc = fail(ctx, FHX_ERR_ARG, "contact rows hold a negative midpoint or chromosome id");
+    }
+    if (rc == FHX_OK && n_slots >= (1ll << 31)) rc = fail(ctx, FHX_ERR_UNSUPPORTED, "more than 2^31 loci");
+    if (rc == FHX_OK) {
+        ctx->n_slots = n_slots;
+        ctx->n_dist = 1;
+        ctx->grid.clear();
+        rc = alloc_row_arrays(ctx, n, 1);
+    }
+    if (rc == FHX_OK) {
+        hipLaunchKernelGGL(nf_finish_rows, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, c1, c2, cnt, (const int32_t*)loc, n,
+                           ctx->d_loc1, ctx->d_loc2, ctx->d_count);
+        dev_free(ctx->d_slot_mid);
+        dev_free(ctx->d_slot_chr);
+        const size_t ns = (size_t)std::max<int64_t>(n_slots, 1);
+        FHX_HIP(hipMalloc(&ctx->d_slot_mid, ns * sizeof(int32_t)));
+        FHX_HIP(hipMalloc(&ctx->d_slot_chr, ns * sizeof(int16_t)));
+        hipLaunchKernelGGL(nf_slot_tables, dim3(grid_for(n_slots, 256)), dim3(256), 0, ctx->stream,
+                           (const unsigned long long*)slot_key, n_slots, ctx->d_slot_mid, ctx->d_slot_chr);
+        ctx->h_slot_keys.assign((size_t)n_slots, 0ull);
+        if (n_slots)
+            FHX_HIP(hipMemcpyAsync(ctx->h_slot_keys.data(), slot_key, (size_t)n_slots * sizeof(unsigned long long),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+        dev_free(ctx->d_seg_ids);
+        dev_free(ctx->d_seg_tiles);
+        const size_t cap = std::max<size_t>(4, (size_t)n);
+        FHX_HIP(hipMalloc(&ctx->d_seg_ids, cap * sizeof(unsigned int)));
+        FHX_HIP(hipMalloc(&ctx->d_seg_tiles, (cap / SEG_TILE + 2) * sizeof(unsigned int)));
+        FHX_HIP(hipGetLastError());
+        FHX_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->h_outlier_dists.clear();
+        ctx->h_dist_keys.clear();
+    }
+    for (int b = 0; b < 2; ++b) {
+        dev_free(keys[b]);
+        dev_free(vals[b]);
+    }
+    dev_free(ids);
+    dev_free(tiles);
+    dev_free(loc);
+    dev_free(slot_key);
+    dev_free(bad);
+    return rc;
 }
 
 int ingest_device_rows(fhx_ctx* ctx, const int32_t* c1, const int32_t* m1, const int32_t* c2, const int32_t* m2,
@@ -1153,6 +1625,19 @@ int ingest_device_rows(fhx_ctx* ctx, const int32_t* c1, const int32_t* m1, const
     FHX_HIP(hipMalloc(&ctx->d_grid, std::max<size_t>(1, ctx->grid.size()) * sizeof(ChrGrid)));
     FHX_HIP(hipMemcpyAsync(ctx->d_grid, ctx->grid.data(), ctx->grid.size() * sizeof(ChrGrid), hipMemcpyHostToDevice,
                            ctx->stream));
+    {
+        const int rc = alloc_row_arrays(ctx, n, n_dist);
+        if (rc != FHX_OK) return rc;
+    }
+    hipLaunchKernelGGL(k0_slots, dim3(blocks), dim3(256), 0, ctx->stream, c1, m1, c2, m2, cnt, n, res, ctx->d_grid,
+                       ctx->d_loc1, ctx->d_loc2, ctx->d_count);
+    FHX_HIP(hipGetLastError());
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    return FHX_OK;
+}
+
+// per-row device arrays, histograms and workspaces for n rows; resets the pass state
+int alloc_row_arrays(fhx_ctx* ctx, int64_t n, int64_t n_dist) {
     // row arrays (padded to a multiple of 4 rows for the 16-byte loads)
     const size_t cap = std::max<size_t>(4, ((size_t)n + 3) / 4 * 4);
     dev_free(ctx->d_loc1);
@@ -1175,16 +1660,15 @@ int ingest_device_rows(fhx_ctx* ctx, const int32_t* c1, const int32_t* m1, const
     FHX_HIP(hipMemsetAsync(ctx->d_skip, 0, cap, ctx->stream));
     FHX_HIP(hipMemsetAsync(ctx->d_outlier, 0, cap, ctx->stream));
     FHX_HIP(hipMemsetAsync(ctx->d_seen_twice, 0, cap, ctx->stream));
-    hipLaunchKernelGGL(k0_slots, dim3(blocks), dim3(256), 0, ctx->stream, c1, m1, c2, m2, cnt, n, res, ctx->d_grid,
-                       ctx->d_loc1, ctx->d_loc2, ctx->d_count);
     // histograms
     dev_free(ctx->d_hist_cc);
     dev_free(ctx->d_hist_np);
     dev_free(ctx->d_out_hist);
-    FHX_HIP(hipMalloc(&ctx->d_hist_cc, n_dist * sizeof(unsigned long long)));
-    FHX_HIP(hipMalloc(&ctx->d_hist_np, n_dist * sizeof(unsigned long long)));
-    FHX_HIP(hipMalloc(&ctx->d_out_hist, n_dist * sizeof(unsigned long long)));
-    FHX_HIP(hipMemsetAsync(ctx->d_out_hist, 0, n_dist * sizeof(unsigned long long), ctx->stream));
+    const size_t hist_len = ctx->nonfixed ? cap : (size_t)n_dist;       // -r 0: at most one distinct distance per row
+    FHX_HIP(hipMalloc(&ctx->d_hist_cc, hist_len * sizeof(unsigned long long)));
+    FHX_HIP(hipMalloc(&ctx->d_hist_np, hist_len * sizeof(unsigned long long)));
+    FHX_HIP(hipMalloc(&ctx->d_out_hist, hist_len * sizeof(unsigned long long)));
+    FHX_HIP(hipMemsetAsync(ctx->d_out_hist, 0, hist_len * sizeof(unsigned long long), ctx->stream));
     if (!ctx->d_sums) FHX_HIP(hipMalloc(&ctx->d_sums, sizeof(K1Sums)));
     if (!ctx->d_misc) FHX_HIP(hipMalloc(&ctx->d_misc, 128 * sizeof(unsigned long long)));
     // sort workspace
@@ -1285,6 +1769,11 @@ void fhx_destroy(fhx_ctx* ctx) {
         dev_free(ctx->d_top_hist);
         dev_free(ctx->d_queue[0]);
         dev_free(ctx->d_queue[1]);
+        dev_free(ctx->d_slot_mid);
+        dev_free(ctx->d_table_x);
+        dev_free(ctx->d_table_y);
+        dev_free(ctx->d_seg_ids);
+        dev_free(ctx->d_seg_tiles);
         dev_free(ctx->d_tile_max);
         for (auto& e : ctx->ev)
             if (e) (void)hipEventDestroy(e);
@@ -1297,8 +1786,7 @@ const char* fhx_last_error(fhx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null
 
 int fhx_set_params(fhx_ctx* ctx, const fhx_params* p) {
     if (!ctx || !p) return FHX_ERR_ARG;
-    if (p->resolution <= 0)
-        return fail(ctx, FHX_ERR_UNSUPPORTED, "resolution must be > 0 (the -r 0 non-fixed-size mode is not accelerated)");
+    if (p->resolution < 0) return fail(ctx, FHX_ERR_ARG, "resolution must be >= 0 (0 = non-fixed-size data)");
     if (p->resolution > INT32_MAX) return fail(ctx, FHX_ERR_ARG, "resolution too large");
     if (p->n_bins <= 0 || p->mapp_thres < 0 || p->mode < 0 || p->mode > 2) return fail(ctx, FHX_ERR_ARG, "bad parameter");
     if (p->bias_low > p->bias_up)
@@ -1306,6 +1794,7 @@ int fhx_set_params(fhx_ctx* ctx, const fhx_params* p) {
     if (ctx->n_rows > 0 && ctx->have_params && p->resolution != ctx->prm.resolution)
         return fail(ctx, FHX_ERR_ARG, "the resolution cannot change after the contact rows were loaded");
     ctx->prm = *p;
+    ctx->nonfixed = p->resolution == 0;
     ctx->have_params = true;
     ctx->tables_dirty = true;
     return FHX_OK;
@@ -1317,6 +1806,7 @@ int fhx_load_fragments(fhx_ctx* ctx, const int32_t* chr, const int32_t* mid, con
     if (!ctx->have_params) return fail(ctx, FHX_ERR_ARG, "fhx_set_params must be called first");
     std::vector<int64_t> cnt(n_chr, 0), mx(n_chr, -1);
     std::vector<uint8_t> present(n_chr, 0);
+    std::vector<std::vector<int32_t>> mids_of(ctx->nonfixed ? n_chr : 0);
     for (int64_t i = 0; i < n; ++i) {
         const int c = chr[i];
         if (c < 0 || c >= n_chr) return fail(ctx, FHX_ERR_ARG, "fragment chromosome id out of range");
@@ -1324,6 +1814,7 @@ int fhx_load_fragments(fhx_ctx* ctx, const int32_t* chr, const int32_t* mid, con
         if (hits[i] >= ctx->prm.mapp_thres) {
             ++cnt[c];
             mx[c] = std::max<int64_t>(mx[c], mid[i]);
+            if (ctx->nonfixed) mids_of[c].push_back(mid[i]);
         }
     }
     std::vector<int> order;
@@ -1335,6 +1826,10 @@ int fhx_load_fragments(fhx_ctx* ctx, const int32_t* chr, const int32_t* mid, con
         ctx->frags.chr_id.push_back(c);
         ctx->frags.n_mappable.push_back(cnt[c]);
         ctx->frags.max_mid.push_back(mx[c]);
+        if (ctx->nonfixed) {
+            std::sort(mids_of[c].begin(), mids_of[c].end());
+            ctx->frags.mids.push_back(std::move(mids_of[c]));
+        }
     }
     ctx->n_chr = std::max(ctx->n_chr, n_chr);
     ctx->have_frags = true;
@@ -1357,6 +1852,9 @@ int fhx_load_pairs_device(fhx_ctx* ctx, const void* c1, const void* m1, const vo
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
     FHX_HIP(hipSetDevice(ctx->device));
     if (stream) FHX_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (ctx->have_params && ctx->nonfixed)
+        return ingest_device_rows_nonfixed(ctx, (const int32_t*)c1, (const int32_t*)m1, (const int32_t*)c2, (const int32_t*)m2,
+                                           (const int32_t*)cnt, n);
     return ingest_device_rows(ctx, (const int32_t*)c1, (const int32_t*)m1, (const int32_t*)c2, (const int32_t*)m2,
                               (const int32_t*)cnt, n);
 }
@@ -1373,9 +1871,69 @@ int fhx_load_pairs(fhx_ctx* ctx, const int32_t* chr1, const int32_t* mid1, const
         if (n) FHX_HIP(hipMemcpyAsync(d[k], h[k], (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     }
     FHX_HIP(hipStreamSynchronize(ctx->stream));
-    const int rc = ingest_device_rows(ctx, d[0], d[1], d[2], d[3], d[4], n);
+    const int rc = (ctx->have_params && ctx->nonfixed) ? ingest_device_rows_nonfixed(ctx, d[0], d[1], d[2], d[3], d[4], n)
+                                                       : ingest_device_rows(ctx, d[0], d[1], d[2], d[3], d[4], n);
     for (int k = 0; k < 5; ++k) dev_free(d[k]);
     return rc;
+}
+
+// -r 0: classification + sums as K1, then the in-range (distance, count) pairs are radix-sorted by distance and the runs
+// are reduced to (distinct distance, sum of counts, rows): the reference's mainDic for arbitrary distances
+static int pass_stats_nonfixed(fhx_ctx* ctx, fhx_stats* out) {
+    unsigned long long* counter = ctx->d_misc + 10;
+    FHX_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
+    FHX_HIP(hipMemsetAsync(ctx->d_sums, 0, sizeof(K1Sums), ctx->stream));
+    FHX_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    hipLaunchKernelGGL(nf_k1_classify, dim3(grid_for(ctx->n_rows, SORT_TILE, 256 * 8)), dim3(SORT_THREADS), 0, ctx->stream,
+                       ctx->d_loc1, ctx->d_loc2, ctx->d_count, ctx->skip_active ? ctx->d_skip : (const uint8_t*)nullptr,
+                       ctx->skip_limit, (ctx->skip_limit != INT64_MAX) ? (const long long*)ctx->d_grow : (const long long*)nullptr,
+                       ctx->n_rows, (const int32_t*)ctx->d_slot_mid, (long long)ctx->prm.dist_low, (long long)ctx->prm.dist_up,
+                       ctx->d_keys[0], ctx->d_vals[0], counter, ctx->d_sums);
+    int buf = 0;
+    int rc = radix_sort_pairs(ctx, ctx->d_keys, ctx->d_vals, counter, 3, &buf);       // distances < 2^31: 33 key bits
+    if (rc != FHX_OK) return rc;
+    K1Sums s{};
+    unsigned long long n_keys = 0;
+    FHX_HIP(hipMemcpyAsync(&s, ctx->d_sums, sizeof(K1Sums), hipMemcpyDeviceToHost, ctx->stream));
+    FHX_HIP(hipMemcpyAsync(&n_keys, counter, sizeof(n_keys), hipMemcpyDeviceToHost, ctx->stream));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    int64_t n_runs = 0;
+    rc = run_ids(ctx, ctx->d_keys[buf], (int64_t)n_keys, ctx->d_seg_ids, ctx->d_seg_tiles, &n_runs);
+    if (rc != FHX_OK) return rc;
+    ctx->h_dist_keys.assign((size_t)n_runs, 0);
+    ctx->h_hist_cc.assign((size_t)n_runs, 0);
+    ctx->h_hist_np.assign((size_t)n_runs, 0);
+    if (n_runs) {
+        FHX_HIP(hipMemsetAsync(ctx->d_hist_cc, 0, (size_t)n_runs * sizeof(unsigned long long), ctx->stream));
+        FHX_HIP(hipMemsetAsync(ctx->d_hist_np, 0, (size_t)n_runs * sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(nf_accumulate_runs, dim3(grid_for((int64_t)n_keys, 256)), dim3(256), 0, ctx->stream,
+                           (const unsigned long long*)ctx->d_keys[buf], (const unsigned int*)ctx->d_vals[buf],
+                           (const unsigned int*)ctx->d_seg_ids, (int64_t)n_keys, ctx->d_out_hist, ctx->d_hist_cc, ctx->d_hist_np);
+        FHX_HIP(hipGetLastError());
+        FHX_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+        FHX_HIP(hipMemcpyAsync(ctx->h_dist_keys.data(), ctx->d_out_hist, (size_t)n_runs * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        FHX_HIP(hipMemcpyAsync(ctx->h_hist_cc.data(), ctx->d_hist_cc, (size_t)n_runs * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        FHX_HIP(hipMemcpyAsync(ctx->h_hist_np.data(), ctx->d_hist_np, (size_t)n_runs * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        FHX_HIP(hipStreamSynchronize(ctx->stream));
+    } else {
+        FHX_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    }
+    ctx->ev_valid[0] = true;
+    fhx_stats& st = ctx->stats;
+    st.n_rows = ctx->n_rows;
+    st.inter_count = s.inter_count;
+    st.inter_sum = s.inter_sum;
+    st.intra_all_count = s.intra_all_count;
+    st.intra_all_sum = s.intra_all_sum;
+    st.in_range_count = s.in_range_count;
+    st.in_range_sum = s.in_range_sum;
+    st.max_count = s.max_count;
+    st.n_dist = n_runs;
+    st.n_skipped = s.n_skipped;
+    ctx->have_stats = true;
+    ctx->have_fit = ctx->have_bins = ctx->have_p = ctx->have_q = false;
+    if (out) *out = st;
+    return FHX_OK;
 }
 
 int fhx_pass_stats(fhx_ctx* ctx, fhx_stats* out) {
@@ -1383,6 +1941,7 @@ int fhx_pass_stats(fhx_ctx* ctx, fhx_stats* out) {
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
     if (!ctx->d_loc1) return fail(ctx, FHX_ERR_ARG, "no contact rows loaded");
     FHX_HIP(hipSetDevice(ctx->device));
+    if (ctx->nonfixed) return pass_stats_nonfixed(ctx, out);
     const int64_t res = ctx->prm.resolution;
     const int64_t lo = (ctx->prm.dist_low + res - 1) / res;
     const int64_t hi = std::min<int64_t>(ctx->prm.dist_up / res, ctx->n_dist - 1);
@@ -1428,6 +1987,8 @@ int fhx_pass_stats(fhx_ctx* ctx, fhx_stats* out) {
 int fhx_set_global_stats(fhx_ctx* ctx, const fhx_stats* g, const int64_t* hist_sumcc, const int64_t* hist_npairs,
                          int64_t n_dist) {
     if (!ctx || !g || !hist_sumcc || !hist_npairs || n_dist <= 0) return FHX_ERR_ARG;
+    if (ctx->nonfixed && ctx->h_dist_keys.size() != (size_t)n_dist)
+        return fail(ctx, FHX_ERR_UNSUPPORTED, "-r 0: call fhx_set_dist_keys with the distinct distances first (sharded runs are fixed-size only)");
     const int64_t rows = ctx->n_rows;
     ctx->stats = *g;
     ctx->stats.n_rows = rows > 0 ? rows : g->n_rows;
@@ -1439,6 +2000,21 @@ int fhx_set_global_stats(fhx_ctx* ctx, const fhx_stats* g, const int64_t* hist_s
     ctx->h_hist_np.resize((size_t)len, 0);
     ctx->have_stats = true;
     ctx->have_fit = false;
+    return FHX_OK;
+}
+
+int fhx_set_dist_keys(fhx_ctx* ctx, const int64_t* keys, int64_t n) {
+    if (!ctx || n < 0 || (n > 0 && !keys)) return FHX_ERR_ARG;
+    if (!ctx->nonfixed) return fail(ctx, FHX_ERR_ARG, "distance keys are implicit (index * resolution) in fixed-size mode");
+    ctx->h_dist_keys.assign(keys, keys + n);
+    return FHX_OK;
+}
+
+int fhx_set_outlier_dists(fhx_ctx* ctx, const int64_t* dists, int64_t n) {
+    if (!ctx || n < 0 || (n > 0 && !dists)) return FHX_ERR_ARG;
+    ctx->h_outlier_dists.assign(dists, dists + n);
+    std::sort(ctx->h_outlier_dists.begin(), ctx->h_outlier_dists.end());
+    if (ctx->pass_no < 1) ctx->pass_no = 1;
     return FHX_OK;
 }
 
@@ -1461,6 +2037,15 @@ static void fill_pass_inputs(fhx_ctx* ctx, PassInputs& in) {
     in.in_range_sum = ctx->stats.in_range_sum;
     in.inter_count = ctx->stats.inter_count;
     in.inter_sum = ctx->stats.inter_sum;
+    if (ctx->nonfixed) {
+        in.dist_keys = ctx->h_dist_keys.data();
+        in.outlier_dists = ctx->pass_no > 0 ? ctx->h_outlier_dists.data() : nullptr;
+        in.n_outlier_dists = (int64_t)ctx->h_outlier_dists.size();
+        static const int64_t none = 0;
+        if (ctx->pass_no > 0 && ctx->h_outlier_dists.empty()) in.outlier_dists = &none;      // an empty multiset, not "pass 1"
+        in.outlier_dist_hist = nullptr;
+        return;
+    }
     if (ctx->h_out_hist.size() < ctx->h_hist_cc.size()) ctx->h_out_hist.resize(ctx->h_hist_cc.size(), 0);
     in.outlier_dist_hist = ctx->pass_no > 0 ? ctx->h_out_hist.data() : nullptr;
 }
@@ -1496,11 +2081,23 @@ int fhx_fit(fhx_ctx* ctx, fhx_fit_info* out) {
             const int r2 = build_slot_tables(ctx);
             if (r2 != FHX_OK) return r2;
         }
-        // prior LUT + the two per-count tables
+        // prior LUT (fixed-size) or the spline table itself (-r 0) + the two per-count tables
         dev_free(ctx->d_lut);
         FHX_HIP(hipMalloc(&ctx->d_lut, f.prior_lut.size() * sizeof(double)));
         FHX_HIP(hipMemcpyAsync(ctx->d_lut, f.prior_lut.data(), f.prior_lut.size() * sizeof(double), hipMemcpyHostToDevice,
                                ctx->stream));
+        std::vector<double> tx(f.table_x.begin(), f.table_x.end());
+        if (ctx->nonfixed) {
+            dev_free(ctx->d_table_x);
+            dev_free(ctx->d_table_y);
+            const size_t nt = std::max<size_t>(tx.size(), 1);
+            FHX_HIP(hipMalloc(&ctx->d_table_x, nt * sizeof(double)));
+            FHX_HIP(hipMalloc(&ctx->d_table_y, nt * sizeof(double)));
+            if (!tx.empty()) {
+                FHX_HIP(hipMemcpyAsync(ctx->d_table_x, tx.data(), tx.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+                FHX_HIP(hipMemcpyAsync(ctx->d_table_y, f.table_y.data(), tx.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            }
+        }
         const int64_t mc = std::max<int64_t>(ctx->stats.max_count, 1);
         std::vector<double> lb_a, ib_a, lb_e, ib_e;
         build_lbeta_table((double)ctx->stats.in_range_sum, mc, lb_a, ib_a);
@@ -1953,6 +2550,30 @@ int fhx_next_pass(fhx_ctx* ctx, int64_t* n_outliers_total) {
     unsigned long long* first_dup = ctx->d_misc + 4;
     FHX_HIP(hipMemsetAsync(n_out, 0, sizeof(unsigned long long), ctx->stream));
     FHX_HIP(hipMemsetAsync(first_dup, 0xFF, sizeof(unsigned long long), ctx->stream));
+    if (ctx->nonfixed) {
+        // the distances of this pass's outliers go to a list (reusing the sort workspace), then into the sorted multiset
+        hipLaunchKernelGGL(nf_fold_outliers, dim3(grid_for(ctx->n_rows, 256)), dim3(256), 0, ctx->stream, ctx->d_loc1, ctx->d_loc2,
+                           ctx->d_p, 1.0 / ctx->fit.bh_total_tests, ctx->d_skip, ctx->d_seen_twice, ctx->n_rows,
+                           (const int32_t*)ctx->d_slot_mid, ctx->d_keys[0], n_out, first_dup, (const long long*)ctx->d_grow);
+        FHX_HIP(hipGetLastError());
+        unsigned long long added = 0, dup = ~0ull;
+        FHX_HIP(hipMemcpyAsync(&added, n_out, sizeof(added), hipMemcpyDeviceToHost, ctx->stream));
+        FHX_HIP(hipMemcpyAsync(&dup, first_dup, sizeof(dup), hipMemcpyDeviceToHost, ctx->stream));
+        FHX_HIP(hipStreamSynchronize(ctx->stream));
+        std::vector<int64_t> fresh((size_t)added);
+        if (added) {
+            FHX_HIP(hipMemcpyAsync(fresh.data(), ctx->d_keys[0], (size_t)added * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+            FHX_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        ctx->h_outlier_dists.insert(ctx->h_outlier_dists.end(), fresh.begin(), fresh.end());
+        std::sort(ctx->h_outlier_dists.begin(), ctx->h_outlier_dists.end());
+        ctx->n_outliers_total += (int64_t)added;
+        if (dup != ~0ull) ctx->skip_limit = std::min<int64_t>(ctx->skip_limit, (int64_t)dup);
+        ctx->skip_active = true;
+        ctx->pass_no += 1;
+        if (n_outliers_total) *n_outliers_total = ctx->n_outliers_total;
+        return FHX_OK;
+    }
     hipLaunchKernelGGL(k_fold_outliers, dim3(grid_for(ctx->n_rows, 256)), dim3(256), 0, ctx->stream, ctx->d_loc1, ctx->d_loc2,
                        ctx->d_p, 1.0 / ctx->fit.bh_total_tests, ctx->d_skip, ctx->d_seen_twice, ctx->n_rows, (int)ctx->prm.resolution, (int)ctx->n_dist,
                        ctx->d_slot_chr, ctx->d_grid, ctx->d_out_hist, n_out, first_dup, (const long long*)ctx->d_grow);
@@ -2034,6 +2655,8 @@ int fhx_get_array(fhx_ctx* ctx, int which, void* dst, int64_t cap, int64_t* n_ou
         case FHX_A_HIST_SUMCC: return put(ctx->h_hist_cc.data(), ctx->h_hist_cc.size(), sizeof(int64_t));
         case FHX_A_HIST_NPAIRS: return put(ctx->h_hist_np.data(), ctx->h_hist_np.size(), sizeof(int64_t));
         case FHX_A_OUTLIER_DIST_HIST: return put(ctx->h_out_hist.data(), ctx->h_out_hist.size(), sizeof(int64_t));
+        case FHX_A_DIST_KEYS: return put(ctx->h_dist_keys.data(), ctx->h_dist_keys.size(), sizeof(int64_t));
+        case FHX_A_OUTLIER_DISTS: return put(ctx->h_outlier_dists.data(), ctx->h_outlier_dists.size(), sizeof(int64_t));
         default: break;
     }
     if (which == FHX_A_FDR_COUNTS) {

@@ -742,7 +742,7 @@ void make_bins_stage(const PassInputs& in, PassFit& out) {
         int64_t prev_ub = -1;
         for (int64_t i = 0; i < in.n_dist; ++i) {
             if (in.hist_npairs[i] <= 0) continue;
-            const int64_t d = i * res;
+            const int64_t d = in.dist_keys ? in.dist_keys[i] : i * res;
             const int64_t cc = in.hist_sumcc[i];
             so_far += cc;
             bool full = false;
@@ -774,7 +774,14 @@ void make_bins_stage(const PassInputs& in, PassFit& out) {
         }
         // distances that never filled a bin are dropped, exactly as the reference drops them (A10)
     }
-    if (in.outlier_dist_hist != nullptr && !out.bins.empty()) {
+    if (in.outlier_dists != nullptr && !out.bins.empty()) {          // -r 0: explicit ascending list
+        size_t cur = 0;
+        for (int64_t i = 0; i < in.n_outlier_dists; ++i) {
+            cur = advance_cursor(out.bins, cur, in.outlier_dists[i]);
+            out.bins[cur].poss7 -= 1;
+            out.bins[cur].poss -= 1;
+        }
+    } else if (in.outlier_dist_hist != nullptr && !out.bins.empty()) {
         size_t cur = 0;
         for (int64_t i = 0; i < in.n_dist; ++i) {
             const int64_t mult = in.outlier_dist_hist[i];
@@ -791,8 +798,63 @@ int run_host_pass(const PassInputs& in, const FragTable& frags, PassFit& out, st
     make_bins_stage(in, out);
     const int64_t res = in.resolution;
 
-    // ---- generate_FragPairs, fixed-size branch (fithic.py:592-689) ---------------------------------
-    {
+    // ---- generate_FragPairs ---------------------------------------------------------------------------
+    if (res == 0) {
+        // non-fixed-size branch (fithic.py:691-778): every in-range pair of mappable fragments in (x, y) order, bin cursor
+        // restarted for every x, npairs = n - (#in-range y seen so far for this x) weights slots [7] and [3], slot [1]
+        // counts pairs; slot [3] is a sequential double sum in visiting order.  Chromosomes without mappable fragments are
+        // skipped here (no error in this branch).
+        int64_t n_frags = 0;
+        for (const auto& m : frags.mids) n_frags += (int64_t)m.size();
+        int64_t poss_in_range = 0, poss_inter2 = 0, poss_intra_all = 0;
+        double max_possible = 0.0;
+        const double lo = static_cast<double>(in.dist_low);
+        const bool bounded = in.dist_up != INT64_MAX;
+        const double hi = static_cast<double>(in.dist_up);
+        for (const auto& m : frags.mids) {                       // already in sorted(name) order
+            const int64_t n = (int64_t)m.size();
+            if (n == 0) continue;
+            poss_inter2 += (n_frags - n) * n;
+            int64_t per_chr = 0;
+            for (int64_t x = 0; x < n; ++x) {
+                size_t cur = 0;
+                int64_t k = 0;
+                const double fx = static_cast<double>(m[x]);
+                for (int64_t y = x + 1; y < n; ++y) {
+                    const double dist = std::fabs(fx - static_cast<double>(m[y]));
+                    if (bounded && dist > hi) break;             // ascending in y: nothing further is in range
+                    if (dist < lo) continue;
+                    ++per_chr;
+                    max_possible = std::max(max_possible, dist);
+                    const int64_t npairs = n - k;
+                    ++k;
+                    if (!out.bins.empty()) {
+                        while (!(static_cast<double>(out.bins[cur].lb) <= dist && dist <= static_cast<double>(out.bins[cur].ub))) {
+                            ++cur;
+                            if (cur >= out.bins.size()) {
+                                --cur;
+                                break;
+                            }
+                        }
+                        Bin& b = out.bins[cur];
+                        b.poss7 += npairs;
+                        b.poss += 1;
+                        b.sumdist += (dist / 1000000.0) * static_cast<double>(npairs);
+                        poss_intra_all += 1;
+                    }
+                }
+            }
+            poss_in_range += per_chr;
+        }
+        out.n_frags = n_frags;
+        out.max_possible_dist = max_possible;
+        out.poss_intra_in_range = poss_in_range;
+        out.poss_inter_all = static_cast<double>(poss_inter2) / 2;
+        out.poss_intra_all = static_cast<double>(poss_intra_all);
+        out.inter_chr_prob = in.inter_count > 0 ? 1.0 / static_cast<double>(in.inter_count) : 0.0;
+        out.baseline_intra_prob = poss_intra_all > 0 ? 1.0 / static_cast<double>(poss_intra_all) : 0.0;
+    } else {
+        // fixed-size branch (fithic.py:592-689)
         int64_t n_frags = 0;
         double max_possible = 0.0;
         for (size_t c = 0; c < frags.n_mappable.size(); ++c) {
@@ -903,9 +965,10 @@ int run_host_pass(const PassInputs& in, const FragTable& frags, PassFit& out, st
     std::vector<double> tx;
     for (int64_t i = 0; i < in.n_dist; ++i) {
         if (in.hist_npairs[i] <= 0) continue;
-        const double d = static_cast<double>(i * res);
+        const int64_t key = in.dist_keys ? in.dist_keys[i] : i * res;
+        const double d = static_cast<double>(key);
         if (out.min_x <= d && d <= out.max_x) {
-            out.table_x.push_back(i * res);
+            out.table_x.push_back(key);
             tx.push_back(d);
         }
     }
@@ -927,8 +990,8 @@ int run_host_pass(const PassInputs& in, const FragTable& frags, PassFit& out, st
         }
         out.residual = numpy_sum(sq.data(), m);
     }
-    // dense LUT over distance indices: clamp, bisect_left, cap (fithic.py:1066-1069)
-    {
+    // dense LUT over distance indices: clamp, bisect_left, cap (fithic.py:1066-1069); -r 0 does the same search per row
+    if (res > 0) {
         const size_t nt = tx.size();
         size_t pos = 0;                                       // bisect_left is monotone in the clamped distance
         for (int64_t i = 0; i < in.n_dist; ++i) {

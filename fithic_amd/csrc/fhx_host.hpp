@@ -52,6 +52,8 @@ struct FragTable {             // fragments file reduced to what generate_FragPa
     std::vector<int64_t> n_mappable;      // len(allFragsDic[ch])
     std::vector<int64_t> max_mid;         // max mappable mid (only valid when n_mappable > 0)
     std::vector<int32_t> chr_id;
+    // non-fixed-size mode (-r 0) only: the mappable mids of every chromosome, ascending (fithic.py:699)
+    std::vector<std::vector<int32_t>> mids;
 };
 
 struct PassInputs {
@@ -65,6 +67,11 @@ struct PassInputs {
     int64_t in_range_sum = 0, inter_count = 0, inter_sum = 0;
     // outlier-distance multiset of earlier passes (nullptr in pass 1): count per distance index
     const int64_t* outlier_dist_hist = nullptr;
+    // non-fixed-size mode (resolution == 0): entry i of the histogram arrays belongs to distance dist_keys[i] (ascending,
+    // distinct) instead of i*resolution, and the outlier multiset is an ascending list of distances
+    const int64_t* dist_keys = nullptr;
+    const int64_t* outlier_dists = nullptr;
+    int64_t n_outlier_dists = 0;
 };
 
 struct PassFit {
@@ -82,7 +89,7 @@ struct PassFit {
     double bh_total_tests = 0.0;
     // dense per-distance-index prior LUT for the kernel: lut[i] = newSplineY[min(bisect_left(splineX,
     // clamp(i*res, min x, max x)), len-1)]   (fithic/fithic.py:1066-1069)
-    std::vector<double> prior_lut;
+    std::vector<double> prior_lut;               // fixed-size mode only; -r 0 searches (table_x, table_y) on the device
 };
 
 // makeBinsFromInteractions alone (fithic.py:463-553): fills out.bins (lb, ub, sumcc, outlier decrements)

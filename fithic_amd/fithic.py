@@ -73,9 +73,9 @@ class _Session:
         return self.engine
 
     def configure(self):
-        if resolution is None or resolution <= 0:
-            raise RuntimeError("fithic_amd.fithic.resolution must be set to the fixed-size resolution before "
-                               "read_Interactions (the accelerated path is the reference's fixed-size fast path)")
+        if resolution is None or resolution < 0:
+            raise RuntimeError("fithic_amd.fithic.resolution must be set before read_Interactions (the -r value; 0 = "
+                               "non-fixed-size data): the engine builds its locus grid when the contacts go to the GPU")
         self.ensure_engine().configure(resolution, distLowThres, distUpThres, self.n_bins, mappThres, self.mode(),
                                        biasLowerBound, biasUpperBound)
 
@@ -133,13 +133,11 @@ def read_Interactions(contactCountsFile, biasFile, outliers=None):
     S.stats = st.as_dict()
     S.fit_done = False
     S.pass_started += 1
-    hist_cc = S.engine.ctx.get_array(_capi.A_HIST_SUMCC)
-    hist_np = S.engine.ctx.get_array(_capi.A_HIST_NPAIRS)
-    idx = np.flatnonzero(hist_np > 0)
-    mainDic = {int(i) * resolution: [0, int(hist_cc[i])] for i in idx}
+    keys, hist_cc = _dist_keys(S)
+    mainDic = {int(k): [0, int(c)] for k, c in zip(keys, hist_cc)}
     print("Interactions file read. Time took %s" % (time.time() - t0))
-    lo = int(idx[0]) * resolution if len(idx) else float("inf")
-    hi = int(idx[-1]) * resolution if len(idx) else 0
+    lo = int(keys[0]) if len(keys) else float("inf")
+    hi = int(keys[-1]) if len(keys) else 0
     _log("\n\nInteractions file read successfully\n"
          "------------------------------------------------------------------------------------\n"
          "Observed, Intra-chr in range: pairs= %s\t totalCount= %s\n"
@@ -150,10 +148,19 @@ def read_Interactions(contactCountsFile, biasFile, outliers=None):
     return (mainDic, st.inter_count, st.inter_sum, st.intra_all_sum, st.in_range_sum)
 
 
+def _dist_keys(S):
+    """(distinct in-range distances ascending, their summed counts) = the reference's mainDic"""
+    hist_cc = S.engine.ctx.get_array(_capi.A_HIST_SUMCC)
+    hist_np = S.engine.ctx.get_array(_capi.A_HIST_NPAIRS)
+    if resolution == 0:
+        return S.engine.ctx.get_array(_capi.A_DIST_KEYS), hist_cc
+    idx = np.flatnonzero(hist_np > 0)
+    return idx * resolution, hist_cc[idx]
+
+
 def _bin_stats(S, poss_key):
     a = S.arrays
-    hist_np = S.engine.ctx.get_array(_capi.A_HIST_NPAIRS)
-    keys = np.flatnonzero(hist_np > 0) * resolution
+    keys = _dist_keys(S)[0]
     out = {}
     for b in range(len(a["bin_lb"])):
         lb, ub = int(a["bin_lb"][b]), int(a["bin_ub"][b])
@@ -196,12 +203,10 @@ def generate_FragPairs(observedInterAllCount, observedInterAllSum, binStats, fra
     """fithic/fithic.py:561-793 (fixed-size branch).  Returns (binStats, noOfFrags, maxPossibleGenomicDist,
     possibleIntraInRangeCount, possibleInterAllCount, interChrProb, baselineIntraChrProb)."""
     global interChrProb, baselineIntraChrProb
-    if not resolution:
-        raise _capi.FhxError(_capi.FHX_ERR_UNSUPPORTED, "the non-fixed-size mode (-r 0) is not accelerated")
     S = _S
     t0 = time.time()
-    _log("Looping through all possible fragment pairs in-range\n"
-         "------------------------------------------------------------------------------------\n")
+    _log(("Looping through all possible fragment pairs in-range\n" if resolution else "Enumerating all possible fragment pairs in-range\n")
+         + "------------------------------------------------------------------------------------\n")
     _load_fragments(S, fragsfile)
     info = S.ensure_fit()
     full = _bin_stats(S, "bin_poss")
@@ -217,20 +222,33 @@ def generate_FragPairs(observedInterAllCount, observedInterAllSum, binStats, fra
     for c in sorted(set(fc.tolist()), key=lambda i: names[i]):
         sel = (fc == c) & (fh >= mappThres)
         n = int(sel.sum())
-        stop = int(fm[sel].max() - resolution / 2 + 1)
-        d = np.arange(0, max(stop, 0), resolution)
-        npairs = n - np.arange(len(d))
-        rng = (d >= distLowThres) & (d <= distUpThres)
-        per = int(npairs[rng].sum()) * (2 if len(full) else 1)
-        if rng.any():
-            min_poss = min(min_poss, int(d[rng][0]))
+        if n == 0:
+            continue
+        if resolution:
+            stop = int(fm[sel].max() - resolution / 2 + 1)
+            d = np.arange(0, max(stop, 0), resolution)
+            npairs = n - np.arange(len(d))
+            rng = (d >= distLowThres) & (d <= distUpThres)
+            per = int(npairs[rng].sum()) * (2 if len(full) else 1)
+            if rng.any():
+                min_poss = min(min_poss, int(d[rng][0]))
+        else:
+            m = np.sort(fm[sel].astype(np.int64))
+            hi_edge = np.searchsorted(m, m + (distUpThres if distUpThres != float("inf") else m[-1]), side="right")
+            lo_edge = np.searchsorted(m, m + distLowThres, side="left")
+            lo_edge = np.maximum(lo_edge, np.arange(n) + 1)
+            per = int(np.maximum(hi_edge - lo_edge, 0).sum())
+            ok = hi_edge > lo_edge
+            if ok.any():
+                min_poss = min(min_poss, float((m[np.minimum(lo_edge, n - 1)] - m)[ok].min()))
         _log("Chromosome %r,\t%s mappable fragments, \t%s possible intra-chr fragment pairs in range,\t%s possible inter-chr "
              "fragment pairs\n" % (names[c], n, per, (n_frags - n) * n))
     print("Fragments file read. Time took %s" % (time.time() - t0))
     interChrProb = info["inter_chr_prob"] if info["inter_chr_prob"] else 0
     baselineIntraChrProb = info["baseline_intra_prob"]
     _log("Number of all fragments= %s\nPossible, Intra-chr in range: pairs= %s \nPossible, Intra-chr all: pairs= %s \n"
-         "Possible, Inter-chr all: pairs= %s \n" % (n_frags, info["possible_intra_in_range"], info["possible_intra_all"],
+         "Possible, Inter-chr all: pairs= %s \n" % (n_frags, info["possible_intra_in_range"],
+                                                    info["possible_intra_all"] if resolution else int(info["possible_intra_all"]),
                                                     info["possible_inter_all"]))
     _log("Desired genomic distance range   [%d %s] \n" % (distLowThres, distUpThres))
     try:

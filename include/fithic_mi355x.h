@@ -50,7 +50,7 @@ typedef struct fhx_ctx fhx_ctx;
 
 /* The reference's module globals (fithic/fithic.py:203-260) after its "zero means unset" rule. */
 typedef struct fhx_params {
-    int64_t resolution;            /* -r, > 0 (fixed-size mode only) */
+    int64_t resolution;            /* -r; 0 = non-fixed-size data (arbitrary midpoints, fithic/fithic.py:691-778) */
     int64_t dist_low;              /* -L, default 0 */
     int64_t dist_up;               /* -U, INT64_MAX for +inf */
     int32_t n_bins;                /* -b, default 100 */
@@ -115,7 +115,9 @@ enum fhx_array {
     FHX_A_TABLE_Y = 14,            /* double[n_table] newSplineY */
     FHX_A_OUTLIER_DIST_HIST = 15,  /* int64[n_dist]   multiset of outlier distances accumulated so far */
     FHX_A_FDR_COUNTS = 16,         /* int64[51]       plot_qvalues' shifted cumulative counts */
-    FHX_A_BIN_POSS0 = 17           /* int64   binStats[b][1] right after makeBinsFromInteractions */
+    FHX_A_BIN_POSS0 = 17,          /* int64   binStats[b][1] right after makeBinsFromInteractions */
+    FHX_A_DIST_KEYS = 18,          /* int64[n_dist]   -r 0 only: the distinct in-range distances the histogram arrays belong to */
+    FHX_A_OUTLIER_DISTS = 19       /* int64[...]      -r 0 only: ascending multiset of outlier distances accumulated so far */
 };
 
 /* ---- life cycle --------------------------------------------------------------------------------- */
@@ -144,6 +146,10 @@ int fhx_pass_stats(fhx_ctx* ctx, fhx_stats* out);                       /* K1, t
 /* Distributed runs: replace the local histogram / sums by the all-reduced ones before fhx_fit. */
 int fhx_set_global_stats(fhx_ctx* ctx, const fhx_stats* global_stats, const int64_t* hist_sumcc,
                          const int64_t* hist_npairs, int64_t n_dist);
+/* -r 0 only (host-side testing / callers that bring their own histogram): the distinct distances of the histogram arrays
+ * handed to fhx_set_global_stats, and the ascending multiset of outlier distances of earlier passes. */
+int fhx_set_dist_keys(fhx_ctx* ctx, const int64_t* keys, int64_t n);
+int fhx_set_outlier_dists(fhx_ctx* ctx, const int64_t* dists, int64_t n);
 /* Distributed runs, pass >= 2: replace the local multiset of outlier distances (count per distance index,
  * accumulated over all earlier passes) by the all-reduced one. */
 int fhx_set_outlier_dist_hist(fhx_ctx* ctx, const int64_t* hist, int64_t n_dist);

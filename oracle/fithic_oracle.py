@@ -335,6 +335,60 @@ def generate_frag_pairs(frags, bins, resolution, L, U, mapp_thres, inter_count):
                 poss_inter=poss_inter, inter_prob=inter_prob, base_prob=base_prob)
 
 
+def generate_frag_pairs_nonfixed(frags, bins, L, U, mapp_thres, inter_count):
+    """fithic.py:691-778 (the -r 0 branch): every in-range pair of mappable fragments of a chromosome is visited in
+    (x, y) order; the bin cursor restarts at bin 0 for every x; `npairs = n - (number of in-range y seen so far for this x)`
+    weights slots [7] and [3] while slot [1] counts pairs.  Slot [3] is a sequential float sum in visiting order."""
+    per_chr = {}
+    for ch, mid, hits in frags:
+        lst = per_chr.setdefault(ch, [])
+        if hits >= mapp_thres:
+            lst.append(mid)
+    n_frags = sum(len(v) for v in per_chr.values())
+    poss_in_range = 0
+    poss_inter = 0
+    poss_intra_all = 0
+    max_possible = 0
+    ubs = np.array([b["ub"] for b in bins], np.float64)
+    contrib_bin, contrib_val = [], []
+    for ch in sorted(per_chr):
+        if not per_chr[ch]:
+            continue
+        F = np.array(sorted(per_chr[ch]), np.float64)
+        n = len(F)
+        poss_inter += (n_frags - n) * n
+        per = 0
+        for x in range(n):
+            dist = np.abs(F[x] - F[x + 1:])
+            sel = dist[(dist >= L) & (dist <= U)]
+            k = len(sel)
+            if k == 0:
+                continue
+            per += k
+            max_possible = max(max_possible, float(sel.max()))
+            if bins:
+                npairs = n - np.arange(k)
+                idx = np.minimum(np.searchsorted(ubs, sel, side="left"), len(bins) - 1)
+                for b, c in zip(*np.unique(idx, return_counts=True)):
+                    bins[int(b)]["s1"] += int(c)
+                for b in np.unique(idx):
+                    bins[int(b)]["s7"] += int(npairs[idx == b].sum())
+                contrib_bin.append(idx)
+                contrib_val.append((sel / 1000000.0) * npairs)
+                poss_intra_all += k
+        poss_in_range += per
+    if contrib_bin:
+        cb = np.concatenate(contrib_bin)
+        cv = np.concatenate(contrib_val)
+        for b in np.unique(cb):
+            bins[int(b)]["s3"] = float(np.cumsum(cv[cb == b])[-1])         # sequential, in visiting order
+    poss_inter /= 2
+    inter_prob = 1.0 / inter_count if inter_count > 0 else 0
+    base_prob = 1.0 / poss_intra_all if poss_intra_all > 0 else 0
+    return dict(n_frags=n_frags, max_possible_dist=max_possible, poss_in_range=poss_in_range,
+                poss_inter=poss_inter, inter_prob=inter_prob, base_prob=base_prob)
+
+
 def calculate_probabilities(bins, in_range_sum):
     """fithic.py:843-918 -> x, y, and the text of the .fithic_passN file."""
     x, y = [], []
@@ -564,7 +618,10 @@ def run(contacts, frags, bias_path, resolution, n_bins=100, passes=1, mode=INTRA
         keys, sumcc, icnt, isum, intra_all, rng_sum = read_interactions(pairs, L, U, skip)
         bins = make_bins(keys, sumcc, n_bins, rng_sum, outlier_dists if pass_no > 1 else None)
         bins0 = [dict(b) for b in bins]
-        frag = generate_frag_pairs(frag_rows, bins, resolution, L, U, mapp_thres, icnt)
+        if resolution:
+            frag = generate_frag_pairs(frag_rows, bins, resolution, L, U, mapp_thres, icnt)
+        else:
+            frag = generate_frag_pairs_nonfixed(frag_rows, bins, L, U, mapp_thres, icnt)
         x, y, pass_txt = calculate_probabilities(bins, rng_sum)
         R = fit_spline(pairs, keys, x, y, b1, b2, mode, L, U, tL, tU, (icnt, isum, intra_all, rng_sum), frag,
                        use_scipy=use_scipy)

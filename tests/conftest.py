@@ -43,8 +43,10 @@ def case_args(meta):
         tL=opt("-tL", float) or 0.5, tU=opt("-tU", float) or 2)
 
 
-ALL_CASES = ["f1_nobias", "f1_bias", "f2_all", "f2_inter", "f2_intra", "f2_all_nobias",
-             "f6_quirk_all", "f6_quirk_intra_nobounds", "f6_quirk_zero_flags", "f6_quirk_mapp2"]
+FIXED_CASES = ["f1_nobias", "f1_bias", "f2_all", "f2_inter", "f2_intra", "f2_all_nobias",
+               "f6_quirk_all", "f6_quirk_intra_nobounds", "f6_quirk_zero_flags", "f6_quirk_mapp2", "f7_pfal_all"]
+NONFIXED_CASES = ["f8_nonfixed_hESC", "f8_nonfixed_all", "f8_nonfixed_nobounds"]        # -r 0
+ALL_CASES = FIXED_CASES + NONFIXED_CASES
 SMALL_CASES = [c for c in ALL_CASES if not c.startswith("f1_")]
 
 

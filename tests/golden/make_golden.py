@@ -151,8 +151,9 @@ def _md5_decompressed(path):
 
 def _collect_outputs(outdir, lib, res, npasses):
     meta = {}
+    tag = (".res%d" % res) if res else ""
     for i in range(1, npasses + 1):
-        sig = os.path.join(outdir, "%s.spline_pass%d.res%d.significances.txt.gz" % (lib, i, res))
+        sig = os.path.join(outdir, "%s.spline_pass%d%s.significances.txt.gz" % (lib, i, tag))
         if os.path.exists(sig):
             meta["sig_md5_pass%d" % i] = _md5_decompressed(sig)
             with gzip.open(sig, "rt") as f:
@@ -161,7 +162,7 @@ def _collect_outputs(outdir, lib, res, npasses):
             # a few verbatim output rows (head / middle / tail) as text known-answers
             idx = sorted(set([0, 1, 2, 3, len(lines) // 2, len(lines) - 2, len(lines) - 1]))
             meta["sig_sample_pass%d" % i] = {str(j): lines[j] for j in idx if 0 <= j < len(lines)}
-        fp = os.path.join(outdir, "%s.fithic_pass%d.res%d.txt" % (lib, i, res))
+        fp = os.path.join(outdir, "%s.fithic_pass%d%s.txt" % (lib, i, tag))
         if os.path.exists(fp):
             meta["fithic_pass%d_txt" % i] = open(fp).read()
     log = os.path.join(outdir, lib + ".fithic.log")
@@ -480,8 +481,102 @@ def make_f6():
     run_case("f6_quirk_mapp2", c, f, b, res, ["-b", "8", "-p", "1", "-m", "2", "-x", "All", "-tL", "0.4", "-tU", "2.5"])
 
 
+# ------------------------------------------------------------------------------------------------ F7 / F8
+def make_f7():
+    """Fixed-size, 14 chromosomes: synthetic contacts over the bundled P. falciparum 10 kb loci (run_tests-git.sh:52-54)."""
+    print("F7: synthetic contacts over Ay_Rings_MboI_Pfal_w10000 loci, -x All")
+    shutil.copy("/root/reference/fithic/tests/data/fragmentLists/Ay_Rings_MboI_Pfal_w10000.gz", os.path.join(DATA, "Pfal_w10000.frags.gz"))
+    rng = np.random.default_rng(77)
+    loci = {}
+    order = []
+    with gzip.open(os.path.join(DATA, "Pfal_w10000.frags.gz"), "rt") as f:
+        for line in f:
+            w = line.split()
+            if w[0] not in loci:
+                loci[w[0]] = []
+                order.append(w[0])
+            loci[w[0]].append(int(w[2]))
+    rows = []
+    for ch in order:
+        m = loci[ch]
+        for i in range(len(m)):
+            for j in range(i, len(m)):
+                lam = 60.0 / (1 + (j - i)) ** 1.1
+                c = rng.poisson(lam * rng.lognormal(0, 0.4))
+                if c >= 1 and rng.random() < 0.7:
+                    rows.append("%s\t%d\t%s\t%d\t%d\n" % (ch, m[i], ch, m[j], c))
+    allloci = [(ch, v) for ch in order for v in loci[ch]]
+    for _ in range(9000):
+        a, b = allloci[rng.integers(len(allloci))], allloci[rng.integers(len(allloci))]
+        if a[0] != b[0]:
+            rows.append("%s\t%d\t%s\t%d\t%d\n" % (a[0], a[1], b[0], b[1], 1 + rng.poisson(1.0)))
+    perm = rng.permutation(len(rows))
+    _write_gz(os.path.join(DATA, "synth_Pfal_w10000.contacts.gz"), "".join(rows[i] for i in perm))
+    run_case("f7_pfal_all", "synth_Pfal_w10000.contacts.gz", "Pfal_w10000.frags.gz", None, 10000, ["-b", "200", "-p", "2", "-x", "All"])
+
+
+def make_f8():
+    """Non-fixed-size mode (-r 0): synthetic contacts over the bundled hESC combineFrags10 chr1 fragments
+    (run_tests-git.sh:28-30) and over a small irregular 3-chromosome fragment set with bias and inter-chromosomal rows."""
+    print("F8: -r 0 (non-fixed-size)")
+    shutil.copy("/root/reference/fithic/tests/data/fragmentLists/Dixon_hESC_HindIII_hg18_combineFrags10_chr1.gz",
+                os.path.join(DATA, "hESC_combineFrags10_chr1.frags.gz"))
+    rng = np.random.default_rng(88)
+    mids, hits = [], []
+    with gzip.open(os.path.join(DATA, "hESC_combineFrags10_chr1.frags.gz"), "rt") as f:
+        for line in f:
+            w = line.split()
+            mids.append(int(w[2]))
+            hits.append(int(w[3]))
+    mids = np.array(mids)
+    rows = []
+    n = len(mids)
+    for i in range(n):
+        js = np.arange(i + 1, min(n, i + 160))
+        d = np.abs(mids[js] - mids[i]).astype(np.float64)
+        lam = 2.5e6 / np.maximum(d, 2e4) ** 1.05
+        c = rng.poisson(lam * rng.lognormal(0, 0.5, len(js)))
+        keep = (c >= 1) & (rng.random(len(js)) < 0.6)
+        for j, cc in zip(js[keep], c[keep]):
+            rows.append("1\t%d\t1\t%d\t%d\n" % (mids[i], mids[j], cc))
+    perm = rng.permutation(len(rows))
+    _write_gz(os.path.join(DATA, "synth_hESC_combineFrags10_chr1.contacts.gz"), "".join(rows[i] for i in perm))
+    print("  %d synthetic rows over %d fragments" % (len(rows), n))
+    run_case("f8_nonfixed_hESC", "synth_hESC_combineFrags10_chr1.contacts.gz", "hESC_combineFrags10_chr1.frags.gz", None, 0,
+             ["-L", "50000", "-U", "5000000", "-b", "200", "-p", "1", "-x", "intraOnly"], subsample=3)
+    # small irregular multi-chromosome set: bias file, inter rows, two passes, All
+    frag_lines, bias_lines, loci = [], [], {}
+    for ch, nl in (("chrA", 90), ("chrB", 70), ("chrC", 40)):
+        pos = np.cumsum(rng.integers(3000, 40000, nl))
+        loci[ch] = pos
+        for k, m in enumerate(pos):
+            frag_lines.append("%s\t0\t%d\t%d\t1\n" % (ch, m, 0 if k % 23 == 7 else 1 + k % 3))
+            if k % 29 != 3:
+                bias_lines.append("%s\t%d\t%.5f\n" % (ch, m, float(np.exp(rng.normal(0, 0.35)))))
+    _write_gz(os.path.join(DATA, "irregular.frags.gz"), "".join(frag_lines))
+    _write_gz(os.path.join(DATA, "irregular.bias.gz"), "".join(bias_lines))
+    rows = []
+    for ch, pos in loci.items():
+        for i in range(len(pos)):
+            for j in range(i + 1, len(pos)):
+                d = float(pos[j] - pos[i])
+                c = rng.poisson(3e5 / d ** 0.95)
+                if c >= 1 and rng.random() < 0.6:
+                    rows.append("%s\t%d\t%s\t%d\t%d\n" % (ch, pos[i], ch, pos[j], c))
+    names = list(loci)
+    for _ in range(400):
+        a, b = rng.choice(3, 2, replace=False)
+        rows.append("%s\t%d\t%s\t%d\t%d\n" % (names[a], rng.choice(loci[names[a]]), names[b], rng.choice(loci[names[b]]), 1 + rng.poisson(0.6)))
+    perm = rng.permutation(len(rows))
+    _write_gz(os.path.join(DATA, "irregular.contacts.gz"), "".join(rows[i] for i in perm))
+    run_case("f8_nonfixed_all", "irregular.contacts.gz", "irregular.frags.gz", "irregular.bias.gz", 0,
+             ["-b", "15", "-p", "2", "-x", "All", "-L", "10000", "-U", "900000"])
+    run_case("f8_nonfixed_nobounds", "irregular.contacts.gz", "irregular.frags.gz", "irregular.bias.gz", 0,
+             ["-b", "10", "-p", "1", "-x", "intraOnly"])
+
+
 if __name__ == "__main__":
-    which = [a.lower() for a in sys.argv[1:]] or ["f1", "f2", "f3", "f4", "f5", "f6"]
-    jobs = dict(f1=make_f1, f2=make_f2, f3=make_f3, f4=make_f4, f5=make_f5, f6=make_f6)
+    which = [a.lower() for a in sys.argv[1:]] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8"]
+    jobs = dict(f1=make_f1, f2=make_f2, f3=make_f3, f4=make_f4, f5=make_f5, f6=make_f6, f7=make_f7, f8=make_f8)
     for w in which:
         jobs[w]()

@@ -184,9 +184,13 @@ def test_pipeline_matches_reference_goldens(name):
         st = out.stats
         # integer results: bit-exact
         assert [st["inter_count"], st["inter_sum"], st["intra_all_sum"], st["in_range_sum"]] == [int(v) for v in g[P + "sums"]]
-        keys = np.flatnonzero(out.arrays["hist_npairs"] > 0) * res
-        assert np.array_equal(keys, g[P + "dist_keys"])
-        assert np.array_equal(out.arrays["hist_sumcc"][keys // res], g[P + "dist_sumcc"])
+        if res:
+            keys = np.flatnonzero(out.arrays["hist_npairs"] > 0) * res
+            assert np.array_equal(keys, g[P + "dist_keys"])
+            assert np.array_equal(out.arrays["hist_sumcc"][keys // res], g[P + "dist_sumcc"])
+        else:                                   # -r 0: explicit distinct distances
+            assert np.array_equal(out.arrays["dist_keys"], g[P + "dist_keys"])
+            assert np.array_equal(out.arrays["hist_sumcc"], g[P + "dist_sumcc"])
         for k, mine in (("lb", "bin_lb"), ("ub", "bin_ub"), ("s1", "bin_poss"), ("s2", "bin_sumcc"), ("s7", "bin_poss7")):
             assert np.array_equal(out.arrays[mine], g[P + "bins1_" + k]), k
         assert bits_equal(out.arrays["x"], g[P + "x"]) and bits_equal(out.arrays["y"], g[P + "y"])
@@ -264,7 +268,7 @@ def test_three_passes_match_oracle(name):
     eng.close()
 
 
-@pytest.mark.parametrize("name", ["f1_nobias", "f1_bias", "f2_all", "f6_quirk_all"])
+@pytest.mark.parametrize("name", ["f1_nobias", "f1_bias", "f2_all", "f6_quirk_all", "f7_pfal_all", "f8_nonfixed_hESC", "f8_nonfixed_all"])
 def test_cli_writes_the_reference_files(name, tmp_path, capsys):
     """The drop-in command line: decompressed .significances.txt and .fithic_passN.txt equal the reference's byte for byte."""
     import gzip
@@ -277,12 +281,13 @@ def test_cli_writes_the_reference_files(name, tmp_path, capsys):
         argv += ["-t", kw["bias_path"]]
     cli.main(argv)
     res = kw["resolution"]
+    tag = (".res%d" % res) if res else ""
     for pi in range(1, meta["n_passes"] + 1):
-        with gzip.open(os.path.join(str(tmp_path), "G.spline_pass%d.res%d.significances.txt.gz" % (pi, res)), "rb") as f:
+        with gzip.open(os.path.join(str(tmp_path), "G.spline_pass%d%s.significances.txt.gz" % (pi, tag)), "rb") as f:
             text = f.read()
         assert text.count(b"\n") - 1 == meta["sig_rows_pass%d" % pi]
         assert hashlib.md5(text).hexdigest() == meta["sig_md5_pass%d" % pi]
-        with open(os.path.join(str(tmp_path), "G.fithic_pass%d.res%d.txt" % (pi, res))) as f:
+        with open(os.path.join(str(tmp_path), "G.fithic_pass%d%s.txt" % (pi, tag))) as f:
             assert f.read() == meta["fithic_pass%d_txt" % pi]
     # the log keeps the reference's text (it is truncated by every read_Interactions); paths differ
     with open(os.path.join(str(tmp_path), "G.fithic.log")) as f:

@@ -72,21 +72,27 @@ def test_host_fit_matches_reference(name):
         ctx.set_params(res, kw["L"], kw["U"], kw["n_bins"], kw["mapp_thres"], MODES[kw["mode"]], kw["tL"], kw["tU"])
         ctx.load_fragments(fc, fm, fh, chroms.sort_rank())
         keys, sumcc = g[P + "dist_keys"], g[P + "dist_sumcc"]
-        n_dist = int(keys.max() // res + 1) if len(keys) else 1
-        if pi > 1:
-            od = g["p%d_outliersdist" % (pi - 1)]
-            n_dist = max(n_dist, int(-(-od.max() // res)) + 1)
-        hist_cc = np.zeros(n_dist, np.int64)
-        hist_np = np.zeros(n_dist, np.int64)
-        hist_cc[keys // res] = sumcc
-        hist_np[keys // res] = 1
         st = _capi.FhxStats()
         st.inter_count, st.inter_sum, st.intra_all_sum, st.in_range_sum = [int(v) for v in g[P + "sums"]]
-        ctx.set_global_stats(st, hist_cc, hist_np)
-        if pi > 1:
-            oh = np.zeros(n_dist, np.int64)
-            np.add.at(oh, -(-od // res), 1)          # ceil: bins end on grid distances
-            ctx.set_outlier_dist_hist(oh)
+        if res == 0:                                  # -r 0: explicit distance keys and an explicit outlier multiset
+            ctx.set_dist_keys(keys)
+            ctx.set_global_stats(st, sumcc, np.ones(len(keys), np.int64))
+            if pi > 1:
+                ctx.set_outlier_dists(g["p%d_outliersdist" % (pi - 1)])
+        else:
+            n_dist = int(keys.max() // res + 1) if len(keys) else 1
+            if pi > 1:
+                od = g["p%d_outliersdist" % (pi - 1)]
+                n_dist = max(n_dist, int(-(-od.max() // res)) + 1)
+            hist_cc = np.zeros(n_dist, np.int64)
+            hist_np = np.zeros(n_dist, np.int64)
+            hist_cc[keys // res] = sumcc
+            hist_np[keys // res] = 1
+            ctx.set_global_stats(st, hist_cc, hist_np)
+            if pi > 1:
+                oh = np.zeros(n_dist, np.int64)
+                np.add.at(oh, -(-od // res), 1)          # ceil: bins end on grid distances
+                ctx.set_outlier_dist_hist(oh)
         info = ctx.fit()
         for k, w in (("lb", _capi.A_BIN_LB), ("ub", _capi.A_BIN_UB), ("s1", _capi.A_BIN_POSS), ("s2", _capi.A_BIN_SUMCC),
                      ("s7", _capi.A_BIN_POSS7)):
