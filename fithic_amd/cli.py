@@ -33,7 +33,7 @@ def parse_args(argv=None):
                         help="OPTIONAL: upper bound on the intra-chromosomal distance range (bp). DEFAULT no limit.")
     parser.add_argument("-L", "--lowerbound", dest="distLowThres", type=int, required=False,
                         help="OPTIONAL: lower bound on the intra-chromosomal distance range (bp). DEFAULT no limit.")
-    parser.add_argument("-v", "--visual", action="store_true", dest="visual", required=False, help="OPTIONAL: generate plots (not accelerated; ignored)")
+    parser.add_argument("-v", "--visual", action="store_true", dest="visual", required=False, help="OPTIONAL: use this flag for generating plots. DEFAULT is False.")
     parser.add_argument("-x", "--contactType", dest="contactType", required=False,
                         help="OPTIONAL: which chromosomal regions to study (intraOnly, interOnly, All). DEFAULT is intraOnly")
     parser.add_argument("-tL", "--biasLowerBound", dest="biasLowerBound", type=float, required=False,
@@ -114,7 +114,8 @@ def main(argv=None):
     print("Lower Distance threshold is %s" % F.distLowThres)
     F.visual = False
     if args.visual:
-        print("Graphs are not produced by fithic-mi355x (the -v plots are outside the accelerated path)")
+        print("Graphs will be outputted")
+        F.visual = True
     region = args.contactType if args.contactType is not None else "intraOnly"
     F.interOnly = F.allReg = False
     if region == "All":
@@ -182,6 +183,10 @@ def main(argv=None):
             outliersdist, observedIntraInRangeSum, possibleIntraInRangeCount, possibleInterAllCount, observedInterAllCount,
             observedIntraAllSum, observedInterAllSum, F.biasLowerBound, F.biasUpperBound, resolution, i)
         print("Spline fit Pass %s completed. Time took %s" % (i, (t_first_end - t_first)))   # the reference prints pass 1's time (:372)
+        if F.visual:
+            from . import plots
+            plots.compare_Spline_FDR(FDRXinit, FDRYinit, FDRX, FDRY, os.path.join(outputPath, libName + ".spline_FDR_comparison"), str(i))
+            plots.compareFits_Spline(splineXinit, splineYinit, splineX, splineY, os.path.join(outputPath, libName + ".spline_comparison"), str(i))
     print("=========================")
     print("Fit-Hi-C completed successfully")
     print("\n")

@@ -323,6 +323,9 @@ def fit_Spline(mainDic, x, y, yerr, infilename, outfilename, biasDic, outliersli
         splineX = [int(v) for v in S.arrays["table_x"]]
         newSplineY = np.array(S.arrays["table_y"])
         residual = info["residual"]
+        if visual:
+            from . import plots
+            plots.plot_spline_fit(outfilename, passNo, x, y, yerr, splineX, newSplineY, distLowThres, distUpThres)
     eng = S.engine
     eng.ctx.pvalues()                                   # K2
     eng.ctx.bh(info["bh_total_tests"])                  # K3
@@ -349,7 +352,11 @@ def fit_Spline(mainDic, x, y, yerr, infilename, outfilename, biasDic, outliersli
         outliersline.sort()
         outliersdist.sort()
     FDRx = np.arange(0.0, 0.05 + 0.001, 0.001)
-    FDRy = [int(c) for c in eng.fdr_counts()]
+    FDRy = [int(c) for c in eng.fdr_counts()]                # plot_qvalues' counts (fithic.py:1235-1254), device histogram
+    if visual:
+        from . import plots
+        print("Plotting q-values to file %s" % outfilename + ".qplot.png")
+        plots.plot_qvalues(FDRx, FDRy, outfilename + ".qplot")
     _log("Spline successfully fit\n\n\n")
     return [splineX, newSplineY, residual, outliersline, outliersdist, FDRx, FDRy]
 

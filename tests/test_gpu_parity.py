@@ -296,6 +296,28 @@ def test_cli_writes_the_reference_files(name, tmp_path, capsys):
     assert mine == want
 
 
+def test_cli_visual_flag_writes_figures_and_same_tables(tmp_path):
+    """-v (fithic.py:225-229, 374-376): the figures appear and the significances stay byte-identical."""
+    import gzip
+    import hashlib
+    pytest.importorskip("matplotlib")
+    from fithic_amd import cli
+    meta, g = load_case("f1_bias")
+    kw = case_args(meta)
+    cli.main(["-i", kw["contacts"], "-f", kw["frags"], "-o", str(tmp_path), "-l", "G", "-t", kw["bias_path"], "-v"] + meta["argv"])
+    tag = ".res%d" % kw["resolution"]
+    want = ["G.spline_pass%d.png" % pi for pi in range(1, meta["n_passes"] + 1)]
+    want += ["G.spline_pass%d.qplot.png" % pi for pi in range(1, meta["n_passes"] + 1)]
+    if meta["n_passes"] > 1:
+        want += ["G.spline_FDR_comparison.png", "G.spline_comparison.png"]
+    for name in want:
+        f = tmp_path / name
+        assert f.exists() and f.read_bytes()[:4] == b"\x89PNG"
+    for pi in range(1, meta["n_passes"] + 1):
+        with gzip.open(str(tmp_path / ("G.spline_pass%d%s.significances.txt.gz" % (pi, tag))), "rb") as f:
+            assert hashlib.md5(f.read()).hexdigest() == meta["sig_md5_pass%d" % pi]
+
+
 def test_mirror_benjamini_hochberg_signature():
     from fithic_amd import fithic as F
     q = F.benjamini_hochberg_correction([0.03, 0.4, 0.7, 0.01], 10)

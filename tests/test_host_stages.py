@@ -115,3 +115,23 @@ def test_host_fit_matches_reference(name):
             assert info.spline_s == s and info.spline_fp == fp and info.spline_ier == int(ier)
             assert info.residual == g[P + "residual"][0]
         ctx.close()
+
+
+def test_visual_plots_write_the_reference_figures(tmp_path):
+    """-v: the four figure kinds of fithic.py:970-999,1256-1321 are produced from host arrays."""
+    pytest.importorskip("matplotlib")
+    from fithic_amd import plots
+    x = np.linspace(2e4, 2e6, 40)
+    y = 1e-5 * (x / 2e4) ** -1.1
+    sx = np.arange(20000, 2000001, 5000)
+    sy = 1e-5 * (sx / 2e4) ** -1.08
+    fdrx = np.arange(0.0, 0.051, 0.001)
+    fdry = np.cumsum(np.arange(51))
+    base = str(tmp_path / "lib.spline_pass1")
+    plots.plot_spline_fit(base, 1, list(x), list(y), [0] * len(x), list(sx), sy, 20000, 2000000)
+    plots.plot_qvalues(fdrx, list(fdry), base + ".qplot")
+    plots.compare_Spline_FDR(fdrx, list(fdry), fdrx, list(fdry * 2), str(tmp_path / "lib.spline_FDR_comparison"), "2")
+    plots.compareFits_Spline(list(sx), sy, list(sx), sy * 0.9, str(tmp_path / "lib.spline_comparison"), "2")
+    for name in ("lib.spline_pass1.png", "lib.spline_pass1.qplot.png", "lib.spline_FDR_comparison.png", "lib.spline_comparison.png"):
+        f = tmp_path / name
+        assert f.exists() and f.read_bytes()[:8] == b"\x89PNG\r\n\x1a\n" and f.stat().st_size > 2000
