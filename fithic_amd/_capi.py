@@ -114,11 +114,27 @@ SYMBOLS = {
     "fhx_host_spline_eval": (ctypes.c_int, [_F64P, _F64P, ctypes.c_int32, _F64P, ctypes.c_int64, _F64P]),
     "fhx_host_pava_decreasing": (ctypes.c_int, [_F64P, ctypes.c_int64, _F64P]),
     "fhx_host_lbeta_table": (ctypes.c_int, [ctypes.c_double, ctypes.c_int64, _F64P, _F64P]),
+    # Knight-Ruiz bias vectors (fithic/utils/HiCKRy.py)
+    "fhx_kr_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "fhx_kr_destroy": (None, [ctypes.c_void_p]),
+    "fhx_kr_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "fhx_kr_load_loci": (ctypes.c_int, [ctypes.c_void_p, _I32P, _I32P, ctypes.c_int64]),
+    "fhx_kr_load_pairs": (ctypes.c_int, [ctypes.c_void_p, _I32P, _I32P, _I32P, _I32P, _F64P, ctypes.c_int64, _I64P]),
+    "fhx_kr_shape": (ctypes.c_int, [ctypes.c_void_p, _I64P, _I64P, _I64P, _I64P]),
+    "fhx_kr_get_csr": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, _I64P, _I32P, _F64P]),
+    "fhx_kr_row_sums": (ctypes.c_int, [ctypes.c_void_p, _F64P]),
+    "fhx_kr_remove_sparse": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, _I64P, _F64P, _I64P]),
+    "fhx_kr_get_removed": (ctypes.c_int, [ctypes.c_void_p, _I64P, ctypes.c_int64, _I64P]),
+    "fhx_kr_balance": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p]),
+    "fhx_kr_get_x": (ctypes.c_int, [ctypes.c_void_p, _F64P]),
+    "fhx_kr_bias": (ctypes.c_int, [ctypes.c_void_p, _F64P]),
+    "fhx_kr_spmv": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, _F64P, _F64P, ctypes.c_int32, _F64P]),
+    "fhx_kr_dot": (ctypes.c_int, [ctypes.c_void_p, _F64P, _F64P, ctypes.c_int64, _F64P]),
 }
 
 BUILD_CMD = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
              "-fno-fast-math", "-pthread", "-o", os.path.join(_PKG, "libfithic_mi355x.so"), os.path.join(CSRC, "fhx_device.hip"),
-             os.path.join(CSRC, "fhx_host.cpp"), os.path.join(CSRC, "fhx_io.cpp"), "-lz"]
+             os.path.join(CSRC, "fhx_kr.hip"), os.path.join(CSRC, "fhx_host.cpp"), os.path.join(CSRC, "fhx_io.cpp"), "-lz"]
 
 
 def build(force=False):
@@ -458,3 +474,106 @@ def host_lbeta_table(n_total, max_count):
     if rc != FHX_OK:
         raise FhxError(rc, "fhx_host_lbeta_table")
     return lb, ib
+
+
+# ---- Knight-Ruiz (fhx_kr_*) ------------------------------------------------------------------------------------------
+class KrInfo(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int64), ("nnz", ctypes.c_int64), ("outer_iterations", ctypes.c_int32),
+                ("inner_iterations", ctypes.c_int32), ("matvecs", ctypes.c_int64), ("boundary_steps", ctypes.c_int64),
+                ("residual", ctypes.c_double), ("spmv_seconds", ctypes.c_double), ("spmv_timed", ctypes.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class KrContext:
+    """One Knight-Ruiz balancing context on one GPU (fhx_kr_*).  Raises without the built library or without a GPU."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        self.h = ctypes.c_void_p()
+        rc = self.L.fhx_kr_create(int(device), ctypes.byref(self.h))
+        if rc != FHX_OK:
+            self.h = None
+            raise FhxError(rc, "fhx_kr_create(device=%d) failed: no usable MI355X / HIP runtime" % device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.fhx_kr_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _chk(self, rc):
+        if rc != FHX_OK:
+            raise FhxError(rc, (self.L.fhx_kr_last_error(self.h) or b"").decode())
+
+    def load_loci(self, chr_ids, mids):
+        c, m = _i32(chr_ids), _i32(mids)
+        self._chk(self.L.fhx_kr_load_loci(self.h, _ptr(c, ctypes.c_int32), _ptr(m, ctypes.c_int32), len(c)))
+
+    def load_pairs(self, chr1, mid1, chr2, mid2, value):
+        a = [_i32(v) for v in (chr1, mid1, chr2, mid2)]
+        z = np.ascontiguousarray(value, np.float64)
+        bad = ctypes.c_int64(-1)
+        rc = self.L.fhx_kr_load_pairs(self.h, *[_ptr(v, ctypes.c_int32) for v in a], _ptr(z, ctypes.c_double), len(z), ctypes.byref(bad))
+        if rc == FHX_ERR_REFERENCE_EXIT and bad.value >= 0:
+            raise KeyError(bad.value)
+        self._chk(rc)
+
+    def shape(self):
+        v = [ctypes.c_int64() for _ in range(4)]
+        self._chk(self.L.fhx_kr_shape(self.h, *[ctypes.byref(x) for x in v]))
+        return tuple(x.value for x in v)
+
+    def get_csr(self, which=0):
+        n_full, nnz_full, n_red, nnz_red = self.shape()
+        n, nnz = (n_red, nnz_red) if which else (n_full, nnz_full)
+        indptr, col, val = np.zeros(n + 1, np.int64), np.zeros(nnz, np.int32), np.zeros(nnz, np.float64)
+        self._chk(self.L.fhx_kr_get_csr(self.h, which, _ptr(indptr, ctypes.c_int64), _ptr(col, ctypes.c_int32), _ptr(val, ctypes.c_double)))
+        return indptr, col, val
+
+    def row_sums(self):
+        out = np.zeros(self.shape()[0], np.float64)
+        self._chk(self.L.fhx_kr_row_sums(self.h, _ptr(out, ctypes.c_double)))
+        return out
+
+    def remove_sparse(self, perc):
+        nrem, val, rem = ctypes.c_int64(), ctypes.c_double(), ctypes.c_int64()
+        rc = self.L.fhx_kr_remove_sparse(self.h, float(perc), ctypes.byref(nrem), ctypes.byref(val), ctypes.byref(rem))
+        if rc == FHX_ERR_REFERENCE_EXIT:
+            raise IndexError((self.L.fhx_kr_last_error(self.h) or b"").decode())
+        self._chk(rc)
+        idx = np.zeros(nrem.value, np.int64)
+        self._chk(self.L.fhx_kr_get_removed(self.h, _ptr(idx, ctypes.c_int64), len(idx), None))
+        return idx, val.value, rem.value
+
+    def balance(self, tol=1e-6):
+        info = KrInfo()
+        rc = self.L.fhx_kr_balance(self.h, float(tol), ctypes.byref(info))
+        if rc == FHX_ERR_REFERENCE_EXIT:
+            raise ValueError((self.L.fhx_kr_last_error(self.h) or b"").decode())
+        self._chk(rc)
+        x = np.zeros(info.n, np.float64)
+        if info.n:
+            self._chk(self.L.fhx_kr_get_x(self.h, _ptr(x, ctypes.c_double)))
+        return x, info
+
+    def bias(self):
+        out = np.zeros(self.shape()[0], np.float64)
+        self._chk(self.L.fhx_kr_bias(self.h, _ptr(out, ctypes.c_double)))
+        return out
+
+    def spmv(self, x, which=0, repeats=1):
+        x = np.ascontiguousarray(x, np.float64)
+        y = np.zeros_like(x)
+        sec = ctypes.c_double()
+        self._chk(self.L.fhx_kr_spmv(self.h, which, _ptr(x, ctypes.c_double), _ptr(y, ctypes.c_double), int(repeats), ctypes.byref(sec)))
+        return y, sec.value
+
+    def dot(self, a, b=None):
+        a = np.ascontiguousarray(a, np.float64)
+        out = ctypes.c_double()
+        bb = np.ascontiguousarray(b, np.float64) if b is not None else None
+        self._chk(self.L.fhx_kr_dot(self.h, _ptr(a, ctypes.c_double), _ptr(bb, ctypes.c_double) if bb is not None else None, len(a), ctypes.byref(out)))
+        return out.value

@@ -17,6 +17,13 @@ class ChromIndex:
         self.names = []
         self._ids = {}
 
+    def intern(self, name):
+        j = self._ids.get(name)
+        if j is None:
+            j = self._ids[name] = len(self.names)
+            self.names.append(name)
+        return j
+
     def sort_rank(self):
         order = sorted(range(len(self.names)), key=lambda i: self.names[i])
         rank = np.empty(len(self.names), np.int32)

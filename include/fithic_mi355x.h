@@ -250,6 +250,46 @@ int fhx_host_write_significances(const char* path, const char* const* chr_names,
                                  const double* expcc, int64_t n_rows, int32_t mode, int64_t dist_low, int64_t dist_up,
                                  int32_t gzip_level, int32_t n_threads, int64_t* rows_written);
 
+/* ---- Knight-Ruiz bias vectors (fithic/utils/HiCKRy.py; SURVEY 8f rank 4, the step before Fit-Hi-C) --------------------
+ * One fhx_kr per GPU, independent of fhx_ctx.  Call order: load_loci -> load_pairs -> [remove_sparse] -> balance -> bias.
+ * Summation orders are fixed by the kernels (csrc/fhx_kr.hip header) and restated by oracle/kr_oracle.c. */
+typedef struct fhx_kr fhx_kr;
+typedef struct fhx_kr_info {
+    int64_t n, nnz;                 /* matrix that was balanced (after row removal) */
+    int32_t outer_iterations;       /* `i` of knightRuizAlg's return value (31 = the 30-iteration cap was hit, HiCKRy.py:174) */
+    int32_t inner_iterations;       /* `k` of the last outer iteration */
+    int64_t matvecs;                /* A.dot calls */
+    int64_t boundary_steps;         /* inner loops that ended on the cone boundary (HiCKRy.py:199-212) */
+    double residual;                /* rout = |1 - x*(A x)|^2 at exit */
+    double spmv_seconds;            /* HIP-event time of the timed SpMV launches */
+    int64_t spmv_timed;
+} fhx_kr_info;
+int fhx_kr_create(int device, fhx_kr** out);
+void fhx_kr_destroy(fhx_kr* kr);
+const char* fhx_kr_last_error(const fhx_kr* kr);
+/* fragments file, HiCKRy.py:21-33: locus index = line number; a repeated (chr, mid) maps to its last line. */
+int fhx_kr_load_loci(fhx_kr* kr, const int32_t* chr, const int32_t* mid, int64_t n);
+/* interactions file, HiCKRy.py:34-54: rawMatrix = coo((value,(x,y))) + its transpose, assembled as CSR in HBM.  A row whose
+ * locus is not in the fragments file returns FHX_ERR_REFERENCE_EXIT (KeyError) and its row number. */
+int fhx_kr_load_pairs(fhx_kr* kr, const int32_t* chr1, const int32_t* mid1, const int32_t* chr2, const int32_t* mid2,
+                      const double* value, int64_t m, int64_t* first_unknown_row);
+int fhx_kr_shape(const fhx_kr* kr, int64_t* n_full, int64_t* nnz_full, int64_t* n_reduced, int64_t* nnz_reduced);
+/* which 0 = raw matrix, 1 = after remove_sparse; any output pointer may be NULL */
+int fhx_kr_get_csr(fhx_kr* kr, int32_t which, int64_t* indptr, int32_t* col, double* val);
+/* mtx.sum(axis=0), HiCKRy.py:78 */
+int fhx_kr_row_sums(fhx_kr* kr, double* out);
+/* removeZeroDiagonalCSR, HiCKRy.py:74-101: drops every row/column whose sum is <= the int(perc*n)-th smallest sum. */
+int fhx_kr_remove_sparse(fhx_kr* kr, double perc, int64_t* n_removed, double* val_to_remove, int64_t* rem_rows);
+int fhx_kr_get_removed(const fhx_kr* kr, int64_t* idx, int64_t capacity, int64_t* n_out);
+/* knightRuizAlg, HiCKRy.py:139-243 (tol = 1e-6 in the reference's call) */
+int fhx_kr_balance(fhx_kr* kr, double tol, fhx_kr_info* out);
+int fhx_kr_get_x(const fhx_kr* kr, double* x);
+/* computeBiasVector + addZeroBiases, HiCKRy.py:103-115: n_full values, -1 at the removed rows */
+int fhx_kr_bias(fhx_kr* kr, double* bias);
+/* test / measurement hooks: y = A x (host vectors), repeated `repeats` times with HIP-event timing; ordered dot product */
+int fhx_kr_spmv(fhx_kr* kr, int32_t which, const double* x, double* y, int32_t repeats, double* seconds_per_call);
+int fhx_kr_dot(fhx_kr* kr, const double* a, const double* b, int64_t n, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,8 @@ Fixture sets:
   F4  UnivariateSpline known-answer vectors (t, c, fp, ier; incl. nest restarts, s=0)
   F5  myStats.benjamini_hochberg_correction known-answer vectors
   F6  quirk probes (small hand-made inputs through the full reference main())
+  F7  fixed-size 14-chromosome set; F8 non-fixed-size (-r 0) sets
+  F9  utils/HiCKRy.py (Knight-Ruiz bias vectors): removed rows, KR vector, bias file, iteration counts
 
 Usage:  python tests/golden/make_golden.py [f1] [f2] [f3] [f4] [f5] [f6]     (default: all)
 """
@@ -575,8 +577,55 @@ def make_f8():
              ["-b", "10", "-p", "1", "-x", "intraOnly"])
 
 
+def make_f9():
+    """Knight-Ruiz bias vectors (fithic/utils/HiCKRy.py) for the bundled hESC map and the synthetic sets, through the
+    reference's own main(); intermediate results through its functions."""
+    print("F9: HiCKRy")
+    sys.path.insert(0, os.path.join(REF_PKG, "utils"))
+    import HiCKRy as K
+    cases = [("k1_kr_hESC", "hESC_chr1_w40000.contacts.gz", "hESC_chr1_w40000.frags.gz", 0.12),
+             ("k1_kr_hESC_default", "hESC_chr1_w40000.contacts.gz", "hESC_chr1_w40000.frags.gz", 0.05),   # hits the 30-iteration cap
+             ("k2_kr_pfal", "synth_Pfal_w10000.contacts.gz", "Pfal_w10000.frags.gz", 0.05),
+             ("k3_kr_imr90", "synth_IMR90_w1Mb.contacts.gz", "IMR90_w1Mb.frags.gz", 0.1),               # non-integer counts
+             ("k4_kr_irregular", "irregular.contacts.gz", "irregular.frags.gz", 0.0),
+             ("k5_kr_combine", "synth_hESC_combineFrags10_chr1.contacts.gz", "hESC_combineFrags10_chr1.frags.gz", 0.03)]
+    for name, con, frg, perc in cases:
+        cpath, fpath = os.path.join(DATA, con), os.path.join(DATA, frg)
+        tmp = tempfile.mkdtemp(prefix="kr_golden_")
+        out = os.path.join(tmp, "bias.gz")
+        buf = io.StringIO()
+        argv0 = sys.argv
+        sys.argv = ["HiCKRy.py", "-i", cpath, "-f", fpath, "-o", out, "-x", str(perc)]
+        try:
+            with contextlib.redirect_stdout(buf):
+                K.main()
+        finally:
+            sys.argv = argv0
+        with gzip.open(out, "rb") as f:
+            text = f.read()
+        with contextlib.redirect_stdout(io.StringIO()):
+            M, rev = K.loadfastfithicInteractions(cpath, fpath)
+            sums = np.array(M.sum(axis=0)).reshape(-1)
+            mtx, removed = K.removeZeroDiagonalCSR(M, perc)
+            x, i, k = K.knightRuizAlg(mtx)
+            bias = K.addZeroBiases(removed, K.computeBiasVector(x)).ravel()
+        file_bias = np.array([float(ln.split(b"\t")[2]) for ln in text.splitlines()])
+        assert np.array_equal(file_bias, bias)
+        stdout = "\n".join(ln for ln in buf.getvalue().splitlines() if "took" not in ln)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), removed=np.array(removed, np.int64), x=x.ravel(), bias=bias,
+                            row_sums=sums, indptr_reduced=mtx.indptr.astype(np.int64),
+                            data_checksum=np.array([M.data.sum(), mtx.data.sum()]))
+        meta = dict(name=name, contacts=con, frags=frg, perc=perc, n=int(M.shape[0]), nnz=int(M.nnz), nnz_reduced=int(mtx.nnz),
+                    outer=int(i), inner=int(k), out_md5=hashlib.md5(text).hexdigest(), out_lines=text.count(b"\n"),
+                    stdout=stdout, first_lines=text.decode().splitlines()[:5])
+        with open(os.path.join(HERE, name + ".json"), "w") as f:
+            json.dump(meta, f, indent=1)
+        shutil.rmtree(tmp)
+        print("  %s: n=%d nnz=%d removed=%d iterations=(%d,%d)" % (name, M.shape[0], M.nnz, len(removed), i, k))
+
+
 if __name__ == "__main__":
-    which = [a.lower() for a in sys.argv[1:]] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8"]
-    jobs = dict(f1=make_f1, f2=make_f2, f3=make_f3, f4=make_f4, f5=make_f5, f6=make_f6, f7=make_f7, f8=make_f8)
+    which = [a.lower() for a in sys.argv[1:]] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9"]
+    jobs = dict(f1=make_f1, f2=make_f2, f3=make_f3, f4=make_f4, f5=make_f5, f6=make_f6, f7=make_f7, f8=make_f8, f9=make_f9)
     for w in which:
         jobs[w]()
