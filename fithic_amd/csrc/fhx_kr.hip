@@ -69,20 +69,31 @@ __device__ inline void tile_reduce_store(double acc, double* partials) {
     }
 }
 
-// final pass over the tile partials: strictly left to right for sums
-__global__ __launch_bounds__(THREADS) void kr_finish(const double* partials, int64_t n_tiles, int op, double* out) {
+// final pass over the tile partials: strictly left to right for sums (one thread; loads staged through LDS in blocks
+// of 8 so that only the adds are serial)
+template <int OP>
+__global__ __launch_bounds__(THREADS) void kr_finish(const double* partials, int64_t n_tiles, double* out) {
     __shared__ double buf[TILE];
     double total = 0.0;
     for (int64_t base = 0; base < n_tiles; base += TILE) {
-        const int64_t len = min((int64_t)TILE, n_tiles - base);
+        const int len = (int)min((int64_t)TILE, n_tiles - base);
         for (int i = threadIdx.x; i < len; i += THREADS) buf[i] = partials[base + i];
         __syncthreads();
         if (threadIdx.x == 0) {
-            for (int64_t i = 0; i < len; ++i) {
-                const double v = buf[i];
-                if (base == 0 && i == 0) total = v;
-                else total = op == 0 ? total + v : (op == 1 ? nan_min(total, v) : nan_max(total, v));
+            int i = 0;
+            if (base == 0) {
+                total = buf[0];
+                i = 1;
             }
+            auto fold = [](double t, double v) { return OP == 0 ? t + v : (OP == 1 ? nan_min(t, v) : nan_max(t, v)); };
+            for (; i + 8 <= len; i += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = buf[i + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) total = fold(total, v[u]);
+            }
+            for (; i < len; ++i) total = fold(total, buf[i]);
         }
         __syncthreads();
     }
@@ -109,17 +120,22 @@ __global__ __launch_bounds__(THREADS) void kr_spmv(int64_t n, const int64_t* __r
     const int64_t b = indptr[row], e = indptr[row + 1];
     double acc = 0.0;
     int64_t j = b + lane;
-    for (; j + 192 < e; j += 256) {          // four independent loads in flight, adds stay in order
-        const double p0 = val[j] * in[col[j]];
-        const double p1 = val[j + 64] * in[col[j + 64]];
-        const double p2 = val[j + 128] * in[col[j + 128]];
-        const double p3 = val[j + 192] * in[col[j + 192]];
+    // measured on the C3 matrix: nontemporal loads of col/val -1.6 %; 8-cell unroll -10 %; predicated chunks no gain
+#define LD_COL(k) col[k]
+#define LD_VAL(k) val[k]
+    for (; j + 192 < e; j += 256) {          // four independent loads in flight, adds stay in cell order
+        const double p0 = LD_VAL(j) * in[LD_COL(j)];
+        const double p1 = LD_VAL(j + 64) * in[LD_COL(j + 64)];
+        const double p2 = LD_VAL(j + 128) * in[LD_COL(j + 128)];
+        const double p3 = LD_VAL(j + 192) * in[LD_COL(j + 192)];
         acc = acc + p0;
         acc = acc + p1;
         acc = acc + p2;
         acc = acc + p3;
     }
-    for (; j < e; j += 64) acc = acc + val[j] * in[col[j]];
+    for (; j < e; j += 64) acc = acc + LD_VAL(j) * in[LD_COL(j)];
+#undef LD_COL
+#undef LD_VAL
     const double t = wave_tree_sum(acc);
     if (lane == 0) {
         if (MODE == 0) {
@@ -467,8 +483,8 @@ void launch_spmv(fhx_kr* kr, int64_t n, const int64_t* ptr, const int32_t* col, 
                  double* out1, const double* a0, const double* a1, const double* a2) {
     const int64_t n_blocks = (n + 3) / 4;
     const int64_t per = (n_blocks + 7) / 8;
-    hipLaunchKernelGGL(krd::kr_spmv<MODE>, dim3((unsigned)std::max<int64_t>(1, per * 8)), dim3(krd::THREADS), 0, kr->stream, n, ptr, col,
-                       val, in, out0, out1, a0, a1, a2, n_blocks);
+    hipLaunchKernelGGL((krd::kr_spmv<MODE>), dim3((unsigned)std::max<int64_t>(1, per * 8)), dim3(krd::THREADS), 0, kr->stream, n, ptr,
+                       col, val, in, out0, out1, a0, a1, a2, n_blocks);
 }
 
 int ensure_vectors(fhx_kr* kr, int64_t n) {
@@ -492,9 +508,12 @@ int ensure_vectors(fhx_kr* kr, int64_t n) {
 // finish the partial arrays `which` (bit mask over the 3 arrays; ops in `ops`) and bring the scalars to the host
 int finish_scalars(fhx_kr* kr, int64_t n, int n_arrays, const int* ops, double* out) {
     const int64_t t = tiles_of(n);
-    for (int a = 0; a < n_arrays; ++a)
-        hipLaunchKernelGGL(krd::kr_finish, dim3(1), dim3(krd::THREADS), 0, kr->stream, kr->d_part + (int64_t)a * kr->part_cap, t, ops[a],
-                           kr->d_scalars + a);
+    for (int a = 0; a < n_arrays; ++a) {
+        const double* part = kr->d_part + (int64_t)a * kr->part_cap;
+        if (ops[a] == 0) hipLaunchKernelGGL(krd::kr_finish<0>, dim3(1), dim3(krd::THREADS), 0, kr->stream, part, t, kr->d_scalars + a);
+        else if (ops[a] == 1) hipLaunchKernelGGL(krd::kr_finish<1>, dim3(1), dim3(krd::THREADS), 0, kr->stream, part, t, kr->d_scalars + a);
+        else hipLaunchKernelGGL(krd::kr_finish<2>, dim3(1), dim3(krd::THREADS), 0, kr->stream, part, t, kr->d_scalars + a);
+    }
     KR_HIP(hipGetLastError());
     KR_HIP(hipMemcpyAsync(out, kr->d_scalars, n_arrays * sizeof(double), hipMemcpyDeviceToHost, kr->stream));
     KR_HIP(hipStreamSynchronize(kr->stream));

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Measurement of the Knight-Ruiz path (fhx_kr_*) on the C3-synth contact map (22 hg19 autosomes at
+5 kb, the same rows bench.py uses): assembly, row removal, balance; roofline of the dominant kernel kr_spmv from the
+HIP-event time of the SpMV launches inside fhx_kr_balance.  One JSON line on stdout.
+
+    python profiles/kr_bench.py [--max-chroms K] [--no-cpu-baseline]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--max-chroms", type=int, default=0)
+    ap.add_argument("--perc", type=float, default=0.05)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    from fithic_amd import synth, _capi
+    res, lo_idx, hi_idx = 5000, 4, 400
+    device = torch.device("cuda", 0)
+    lengths = synth.HG19_AUTOSOMES[:args.max_chroms] if args.max_chroms else None
+    genome = synth.Genome(res, lengths)
+    amp = synth.solve_amplitude(0.66, lo_idx, hi_idx)
+    parts = [synth.cis_contacts(genome, c, lo_idx, hi_idx, amp, device=device) for c in range(len(genome))]
+    cols = [torch.cat([p[k] for p in parts]).cpu().numpy() for k in range(5)]
+    del parts
+    torch.cuda.empty_cache()
+    m = len(cols[0])
+    f_chr, f_mid, _ = genome.fragments()
+    kr = _capi.KrContext(0)
+    kr.load_loci(f_chr, f_mid)
+    t0 = time.perf_counter()
+    kr.load_pairs(cols[0], cols[1], cols[2], cols[3], cols[4].astype(np.float64))
+    t_asm = time.perf_counter() - t0
+    n_full, nnz_full, _, _ = kr.shape()
+    t0 = time.perf_counter()
+    removed, val, _ = kr.remove_sparse(args.perc)
+    t_rem = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    x, info = kr.balance(1e-6)
+    t_bal = time.perf_counter() - t0
+    bias = kr.bias()
+    n, nnz = info.n, info.nnz
+    spmv = info.spmv_seconds / max(info.spmv_timed, 1)
+    algo = 12.0 * nnz + 24.0 * n + 8.0 * (n + 1)        # value 8 + column 4 per cell; in/out/epilogue vectors; indptr
+    # isolated SpMV (plain epilogue), many repeats
+    _, spmv_iso = kr.spmv(np.ones(n), which=1, repeats=50)
+    out = {
+        "metric": "Knight-Ruiz balancing of the C3-synth 5 kb contact map (HiCKRy path)", "n_gpus": 1, "dtype": "f64",
+        "config": {"workload": "C3-synth: %d chromosomes @%d bp, %d contact rows -> %d loci, %d stored cells (symmetric CSR)"
+                               % (len(genome), res, m, n_full, nnz_full), "perc": args.perc},
+        "removed_rows": int(len(removed)), "balanced": {"n": n, "nnz": nnz}, "outer_iterations": info.outer_iterations,
+        "inner_iterations_last": info.inner_iterations, "matvecs": info.matvecs, "residual": info.residual,
+        "seconds": {"assemble_incl_h2d": t_asm, "remove_sparse": t_rem, "balance": t_bal},
+        "bias_mean": float(np.mean(bias[bias > 0])),
+        "roofline": {"bound": "hbm", "kernel": "kr_spmv", "achieved": algo / spmv / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": algo / spmv / 1e9 / HBM_PEAK_GBS, "traffic": None, "launch_seconds": spmv,
+                     "isolated_launch_seconds": spmv_iso, "isolated_frac": algo / spmv_iso / 1e9 / HBM_PEAK_GBS,
+                     "algorithmic_bytes_per_launch": algo,
+                     "note": "12 B per stored cell (8 value + 4 column) + 32 B per row (indptr, gathered input, output, epilogue)"},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(genome, cols, args.perc)
+    kr.close()
+    print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(genome, cols, perc):
+    """The oracle (numpy + plain-C SpMV, 1 thread) on the rows of the four smallest chromosomes."""
+    import numpy as np
+    from oracle import hickry_oracle as ho
+    small = np.argsort(np.array(genome.n_loci))[:4]
+    sel = np.isin(cols[0], small)
+    offs = {}
+    n = 0
+    for c in sorted(small.tolist()):
+        offs[c] = n
+        n += int(genome.n_loci[c])
+    res = genome.res
+    base = np.vectorize(offs.get)(cols[0][sel]).astype(np.int64)
+    x = base + (cols[1][sel].astype(np.int64) - res // 2) // res
+    y = base + (cols[3][sel].astype(np.int64) - res // 2) // res
+    z = cols[4][sel].astype(np.float64)
+    ho.build()
+    t0 = time.perf_counter()
+    A = ho.assemble(x, y, z, n)
+    removed, _, _ = ho.sparse_rows(A, perc)
+    R = ho.drop(A, removed)
+    xv, i, k = ho.knight_ruiz(R)
+    dt = time.perf_counter() - t0
+    return {"value": dt, "unit": "s (assemble + remove + balance)", "cores": 1, "kind": "port",
+            "sample": "%d rows of the 4 smallest chromosomes -> %d loci, %d cells, %d outer iterations" % (int(sel.sum()), n, A.nnz, i)}
+
+
+if __name__ == "__main__":
+    main()
