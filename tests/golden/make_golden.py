@@ -20,6 +20,7 @@ Fixture sets:
   F6  quirk probes (small hand-made inputs through the full reference main())
   F7  fixed-size 14-chromosome set; F8 non-fixed-size (-r 0) sets
   F9  utils/HiCKRy.py (Knight-Ruiz bias vectors): removed rows, KR vector, bias file, iteration counts
+  F10 utils/CombineNearbyInteraction.py: merged loop lists (output files) in the modes its flags offer
 
 Usage:  python tests/golden/make_golden.py [f1] [f2] [f3] [f4] [f5] [f6]     (default: all)
 """
@@ -624,8 +625,74 @@ def make_f9():
         print("  %s: n=%d nnz=%d removed=%d iterations=(%d,%d)" % (name, M.shape[0], M.nnz, len(removed), i, k))
 
 
+def make_f10():
+    """utils/CombineNearbyInteraction.py: merged loop lists for a real significances file (the reference's own Fit-Hi-C run on
+    the bundled hESC chr1 set, rows with q < 1e-20) and for a synthetic 3-chromosome cluster set, in the modes its flags offer."""
+    import subprocess
+    print("F10: CombineNearbyInteraction")
+    tool = os.path.join(REF_PKG, "utils", "CombineNearbyInteraction.py")
+    # (a) real: run the reference Fit-Hi-C, keep the significant rows as they were written
+    tmp = tempfile.mkdtemp(prefix="cni_golden_")
+    run_reference(["-i", os.path.join(DATA, "hESC_chr1_w40000.contacts.gz"), "-f", os.path.join(DATA, "hESC_chr1_w40000.frags.gz"),
+                   "-t", os.path.join(DATA, "hESC_chr1_w40000.bias.gz"), "-o", tmp, "-l", "G", "-r", "40000", "-L", "50000",
+                   "-U", "5000000", "-b", "50", "-p", "1", "-x", "intraOnly"])
+    with gzip.open(os.path.join(tmp, "G.spline_pass1.res40000.significances.txt.gz"), "rt") as f:
+        lines = f.read().splitlines(True)
+    keep = [lines[0]] + [ln for ln in lines[1:] if float(ln.split()[6]) < 1e-20]     # 6.5 k rows: the reference pairs all nodes (O(n^2))
+    _write_gz(os.path.join(DATA, "hESC_chr1_sig_q1e20.txt.gz"), "".join(keep))
+    print("  real input: %d significant rows" % (len(keep) - 1))
+    shutil.rmtree(tmp)
+    # (b) synthetic: clusters on three chromosomes, duplicates, a diagonal cell, tied q-values, one inter-chromosomal row
+    rng = np.random.default_rng(1010)
+    res = 40000
+    rows = []
+    for ch in ("chr2", "chr10", "chr1"):
+        for _ in range(14):
+            a, d = int(rng.integers(5, 200)), int(rng.integers(0, 60))
+            for _ in range(int(rng.integers(1, 45))):
+                b1 = a + int(rng.integers(-3, 4))
+                b2 = b1 + d + int(rng.integers(-3, 4))
+                if b1 < 0 or b2 < b1:
+                    continue
+                q = float(np.round(10 ** rng.uniform(-12, -2), 13)) if rng.random() < 0.8 else 1e-6
+                rows.append("%s\t%d\t%s\t%d\t%d\t%e\t%e\t1.0\t1.0\t%f\n" % (ch, b1 * res + res // 2, ch, b2 * res + res // 2,
+                                                                              int(rng.integers(5, 200)), q / 50, q, 1.0))
+    rows.append("chr1\t20000\tchr2\t60000\t5\t1.000000e-05\t1.000000e-04\t1.0\t1.0\t1.000000\n")
+    rows += [rows[3], rows[40]]                                   # the same cell twice: the first row keeps its values
+    perm = rng.permutation(len(rows))
+    body = "".join(rows[i] for i in perm)
+    head = "chr1\tfragmentMid1\tchr2\tfragmentMid2\tcontactCount\tp-value\tq-value\tbias1\tbias2\tExpCC\n"
+    _write_gz(os.path.join(DATA, "synth_sig_clusters.txt.gz"), head + body)
+    _write_gz(os.path.join(DATA, "synth_sig_clusters_nohdr.txt.gz"), body)
+    cases = [("c1_combine_hESC_default", "hESC_chr1_sig_q1e20.txt.gz", []),
+             ("c1_combine_hESC_c4_n1", "hESC_chr1_sig_q1e20.txt.gz", ["-c", "4", "-n", "1"]),
+             ("c1_combine_hESC_p50", "hESC_chr1_sig_q1e20.txt.gz", ["-p", "50"]),
+             ("c2_combine_synth_default", "synth_sig_clusters.txt.gz", []),
+             ("c2_combine_synth_c4", "synth_sig_clusters.txt.gz", ["-c", "4"]),
+             ("c2_combine_synth_p50", "synth_sig_clusters.txt.gz", ["-p", "50"]),
+             ("c2_combine_synth_p10_n3", "synth_sig_clusters.txt.gz", ["-p", "10", "-n", "3"]),
+             ("c2_combine_synth_s1", "synth_sig_clusters.txt.gz", ["-s", "1"]),
+             ("c2_combine_synth_p30_s1", "synth_sig_clusters.txt.gz", ["-p", "30", "-s", "1"]),
+             ("c2_combine_synth_nohdr", "synth_sig_clusters_nohdr.txt.gz", ["-H", "0"])]
+    for name, inp, extra in cases:
+        tmp = tempfile.mkdtemp(prefix="cni_golden_")
+        out = os.path.join(tmp, "merged.gz")
+        env = dict(os.environ, LC_ALL="C")
+        subprocess.run([sys.executable, tool, "-i", os.path.join(DATA, inp), "-o", out, "-r", "40000"] + extra, check=True,
+                       stdout=subprocess.DEVNULL, env=env)
+        with gzip.open(out, "rb") as f:
+            text = f.read()
+        _write_gz(os.path.join(HERE, name + ".out.gz"), text.decode())
+        with open(os.path.join(HERE, name + ".json"), "w") as f:
+            json.dump(dict(name=name, input=inp, argv=["-r", "40000"] + extra, out_md5=hashlib.md5(text).hexdigest(),
+                           out_lines=len(text.decode().split("\n"))), f, indent=1)
+        shutil.rmtree(tmp)
+        print("  %s: %d lines" % (name, len(text.decode().split("\n"))))
+
+
 if __name__ == "__main__":
-    which = [a.lower() for a in sys.argv[1:]] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9"]
-    jobs = dict(f1=make_f1, f2=make_f2, f3=make_f3, f4=make_f4, f5=make_f5, f6=make_f6, f7=make_f7, f8=make_f8, f9=make_f9)
+    which = [a.lower() for a in sys.argv[1:]] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10"]
+    jobs = dict(f1=make_f1, f2=make_f2, f3=make_f3, f4=make_f4, f5=make_f5, f6=make_f6, f7=make_f7, f8=make_f8, f9=make_f9,
+                f10=make_f10)
     for w in which:
         jobs[w]()
