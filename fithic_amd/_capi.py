@@ -130,11 +130,18 @@ SYMBOLS = {
     "fhx_kr_bias": (ctypes.c_int, [ctypes.c_void_p, _F64P]),
     "fhx_kr_spmv": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, _F64P, _F64P, ctypes.c_int32, _F64P]),
     "fhx_kr_dot": (ctypes.c_int, [ctypes.c_void_p, _F64P, _F64P, ctypes.c_int64, _F64P]),
+    # merging of nearby significant contacts (fithic/utils/CombineNearbyInteraction.py)
+    "fhx_cni_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "fhx_cni_destroy": (None, [ctypes.c_void_p]),
+    "fhx_cni_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "fhx_cni_load": (ctypes.c_int, [ctypes.c_void_p, _I32P, _I64P, _I64P, _I64P, _F64P, _F64P, ctypes.c_int64, ctypes.c_int64, _I64P]),
+    "fhx_cni_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
+    "fhx_cni_get_records": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, _I64P]),
 }
 
 BUILD_CMD = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
              "-fno-fast-math", "-pthread", "-o", os.path.join(_PKG, "libfithic_mi355x.so"), os.path.join(CSRC, "fhx_device.hip"),
-             os.path.join(CSRC, "fhx_kr.hip"), os.path.join(CSRC, "fhx_host.cpp"), os.path.join(CSRC, "fhx_io.cpp"), "-lz"]
+             os.path.join(CSRC, "fhx_kr.hip"), os.path.join(CSRC, "fhx_cni.hip"), os.path.join(CSRC, "fhx_host.cpp"), os.path.join(CSRC, "fhx_io.cpp"), "-lz"]
 
 
 def build(force=False):
@@ -577,3 +584,57 @@ class KrContext:
         bb = np.ascontiguousarray(b, np.float64) if b is not None else None
         self._chk(self.L.fhx_kr_dot(self.h, _ptr(a, ctypes.c_double), _ptr(bb, ctypes.c_double) if bb is not None else None, len(a), ctypes.byref(out)))
         return out.value
+
+
+# ---- merging of nearby contacts (fhx_cni_*) --------------------------------------------------------------------------
+class CniInfo(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int64) for k in ("rows", "nodes", "components", "selected", "pick_rounds", "largest_component")]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+CNI_RECORD = np.dtype([("chr", np.int32), ("reserved", np.int32), ("n_lo", np.int64), ("n_hi", np.int64), ("cc", np.int64),
+                       ("p", np.float64), ("q", np.float64), ("box_min_lo", np.int64), ("box_max_lo", np.int64),
+                       ("box_min_hi", np.int64), ("box_max_hi", np.int64), ("sum_cc", np.int64), ("box_cells", np.int64),
+                       ("component_size", np.int64), ("first_row", np.int64)])
+
+
+class CniContext:
+    """Connected-component merging of significant contacts on one GPU (fhx_cni_*).  Raises without the library or a GPU."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        self.h = ctypes.c_void_p()
+        rc = self.L.fhx_cni_create(int(device), ctypes.byref(self.h))
+        if rc != FHX_OK:
+            self.h = None
+            raise FhxError(rc, "fhx_cni_create(device=%d) failed: no usable MI355X / HIP runtime" % device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.fhx_cni_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _chk(self, rc):
+        if rc != FHX_OK:
+            raise FhxError(rc, (self.L.fhx_cni_last_error(self.h) or b"").decode())
+
+    def load(self, chr_ids, n1, n2, cc, p, q, bin_size):
+        c = _i32(chr_ids)
+        a = [np.ascontiguousarray(v, np.int64) for v in (n1, n2, cc)]
+        f = [np.ascontiguousarray(v, np.float64) for v in (p, q)]
+        nodes = ctypes.c_int64()
+        self._chk(self.L.fhx_cni_load(self.h, _ptr(c, ctypes.c_int32), *[_ptr(v, ctypes.c_int64) for v in a],
+                                      *[_ptr(v, ctypes.c_double) for v in f], len(c), int(bin_size), ctypes.byref(nodes)))
+        return nodes.value
+
+    def run(self, connectivity=8, top_percent=100, neighborhood=2, sort_order=0):
+        info = CniInfo()
+        self._chk(self.L.fhx_cni_run(self.h, connectivity, top_percent, neighborhood, sort_order, ctypes.byref(info)))
+        out = np.zeros(info.selected, CNI_RECORD)
+        if info.selected:
+            self._chk(self.L.fhx_cni_get_records(self.h, out.ctypes.data_as(ctypes.c_void_p), len(out), None))
+        return out, info

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "../../include/fithic_mi355x.h"
+#include "fhx_scan.hpp"
 
 namespace krd {
 
@@ -279,57 +280,8 @@ __global__ __launch_bounds__(THREADS) void kr_lookup(int64_t m, const int32_t* c
     }
 }
 
-// ordered block-wide exclusive scan of one small count per thread
-__device__ inline unsigned int block_exclusive_scan(unsigned int v, unsigned int* total) {
-    __shared__ unsigned int wsum[4];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    unsigned int inc = v;
-    for (int s = 1; s < 64; s <<= 1) {
-        const unsigned int up = __shfl_up(inc, s, 64);
-        if (lane >= s) inc += up;
-    }
-    if (lane == 63) wsum[w] = inc;
-    __syncthreads();
-    unsigned int base = 0, all = 0;
-    for (int k = 0; k < 4; ++k) {
-        if (k < w) base += wsum[k];
-        all += wsum[k];
-    }
-    __syncthreads();
-    *total = all;
-    return base + inc - v;
-}
-
-__device__ inline bool is_head(const unsigned long long* keys, int64_t i) { return i == 0 || keys[i] != keys[i - 1]; }
-
-__global__ __launch_bounds__(THREADS) void kr_count_heads(const unsigned long long* keys, int64_t N, unsigned int* tile_counts) {
-    const int64_t base = (int64_t)blockIdx.x * TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
-    unsigned int c = 0;
-    for (int k = 0; k < SCAN_ITEMS; ++k)
-        if (base + k < N && is_head(keys, base + k)) ++c;
-    unsigned int total;
-    block_exclusive_scan(c, &total);
-    if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
-}
-
-// exclusive scan of the tile counts (one block, any number of tiles); offsets are 64-bit
-__global__ __launch_bounds__(THREADS) void kr_scan_tiles(const unsigned int* tile_counts, int64_t n_tiles, unsigned long long* tile_offsets,
-                                                         unsigned long long* total_out) {
-    __shared__ unsigned long long carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int64_t base = 0; base < n_tiles; base += THREADS) {
-        const int64_t i = base + threadIdx.x;
-        const unsigned int v = i < n_tiles ? tile_counts[i] : 0;
-        unsigned int total;
-        const unsigned int ex = block_exclusive_scan(v, &total);
-        if (i < n_tiles) tile_offsets[i] = carry + ex;
-        __syncthreads();
-        if (threadIdx.x == 0) carry += total;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *total_out = carry;
-}
+using fhxscan::block_exclusive_scan;
+using fhxscan::is_head;
 
 // every run head adds its run one by one (stable sort => file order) and writes one CSR cell
 __global__ __launch_bounds__(THREADS) void kr_emit_cells(const unsigned long long* keys, const unsigned int* perm, const double* z,
@@ -695,8 +647,8 @@ int fhx_kr_load_pairs(fhx_kr* kr, const int32_t* chr1, const int32_t* mid1, cons
     const int64_t tiles = (N + krd::TILE - 1) / krd::TILE;
     KR_TRY(hipMalloc(&tile_cnt, (size_t)tiles * 4));
     KR_TRY(hipMalloc(&tile_off, (size_t)tiles * 8));
-    hipLaunchKernelGGL(krd::kr_count_heads, dim3((unsigned)tiles), dim3(krd::THREADS), 0, kr->stream, skeys, N, tile_cnt);
-    hipLaunchKernelGGL(krd::kr_scan_tiles, dim3(1), dim3(krd::THREADS), 0, kr->stream, tile_cnt, tiles, tile_off, kr->d_counter + 1);
+    hipLaunchKernelGGL(fhxscan::count_heads, dim3((unsigned)tiles), dim3(krd::THREADS), 0, kr->stream, skeys, N, tile_cnt);
+    hipLaunchKernelGGL(fhxscan::scan_tiles, dim3(1), dim3(krd::THREADS), 0, kr->stream, tile_cnt, tiles, tile_off, kr->d_counter + 1);
     KR_TRY(hipGetLastError());
     unsigned long long nnz = 0;
     KR_TRY(hipMemcpyAsync(&nnz, kr->d_counter + 1, 8, hipMemcpyDeviceToHost, kr->stream));

@@ -290,6 +290,36 @@ int fhx_kr_bias(fhx_kr* kr, double* bias);
 int fhx_kr_spmv(fhx_kr* kr, int32_t which, const double* x, double* y, int32_t repeats, double* seconds_per_call);
 int fhx_kr_dot(fhx_kr* kr, const double* a, const double* b, int64_t n, double* out);
 
+/* ---- merging of nearby significant contacts (fithic/utils/CombineNearbyInteraction.py; SURVEY 8f rank 4, the step after
+ * Fit-Hi-C).  The caller parses the significances table, keeps the rows with chr1 == chr2 (:258-266), numbers the chromosomes
+ * in the order they are to be written (byte-sorted names, :204-212) and passes n = int(float(mid) + res/2) (:301-303).
+ * All numerators must share one offset modulo the resolution (true for every fixed-size Fit-Hi-C output); -p 0 is refused:
+ * its result depends on CPython's set iteration order (:417-437). */
+typedef struct fhx_cni fhx_cni;
+typedef struct fhx_cni_info {
+    int64_t rows, nodes, components, selected, pick_rounds, largest_component;
+} fhx_cni_info;
+typedef struct fhx_cni_record {        /* one output line (:589-600); bins are n / res */
+    int32_t chr, reserved;
+    int64_t n_lo, n_hi;                /* the picked cell */
+    int64_t cc;
+    double p, q;                       /* of the first row of that cell */
+    int64_t box_min_lo, box_max_lo, box_min_hi, box_max_hi;   /* bounding box of its component (numerators) */
+    int64_t sum_cc;                    /* over the component's cells */
+    int64_t box_cells;                 /* cells of the chromosome inside the box (0 when bins are not whole numbers) */
+    int64_t component_size;
+    int64_t first_row;                 /* input row the cell's values come from */
+} fhx_cni_record;
+int fhx_cni_create(int device, fhx_cni** out);
+void fhx_cni_destroy(fhx_cni* cn);
+const char* fhx_cni_last_error(const fhx_cni* cn);
+int fhx_cni_load(fhx_cni* cn, const int32_t* chr, const int64_t* n1, const int64_t* n2, const int64_t* cc, const double* p,
+                 const double* q, int64_t rows, int64_t bin_size, int64_t* n_nodes);
+/* connectivity 8|4 (-c), top_percent 1..100 (-p), neighborhood in bins (-n), sort_order 0|1 (-s) */
+int fhx_cni_run(fhx_cni* cn, int32_t connectivity, int32_t top_percent, int32_t neighborhood, int32_t sort_order,
+                fhx_cni_info* info);
+int fhx_cni_get_records(const fhx_cni* cn, fhx_cni_record* out, int64_t capacity, int64_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif
