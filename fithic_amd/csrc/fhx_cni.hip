@@ -16,8 +16,8 @@
 //                         is picked.  Run as rounds over all undecided nodes: decided as soon as every earlier node in
 //                         its window is decided (the greedy result is unique, so the rounds reproduce it)   cn_pick_round
 //
-// Everything is integer / index work: results are bit-exact by construction.  The host keeps O(components) bookkeeping
-// (ordering of the output, percentile bounds) and formats nothing: text is the caller's job.
+// Everything is integer / index work: results are bit-exact by construction.  The output order (chromosome, component size,
+// first row, rank) is two more stable sorts; the host only moves the finished records and formats nothing.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -137,9 +137,17 @@ __global__ __launch_bounds__(THREADS) void cn_union(const unsigned long long* no
     }
 }
 
-__global__ __launch_bounds__(THREADS) void cn_flatten(unsigned int* parent, int64_t n) {
-    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n; u += (int64_t)gridDim.x * blockDim.x)
-        parent[u] = uf_find(parent, (unsigned int)u);
+// root[u] into a second array with a read-only walk: a walk that also compresses paths could overwrite, late, the final
+// value another thread has just stored for the same node
+__global__ __launch_bounds__(THREADS) void cn_flatten(const unsigned int* parent, int64_t n, unsigned int* root) {
+    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n; u += (int64_t)gridDim.x * blockDim.x) {
+        unsigned int a = (unsigned int)u, p = parent[a];
+        while (p != a) {
+            a = p;
+            p = parent[a];
+        }
+        root[u] = a;
+    }
 }
 
 struct CompStats {            // indexed by root node
@@ -281,6 +289,108 @@ __global__ __launch_bounds__(THREADS) void cn_pick_round(const unsigned long lon
     }
 }
 
+// segments of the final order (grouped by root): where each component starts; also counts the components
+__global__ __launch_bounds__(THREADS) void cn_seg_starts(const unsigned int* order, const unsigned int* root, int64_t n, unsigned int* seg_start,
+                                                         unsigned long long* n_components) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned int r = root[order[t]];
+        if (t == 0 || root[order[t - 1]] != r) {
+            seg_start[r] = (unsigned int)t;
+            atomicAdd(n_components, 1ull);
+        }
+    }
+}
+
+// per component: how many leading candidates the greedy loop looks at.  -p 100: all.  0 < -p < 100: custom_percent (:36-52)
+// of the component's q list gives a bound; the loop stops at the first element failing it (:508-509)
+__global__ __launch_bounds__(THREADS) void cn_limits(const unsigned int* root, const unsigned int* order, const unsigned int* node_row,
+                                                     const double* q, const CompStats* st, const unsigned int* seg_start, int64_t n,
+                                                     int top_percent, int sort_order, unsigned int* limit, unsigned long long* largest) {
+    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n; u += (int64_t)gridDim.x * blockDim.x) {
+        if (root[u] != (unsigned int)u) continue;
+        const unsigned int L = st[u].size, s0 = seg_start[u];
+        atomicMax(largest, (unsigned long long)L);
+        unsigned int lim = L;
+        if (top_percent < 100) {
+            const long long index = ((long long)L * top_percent) / 100;
+            const unsigned int at = index <= 1 ? L - 1 : (unsigned int)index;
+            const double bound = q[node_row[order[s0 + at]]];
+            if (sort_order == 0) {                        // ascending q: first element with q > bound
+                unsigned int lo = 0, hi = L;
+                while (lo < hi) {
+                    const unsigned int mid = (lo + hi) / 2;
+                    if (q[node_row[order[s0 + mid]]] > bound) hi = mid;
+                    else lo = mid + 1;
+                }
+                lim = lo;
+            } else {                                      // keys are -q: the first one decides, later ones are larger
+                lim = (-q[node_row[order[s0]]] < bound) ? 0u : L;
+            }
+        }
+        limit[u] = lim;
+    }
+}
+
+// output order of the components (:204-212, 354): chromosome, size (largest first), first row.  Two stable sorts.
+__global__ __launch_bounds__(THREADS) void cn_key_first_row(const unsigned int* root, const CompStats* st, int64_t n, unsigned long long* out) {
+    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n; u += (int64_t)gridDim.x * blockDim.x)
+        out[u] = root[u] == (unsigned int)u ? (unsigned long long)st[u].first_row : ~0ull;
+}
+
+__global__ __launch_bounds__(THREADS) void cn_key_chr_size(const unsigned int* nodes_in, const unsigned long long* node_key, const unsigned int* root,
+                                                           const CompStats* st, int64_t n, unsigned long long* out) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned int u = nodes_in[t];
+        out[t] = root[u] == u ? ((node_key[u] >> (2 * BIN_BITS)) << 32) | (unsigned long long)(0xffffffffu - st[u].size) : ~0ull;
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void cn_comp_ranks(const unsigned int* comps_sorted, int64_t n_components, unsigned int* comp_rank) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_components; t += (int64_t)gridDim.x * blockDim.x)
+        comp_rank[comps_sorted[t]] = (unsigned int)t;
+}
+
+// picked nodes sort by (component rank, position in the component's ranking); the rest goes to the end
+__global__ __launch_bounds__(THREADS) void cn_key_output(const unsigned char* state, const unsigned int* root, const unsigned int* comp_rank,
+                                                         const unsigned int* pos, int64_t n, unsigned long long* out, unsigned long long* n_selected) {
+    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n; u += (int64_t)gridDim.x * blockDim.x) {
+        if (state[u] == 1) {
+            out[u] = ((unsigned long long)comp_rank[root[u]] << 32) | pos[u];
+            atomicAdd(n_selected, 1ull);
+        } else {
+            out[u] = ~0ull;
+        }
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void cn_records(const unsigned int* out_nodes, int64_t n_selected, const unsigned long long* node_key,
+                                                      const unsigned int* node_row, const unsigned int* root, const CompStats* st,
+                                                      const int64_t* cc, const double* p, const double* q, int64_t res, int64_t r0,
+                                                      fhx_cni_record* rec) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_selected; t += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned int u = out_nodes[t];
+        const unsigned long long key = node_key[u];
+        const unsigned int row = node_row[u];
+        const CompStats s = st[root[u]];
+        fhx_cni_record r{};
+        r.chr = (int32_t)(key >> (2 * BIN_BITS));
+        r.n_lo = (int64_t)((key >> BIN_BITS) & BIN_MASK) * res + r0;
+        r.n_hi = (int64_t)(key & BIN_MASK) * res + r0;
+        r.cc = cc[row];
+        r.p = p[row];
+        r.q = q[row];
+        r.box_min_lo = (int64_t)s.min_lo * res + r0;
+        r.box_max_lo = (int64_t)s.max_lo * res + r0;
+        r.box_min_hi = (int64_t)s.min_hi * res + r0;
+        r.box_max_hi = (int64_t)s.max_hi * res + r0;
+        r.sum_cc = s.sum_cc;
+        r.box_cells = (int64_t)s.have;
+        r.component_size = (int64_t)s.size;
+        r.first_row = (int64_t)row;
+        rec[t] = r;
+    }
+}
+
 }  // namespace cnd
 
 // ===================================================================================================================
@@ -290,11 +400,9 @@ struct fhx_cni {
     std::string err;
     fhx_ctx* sorter = nullptr;
     int64_t rows = 0, res = 0, lattice_r = 0;
-    std::vector<int32_t> h_chr;
-    std::vector<int64_t> h_n1, h_n2, h_cc;
-    std::vector<double> h_p, h_q;
     int64_t* d_cc = nullptr;
     double* d_q = nullptr;
+    double* d_p = nullptr;
     int64_t n_nodes = 0;
     unsigned long long* d_node_key = nullptr;
     unsigned int* d_node_row = nullptr;
@@ -364,6 +472,7 @@ void fhx_cni_destroy(fhx_cni* cn) {
     if (cn->stream) (void)hipStreamSynchronize(cn->stream);
     cfree(cn->d_cc);
     cfree(cn->d_q);
+    cfree(cn->d_p);
     cfree(cn->d_node_key);
     cfree(cn->d_node_row);
     if (cn->sorter) fhx_destroy(cn->sorter);
@@ -380,18 +489,13 @@ int fhx_cni_load(fhx_cni* cn, const int32_t* chr, const int64_t* n1, const int64
     CN_HIP(hipSetDevice(cn->device));
     cfree(cn->d_cc);
     cfree(cn->d_q);
+    cfree(cn->d_p);
     cfree(cn->d_node_key);
     cfree(cn->d_node_row);
     cn->out.clear();
     cn->rows = rows;
     cn->res = bin_size;
     cn->n_nodes = 0;
-    cn->h_chr.assign(chr, chr + rows);
-    cn->h_n1.assign(n1, n1 + rows);
-    cn->h_n2.assign(n2, n2 + rows);
-    cn->h_cc.assign(cc, cc + rows);
-    cn->h_p.assign(p, p + rows);
-    cn->h_q.assign(q, q + rows);
     if (n_nodes) *n_nodes = 0;
     if (rows == 0) return FHX_OK;
     // the lattice: every numerator must sit at the same offset r modulo the bin size
@@ -412,11 +516,13 @@ int fhx_cni_load(fhx_cni* cn, const int32_t* chr, const int64_t* n1, const int64
     CN_HIP(pool.get(&d_bad, 4));
     CN_HIP(hipMalloc(&cn->d_cc, (size_t)rows * 8));
     CN_HIP(hipMalloc(&cn->d_q, (size_t)rows * 8));
+    CN_HIP(hipMalloc(&cn->d_p, (size_t)rows * 8));
     CN_HIP(hipMemcpyAsync(d_chr, chr, (size_t)rows * 4, hipMemcpyHostToDevice, cn->stream));
     CN_HIP(hipMemcpyAsync(d_n1, n1, (size_t)rows * 8, hipMemcpyHostToDevice, cn->stream));
     CN_HIP(hipMemcpyAsync(d_n2, n2, (size_t)rows * 8, hipMemcpyHostToDevice, cn->stream));
     CN_HIP(hipMemcpyAsync(cn->d_cc, cc, (size_t)rows * 8, hipMemcpyHostToDevice, cn->stream));
     CN_HIP(hipMemcpyAsync(cn->d_q, q, (size_t)rows * 8, hipMemcpyHostToDevice, cn->stream));
+    CN_HIP(hipMemcpyAsync(cn->d_p, p, (size_t)rows * 8, hipMemcpyHostToDevice, cn->stream));
     CN_HIP(hipMemsetAsync(d_bad, 0, 16, cn->stream));
     hipLaunchKernelGGL(cnd::cn_keys, dim3(grid_of(rows)), dim3(cnd::THREADS), 0, cn->stream, rows, d_chr, d_n1, d_n2, bin_size, r, keys, d_bad);
     CN_HIP(hipGetLastError());
@@ -465,11 +571,12 @@ int fhx_cni_run(fhx_cni* cn, int32_t connectivity, int32_t top_percent, int32_t 
         return FHX_OK;
     }
     DevPool pool;
-    unsigned int *parent = nullptr, *order_a = nullptr, *order_b = nullptr, *perm = nullptr, *pos = nullptr, *d_seg = nullptr, *d_limit = nullptr;
+    unsigned int *parent = nullptr, *uf_parent = nullptr, *order_a = nullptr, *order_b = nullptr, *perm = nullptr, *pos = nullptr, *d_seg = nullptr, *d_limit = nullptr;
     unsigned long long *k_in = nullptr, *k_out = nullptr, *d_counter = nullptr;
     cnd::CompStats* st = nullptr;
     unsigned char* state = nullptr;
-    CN_HIP(pool.get(&parent, n));
+    CN_HIP(pool.get(&parent, n));                         // root of every node, after cn_flatten
+    CN_HIP(pool.get(&uf_parent, n));
     CN_HIP(pool.get(&st, n));
     CN_HIP(pool.get(&order_a, n));
     CN_HIP(pool.get(&order_b, n));
@@ -479,13 +586,13 @@ int fhx_cni_run(fhx_cni* cn, int32_t connectivity, int32_t top_percent, int32_t 
     CN_HIP(pool.get(&d_limit, n));
     CN_HIP(pool.get(&k_in, n));
     CN_HIP(pool.get(&k_out, n));
-    CN_HIP(pool.get(&d_counter, 2));
+    CN_HIP(pool.get(&d_counter, 4));
     CN_HIP(pool.get(&state, n));
     const dim3 g(grid_of(n)), b(cnd::THREADS);
     // components
-    hipLaunchKernelGGL(cnd::cn_init_stats, g, b, 0, cn->stream, st, parent, n);
-    hipLaunchKernelGGL(cnd::cn_union, g, b, 0, cn->stream, cn->d_node_key, n, (int)connectivity, parent);
-    hipLaunchKernelGGL(cnd::cn_flatten, g, b, 0, cn->stream, parent, n);
+    hipLaunchKernelGGL(cnd::cn_init_stats, g, b, 0, cn->stream, st, uf_parent, n);
+    hipLaunchKernelGGL(cnd::cn_union, g, b, 0, cn->stream, cn->d_node_key, n, (int)connectivity, uf_parent);
+    hipLaunchKernelGGL(cnd::cn_flatten, g, b, 0, cn->stream, uf_parent, n, parent);
     hipLaunchKernelGGL(cnd::cn_stats, g, b, 0, cn->stream, cn->d_node_key, cn->d_node_row, parent, cn->d_cc, n, st);
     if (cn->lattice_r == 0)                               // integer cells only equal the float keys when bins are whole numbers
         hipLaunchKernelGGL(cnd::cn_box_count, dim3(grid_of(n * 64)), b, 0, cn->stream, cn->d_node_key, parent, n, st);
@@ -508,106 +615,64 @@ int fhx_cni_run(fhx_cni* cn, int32_t connectivity, int32_t top_percent, int32_t 
     hipLaunchKernelGGL(cnd::cn_compose, g, b, 0, cn->stream, order_b, perm, n, order_a);       // final order
     hipLaunchKernelGGL(cnd::cn_positions, g, b, 0, cn->stream, order_a, n, pos);
     CN_HIP(hipGetLastError());
-    // host bookkeeping over components
-    std::vector<unsigned int> h_root((size_t)n), h_order((size_t)n), h_row((size_t)n);
-    std::vector<unsigned long long> h_key((size_t)n);
-    std::vector<cnd::CompStats> h_st((size_t)n);
-    CN_HIP(hipMemcpyAsync(h_root.data(), parent, (size_t)n * 4, hipMemcpyDeviceToHost, cn->stream));
-    CN_HIP(hipMemcpyAsync(h_order.data(), order_a, (size_t)n * 4, hipMemcpyDeviceToHost, cn->stream));
-    CN_HIP(hipMemcpyAsync(h_row.data(), cn->d_node_row, (size_t)n * 4, hipMemcpyDeviceToHost, cn->stream));
-    CN_HIP(hipMemcpyAsync(h_key.data(), cn->d_node_key, (size_t)n * 8, hipMemcpyDeviceToHost, cn->stream));
-    CN_HIP(hipMemcpyAsync(h_st.data(), st, (size_t)n * sizeof(cnd::CompStats), hipMemcpyDeviceToHost, cn->stream));
-    CN_HIP(hipStreamSynchronize(cn->stream));
-    std::vector<unsigned int> roots;
-    for (int64_t u = 0; u < n; ++u)
-        if (h_root[(size_t)u] == (unsigned int)u) roots.push_back((unsigned int)u);
-    // segments of the final order are sorted by root index
-    std::vector<unsigned int> seg_start((size_t)n, 0), limit((size_t)n, 0);
-    {
-        unsigned int at = 0;
-        for (unsigned int r : roots) {
-            seg_start[r] = at;
-            at += h_st[r].size;
-        }
-    }
-    for (unsigned int r : roots) {
-        const unsigned int L = h_st[r].size, s0 = seg_start[r];
-        unsigned int lim = L;
-        if (top_percent < 100) {                          // custom_percent (:36-52) of the component's q list
-            const int64_t index = ((int64_t)L * top_percent) / 100;
-            const unsigned int at = index <= 1 ? L - 1 : (unsigned int)index;
-            const double bound = cn->h_q[h_row[h_order[s0 + at]]];
-            if (sort_order == 0) {                        // stop at the first q > bound (:508)
-                unsigned int lo = 0, hi = L;
-                while (lo < hi) {
-                    const unsigned int mid = (lo + hi) / 2;
-                    if (cn->h_q[h_row[h_order[s0 + mid]]] > bound) hi = mid;
-                    else lo = mid + 1;
-                }
-                lim = lo;
-            } else {                                      // -q < bound is tested on the first element; later ones have larger -q
-                const double first = -cn->h_q[h_row[h_order[s0]]];
-                lim = first < bound ? 0 : L;
-            }
-        }
-        limit[r] = lim;
-    }
-    CN_HIP(hipMemcpyAsync(d_seg, seg_start.data(), (size_t)n * 4, hipMemcpyHostToDevice, cn->stream));
-    CN_HIP(hipMemcpyAsync(d_limit, limit.data(), (size_t)n * 4, hipMemcpyHostToDevice, cn->stream));
+    // segments, candidate limits
+    CN_HIP(hipMemsetAsync(d_counter, 0, 4 * 8, cn->stream));
+    hipLaunchKernelGGL(cnd::cn_seg_starts, g, b, 0, cn->stream, order_a, parent, n, d_seg, d_counter + 0);
+    hipLaunchKernelGGL(cnd::cn_limits, g, b, 0, cn->stream, parent, order_a, cn->d_node_row, cn->d_q, st, d_seg, n, (int)top_percent,
+                       (int)sort_order, d_limit, d_counter + 1);
     hipLaunchKernelGGL(cnd::cn_pick_init, g, b, 0, cn->stream, parent, pos, d_seg, d_limit, n, state);
+    CN_HIP(hipGetLastError());
     int rounds = 0;
     while (true) {
-        CN_HIP(hipMemsetAsync(d_counter, 0, 8, cn->stream));
-        hipLaunchKernelGGL(cnd::cn_pick_round, g, b, 0, cn->stream, cn->d_node_key, parent, pos, n, (int)neighborhood, state, d_counter);
+        CN_HIP(hipMemsetAsync(d_counter + 2, 0, 8, cn->stream));
+        hipLaunchKernelGGL(cnd::cn_pick_round, g, b, 0, cn->stream, cn->d_node_key, parent, pos, n, (int)neighborhood, state, d_counter + 2);
         unsigned long long left = 0;
-        CN_HIP(hipMemcpyAsync(&left, d_counter, 8, hipMemcpyDeviceToHost, cn->stream));
+        CN_HIP(hipMemcpyAsync(&left, d_counter + 2, 8, hipMemcpyDeviceToHost, cn->stream));
         CN_HIP(hipStreamSynchronize(cn->stream));
         ++rounds;
         if (left == 0) break;
         if (rounds > 1000000) return cfail(cn, FHX_ERR_HIP, "pick rounds do not converge");
     }
+    // output order of the components: first row, then (chromosome, size descending) - two stable sorts over the roots
+    hipLaunchKernelGGL(cnd::cn_key_first_row, g, b, 0, cn->stream, parent, st, n, k_in);
+    CN_HIP(hipStreamSynchronize(cn->stream));
+    rc = fhx_sort_u64(cn->sorter, k_in, n, k_out, perm);
+    if (rc != FHX_OK) return cfail(cn, rc, std::string("sort: ") + fhx_last_error(cn->sorter));
+    hipLaunchKernelGGL(cnd::cn_compose, g, b, 0, cn->stream, (const unsigned int*)nullptr, perm, n, order_b);
+    hipLaunchKernelGGL(cnd::cn_key_chr_size, g, b, 0, cn->stream, order_b, cn->d_node_key, parent, st, n, k_in);
+    CN_HIP(hipStreamSynchronize(cn->stream));
+    rc = fhx_sort_u64(cn->sorter, k_in, n, k_out, perm);
+    if (rc != FHX_OK) return cfail(cn, rc, std::string("sort: ") + fhx_last_error(cn->sorter));
+    unsigned long long h_counts[3] = {0, 0, 0};
+    CN_HIP(hipMemcpy(h_counts, d_counter, 16, hipMemcpyDeviceToHost));
+    const int64_t n_comp = (int64_t)h_counts[0];
+    unsigned int* comps_sorted = d_limit;                 // limits are no longer needed
+    hipLaunchKernelGGL(cnd::cn_compose, g, b, 0, cn->stream, order_b, perm, n, comps_sorted);
+    unsigned int* comp_rank = d_seg;                      // nor are the segment starts
+    hipLaunchKernelGGL(cnd::cn_comp_ranks, dim3(grid_of(n_comp)), b, 0, cn->stream, comps_sorted, n_comp, comp_rank);
+    // picked nodes in output order
+    CN_HIP(hipMemsetAsync(d_counter + 3, 0, 8, cn->stream));
+    hipLaunchKernelGGL(cnd::cn_key_output, g, b, 0, cn->stream, state, parent, comp_rank, pos, n, k_in, d_counter + 3);
     CN_HIP(hipGetLastError());
-    std::vector<unsigned char> h_state((size_t)n);
-    CN_HIP(hipMemcpy(h_state.data(), state, (size_t)n, hipMemcpyDeviceToHost));
-    // output order: chromosome, then components by size (largest first, ties by first row), picks in rank order (:204-212, 354)
-    std::vector<unsigned int> comp_order(roots);
-    std::stable_sort(comp_order.begin(), comp_order.end(), [&](unsigned int a, unsigned int c) {
-        const unsigned int ca = (unsigned int)(h_key[a] >> (2 * cnd::BIN_BITS)), cb = (unsigned int)(h_key[c] >> (2 * cnd::BIN_BITS));
-        if (ca != cb) return ca < cb;
-        if (h_st[a].size != h_st[c].size) return h_st[a].size > h_st[c].size;
-        return h_st[a].first_row < h_st[c].first_row;
-    });
-    const int64_t res = cn->res, r0 = cn->lattice_r;
-    for (unsigned int r : comp_order) {
-        const cnd::CompStats& s = h_st[r];
-        for (unsigned int t = seg_start[r]; t < seg_start[r] + s.size; ++t) {
-            const unsigned int u = h_order[t];
-            if (h_state[u] != 1) continue;
-            const unsigned long long key = h_key[u];
-            const unsigned int row = h_row[u];
-            fhx_cni_record rec{};
-            rec.chr = (int32_t)(key >> (2 * cnd::BIN_BITS));
-            rec.n_lo = (int64_t)((key >> cnd::BIN_BITS) & cnd::BIN_MASK) * res + r0;
-            rec.n_hi = (int64_t)(key & cnd::BIN_MASK) * res + r0;
-            rec.cc = cn->h_cc[row];
-            rec.p = cn->h_p[row];
-            rec.q = cn->h_q[row];
-            rec.box_min_lo = (int64_t)s.min_lo * res + r0;
-            rec.box_max_lo = (int64_t)s.max_lo * res + r0;
-            rec.box_min_hi = (int64_t)s.min_hi * res + r0;
-            rec.box_max_hi = (int64_t)s.max_hi * res + r0;
-            rec.sum_cc = s.sum_cc;
-            rec.box_cells = (int64_t)s.have;
-            rec.component_size = (int64_t)s.size;
-            rec.first_row = (int64_t)row;
-            cn->out.push_back(rec);
-        }
+    unsigned long long n_sel = 0;
+    CN_HIP(hipMemcpyAsync(&n_sel, d_counter + 3, 8, hipMemcpyDeviceToHost, cn->stream));
+    CN_HIP(hipStreamSynchronize(cn->stream));
+    rc = fhx_sort_u64(cn->sorter, k_in, n, k_out, perm);
+    if (rc != FHX_OK) return cfail(cn, rc, std::string("sort: ") + fhx_last_error(cn->sorter));
+    cn->out.resize((size_t)n_sel);
+    if (n_sel) {
+        fhx_cni_record* d_rec = nullptr;
+        CN_HIP(pool.get(&d_rec, (size_t)n_sel));
+        hipLaunchKernelGGL(cnd::cn_records, dim3(grid_of((int64_t)n_sel)), b, 0, cn->stream, perm, (int64_t)n_sel, cn->d_node_key,
+                           cn->d_node_row, parent, st, cn->d_cc, cn->d_p, cn->d_q, cn->res, cn->lattice_r, d_rec);
+        CN_HIP(hipGetLastError());
+        CN_HIP(hipMemcpyAsync(cn->out.data(), d_rec, (size_t)n_sel * sizeof(fhx_cni_record), hipMemcpyDeviceToHost, cn->stream));
+        CN_HIP(hipStreamSynchronize(cn->stream));
     }
-    info.components = (int64_t)roots.size();
-    info.selected = (int64_t)cn->out.size();
+    info.components = n_comp;
+    info.selected = (int64_t)n_sel;
     info.pick_rounds = rounds;
-    info.largest_component = 0;
-    for (unsigned int r : roots) info.largest_component = std::max<int64_t>(info.largest_component, h_st[r].size);
+    info.largest_component = (int64_t)h_counts[1];
     cn->info = info;
     if (info_out) *info_out = info;
     return FHX_OK;

@@ -33,7 +33,7 @@ def main(path):
     print("%-40s %7s %14s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
     other = 0.0
     for name, calls, total, avg, pct in rows:
-        if "fhx::" in name or "krd::" in name:
+        if "fhx::" in name or "krd::" in name or "cnd::" in name or "fhxscan::" in name:
             print("%-40s %7d %14.1f %12.1f %6.2f%%" % (short(name), calls, total, avg, pct))
         else:
             other += pct

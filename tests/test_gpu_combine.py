@@ -81,3 +81,21 @@ def test_half_bin_offsets_keep_float_bins(tmp_path):
     want = co.combine_lines(path, 1000)
     names, rec, info = combine.combine_records(combine.read_significances(path, 1), 1000)
     assert combine.format_lines(names, rec, 1000) == want and len(want) == 2 and want[0].endswith("\t0.0")
+
+
+def test_repeated_runs_are_identical():
+    """The union-find is lock-free: 12 runs over the same 3e5 cells must give the same records every time."""
+    from fithic_amd import _capi
+    rng = np.random.default_rng(21)
+    n = 400_000
+    b1 = rng.integers(0, 3000, n)
+    b2 = np.minimum(b1 + rng.geometric(0.03, n) - 1, 2999)
+    q = np.round(10 ** rng.uniform(-9, -2, n), 10)
+    cn = _capi.CniContext(0)
+    cn.load(rng.integers(0, 3, n), (b1 + 1) * 5000, (b2 + 1) * 5000, rng.integers(1, 99, n), q / 7, q, 5000)
+    first, info0 = cn.run(4, 100, 1, 0)
+    assert info0.largest_component > 200
+    for _ in range(11):
+        rec, info = cn.run(4, 100, 1, 0)
+        assert info.as_dict() == info0.as_dict() and rec.tobytes() == first.tobytes()
+    cn.close()
