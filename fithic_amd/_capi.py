@@ -156,6 +156,27 @@ def build(force=False):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so.7 (+ HSA, comgr) next to libtorch and can only
+    work with that copy; if the system copy (/opt/rocm, what this library is linked against, same soname) is loaded first, a
+    later `import torch` finds no device.  So when torch is installed, its copy is loaded first - without importing torch -
+    and this library binds to it; without torch the system runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if not os.path.exists(cand):
+        return None
+    try:
+        return ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except OSError:
+        return None
+
+
 def lib():
     """The loaded library; raises (loudly) when it has not been built - there is no fallback."""
     global _lib
@@ -163,6 +184,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libfithic_mi355x.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; "
                                "g.build()'` or fithic_amd._capi.build(); fithic_amd has no CPU fallback." % LIB_PATH)
+        _share_torch_hip_runtime()
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)        # AttributeError if the .so does not export a declared symbol

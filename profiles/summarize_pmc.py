@@ -49,7 +49,7 @@ def main(fetch_db, write_db):
     print("# traffic is known exactly: 12 B/row of 16-B/lane loads): FETCH_SIZE counts half of the bytes read -> hbm_read = 2*FETCH*1024.")
     print("%-44s %8s %16s %16s %18s %18s" % ("kernel", "launches", "FETCH_SIZE(sum)", "WRITE_SIZE(sum)", "read MB/launch", "write MB/launch"))
     for k in sorted(set(f) | set(w)):
-        if "fhx::" not in k:
+        if "fhx::" not in k and "krd::" not in k and "cnd::" not in k:
             continue
         fv = f.get(k, {}).get("FETCH_SIZE", (0, 0))
         wv = w.get(k, {}).get("WRITE_SIZE", (0, 0))
