@@ -54,6 +54,10 @@ def main():
     algo = 12.0 * nnz + 24.0 * n + 8.0 * (n + 1)        # value 8 + column 4 per cell; in/out/epilogue vectors; indptr
     # isolated SpMV (plain epilogue), many repeats
     _, spmv_iso = kr.spmv(np.ones(n), which=1, repeats=50)
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "kr_pmc_traffic.json")
+    if os.path.exists(tp):
+        traffic = json.load(open(tp))["hbm_bytes_per_algorithmic_byte"] * algo
     out = {
         "metric": "Knight-Ruiz balancing of the C3-synth 5 kb contact map (HiCKRy path)", "n_gpus": 1, "dtype": "f64",
         "config": {"workload": "C3-synth: %d chromosomes @%d bp, %d contact rows -> %d loci, %d stored cells (symmetric CSR)"
@@ -63,7 +67,7 @@ def main():
         "seconds": {"assemble_incl_h2d": t_asm, "remove_sparse": t_rem, "balance": t_bal},
         "bias_mean": float(np.mean(bias[bias > 0])),
         "roofline": {"bound": "hbm", "kernel": "kr_spmv", "achieved": algo / spmv / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": algo / spmv / 1e9 / HBM_PEAK_GBS, "traffic": None, "launch_seconds": spmv,
+                     "frac": algo / spmv / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "launch_seconds": spmv,
                      "isolated_launch_seconds": spmv_iso, "isolated_frac": algo / spmv_iso / 1e9 / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_launch": algo,
                      "note": "12 B per stored cell (8 value + 4 column) + 32 B per row (indptr, gathered input, output, epilogue)"},
