@@ -91,8 +91,15 @@ def main():
     eng.load_contacts_device([t.data_ptr() for t in cols], n_local)
     sample_cols = None
     if rank == 0 and not args.no_cpu_baseline:
-        sample_chroms = [c for c in mine if genome.n_loci[c] <= 13000][-4:] or mine[-1:]
-        sample_cols = [[p[k].cpu().numpy() for k in range(5)] for c, p in zip(mine, parts) if c in sample_chroms]
+        # bounded sample for the CPU oracle: whole chromosomes, smallest first, up to ~3e7 rows (10-15 s of one core)
+        by_size = sorted(range(len(mine)), key=lambda j: parts[j][0].numel())
+        sample_idx, rows = [], 0
+        for j in by_size:
+            if sample_idx and rows + parts[j][0].numel() > 3.0e7:
+                break
+            sample_idx.append(j)
+            rows += parts[j][0].numel()
+        sample_cols = [[parts[j][k].cpu().numpy() for k in range(5)] for j in sorted(sample_idx)]
     del parts, cols
     torch.cuda.empty_cache()
 
