@@ -2066,7 +2066,7 @@ int fhx_set_global_stats(fhx_ctx* ctx, const fhx_stats* g, const int64_t* hist_s
                          int64_t n_dist) {
     if (!ctx || !g || !hist_sumcc || !hist_npairs || n_dist <= 0) return FHX_ERR_ARG;
     if (ctx->nonfixed && ctx->h_dist_keys.size() != (size_t)n_dist)
-        return fail(ctx, FHX_ERR_UNSUPPORTED, "-r 0: call fhx_set_dist_keys with the distinct distances first (sharded runs are fixed-size only)");
+        return fail(ctx, FHX_ERR_UNSUPPORTED, "-r 0: call fhx_set_dist_keys with the distinct distances first (their number must match the histograms)");
     const int64_t rows = ctx->n_rows;
     ctx->stats = *g;
     ctx->stats.n_rows = rows > 0 ? rows : g->n_rows;

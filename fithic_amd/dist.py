@@ -55,6 +55,20 @@ class Comm:
         self._done()
         return [o.to(self.compute_device) for o in out]
 
+    def all_gather_v_i64(self, arr):
+        """Variable-length all-gather of int64 host arrays -> list of numpy arrays, one per rank."""
+        arr = np.ascontiguousarray(arr, np.int64)
+        sizes = self.all_reduce_i64(np.eye(self.world, dtype=np.int64)[self.rank] * len(arr))
+        width = int(sizes.max()) if self.world else 0
+        if width == 0:
+            return [np.zeros(0, np.int64) for _ in range(self.world)]
+        pad = np.zeros(width, np.int64)
+        pad[:len(arr)] = arr
+        t = self.torch.as_tensor(pad).to(self.device)
+        out = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.td.all_gather(out, t)
+        return [o.cpu().numpy()[:int(n)] for o, n in zip(out, sizes)]
+
     def all_gather_f64_scalar(self, v):
         t = self.torch.tensor([float(v)], dtype=self.torch.float64, device=self.device)
         out = [self.torch.empty_like(t) for _ in range(self.world)]
@@ -98,6 +112,18 @@ class LocalOps:
         st = self.ctx.pass_stats()
         return st, self.ctx.get_array(_capi.A_HIST_SUMCC), self.ctx.get_array(_capi.A_HIST_NPAIRS)
 
+    @property
+    def nonfixed(self):
+        return getattr(self.eng, "resolution", 1) == 0
+
+    def local_dist_keys(self):
+        """-r 0: the distinct in-range distances of this rank's rows (its histograms are aligned to them)."""
+        from . import _capi
+        return self.ctx.get_array(_capi.A_DIST_KEYS)
+
+    def set_dist_keys(self, keys):
+        self.ctx.set_dist_keys(keys)
+
     def set_global_and_fit(self, st, hist_cc, hist_np):
         self.ctx.set_global_stats(st, hist_cc, hist_np)
         return self.ctx.fit()
@@ -137,7 +163,20 @@ class LocalOps:
     def next_pass_local(self):
         from . import _capi
         n = self.ctx.next_pass()
+        if self.nonfixed:
+            # the context's list = what was set last (the genome-wide list of the previous pass) + this rank's fresh ones
+            after = self.ctx.get_array(_capi.A_OUTLIER_DISTS)
+            fresh = _multiset_minus(after, self._outlier_global)
+            self._outlier_local = np.sort(np.concatenate([self._outlier_local, fresh]))
+            return n, self._outlier_local
         return n, self.ctx.get_array(_capi.A_OUTLIER_DIST_HIST)
+
+    _outlier_global = np.zeros(0, np.int64)
+    _outlier_local = np.zeros(0, np.int64)
+
+    def set_outlier_dists(self, dists):
+        self._outlier_global = np.sort(np.asarray(dists, np.int64))
+        self.ctx.set_outlier_dists(self._outlier_global)
 
     def set_outlier_hist(self, hist):
         self.ctx.set_outlier_dist_hist(hist)
@@ -147,6 +186,29 @@ class LocalOps:
 
     def set_skip_limit(self, limit):
         self.ctx.set_skip_limit(limit)
+
+
+def _multiset_minus(a, b):
+    """Sorted int64 multiset a minus multiset b (b is contained in a)."""
+    a, b = np.asarray(a, np.int64), np.asarray(b, np.int64)
+    if len(b) == 0:
+        return a.copy()
+    va, ca = np.unique(a, return_counts=True)
+    vb, cb = np.unique(b, return_counts=True)
+    ca = ca.copy()
+    ca[np.searchsorted(va, vb)] -= cb
+    return np.repeat(va, ca)
+
+
+def merge_keyed_histograms(keys_per_rank, cc_per_rank, np_per_rank):
+    """-r 0: union of the ranks' distinct distances and the sums of their histograms on it."""
+    keys = np.unique(np.concatenate(keys_per_rank)) if keys_per_rank else np.zeros(0, np.int64)
+    cc, npairs = np.zeros(len(keys), np.int64), np.zeros(len(keys), np.int64)
+    for k, c, m in zip(keys_per_rank, cc_per_rank, np_per_rank):
+        at = np.searchsorted(keys, k)
+        np.add.at(cc, at, c[:len(k)])
+        np.add.at(npairs, at, m[:len(k)])
+    return keys, cc, npairs
 
 
 def choose_splitters(torch, samples_sorted, world):
@@ -215,6 +277,8 @@ class DistributedPass:
     def run(self):
         comm, ops = self.comm, self.ops
         st, hist_cc, hist_np = ops.local_stats()
+        if getattr(ops, "nonfixed", False):
+            return self._run_nonfixed(st, hist_cc, hist_np)
         if self.n_dist_global is None:
             self.n_dist_global = int(comm.all_reduce_i64(np.array([len(hist_cc)]), op="max")[0])
         nd = self.n_dist_global
@@ -234,9 +298,39 @@ class DistributedPass:
         self.info, self.stats = info, st
         return info
 
+    def _run_nonfixed(self, st, hist_cc, hist_np):
+        """-r 0: the histogram is keyed by the distinct distances, which differ between ranks: gather keys and values
+        (a few thousand int64 per rank), merge on every host, then the same fit / K2 / distributed BH as fixed-size runs."""
+        comm, ops = self.comm, self.ops
+        keys = ops.local_dist_keys()
+        k_all = comm.all_gather_v_i64(keys)
+        cc_all = comm.all_gather_v_i64(np.asarray(hist_cc, np.int64)[:len(keys)])
+        np_all = comm.all_gather_v_i64(np.asarray(hist_np, np.int64)[:len(keys)])
+        gkeys, gcc, gnp = merge_keyed_histograms(k_all, cc_all, np_all)
+        pack = comm.all_reduce_i64(np.array([st.inter_count, st.inter_sum, st.intra_all_count, st.intra_all_sum, st.in_range_count,
+                                             st.in_range_sum, st.n_skipped], np.int64))
+        max_count = int(comm.all_reduce_i64(np.array([st.max_count]), op="max")[0])
+        (st.inter_count, st.inter_sum, st.intra_all_count, st.intra_all_sum, st.in_range_count, st.in_range_sum,
+         st.n_skipped) = [int(v) for v in pack]
+        st.max_count = max_count
+        if len(gkeys) == 0:                                # no in-range row anywhere: keep one key so that the C ABI accepts it
+            gkeys, gcc, gnp = np.zeros(1, np.int64), np.zeros(1, np.int64), np.zeros(1, np.int64)
+        ops.set_dist_keys(gkeys)
+        info = ops.set_global_and_fit(st, gcc, gnp)
+        ops.pvalues()
+        distributed_bh(comm, ops, info.bh_total_tests)
+        self.info, self.stats = info, st
+        return info
+
     def next_pass(self):
         """Fold outliers locally, then make the outlier-distance multiset genome-wide."""
         n_local, hist = self.ops.next_pass_local()
+        if getattr(self.ops, "nonfixed", False):           # `hist` is this rank's cumulative list of outlier distances
+            merged = np.sort(np.concatenate(self.comm.all_gather_v_i64(hist)))
+            self.ops.set_outlier_dists(merged)
+            limit = -int(self.comm.all_reduce_i64(np.array([-min(self.ops.get_skip_limit(), (1 << 62))]), op="max")[0])
+            self.ops.set_skip_limit(limit if limit < (1 << 62) else (1 << 63) - 1)
+            return self.comm.sum_int(n_local)
         nd = max(self.n_dist_global or 0, int(self.comm.all_reduce_i64(np.array([len(hist)]), op="max")[0]))
         buf = np.zeros(nd, np.int64)
         buf[:len(hist)] = hist

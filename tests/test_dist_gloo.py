@@ -64,8 +64,33 @@ def _worker(rank, world, port, case, passes, result_dir):
             self.out_hist = None
             self.n_out = 0
 
+        nonfixed = res == 0
+        out_list = None
+        out_list_local = np.zeros(0, np.int64)
+
+        def local_dist_keys(self):
+            return self._keys
+
+        def set_dist_keys(self, keys):
+            host.set_dist_keys(keys)
+
+        def set_outlier_dists(self, dists):
+            self.out_list = np.asarray(dists, np.int64)
+
         def local_stats(self):
             keys, sumcc, icnt, isum, intra_all, rng_sum = fo.read_interactions(local, kw["L"], kw["U"], self.skip if self.pass_idx else None)
+            if res == 0:                                    # -r 0: histograms aligned to this rank's distinct distances
+                d = np.abs(local.mid1 - local.mid2)
+                keep = ~self.skip if self.pass_idx else np.ones(len(local), bool)
+                m = keep & (local.chr1 == local.chr2) & (d >= kw["L"]) & (d <= kw["U"])
+                self._keys = np.asarray(keys, np.int64)
+                hnp = np.zeros(len(self._keys), np.int64)
+                np.add.at(hnp, np.searchsorted(self._keys, d[m]), 1)
+                st = _capi.FhxStats()
+                st.n_rows, st.inter_count, st.inter_sum, st.intra_all_sum, st.in_range_sum = len(local), icnt, isum, intra_all, rng_sum
+                st.in_range_count = int(m.sum())
+                st.max_count = int(local.count.max()) if len(local) else 0
+                return st, np.asarray(sumcc, np.int64), hnp
             n_dist = int(max(np.abs(local.mid1 - local.mid2).max() // res + 2, 2))
             hcc = np.zeros(n_dist, np.int64)
             hnp = np.zeros(n_dist, np.int64)
@@ -85,6 +110,8 @@ def _worker(rank, world, port, case, passes, result_dir):
             host.set_global_stats(st, hist_cc, hist_np)
             if self.out_hist is not None:
                 host.set_outlier_dist_hist(self.out_hist)
+            if self.out_list is not None:
+                host.set_outlier_dists(self.out_list)
             return host.fit()
 
         def pvalues(self):
@@ -140,6 +167,11 @@ def _worker(rank, world, port, case, passes, result_dir):
                 out = self.p < thr
             self.skip |= out
             d = np.abs(local.mid1 - local.mid2)[out]
+            if res == 0:
+                self.out_list_local = np.sort(np.concatenate([self.out_list_local, d.astype(np.int64)]))
+                self.n_out += int(out.sum())
+                self.pass_idx += 1
+                return self.n_out, self.out_list_local
             n_dist = int(max(np.abs(local.mid1 - local.mid2).max() // res + 2, 2))
             if self.out_hist_local is None:
                 self.out_hist_local = np.zeros(n_dist, np.int64)
@@ -187,7 +219,7 @@ def _worker(rank, world, port, case, passes, result_dir):
     td.destroy_process_group()
 
 
-@pytest.mark.parametrize("case,passes", [("f2_all", 2), ("f6_quirk_all", 2), ("f2_inter", 1)])
+@pytest.mark.parametrize("case,passes", [("f2_all", 2), ("f6_quirk_all", 2), ("f2_inter", 1), ("f8_nonfixed_all", 2)])
 def test_distributed_pass_world2_gloo(case, passes, tmp_path):
     torch = pytest.importorskip("torch")
     import torch.multiprocessing as mp

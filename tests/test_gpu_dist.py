@@ -79,7 +79,7 @@ def _worker(rank, world, port, case, passes, result_dir):
     td.destroy_process_group()
 
 
-@pytest.mark.parametrize("case,passes", [("f2_all", 2), ("f1_bias", 2), ("f6_quirk_all", 3)])
+@pytest.mark.parametrize("case,passes", [("f2_all", 2), ("f1_bias", 2), ("f6_quirk_all", 3), ("f8_nonfixed_all", 3), ("f8_nonfixed_hESC", 1)])
 def test_two_ranks_one_gpu_bit_identical_to_single_gpu(case, passes, tmp_path):
     torch = pytest.importorskip("torch")
     import torch.multiprocessing as mp
