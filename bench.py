@@ -45,6 +45,7 @@ def main():
                     help="0 = synth-v1 (Poisson around the model); s > 0 adds lognormal rate noise: heavier small-p tail, like real maps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-chroms", type=int, default=0, help="debug: use only the first k chromosomes")
+    ap.add_argument("--replicas", type=int, default=0, help="debug: replicate the genome R times per run regardless of --gpus (size test)")
     args = ap.parse_args()
 
     import numpy as np
@@ -71,7 +72,7 @@ def main():
     L, U = 4 * res, 400 * res
     lo_idx, hi_idx = 4, 400
     lengths = synth.HG19_AUTOSOMES[:args.max_chroms] if args.max_chroms else None
-    replicas = 1 if (args.strong or world == 1) else world
+    replicas = args.replicas if args.replicas > 0 else (1 if (args.strong or world == 1) else world)
     genome = synth.Genome(res, lengths, replicas=replicas)
     amp = synth.solve_amplitude(args.keep, lo_idx, hi_idx)
     owner = synth.assign_chromosomes(genome, world)
