@@ -48,6 +48,12 @@ def main():
     ap.add_argument("--replicas", type=int, default=0, help="debug: replicate the genome R times per run regardless of --gpus (size test)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON): libraries that print banners there (RCCL prints its version block to
+    # stdout when the first communicator is created) are diverted to stderr for the whole run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     from fithic_amd import synth, dist
@@ -118,6 +124,8 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
+    if runner:
+        runner.timings.clear()
     kt = np.zeros(3)
     heavy = np.zeros(2)                                # seconds, rows of the dominant launch (k2_queue<swapped CF>)
     barrier()
@@ -135,6 +143,9 @@ def main():
         n_total = comm.sum_int(n_local)
     else:
         n_total = n_local
+    if runner and rank == 0:
+        log("[rank 0] host wall per pass of the distributed stages (ms): " +
+            ", ".join("%s %.2f" % (k, 1e3 * v / max(args.steps, 1)) for k, v in runner.timings.items()))
     kt /= max(args.steps, 1)
     heavy /= max(args.steps, 1)
     mine_row = list(kt) + [float(n_local)] + list(heavy)
@@ -182,7 +193,8 @@ def main():
     if comm:
         comm.barrier()
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     eng.close()
     if comm:
         import torch.distributed as td

@@ -220,13 +220,24 @@ def choose_splitters(torch, samples_sorted, world):
     return samples_sorted[torch.tensor(pos, dtype=torch.int64, device=samples_sorted.device)]
 
 
-def distributed_bh(comm, ops, n_tests):
+def distributed_bh(comm, ops, n_tests, timings=None):
     """Global BH over the p-values of all ranks; leaves q in row order on every rank."""
+    import time
     torch = comm.torch
+    t_last = [time.perf_counter()]
+
+    def lap(name):
+        if timings is not None:
+            now = time.perf_counter()
+            timings[name] = timings.get(name, 0.0) + (now - t_last[0])
+            t_last[0] = now
+
     # exact early cutoff: rows whose q is provably 1 are neither sorted nor exchanged (needs the GLOBAL key histogram)
     ops.set_cutoff(comm.all_reduce_i64(ops.top_hist()), n_tests)
+    lap("bh_cutoff")
     keys = ops.local_sorted_keys()
     n = keys.numel()
+    lap("bh_local_sort")
     # regular samples -> common splitters
     s = SAMPLES_PER_RANK
     if n:
@@ -244,7 +255,9 @@ def distributed_bh(comm, ops, n_tests):
         cuts = [n] * (comm.world - 1)
     bounds = [0] + [int(c) for c in cuts] + [n]
     send_counts = [bounds[r + 1] - bounds[r] for r in range(comm.world)]
+    lap("bh_splitters")
     recv, recv_counts = comm.all_to_all_v(keys, send_counts)
+    lap("bh_exchange_keys")
     # my slice of the global order: sort the received runs, remember where each element came from
     mine_sorted, perm = ops.sort_keys(recv)
     m = mine_sorted.numel()
@@ -254,6 +267,7 @@ def distributed_bh(comm, ops, n_tests):
     maxima = comm.all_gather_f64_scalar(seg_max)
     carry = max([0.0] + maxima[:comm.rank])
     q_sorted, _ = ops.bh_segment(mine_sorted, rank0, carry, n_tests, want_q=True)
+    lap("bh_slice")
     # back to arrival order, then back to the owners (reverse all-to-all), then to row order
     q_arrival = torch.empty_like(q_sorted)
     if m:
@@ -261,6 +275,7 @@ def distributed_bh(comm, ops, n_tests):
     q_back, back_counts = comm.all_to_all_v(q_arrival, recv_counts)
     assert back_counts == send_counts
     ops.scatter_q(q_back)
+    lap("bh_return")
     return n, m
 
 
@@ -273,10 +288,14 @@ class DistributedPass:
         self.n_dist_global = None
         self.info = None
         self.stats = None
+        self.timings = {}                # host wall seconds per stage, summed over the passes run so far
 
     def run(self):
+        import time
         comm, ops = self.comm, self.ops
+        t0 = time.perf_counter()
         st, hist_cc, hist_np = ops.local_stats()
+        self.timings["k1"] = self.timings.get("k1", 0.0) + time.perf_counter() - t0
         if getattr(ops, "nonfixed", False):
             return self._run_nonfixed(st, hist_cc, hist_np)
         if self.n_dist_global is None:
@@ -292,9 +311,14 @@ class DistributedPass:
         (st.inter_count, st.inter_sum, st.intra_all_count, st.intra_all_sum, st.in_range_count, st.in_range_sum,
          st.n_skipped) = [int(v) for v in pack[:7]]
         st.max_count = max_count
+        t1 = time.perf_counter()
         info = ops.set_global_and_fit(st, pack[8:8 + nd], pack[8 + nd:8 + 2 * nd])
+        t2 = time.perf_counter()
         ops.pvalues()
-        distributed_bh(comm, ops, info.bh_total_tests)
+        t3 = time.perf_counter()
+        distributed_bh(comm, ops, info.bh_total_tests, self.timings)
+        for name, dt in (("allreduce_stats", t1 - t0 - 0.0), ("fit", t2 - t1), ("k2_launch", t3 - t2)):
+            self.timings[name] = self.timings.get(name, 0.0) + dt
         self.info, self.stats = info, st
         return info
 
