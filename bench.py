@@ -45,6 +45,9 @@ def main():
                     help="0 = synth-v1 (Poisson around the model); s > 0 adds lognormal rate noise: heavier small-p tail, like real maps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-chroms", type=int, default=0, help="debug: use only the first k chromosomes")
+    ap.add_argument("--path", choices=["fithic", "kr", "cni"], default="fithic",
+                    help="fithic (default): the headline pass.  kr / cni: the neighbouring steps (Knight-Ruiz bias vectors, merging of "
+                         "nearby contacts) measured by profiles/kr_bench.py / profiles/cni_bench.py, plus their cpu_baseline")
     ap.add_argument("--replicas", type=int, default=0, help="debug: replicate the genome R times per run regardless of --gpus (size test)")
     args = ap.parse_args()
 
@@ -53,6 +56,22 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+
+    if args.path != "fithic":
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        if args.path == "kr":
+            import kr_bench
+            out, genome, cols = kr_bench.measure(args.max_chroms)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline_kr(genome, cols, 0.05)
+        else:
+            import cni_bench
+            out, table = cni_bench.measure()
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline_cni(*table)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        return
 
     import numpy as np
     import torch
@@ -225,6 +244,50 @@ def cpu_baseline(genome, sample_cols, res, L, U):
     return {"value": len(pairs) / dt, "unit": "contact-pairs/s", "cores": 1, "kind": "port",
             "sample": "%d rows of %s (same synthetic rows, own genome-wide fit on the sample), %.1f s" %
                       (len(pairs), ",".join(names[c] for c in chr_ids), dt)}
+
+
+def cpu_baseline_kr(genome, cols, perc):
+    """Knight-Ruiz oracle (numpy + plain-C SpMV, 1 thread) on the rows of the four smallest chromosomes."""
+    import numpy as np
+    from oracle import hickry_oracle as ho
+    small = np.argsort(np.array(genome.n_loci))[:4]
+    sel = np.isin(cols[0], small)
+    offs, n = {}, 0
+    for c in sorted(small.tolist()):
+        offs[c] = n
+        n += int(genome.n_loci[c])
+    res = genome.res
+    base = np.vectorize(offs.get)(cols[0][sel]).astype(np.int64)
+    x = base + (cols[1][sel].astype(np.int64) - res // 2) // res
+    y = base + (cols[3][sel].astype(np.int64) - res // 2) // res
+    z = cols[4][sel].astype(np.float64)
+    ho.build()
+    t0 = time.perf_counter()
+    A = ho.assemble(x, y, z, n)
+    removed, _, _ = ho.sparse_rows(A, perc)
+    R = ho.drop(A, removed)
+    xv, i, k = ho.knight_ruiz(R)
+    dt = time.perf_counter() - t0
+    return {"value": dt, "unit": "s (assemble + remove + balance)", "cores": 1, "kind": "port",
+            "sample": "%d rows of the 4 smallest chromosomes -> %d loci, %d cells, %d outer iterations" % (int(sel.sum()), n, A.nnz, i)}
+
+
+def cpu_baseline_cni(c, n1, n2, cc, p, q, res):
+    """CombineNearbyInteraction oracle (pure Python, 1 thread) on the first 2e5 rows, text parse included."""
+    import tempfile
+    from oracle import combine_oracle as co
+    k = min(200_000, len(c))
+    path = os.path.join(tempfile.mkdtemp(), "s.txt")
+    with open(path, "w") as f:
+        f.write("h\n")
+        for i in range(k):
+            f.write("chr%d\t%d\tchr%d\t%d\t%d\t%e\t%e\n" % (c[i], n1[i] - res // 2, c[i], n2[i] - res // 2, cc[i], p[i], q[i]))
+    t0 = time.perf_counter()
+    lines = co.combine_lines(path, res)
+    dt = time.perf_counter() - t0
+    return {"value": k / dt, "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": "the first %d rows (text parse included), %d lines out, %.1f s; the reference itself pairs all nodes of a "
+                      "chromosome in Python (O(n^2))" % (k, len(lines), dt)}
 
 
 if __name__ == "__main__":

@@ -2,7 +2,8 @@
 """Measurement of the nearby-contact merging (fhx_cni_*): a synthetic table of significant 5 kb cells
 (clustered along the diagonal band of 22 chromosomes), arrays handed to the C ABI directly.  One JSON line on stdout.
 
-    python profiles/cni_bench.py [--rows 5000000] [--no-cpu-baseline]
+    python profiles/cni_bench.py [--rows 5000000]          (GPU numbers only)
+    python bench.py --path cni                              (the same + cpu_baseline)
 """
 import argparse
 import gzip
@@ -26,16 +27,13 @@ def table(rng, n_rows, n_chr, span, res):
     return c, (b1 + 1) * res, (b2 + 1) * res, cc, q / 10, q
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--rows", type=int, default=5_000_000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def measure(rows=5_000_000):
+    """-> (result dict, table arrays); the CPU baseline is bench.py's business (oracle/ is imported there only)."""
     import numpy as np
     from fithic_amd import _capi
     rng = np.random.default_rng(7)
     res = 5000
-    c, n1, n2, cc, p, q = table(rng, args.rows, 22, 30000, res)
+    c, n1, n2, cc, p, q = table(rng, rows, 22, 30000, res)
     cn = _capi.CniContext(0)
     cn.load(c[:1000], n1[:1000], n2[:1000], cc[:1000], p[:1000], q[:1000], res)      # warm-up
     cn.run()
@@ -47,24 +45,17 @@ def main():
     t_run = time.perf_counter() - t0
     cn.close()
     out = {"metric": "nearby-contact merging (CombineNearbyInteraction path)", "n_gpus": 1, "dtype": "u64 keys / i64 / f64 compare",
-           "config": {"workload": "%d significant rows on 22 chromosomes at 5 kb -> %d cells, -c 8 -p 100 -n 2" % (args.rows, nodes)},
+           "config": {"workload": "%d significant rows on 22 chromosomes at 5 kb -> %d cells, -c 8 -p 100 -n 2" % (rows, nodes)},
            "info": info.as_dict(), "seconds": {"load_incl_h2d_sort": t_load, "run": t_run},
            "value": nodes / (t_load + t_run), "unit": "cells/s"}
-    if not args.no_cpu_baseline:
-        from oracle import combine_oracle as co
-        k = 200_000
-        tmp = tempfile.mkdtemp()
-        path = os.path.join(tmp, "s.txt")
-        with open(path, "w") as f:
-            f.write("h\n")
-            for i in range(k):
-                f.write("chr%d\t%d\tchr%d\t%d\t%d\t%e\t%e\n" % (c[i], n1[i] - res // 2, c[i], n2[i] - res // 2, cc[i], p[i], q[i]))
-        t0 = time.perf_counter()
-        lines = co.combine_lines(path, res)
-        dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": k / dt, "unit": "rows/s", "cores": 1, "kind": "port",
-                               "sample": "the first %d rows (text parse included), %d lines out, %.1f s; the reference itself pairs "
-                                         "all nodes of a chromosome in Python (O(n^2))" % (k, len(lines), dt)}
+    return out, (c, n1, n2, cc, p, q, res)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=5_000_000)
+    args = ap.parse_args()
+    out, _ = measure(args.rows)
     print(json.dumps(out), flush=True)
 
 

@@ -3,7 +3,8 @@
 5 kb, the same rows bench.py uses): assembly, row removal, balance; roofline of the dominant kernel kr_spmv from the
 HIP-event time of the SpMV launches inside fhx_kr_balance.  One JSON line on stdout.
 
-    python profiles/kr_bench.py [--max-chroms K] [--no-cpu-baseline]
+    python profiles/kr_bench.py [--max-chroms K]          (GPU numbers only)
+    python bench.py --path kr                              (the same + cpu_baseline)
 """
 import argparse
 import json
@@ -16,18 +17,14 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--max-chroms", type=int, default=0)
-    ap.add_argument("--perc", type=float, default=0.05)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def measure(max_chroms=0, perc=0.05):
+    """-> (result dict, genome, host columns); the CPU baseline is bench.py's business (oracle/ is imported there only)."""
     import numpy as np
     import torch
     from fithic_amd import synth, _capi
     res, lo_idx, hi_idx = 5000, 4, 400
     device = torch.device("cuda", 0)
-    lengths = synth.HG19_AUTOSOMES[:args.max_chroms] if args.max_chroms else None
+    lengths = synth.HG19_AUTOSOMES[:max_chroms] if max_chroms else None
     genome = synth.Genome(res, lengths)
     amp = synth.solve_amplitude(0.66, lo_idx, hi_idx)
     parts = [synth.cis_contacts(genome, c, lo_idx, hi_idx, amp, device=device) for c in range(len(genome))]
@@ -43,7 +40,7 @@ def main():
     t_asm = time.perf_counter() - t0
     n_full, nnz_full, _, _ = kr.shape()
     t0 = time.perf_counter()
-    removed, val, _ = kr.remove_sparse(args.perc)
+    removed, val, _ = kr.remove_sparse(perc)
     t_rem = time.perf_counter() - t0
     t0 = time.perf_counter()
     x, info = kr.balance(1e-6)
@@ -61,7 +58,7 @@ def main():
     out = {
         "metric": "Knight-Ruiz balancing of the C3-synth 5 kb contact map (HiCKRy path)", "n_gpus": 1, "dtype": "f64",
         "config": {"workload": "C3-synth: %d chromosomes @%d bp, %d contact rows -> %d loci, %d stored cells (symmetric CSR)"
-                               % (len(genome), res, m, n_full, nnz_full), "perc": args.perc},
+                               % (len(genome), res, m, n_full, nnz_full), "perc": perc},
         "removed_rows": int(len(removed)), "balanced": {"n": n, "nnz": nnz}, "outer_iterations": info.outer_iterations,
         "inner_iterations_last": info.inner_iterations, "matvecs": info.matvecs, "residual": info.residual,
         "seconds": {"assemble_incl_h2d": t_asm, "remove_sparse": t_rem, "balance": t_bal},
@@ -72,37 +69,17 @@ def main():
                      "algorithmic_bytes_per_launch": algo,
                      "note": "12 B per stored cell (8 value + 4 column) + 32 B per row (indptr, gathered input, output, epilogue)"},
     }
-    if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(genome, cols, args.perc)
     kr.close()
+    return out, genome, cols
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--max-chroms", type=int, default=0)
+    ap.add_argument("--perc", type=float, default=0.05)
+    args = ap.parse_args()
+    out, _, _ = measure(args.max_chroms, args.perc)
     print(json.dumps(out), flush=True)
-
-
-def cpu_baseline(genome, cols, perc):
-    """The oracle (numpy + plain-C SpMV, 1 thread) on the rows of the four smallest chromosomes."""
-    import numpy as np
-    from oracle import hickry_oracle as ho
-    small = np.argsort(np.array(genome.n_loci))[:4]
-    sel = np.isin(cols[0], small)
-    offs = {}
-    n = 0
-    for c in sorted(small.tolist()):
-        offs[c] = n
-        n += int(genome.n_loci[c])
-    res = genome.res
-    base = np.vectorize(offs.get)(cols[0][sel]).astype(np.int64)
-    x = base + (cols[1][sel].astype(np.int64) - res // 2) // res
-    y = base + (cols[3][sel].astype(np.int64) - res // 2) // res
-    z = cols[4][sel].astype(np.float64)
-    ho.build()
-    t0 = time.perf_counter()
-    A = ho.assemble(x, y, z, n)
-    removed, _, _ = ho.sparse_rows(A, perc)
-    R = ho.drop(A, removed)
-    xv, i, k = ho.knight_ruiz(R)
-    dt = time.perf_counter() - t0
-    return {"value": dt, "unit": "s (assemble + remove + balance)", "cores": 1, "kind": "port",
-            "sample": "%d rows of the 4 smallest chromosomes -> %d loci, %d cells, %d outer iterations" % (int(sel.sum()), n, A.nnz, i)}
 
 
 if __name__ == "__main__":
