@@ -121,7 +121,8 @@ __global__ __launch_bounds__(THREADS) void kr_spmv(int64_t n, const int64_t* __r
     const int64_t b = indptr[row], e = indptr[row + 1];
     double acc = 0.0;
     int64_t j = b + lane;
-    // measured on the C3 matrix: nontemporal loads of col/val -1.6 %; 8-cell unroll -10 %; predicated chunks no gain
+    // measured on the C3 matrix: nontemporal loads of col/val -1.6 %; 8-cell unroll -10 %; predicated chunks no gain;
+    // 2 / 4 / 8 / 16 consecutive rows per wave -5 / -10 / -15 / -20 % (fewer waves in flight)
 #define LD_COL(k) col[k]
 #define LD_VAL(k) val[k]
     for (; j + 192 < e; j += 256) {          // four independent loads in flight, adds stay in cell order
