@@ -9,9 +9,11 @@
     if count >= 1, 0.1 % of kept pairs multiplied by 4 ("loops"); rows in (chr, mid1, mid2) order
   * A is solved (bias-free expectation, bisection) so that the kept fraction hits the target pair count
 
-Small tables (fragments, bias) are numpy on the host.  The O(#pairs) contact rows are drawn with torch on whatever
-device is given (the GPU in bench.py: torch is plumbing here, the rows are handed to the engine as raw device
-pointers); every chromosome has its own seed, so a shard does not depend on how many ranks share the genome.
+Small tables (fragments, bias) are numpy on the host.  The O(#pairs) contact rows are computed with torch tensor
+arithmetic on whatever device is given (the GPU in bench.py: torch is plumbing here, the rows are handed to the engine as
+raw device pointers).  Randomness is counter-based as SURVEY.md 8d specifies - splitmix64(SEED ^ index), index unique per
+(chromosome, locus, delta) - so a row does not depend on the device, on chunking or on how many ranks share the genome;
+Poisson counts come from sequential CDF inversion of that uniform.
 """
 import math
 
@@ -66,6 +68,41 @@ class Genome:
         return ch, mid, np.concatenate([self.bias(c) for c in range(len(self))])
 
 
+def _splitmix64(torch, x):
+    """splitmix64 finaliser on int64 tensors (wrapping arithmetic; logical shifts emulated with masks)."""
+    def lsr(v, k):
+        return (v >> k) & ((1 << (64 - k)) - 1)
+    z = x + (-7046029254386353131)                         # 0x9E3779B97F4A7C15 as a signed 64-bit value
+    z = (z ^ lsr(z, 30)) * (-4658895280553007687)          # 0xBF58476D1CE4E5B9
+    z = (z ^ lsr(z, 27)) * (-7723592293110705685)          # 0x94D049BB133111EB
+    return z ^ lsr(z, 31)
+
+
+def _uniform(torch, index):
+    """u in [0, 1) from the counter: the top 53 bits of splitmix64(SEED ^ index)."""
+    z = _splitmix64(torch, index ^ SEED)
+    return ((z >> 11) & ((1 << 53) - 1)).to(torch.float64) * (1.0 / (1 << 53))
+
+
+def _poisson_inverse(torch, lam, u):
+    """Poisson(lam) by sequential CDF inversion of the uniform u (float64, vectorised; identical code on host and device)."""
+    lam = lam.to(torch.float64)
+    p = torch.exp(-lam)
+    cdf = p.clone()
+    k = torch.zeros(lam.shape, dtype=torch.int64, device=lam.device)
+    active = u >= cdf
+    steps = 0
+    while bool(active.any()):
+        k = k + active
+        p = torch.where(active, p * lam / k.clamp(min=1).to(torch.float64), p)
+        cdf = torch.where(active, cdf + p, cdf)
+        active = active & (u >= cdf)
+        steps += 1
+        if steps > 4000:
+            break
+    return k
+
+
 def solve_amplitude(keep_fraction, lo_idx, hi_idx):
     """A with mean_delta(1 - exp(-A delta^-1.08)) = keep_fraction over delta in [lo_idx, hi_idx] (delta >= 1)."""
     d = np.arange(max(lo_idx, 1), hi_idx + 1, dtype=np.float64) ** -1.08
@@ -92,32 +129,48 @@ def cis_contacts(genome, chrom, lo_idx, hi_idx, amplitude, device="cpu", max_win
     if hi < lo:
         z = torch.zeros(0, dtype=torch.int32, device=device)
         return z, z, z, z, z
-    gen = torch.Generator(device=device)
-    gen.manual_seed(SEED * 1000 + chrom)
+    gen = None
+    if overdispersion > 0:                                  # variant, not synth-v1: extra rate noise from torch's generator
+        gen = torch.Generator(device=device)
+        gen.manual_seed(SEED * 1000 + chrom)
     b = torch.from_numpy(genome.bias(chrom)).to(device)
-    delta = torch.arange(lo, hi + 1, device=device, dtype=torch.float64)
-    decay = amplitude * torch.where(delta > 0, delta, torch.ones_like(delta)) ** -1.08
     rows = []
-    step = max(1, (1 << 24) // (hi - lo + 1))               # ~16 M candidates per chunk
-    for i0 in range(0, n, step):
-        i1 = min(n, i0 + step)
-        i = torch.arange(i0, i1, device=device)
-        j = i[:, None] + torch.arange(lo, hi + 1, device=device)[None, :]
-        ok = j < n
-        jj = torch.where(ok, j, torch.zeros_like(j))
-        lam = (b[i][:, None] * b[jj]) * decay[None, :]
-        if overdispersion > 0:
-            z = torch.randn(lam.shape, device=device, generator=gen, dtype=torch.float32)
-            lam = lam * torch.exp(overdispersion * z - 0.5 * overdispersion * overdispersion).to(lam.dtype)
-        cnt = torch.poisson(lam.to(torch.float32), generator=gen).to(torch.int32)
-        boost = torch.rand(cnt.shape, device=device, generator=gen) < 0.001
-        cnt = torch.where(boost, cnt * 4, cnt)
-        keep = ok & (cnt >= 1)
-        ii = i[:, None].expand_as(j)[keep]
-        rows.append((ii.to(torch.int32), j[keep].to(torch.int32), cnt[keep]))
+    # delta bands: the Poisson inversion below runs as many steps as the largest rate of its band needs
+    bands, d0 = [], lo
+    for edge in (16, 64, hi + 1):
+        if d0 < min(edge, hi + 1):
+            bands.append((d0, min(edge, hi + 1)))
+            d0 = min(edge, hi + 1)
+    for (da, db) in bands:
+        width = db - da
+        delta = torch.arange(da, db, device=device, dtype=torch.float64)
+        decay = amplitude * torch.where(delta > 0, delta, torch.ones_like(delta)) ** -1.08
+        step = max(1, (1 << 23) // width)                   # ~8 M candidates per chunk
+        for i0 in range(0, n, step):
+            i1 = min(n, i0 + step)
+            i = torch.arange(i0, i1, device=device)
+            dd = torch.arange(da, db, device=device)
+            j = i[:, None] + dd[None, :]
+            ok = j < n
+            jj = torch.where(ok, j, torch.zeros_like(j))
+            lam = (b[i][:, None] * b[jj]) * decay[None, :]
+            if overdispersion > 0:
+                z = torch.randn(lam.shape, device=device, generator=gen, dtype=torch.float32)
+                lam = lam * torch.exp(overdispersion * z - 0.5 * overdispersion * overdispersion).to(lam.dtype)
+            # counter-based uniforms: splitmix64(seed ^ index), index unique per (chromosome, i, delta, stream)
+            index = ((chrom * (1 << 22) + i[:, None]) * (1 << 13) + dd[None, :]) * 2
+            cnt = _poisson_inverse(torch, lam, _uniform(torch, index))
+            boost = _uniform(torch, index + 1) < 0.001
+            cnt = torch.where(boost, cnt * 4, cnt)
+            keep = ok & (cnt >= 1)
+            ii = i[:, None].expand_as(j)[keep]
+            rows.append((ii.to(torch.int32), j[keep].to(torch.int32), cnt[keep].to(torch.int32)))
     i_all = torch.cat([r[0] for r in rows])
     j_all = torch.cat([r[1] for r in rows])
     c_all = torch.cat([r[2] for r in rows])
+    if len(bands) > 1:                                      # rows in (chr, mid1, mid2) order, as a sorted contact file has them
+        order = torch.argsort(i_all.to(torch.int64) * (1 << 32) + j_all.to(torch.int64))
+        i_all, j_all, c_all = i_all[order], j_all[order], c_all[order]
     res = genome.res
     mid1 = i_all * res + res // 2
     mid2 = j_all * res + res // 2
