@@ -58,9 +58,9 @@ def combine_records(df, bin_size, conn=8, pct=100, neigh=2, order=0):
     half = bin_size / 2
     n1 = np.trunc(sub[1].astype(np.float64).to_numpy() + half).astype(np.int64)      # int(float(mid) + bin_size/2)  (:301)
     n2 = np.trunc(sub[3].astype(np.float64).to_numpy() + half).astype(np.int64)
-    cc = np.array([int(v) for v in sub[4]], np.int64)            # int(text): ValueError on "12.0", like the reference (:312)
-    p = np.array([float(v) for v in sub[5]], np.float64)
-    q = np.array([float(v) for v in sub[6]], np.float64)
+    cc = sub[4].to_numpy().astype(np.int64)                      # int(text): ValueError on "12.0", like the reference (:312)
+    p = sub[5].to_numpy().astype(np.float64)                     # float(text), correctly rounded
+    q = sub[6].to_numpy().astype(np.float64)
     cn = _capi.CniContext(device)
     try:
         cn.load(chr_ids, n1, n2, cc, p, q, bin_size)

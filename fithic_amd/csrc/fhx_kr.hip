@@ -788,6 +788,14 @@ int fhx_kr_remove_sparse(fhx_kr* kr, double perc, int64_t* n_removed, double* va
     KR_HIP(hipSetDevice(kr->device));
     int32_t* d_new = nullptr;
     int64_t* d_cnt = nullptr;
+    struct Scratch {                                   // freed on every return path
+        int32_t*& a;
+        int64_t*& b;
+        ~Scratch() {
+            kfree(a);
+            kfree(b);
+        }
+    } scratch{d_new, d_cnt};
     KR_HIP(hipMalloc(&d_new, (size_t)n * 4));
     KR_HIP(hipMalloc(&d_cnt, (size_t)std::max<int64_t>(n2, 1) * 8));
     KR_HIP(hipMemcpyAsync(d_new, newidx.data(), (size_t)n * 4, hipMemcpyHostToDevice, kr->stream));
@@ -807,8 +815,6 @@ int fhx_kr_remove_sparse(fhx_kr* kr, double perc, int64_t* n_removed, double* va
                        kr->d_rptr, kr->d_rcol, kr->d_rval);
     KR_HIP(hipGetLastError());
     KR_HIP(hipStreamSynchronize(kr->stream));
-    kfree(d_new);
-    kfree(d_cnt);
     kr->reduced = true;
     kr->n = n2;
     kr->nnz = nnz2;
