@@ -374,26 +374,42 @@ __global__ __launch_bounds__(K2_THREADS) void k2_classify(K2Params P, K2Queues Q
                 if (row_prior(P, l1, l2, prior, is_inter)) {
                     const dev::BinomTables& T = is_inter ? P.inter : P.intra;
                     cls = dev::bdtrc_class(c, T.n, prior);
-                    if (cls == dev::BC_TRIVIAL) pv = dev::bdtrc_count(c, T, prior);
+                    if (cls == dev::BC_TRIVIAL) pv = dev::bdtrc_count_trivial(c, T, prior);
                     if (is_inter) c = -c;
                 }
                 if (cls == 0) P.p[i] = pv;
             }
-            unsigned int slot = 0;
-#pragma unroll
-            for (int k = 1; k <= K2_QUEUES; ++k) {
-                const unsigned long long m = __ballot(cls == k);
-                if (m) {
-                    unsigned int base = 0;
-                    if (lane == 0) base = atomicAdd(&cnt[k - 1], (unsigned int)__popcll(m));
-                    base = __shfl(base, 0, 64);
-                    if (cls == k) slot = base + __popcll(m & lane_lt);
-                }
-            }
             cls_of[r] = cls;
-            slot_of[r] = slot;
             count_of[r] = c;
             prior_of[r] = prior;
+        }
+        // slot reservation for the whole wave at once: 16 ballots (4 items x 4 classes), then ONE LDS atomic instruction
+        // (lane k reserves class k's total) and four broadcasts.  One atomic + shuffle per (item, class) made 16 dependent
+        // LDS round trips per wave and tile, which the 3 waves/SIMD of this kernel cannot hide.
+        unsigned int before_cls[K2_CL_ITEMS];          // rank of this lane's item r among the wave's items of its class
+        unsigned int tot[K2_QUEUES] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int r = 0; r < K2_CL_ITEMS; ++r) {
+            before_cls[r] = 0;
+#pragma unroll
+            for (int k = 1; k <= K2_QUEUES; ++k) {
+                const unsigned long long m = __ballot(cls_of[r] == k);
+                if (cls_of[r] == k) before_cls[r] = tot[k - 1] + (unsigned int)__popcll(m & lane_lt);
+                tot[k - 1] += (unsigned int)__popcll(m);
+            }
+        }
+        static_assert(K2_QUEUES == 4, "lane k reserves class k");
+        const unsigned int my_tot = lane == 0 ? tot[0] : (lane == 1 ? tot[1] : (lane == 2 ? tot[2] : tot[3]));
+        unsigned int my_base = 0;
+        if (lane < K2_QUEUES && my_tot) my_base = atomicAdd(&cnt[lane], my_tot);
+        unsigned int wave_base[K2_QUEUES];
+#pragma unroll
+        for (int k = 0; k < K2_QUEUES; ++k) wave_base[k] = __shfl(my_base, k, 64);
+#pragma unroll
+        for (int r = 0; r < K2_CL_ITEMS; ++r) {
+            const int k = cls_of[r] - 1;
+            const unsigned int wb = k == 0 ? wave_base[0] : (k == 1 ? wave_base[1] : (k == 2 ? wave_base[2] : wave_base[3]));
+            slot_of[r] = k >= 0 ? wb + before_cls[r] : 0u;
         }
         __syncthreads();
         if (threadIdx.x < K2_QUEUES)
