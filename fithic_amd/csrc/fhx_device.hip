@@ -451,7 +451,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_queue(K2Params P, const QEntry*
 constexpr int K2_SORT_TILE = 1024;
 constexpr int K2_SORT_BUCKETS = 32;
 template <int CLS>
-__global__ __launch_bounds__(K2_THREADS) void k2_queue_by_count(K2Params P, const QEntry* __restrict__ base, int dir,
+__global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void k2_queue_by_count(K2Params P, const QEntry* __restrict__ base, int dir,
                                                                 const unsigned long long* __restrict__ count) {
     static_assert(K2_SORT_TILE == 4 * K2_THREADS, "four entries per thread");
     __shared__ QEntry tile[K2_SORT_TILE];
