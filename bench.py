@@ -185,8 +185,9 @@ def main():
                 traffic = json.load(open(prof)).get("hbm_bytes_per_heavy_row") * hv_rows
             except Exception:
                 traffic = None
-        # fp64 view of the same launch: 300 iterations x ~53 fp64 VALU instructions per row (ISA count, profiles/)
-        fp64_instr = hv_rows * 300.0 * 53.0
+        # fp64 view of the same launch: 300 iterations x 46 fp64 VALU instructions per row (ISA count of the hot path of the
+        # one-Newton-step loop: 2 x 7 division, 6 numerator/denominator products, 8 recurrence, 11 tests, 7 counters, 4 masked)
+        fp64_instr = hv_rows * 300.0 * 46.0
         fp64_issue_peak = 256 * 4 * 16 * 2.4e9          # CUs x SIMDs x fp64 lanes/clk x Hz  (= 78.6 TFLOP/s / 2)
         result = {
             "metric": "contact-pairs/sec through spline+p-value+BH pass (5 kb cis, whole node)",

@@ -183,19 +183,26 @@ __device__ __forceinline__ double lean_div(double n, double d) {
     return __builtin_fma(r0, y2, q0);
 }
 
-// Division modes of the continued-fraction loop: 0 = hipcc's `/`, 1 = lean_div, 2 = lean_div whose reciprocal seed is
+// Division modes of the continued-fraction loop: 0 = hipcc's `/`, 1 = lean_div, 2 / 3 = lean_div whose reciprocal seed is
 // the previous denominator's refined reciprocal instead of v_rcp_f64.  The denominators of both fractions form ONE
 // sequence D_m = (a+m)(a+m+1), m = 0, 1, 2, ... (k3*k4 is D_2n, k7*k8 is D_2n+1), so 1/D_m is within 2/(a+m) of 1/D_m-1;
 // for a >= 1e6 two Newton steps from that seed land on the same reciprocal quality as v_rcp_f64 + two steps
 // (error e -> e^2: 2e-6 -> 4e-12 -> 2e-23, i.e. rounding-limited), and the final fused residual step is identical.
+// MODE 3, for a >= 2e8: consecutive denominators differ by <= 1e-8 relative, so ONE Newton step from the previous
+// reciprocal leaves (1e-8)^2 = 1e-16 + one rounding - as good as the two-step value for the residual-corrected quotient
+// (its correction term is < 1 ulp and inherits only the reciprocal's RELATIVE error): two fma less per division.
+// (Tried on top and rejected: one wave-uniform branch around all rare statements instead of per-lane exec masking -
+// the ballot -> scalar branch dependency made the heavy launch 14 % slower.)
 template <int MODE>
 __device__ __forceinline__ double cf_div(double n, double d, double& y) {
     if (MODE == 0) return n / d;
     if (MODE == 1) return lean_div(n, d);
     double e = __builtin_fma(-d, y, 1.0);
     y = __builtin_fma(y, e, y);
-    e = __builtin_fma(-d, y, 1.0);
-    y = __builtin_fma(y, e, y);
+    if (MODE == 2) {                     // MODE 3 (a >= 2e8): the seed is within 1e-8, ONE step is already rounding-limited
+        e = __builtin_fma(-d, y, 1.0);
+        y = __builtin_fma(y, e, y);
+    }
     const double q0 = n * y;
     const double r0 = __builtin_fma(-d, q0, n);
     return __builtin_fma(r0, y, q0);
@@ -216,11 +223,15 @@ __device__ __forceinline__ double contfrac_lazy_impl(double a, double b, double 
     bool fast_ok = true;
     const double thresh = 3.0 * kMachEp;
     double yrec = 0.0;                  // running reciprocal of the denominator sequence (MODE 2 only)
-    if (MODE == 2) {
+    if (MODE >= 2) {
         const double d0 = k3 * k4;
         yrec = __builtin_amdgcn_rcp(d0);
-        const double e0 = __builtin_fma(-d0, yrec, 1.0);
+        double e0 = __builtin_fma(-d0, yrec, 1.0);
         yrec = __builtin_fma(yrec, e0, yrec);
+        if (MODE == 3) {                 // fully refined before the loop: the loop itself refines once per denominator
+            e0 = __builtin_fma(-d0, yrec, 1.0);
+            yrec = __builtin_fma(yrec, e0, yrec);
+        }
     }
     int n = 0;
     do {
@@ -291,6 +302,7 @@ __device__ __forceinline__ double contfrac_lazy(double a, double b, double x) {
     // arg * k * k' with |k k'| < 1e20, so |arg| in [1e-150, 1e150] keeps every operand inside [1e-200, 1e200] or exactly 0
     const double aa = fabs(arg);
     if (aa > 1e-150 && aa < 1e150 && a >= 1.0 && a < 4.5e15 && b < 4.5e15) {
+        if (a >= 2e8) return contfrac_lazy_impl<KIND, 3>(a, b, arg);
         if (a >= 1e6) return contfrac_lazy_impl<KIND, 2>(a, b, arg);
         return contfrac_lazy_impl<KIND, 1>(a, b, arg);
     }

@@ -90,6 +90,26 @@ def test_continued_fraction_bit_exact(ctx, kind):
     assert bits_equal(lazy, ref)
 
 
+@pytest.mark.parametrize("kind", [0, 1])
+def test_continued_fraction_bit_exact_large_n(ctx, kind):
+    """Totals of 2e8 .. 4e15 contacts: the loop refines the tracked reciprocal with ONE Newton step per denominator
+    (division mode 3); 4e5 fractions x 600 divisions, bit for bit against the oracle's C."""
+    from oracle import fithic_oracle as fo
+    rng = np.random.default_rng(300 + kind)
+    n = 400000
+    ntot = np.floor(10 ** rng.uniform(8.31, 15.6, n))
+    ntot[: n // 2] = np.floor(10 ** rng.uniform(8.31, 9.5, n // 2))          # the realistic range, densely
+    cnt = rng.geometric(0.08, n).astype(np.float64) + 1
+    ratio = np.exp(rng.normal(0.3 if kind == 0 else -0.2, 0.8, n))
+    prior = np.clip(cnt * ratio / ntot, 1e-17, 0.6)
+    a, b, x = ntot - cnt + 1, cnt, 1.0 - prior                               # swapped orientation: a is the huge one
+    ref = fo.contfrac(kind, a, b, x)
+    for lazy in (1, 0):
+        got = ctx.debug_contfrac(kind, lazy, a, b, x)
+        same = (got.view(np.int64) == ref.view(np.int64)) | (np.isnan(got) & np.isnan(ref))      # incbd overflows to NaN on a few
+        assert same.all() and np.isnan(ref).sum() < 20
+
+
 def test_lean_division_matches_ieee(ctx):
     """K2 divides with the core of hipcc's own f64 division expansion (no scaling scaffolding): must equal IEEE n/d
     bit for bit on the operand window it is used in - numerators 0 or arg*k*k', denominators (a+2n)(a+2n+1)."""
