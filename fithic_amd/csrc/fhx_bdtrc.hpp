@@ -249,16 +249,16 @@ __device__ __forceinline__ double contfrac_lazy_impl(double a, double b, double 
         const double mag_sum = aqk + apk;
         const double mag_min = fmin(apk, aqk);
         bool exact = true;
-        if (fast_ok && mag_min > 1e-100 && mag_sum < 1e100) {
+        if (__builtin_expect(fast_ok && mag_min > 1e-100 && mag_sum < 1e100, 1)) {
             const double c1 = rp * qk;
             const double c2 = pk * rq;
-            if (fabs(c1 - c2) > 1e-13 * fabs(c2)) {        // certainly t > thresh: Cephes would set ans = r = pk/qk and go on
+            if (__builtin_expect(fabs(c1 - c2) > 1e-13 * fabs(c2), 1)) {        // certainly t > thresh: Cephes would set ans = r = pk/qk and go on
                 rp = pk;
                 rq = qk;
                 exact = false;
             }
         }
-        if (exact) {
+        if (__builtin_expect(exact, 0)) {
             if (fast_ok) {
                 ans = rp / rq;                               // materialise the pending quotient (x / 1.0 is exact)
                 r = ans;
@@ -285,10 +285,10 @@ __device__ __forceinline__ double contfrac_lazy_impl(double a, double b, double 
         k6 += (KIND == 0) ? -1.0 : 1.0;
         k8 += 2.0;
 
-        if (mag_sum > kBig) {
+        if (__builtin_expect(mag_sum > kBig, 0)) {
             pkm2 *= kBigInv; pkm1 *= kBigInv; qkm2 *= kBigInv; qkm1 *= kBigInv;
         }
-        if (mag_min < kBigInv) {
+        if (__builtin_expect(mag_min < kBigInv, 0)) {
             pkm2 *= kBig; pkm1 *= kBig; qkm2 *= kBig; qkm1 *= kBig;
         }
     } while (++n < 300);
