@@ -116,6 +116,18 @@ class LocalOps:
     def nonfixed(self):
         return getattr(self.eng, "resolution", 1) == 0
 
+    def hist_span(self, n_dist):
+        """Index window of the distance histogram that can be non-zero (only in-range rows are counted): the exchange
+        carries this window instead of one entry per locus of the longest chromosome."""
+        res = getattr(self.eng, "resolution", 0)
+        up = getattr(self.eng, "dist_up", float("inf"))
+        lo = getattr(self.eng, "dist_low", 0)
+        if not res:
+            return 0, n_dist
+        first = max(0, int(lo) // res)
+        last = n_dist if up == float("inf") else min(n_dist, int(up) // res + 2)
+        return min(first, last), last
+
     def local_dist_keys(self):
         """-r 0: the distinct in-range distances of this rank's rows (its histograms are aligned to them)."""
         from . import _capi
@@ -301,18 +313,28 @@ class DistributedPass:
         if self.n_dist_global is None:
             self.n_dist_global = int(comm.all_reduce_i64(np.array([len(hist_cc)]), op="max")[0])
         nd = self.n_dist_global
-        pack = np.zeros(8 + 2 * nd, np.int64)
+        a, b = ops.hist_span(nd) if hasattr(ops, "hist_span") else (0, nd)      # the window that can be non-zero
+        w = b - a
+        full_cc, full_np = np.zeros(nd, np.int64), np.zeros(nd, np.int64)
+        full_cc[:len(hist_cc)] = hist_cc
+        full_np[:len(hist_np)] = hist_np
+        # one SUM all-reduce: 7 sums, one slot per rank for its largest count (a MAX in disguise), the two windows
+        pack = np.zeros(8 + comm.world + 2 * w, np.int64)
         pack[:8] = [st.inter_count, st.inter_sum, st.intra_all_count, st.intra_all_sum, st.in_range_count, st.in_range_sum,
                     st.n_skipped, 0]
-        pack[8:8 + len(hist_cc)] = hist_cc
-        pack[8 + nd:8 + nd + len(hist_np)] = hist_np
+        pack[8 + comm.rank] = st.max_count
+        pack[8 + comm.world:8 + comm.world + w] = full_cc[a:b]
+        pack[8 + comm.world + w:] = full_np[a:b]
         pack = comm.all_reduce_i64(pack)
-        max_count = int(comm.all_reduce_i64(np.array([st.max_count]), op="max")[0])
         (st.inter_count, st.inter_sum, st.intra_all_count, st.intra_all_sum, st.in_range_count, st.in_range_sum,
          st.n_skipped) = [int(v) for v in pack[:7]]
-        st.max_count = max_count
+        st.max_count = int(pack[8:8 + comm.world].max())
+        full_cc[:] = 0
+        full_np[:] = 0
+        full_cc[a:b] = pack[8 + comm.world:8 + comm.world + w]
+        full_np[a:b] = pack[8 + comm.world + w:]
         t1 = time.perf_counter()
-        info = ops.set_global_and_fit(st, pack[8:8 + nd], pack[8 + nd:8 + 2 * nd])
+        info = ops.set_global_and_fit(st, full_cc, full_np)
         t2 = time.perf_counter()
         ops.pvalues()
         t3 = time.perf_counter()
