@@ -1,0 +1,113 @@
+"""Differential fuzzing of the whole pass on the GPU against the oracle (itself bit-identical to the real reference on all
+golden cases): random small genomes, resolutions, bounds, bin counts, modes, bias tables with missing / out-of-range
+entries, unmappable fragments, 1-3 passes, fixed-size and -r 0.  Integer results equal, p/q within 1e-10; where the
+reference would exit or raise, both sides must refuse."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _write(path, text):
+    with gzip.open(path, "wt") as f:
+        f.write(text)
+
+
+def _make_case(rng, d, nonfixed):
+    res = int(rng.choice([1000, 5000, 40000]))
+    n_chr = int(rng.integers(1, 5))
+    names = ["chr%s" % s for s in rng.permutation(["1", "2", "10", "X", "M"])[:n_chr]]
+    loci = {}
+    frag_lines, bias_lines = [], []
+    for ch in names:
+        n = int(rng.integers(20, 110))
+        if nonfixed:
+            mids = np.cumsum(rng.integers(res // 4 + 1, 3 * res, n))
+        else:
+            mids = np.arange(n) * res + res // 2
+        loci[ch] = mids
+        for k, m in enumerate(mids):
+            hits = 0 if rng.random() < 0.04 else int(rng.integers(1, 4))
+            frag_lines.append("%s\t0\t%d\t%d\t1\n" % (ch, m, hits))
+            if rng.random() > 0.05:
+                b = float(np.exp(rng.normal(0, 0.4)))
+                if rng.random() < 0.03:
+                    b = float(rng.choice([0.1, 3.5]))
+                bias_lines.append("%s\t%d\t%.6f\n" % (ch, m, b))
+    rows = []
+    for ch in names:
+        m = loci[ch]
+        for i in range(len(m)):
+            for j in range(i + (0 if rng.random() < 0.02 else 1), len(m)):
+                dist = abs(int(m[j]) - int(m[i])) / res
+                lam = 25.0 / (1.0 + dist) ** 1.1
+                c = int(rng.poisson(lam * rng.lognormal(0, 0.5)))
+                if c >= 1 and rng.random() < 0.7:
+                    rows.append("%s\t%d\t%s\t%d\t%d\n" % (ch, m[i], ch, m[j], c))
+    if n_chr > 1:
+        for _ in range(int(rng.integers(0, 300))):
+            a, b = rng.choice(n_chr, 2, replace=False)
+            rows.append("%s\t%d\t%s\t%d\t%d\n" % (names[a], rng.choice(loci[names[a]]), names[b], rng.choice(loci[names[b]]),
+                                                 1 + int(rng.poisson(0.8))))
+    order = rng.permutation(len(rows))
+    paths = dict(contacts=os.path.join(d, "c.gz"), frags=os.path.join(d, "f.gz"), bias=os.path.join(d, "b.gz"))
+    _write(paths["contacts"], "".join(rows[i] for i in order))
+    _write(paths["frags"], "".join(frag_lines))
+    _write(paths["bias"], "".join(bias_lines))
+    span = max(int(v.max()) for v in loci.values())
+    kw = dict(resolution=0 if nonfixed else res, n_bins=int(rng.integers(4, 40)), passes=int(rng.integers(1, 4)),
+              mode=str(rng.choice(["intraOnly", "All", "interOnly"] if n_chr > 1 else ["intraOnly", "All"])),
+              mapp_thres=int(rng.choice([1, 1, 2])), tL=0.5, tU=2.0, L=0, U=float("inf"))
+    if rng.random() < 0.6:
+        kw["L"] = int(rng.integers(0, 4)) * res
+        kw["U"] = int(rng.integers(8, 60)) * res if rng.random() < 0.8 else float("inf")
+    kw["bias_path"] = paths["bias"] if rng.random() < 0.7 else None
+    return paths, kw, len(rows), span
+
+
+@pytest.mark.parametrize("seed", range(36))
+def test_random_small_runs_match_the_oracle(seed, tmp_path):
+    from fithic_amd import _capi, tables
+    from fithic_amd.engine import Engine
+    from oracle import fithic_oracle as fo
+    rng = np.random.default_rng(9000 + seed)
+    nonfixed = seed % 4 == 3
+    paths, kw, n_rows, span = _make_case(rng, str(tmp_path), nonfixed)
+    try:
+        ref = fo.run(paths["contacts"], paths["frags"], kw["bias_path"], kw["resolution"], kw["n_bins"], kw["passes"], kw["mode"],
+                     kw["L"], kw["U"], kw["mapp_thres"], kw["tL"], kw["tU"])
+        ref_error = None
+    except (SystemExit, ZeroDivisionError, TypeError, ValueError, IndexError, KeyError) as e:      # what the reference raises
+        ref, ref_error = None, e
+    chroms = tables.ChromIndex()
+    con = tables.read_contacts(paths["contacts"], chroms)
+    eng = Engine(0)
+    try:
+        eng.configure(kw["resolution"], kw["L"], kw["U"], kw["n_bins"], kw["mapp_thres"], kw["mode"], kw["tL"], kw["tU"])
+        eng.load_fragments(*tables.read_fragments(paths["frags"], chroms), chroms.sort_rank())
+        if kw["bias_path"]:
+            eng.load_bias(*tables.read_bias(kw["bias_path"], chroms))
+        eng.load_contacts(con.chr1, con.mid1, con.chr2, con.mid2, con.count)
+        if ref_error is not None:
+            with pytest.raises(_capi.FhxError):
+                for _ in range(kw["passes"]):
+                    eng.run_pass()
+                    eng.next_pass()
+            return
+        for pi, r in enumerate(ref):
+            out = eng.run_pass()
+            v = eng.fetch()
+            assert [out.stats["inter_count"], out.stats["inter_sum"], out.stats["intra_all_sum"], out.stats["in_range_sum"]] == list(r.sums)
+            assert out.info["bh_total_tests"] == r.N
+            for key, want in (("p", r.p), ("q", r.q)):
+                got = v[key]
+                assert np.array_equal(np.isnan(got), np.isnan(want)), (key, pi)
+                ok = ~np.isnan(want)
+                assert not ok.any() or np.max(np.abs(got[ok] - want[ok])) <= TOL, (key, pi)
+            assert eng.next_pass() == r.n_outlier_lines_total
+    finally:
+        eng.close()
