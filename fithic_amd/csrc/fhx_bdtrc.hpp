@@ -194,7 +194,8 @@ __device__ __forceinline__ double lean_div(double n, double d) {
 // (Tried on top and rejected: one wave-uniform branch around all rare statements instead of per-lane exec masking -
 // the ballot -> scalar branch dependency made the heavy launch 14 % slower; chunks of 20 iterations without the exact
 // statements plus checkpoint / repeat when a lane needed them - bit-exact, but 6 % slower even with < 1 % repeats:
-// Cephes' rescaling fires every 2.4 iterations per lane, so the per-lane masking stays, and the VALU is ~80 % busy.)
+// Cephes' rescaling fires every 2.4 iterations per lane, so the per-lane masking stays, and the VALU is ~80 % busy;
+// deferring that (exact, power-of-two) rescaling to 2^480 and doing nine steps at once - bit-exact too - changed nothing.)
 template <int MODE>
 __device__ __forceinline__ double cf_div(double n, double d, double& y) {
     if (MODE == 0) return n / d;
