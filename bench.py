@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--path", choices=["fithic", "kr", "cni"], default="fithic",
                     help="fithic (default): the headline pass.  kr / cni: the neighbouring steps (Knight-Ruiz bias vectors, merging of "
                          "nearby contacts) measured by profiles/kr_bench.py / profiles/cni_bench.py, plus their cpu_baseline")
+    ap.add_argument("--no-bias", action="store_true", help="variant: no bias file (p depends on (distance, count) only: table path)")
     ap.add_argument("--replicas", type=int, default=0, help="debug: replicate the genome R times per run regardless of --gpus (size test)")
     args = ap.parse_args()
 
@@ -113,7 +114,8 @@ def main():
     eng = Engine(local_rank)
     eng.configure(res, L, U, n_bins=100, mapp_thres=1, mode="intraOnly")
     eng.load_fragments(*genome.fragments(), genome.sort_rank())
-    eng.load_bias(*genome.bias_table())
+    if not args.no_bias:
+        eng.load_bias(*genome.bias_table())
     eng.load_contacts_device([t.data_ptr() for t in cols], n_local)
     sample_cols = None
     if rank == 0 and not args.no_cpu_baseline:

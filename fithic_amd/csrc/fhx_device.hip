@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -525,6 +526,51 @@ __global__ void k_debug_contfrac(const double* __restrict__ a, const double* __r
 __global__ void k_debug_lean_div(const double* __restrict__ n, const double* __restrict__ d, int64_t len, double* __restrict__ out) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) out[i] = dev::lean_div(n[i], d[i]);
+}
+
+// ---- no bias file: p depends on (distance index, count) only ------------------------------------------------------
+// Without a bias table every in-range intra row has prior = prior_lut[d] exactly (b1 = b2 = 1.0, fithic.py:1069) and every
+// inter row prior = interChrProb, so bdtrc is a function of (d, count) / of count.  K2 then runs on a TABLE of virtual rows
+// - one per (d, count), count <= cap, plus one per count for inter rows - through the same classify + queue kernels, and the
+// real rows gather.  Same function of the same inputs: bit-identical to evaluating every row (a few hundred thousand
+// evaluations instead of one per contact pair).  Rows whose count exceeds the table evaluate in place.
+__global__ __launch_bounds__(256) void k2_memo_rows(int n_d, int lo_idx, int cap, int with_inter, int32_t* __restrict__ loc1,
+                                                   int32_t* __restrict__ loc2, int32_t* __restrict__ count, int64_t n_v) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t intra = (int64_t)n_d * (cap + 1);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_v; i += stride) {
+        if (i < intra) {
+            const int d = lo_idx + (int)(i / (cap + 1));
+            loc1[i] = 0;
+            loc2[i] = d;                                    // |slot 0 - slot d| = d; both slots carry bias 1.0
+            count[i] = (int)(i % (cap + 1));
+        } else {
+            loc1[i] = 0;
+            loc2[i] = ~0;                                   // bit 31: inter-chromosomal
+            count[i] = (int)(i - intra);
+        }
+        (void)with_inter;
+    }
+}
+
+__global__ __launch_bounds__(256) void k2_memo_gather(K2Params P, const double* __restrict__ table, int n_d, int cap, int has_intra,
+                                                     int has_inter) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t intra = has_intra ? (int64_t)n_d * (cap + 1) : 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += stride) {
+        const int l1 = P.loc1[i], l2 = P.loc2[i];
+        const int c = P.count[i];
+        double prior = 1.0, pv = 1.0;
+        bool is_inter = false;
+        if (row_prior(P, l1, l2, prior, is_inter)) {
+            if (c >= 0 && c <= cap && (is_inter ? has_inter : has_intra)) {
+                pv = is_inter ? table[intra + c] : table[(int64_t)(abs(l1 - l2) - P.lo_idx) * (cap + 1) + c];
+            } else {
+                pv = dev::bdtrc_count(c, is_inter ? P.inter : P.intra, prior);     // beyond the table: evaluate here
+            }
+        }
+        P.p[i] = pv;
+    }
 }
 
 // expected contact count and the two biases, recomputed on demand for the writer (fithic.py:1075-1078, :1105-1108)
@@ -2265,12 +2311,42 @@ int fhx_pvalues(fhx_ctx* ctx) {
         const int r2 = build_slot_tables(ctx);
         if (r2 != FHX_OK) return r2;
     }
-    const K2Params P = make_k2_params(ctx);
+    K2Params P = make_k2_params(ctx);
     FHX_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    // no bias table, fixed-size loci: evaluate a (distance, count) table instead of every row (see k2_memo_rows)
+    int32_t *v_loc1 = nullptr, *v_loc2 = nullptr, *v_count = nullptr;
+    double* v_table = nullptr;
+    int memo_cap = -1, memo_nd = 0;
+    const bool memo_intra = ctx->prm.mode != FHX_MODE_INTER_ONLY, memo_inter = ctx->prm.mode != FHX_MODE_INTRA_ONLY;
+    if (!ctx->have_bias && !ctx->nonfixed && !getenv("FHX_NO_MEMO")) {
+        memo_nd = memo_intra ? (int)(P.hi_idx - P.lo_idx + 1) : 0;
+        const int64_t budget = std::min<int64_t>(1ll << 24, ctx->n_rows / 4);
+        const int64_t per_count = (int64_t)memo_nd + (memo_inter ? 1 : 0);
+        if (per_count > 0 && memo_nd >= 0) {
+            const int64_t cap = std::min<int64_t>(ctx->stats.max_count, budget / per_count - 1);
+            if (cap >= 8) memo_cap = (int)cap;
+        }
+    }
+    const K2Params P_rows = P;
+    int64_t k2_n = ctx->n_rows;
+    if (memo_cap >= 0) {
+        k2_n = (int64_t)memo_nd * (memo_cap + 1) + (memo_inter ? (memo_cap + 1) : 0);
+        FHX_HIP(hipMalloc(&v_loc1, (size_t)k2_n * 4));
+        FHX_HIP(hipMalloc(&v_loc2, (size_t)k2_n * 4));
+        FHX_HIP(hipMalloc(&v_count, (size_t)k2_n * 4));
+        FHX_HIP(hipMalloc(&v_table, (size_t)k2_n * 8));
+        hipLaunchKernelGGL(k2_memo_rows, dim3(grid_for(k2_n, 256)), dim3(256), 0, ctx->stream, memo_nd, P.lo_idx, memo_cap, (int)memo_inter,
+                           v_loc1, v_loc2, v_count, k2_n);
+        P.loc1 = v_loc1;
+        P.loc2 = v_loc2;
+        P.count = v_count;
+        P.p = v_table;
+        P.n = k2_n;
+    }
     // queues live in the sort workspace, which is idle until K3: 2 x u32[n] + 2 x u64[n]
     // two entry buffers of n_rows each: [swapped CF up | power series down] and [incbcf up | incbd down]
     K2Queues Q;
-    const long long last = (long long)std::max<int64_t>(ctx->n_rows, 1) - 1;
+    const long long last = (long long)std::max<int64_t>(ctx->n_rows, 1) - 1   /* k2_n <= n_rows / 4 in the table case */;
     Q.base[dev::BC_CF_SWAPPED - 1] = ctx->d_queue[0];
     Q.dir[dev::BC_CF_SWAPPED - 1] = 1;
     Q.base[dev::BC_PSERIES - 1] = ctx->d_queue[0] + last;
@@ -2281,7 +2357,7 @@ int fhx_pvalues(fhx_ctx* ctx) {
     Q.dir[dev::BC_CF_BD - 1] = -1;
     Q.count = ctx->d_misc + 64;
     FHX_HIP(hipMemsetAsync(Q.count, 0, K2_QUEUES * K2_COUNT_STRIDE * sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL(k2_classify, dim3(grid_for(ctx->n_rows, K2_CL_TILE, 256 * 8)), dim3(K2_THREADS), 0, ctx->stream, P, Q);
+    hipLaunchKernelGGL(k2_classify, dim3(grid_for(k2_n, K2_CL_TILE, 256 * 8)), dim3(K2_THREADS), 0, ctx->stream, P, Q);
     const dim3 qgrid(256 * 8), qblock(K2_THREADS);
 #define FHX_LAUNCH_QUEUE(CLS)                                                                                          \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue<CLS>), qgrid, qblock, 0, ctx->stream, P, (const QEntry*)Q.base[(CLS) - 1], \
@@ -2297,6 +2373,16 @@ int fhx_pvalues(fhx_ctx* ctx) {
     FHX_LAUNCH_QUEUE(dev::BC_PSERIES);
 #undef FHX_LAUNCH_QUEUE_BY_COUNT
 #undef FHX_LAUNCH_QUEUE
+    if (memo_cap >= 0) {
+        hipLaunchKernelGGL(k2_memo_gather, dim3(grid_for(ctx->n_rows, 256, 256 * 16)), dim3(256), 0, ctx->stream, P_rows,
+                           (const double*)v_table, memo_nd, memo_cap, (int)memo_intra, (int)memo_inter);
+        FHX_HIP(hipGetLastError());
+        FHX_HIP(hipStreamSynchronize(ctx->stream));
+        dev_free(v_loc1);
+        dev_free(v_loc2);
+        dev_free(v_count);
+        dev_free(v_table);
+    }
     FHX_HIP(hipGetLastError());
     FHX_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
     ctx->ev_valid[1] = true;

@@ -141,3 +141,48 @@ def test_c3_shaped_properties_at_scale():
     v2 = eng.fetch()
     assert bits_equal(v2["p"], v["p"]) and bits_equal(v2["q"], v["q"])
     eng.close()
+
+
+def test_no_bias_table_path_equals_per_row_evaluation(monkeypatch):
+    """Without a bias file K2 evaluates a (distance, count) table and the rows gather (k2_memo_rows / k2_memo_gather):
+    p and q must equal the per-row evaluation bit for bit (3.6e6 rows, intra + inter, counts beyond the table cap)."""
+    import torch
+    from fithic_amd import synth
+    from fithic_amd.engine import Engine
+    res = 5000
+    genome = synth.Genome(res, lengths=synth.HG19_AUTOSOMES[19:22])
+    amp = synth.solve_amplitude(0.66, 4, 400)
+    dev = torch.device("cuda", 0)
+    parts = [synth.cis_contacts(genome, c, 4, 400, amp, device=dev) for c in range(3)]
+    cols = [torch.cat([p[k] for p in parts]).cpu().numpy() for k in range(5)]
+    rng = np.random.default_rng(4)
+    n = len(cols[0])
+    cols[4][rng.integers(0, n, 500)] = rng.integers(2000, 90000, 500)            # counts far beyond the table
+    m = 20000                                                                    # some inter-chromosomal rows
+    mids = [np.arange(genome.n_loci[c]) * res + res // 2 for c in range(3)]
+    c1 = rng.integers(0, 3, m)
+    c2 = (c1 + rng.integers(1, 3, m)) % 3
+    inter = [c1, np.array([rng.choice(mids[c]) for c in c1]), c2, np.array([rng.choice(mids[c]) for c in c2]), 1 + rng.poisson(0.7, m)]
+    cols = [np.concatenate([a, b]).astype(np.int32) for a, b in zip(cols, inter)]
+    out = {}
+    for tag, env in (("table", None), ("rows", "1")):
+        if env is None:
+            monkeypatch.delenv("FHX_NO_MEMO", raising=False)
+        else:
+            monkeypatch.setenv("FHX_NO_MEMO", env)
+        eng = Engine(0)
+        eng.configure(res, 20000, 2000000, n_bins=100, mapp_thres=1, mode="All")
+        eng.load_fragments(*genome.fragments(), genome.sort_rank())
+        eng.load_contacts(*cols)
+        res_passes = []
+        for _ in range(2):
+            eng.run_pass(collect=False)
+            res_passes.append(eng.fetch())
+            eng.next_pass()
+        out[tag] = res_passes
+        eng.close()
+    for a, b in zip(out["table"], out["rows"]):
+        for key in ("p", "q"):
+            same = (a[key].view(np.int64) == b[key].view(np.int64)) | (np.isnan(a[key]) & np.isnan(b[key]))
+            assert same.all(), key
+    assert np.nanmin(out["table"][0]["p"]) < 1e-6
