@@ -95,6 +95,8 @@ SYMBOLS = {
     "fhx_bh_array": (ctypes.c_int, [_P, _F64P, ctypes.c_int64, ctypes.c_double, _F64P]),
     "fhx_bh_top_hist": (ctypes.c_int, [_P, _I64P, ctypes.c_int64]),
     "fhx_bh_set_cutoff": (ctypes.c_int, [_P, _I64P, ctypes.c_int64, ctypes.c_double]),
+    "fhx_bh_top_hist_device": (ctypes.c_int, [_P]),
+    "fhx_bh_set_cutoff_device": (ctypes.c_int, [_P, ctypes.c_double]),
     "fhx_bh_local_sort": (ctypes.c_int, [_P]),
     "fhx_bh_apply_sorted": (ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, ctypes.c_double, _P, _F64P]),
     "fhx_sort_u64": (ctypes.c_int, [_P, _P, ctypes.c_int64, _P, _P]),
@@ -391,6 +393,14 @@ class Context:
     def bh_set_cutoff(self, global_hist, n_total_tests):
         h = np.ascontiguousarray(global_hist, np.int64)
         self._check(self._L.fhx_bh_set_cutoff(self._h, _ptr(h, ctypes.c_int64), len(h), float(n_total_tests)))
+
+    def bh_top_hist_device(self):
+        """Histogram left on the device; returns its address (8192 x uint64) for an in-place all-reduce."""
+        self._check(self._L.fhx_bh_top_hist_device(self._h))
+        return self.device_ptr(4)
+
+    def bh_set_cutoff_device(self, n_total_tests):
+        self._check(self._L.fhx_bh_set_cutoff_device(self._h, float(n_total_tests)))
 
     def bh_local_sort(self):
         self._check(self._L.fhx_bh_local_sort(self._h))

@@ -2463,6 +2463,31 @@ int fhx_bh_top_hist(fhx_ctx* ctx, int64_t* hist_out, int64_t capacity) {
     return FHX_OK;
 }
 
+// Device-resident variant for sharded runs: the histogram stays in HBM (fhx_device_ptr(ctx, 4)), the caller all-reduces it
+// in place (RCCL) and fhx_bh_set_cutoff_device derives the cutoff from it - no host round trip of the 64 KiB table.
+int fhx_bh_top_hist_device(fhx_ctx* ctx) {
+    if (!ctx) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (!ctx->have_p) return fail(ctx, FHX_ERR_ARG, "fhx_pvalues must run first");
+    FHX_HIP(hipSetDevice(ctx->device));
+    FHX_HIP(hipMemsetAsync(ctx->d_top_hist, 0, TOP_BINS * sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(k3_top_hist, dim3(grid_for((ctx->n_rows + 1) / 2, 512, 256 * 4)), dim3(512), 0, ctx->stream, ctx->d_p,
+                       ctx->n_rows, ctx->d_top_hist);
+    FHX_HIP(hipGetLastError());
+    FHX_HIP(hipStreamSynchronize(ctx->stream));           // the caller's collective runs on another stream
+    return FHX_OK;
+}
+
+int fhx_bh_set_cutoff_device(fhx_ctx* ctx, double n_total_tests) {
+    if (!ctx || !(n_total_tests > 0)) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    FHX_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k3_cutoff, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long*)ctx->d_top_hist, n_total_tests,
+                       ctx->d_misc + 6);
+    FHX_HIP(hipGetLastError());
+    return FHX_OK;
+}
+
 int fhx_bh_set_cutoff(fhx_ctx* ctx, const int64_t* global_hist, int64_t n_bins, double n_total_tests) {
     if (!ctx || !global_hist || n_bins != TOP_BINS || !(n_total_tests > 0)) return FHX_ERR_ARG;
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
@@ -2910,6 +2935,7 @@ void* fhx_device_ptr(fhx_ctx* ctx, int which) {
         case 1: return ctx->d_q;
         case 2: return ctx->d_keys[ctx->sorted_buf];
         case 3: return ctx->d_vals[ctx->sorted_buf];
+        case 4: return ctx->d_top_hist;                  // 8192 x u64, valid after fhx_bh_top_hist(_device)
         default: return nullptr;
     }
 }

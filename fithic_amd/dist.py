@@ -75,13 +75,35 @@ class Comm:
         self.td.all_gather(out, t)
         return [float(o.item()) for o in out]
 
-    def all_to_all_v(self, send, send_counts, dtype=None):
-        """send: 1-D tensor laid out rank-major; returns (recv tensor, recv_counts)."""
+    def all_reduce_device_i64(self, ptr, n):
+        """In-place SUM all-reduce of n int64 values living at device address `ptr` (the engine's own buffer): wrapped as a
+        torch tensor without a copy.  With a host transport (gloo in the tests) it is staged through the host."""
         torch = self.torch
-        sc = torch.tensor(send_counts, dtype=torch.int64, device=self.device)
-        rc = torch.empty_like(sc)
-        self.td.all_to_all_single(rc, sc)
-        recv_counts = [int(v) for v in rc.cpu().tolist()]
+
+        class _View:                                    # minimal __cuda_array_interface__ carrier
+            __cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+
+        t = torch.as_tensor(_View(), device=self.compute_device)
+        if self.device.type == "cuda":
+            self.td.all_reduce(t, op=self.td.ReduceOp.SUM)
+            self._done()
+        else:
+            h = t.cpu()
+            self.td.all_reduce(h, op=self.td.ReduceOp.SUM)
+            t.copy_(h)
+            torch.cuda.current_stream(self.compute_device).synchronize()
+
+    def all_to_all_v(self, send, send_counts, dtype=None, recv_counts=None):
+        """send: 1-D tensor laid out rank-major; returns (recv tensor, recv_counts).  recv_counts, when the caller already
+        knows them (the return leg of an exchange), saves the count exchange."""
+        torch = self.torch
+        if recv_counts is None:
+            sc = torch.tensor(send_counts, dtype=torch.int64, device=self.device)
+            rc = torch.empty_like(sc)
+            self.td.all_to_all_single(rc, sc)
+            recv_counts = [int(v) for v in rc.cpu().tolist()]
+        else:
+            recv_counts = [int(v) for v in recv_counts]
         send = send.to(self.device).contiguous()
         recv = torch.empty(sum(recv_counts), dtype=send.dtype, device=self.device)
         self.td.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=[int(v) for v in send_counts])
@@ -148,6 +170,13 @@ class LocalOps:
 
     def set_cutoff(self, global_hist, n_tests):
         self.ctx.bh_set_cutoff(global_hist, n_tests)
+
+    def top_hist_device(self):
+        """(device address, length) of the key histogram, left in HBM for an in-place all-reduce."""
+        return self.ctx.bh_top_hist_device(), 8192
+
+    def set_cutoff_device(self, n_tests):
+        self.ctx.bh_set_cutoff_device(n_tests)
 
     def local_sorted_keys(self):
         """int64 tensor (all keys < 2^62, so signed order = unsigned order) of this rank's sorted p < 1 bit patterns."""
@@ -245,7 +274,12 @@ def distributed_bh(comm, ops, n_tests, timings=None):
             t_last[0] = now
 
     # exact early cutoff: rows whose q is provably 1 are neither sorted nor exchanged (needs the GLOBAL key histogram)
-    ops.set_cutoff(comm.all_reduce_i64(ops.top_hist()), n_tests)
+    if hasattr(ops, "top_hist_device") and comm.compute_device.type == "cuda":
+        ptr, length = ops.top_hist_device()              # histogram stays in HBM: all-reduce in place, cutoff on the device
+        comm.all_reduce_device_i64(ptr, length)
+        ops.set_cutoff_device(n_tests)
+    else:
+        ops.set_cutoff(comm.all_reduce_i64(ops.top_hist()), n_tests)
     lap("bh_cutoff")
     keys = ops.local_sorted_keys()
     n = keys.numel()
@@ -284,8 +318,7 @@ def distributed_bh(comm, ops, n_tests, timings=None):
     q_arrival = torch.empty_like(q_sorted)
     if m:
         q_arrival[perm.to(torch.int64)] = q_sorted
-    q_back, back_counts = comm.all_to_all_v(q_arrival, recv_counts)
-    assert back_counts == send_counts
+    q_back, back_counts = comm.all_to_all_v(q_arrival, recv_counts, recv_counts=send_counts)
     ops.scatter_q(q_back)
     lap("bh_return")
     return n, m

@@ -209,6 +209,10 @@ int fhx_debug_lean_div(fhx_ctx* ctx, const double* n, const double* d, int64_t l
  * back (fhx_bh_set_cutoff) before fhx_bh_local_sort.  Without either call every p < 1 is sorted. */
 int fhx_bh_top_hist(fhx_ctx* ctx, int64_t* hist_out, int64_t capacity);
 int fhx_bh_set_cutoff(fhx_ctx* ctx, const int64_t* global_hist, int64_t n_bins, double n_total_tests);
+/* The same two steps with the histogram left in HBM: fhx_device_ptr(ctx, 4) is the 8192 x uint64 table; the caller
+ * all-reduces it in place between the two calls (no host round trip). */
+int fhx_bh_top_hist_device(fhx_ctx* ctx);
+int fhx_bh_set_cutoff_device(fhx_ctx* ctx, double n_total_tests);
 int fhx_bh_local_sort(fhx_ctx* ctx);                 /* compact p below the cutoff, radix sort (key, row) on this GPU */
 int fhx_bh_apply_sorted(fhx_ctx* ctx, const void* d_sorted_keys, int64_t n, int64_t global_rank0,
                         double carry_in, double n_total_tests, void* d_q_sorted, double* block_max_out);
