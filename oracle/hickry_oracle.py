@@ -2,7 +2,7 @@
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this; the product (fithic_amd.hickry)
 never does.  Each function cites the reference lines it restates.  Summation orders are the engine's (see kr_oracle.c):
-bit-equal to the GPU, and pinned against the real reference by tests/golden/k*_kr_*.npz within 1e-9 relative
+bit-equal to the GPU, and pinned against the real reference by tests/golden/k*_kr_*.npz within 1e-12 relative (measured <= 7e-15)
 (the reference's own last bits depend on its BLAS build, so there is no bit-exact target to hit).
 """
 import ctypes
