@@ -519,7 +519,8 @@ def host_lbeta_table(n_total, max_count):
 class KrInfo(ctypes.Structure):
     _fields_ = [("n", ctypes.c_int64), ("nnz", ctypes.c_int64), ("outer_iterations", ctypes.c_int32),
                 ("inner_iterations", ctypes.c_int32), ("matvecs", ctypes.c_int64), ("boundary_steps", ctypes.c_int64),
-                ("residual", ctypes.c_double), ("spmv_seconds", ctypes.c_double), ("spmv_timed", ctypes.c_int64)]
+                ("residual", ctypes.c_double), ("spmv_seconds", ctypes.c_double), ("spmv_timed", ctypes.c_int64),
+                ("value_bytes", ctypes.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

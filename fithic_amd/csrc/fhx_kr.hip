@@ -105,9 +105,9 @@ __global__ __launch_bounds__(THREADS) void kr_finish(const double* partials, int
 // SpMV: one wave per row.  MODE 0: out0 = A in;  1: out0 = a0*(A in), out1 = 1 - out0  (v, rk; HiCKRy.py:153-154,222-223)
 //                          2: out0 = a0*(A in) + a1*a2                                   (w; HiCKRy.py:192)
 // ---------------------------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, typename VT>
 __global__ __launch_bounds__(THREADS) void kr_spmv(int64_t n, const int64_t* __restrict__ indptr, const int32_t* __restrict__ col,
-                                                   const double* __restrict__ val, const double* __restrict__ in,
+                                                   const VT* __restrict__ val, const double* __restrict__ in,
                                                    double* __restrict__ out0, double* __restrict__ out1,
                                                    const double* __restrict__ a0, const double* __restrict__ a1,
                                                    const double* __restrict__ a2, int64_t n_blocks) {
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(THREADS) void kr_spmv(int64_t n, const int64_t* __r
     // measured on the C3 matrix: nontemporal loads of col/val -1.6 %; 8-cell unroll -10 %; predicated chunks no gain;
     // 2 / 4 / 8 / 16 consecutive rows per wave -5 / -10 / -15 / -20 % (fewer waves in flight)
 #define LD_COL(k) col[k]
-#define LD_VAL(k) val[k]
+#define LD_VAL(k) ((double)val[k])
     for (; j + 192 < e; j += 256) {          // four independent loads in flight, adds stay in cell order
         const double p0 = LD_VAL(j) * in[LD_COL(j)];
         const double p1 = LD_VAL(j + 64) * in[LD_COL(j + 64)];
@@ -150,6 +150,20 @@ __global__ __launch_bounds__(THREADS) void kr_spmv(int64_t n, const int64_t* __r
             out0[row] = a0[row] * t + a1[row] * a2[row];
         }
     }
+}
+
+// Contact counts are integers: when every stored value is exactly representable in binary32 the matrix is streamed as
+// float (8 B per cell instead of 12) and widened in the kernel - the same doubles enter the same products.
+__global__ __launch_bounds__(THREADS) void kr_to_f32(const double* __restrict__ val, int64_t nnz, float* __restrict__ out,
+                                                     unsigned int* __restrict__ inexact) {
+    unsigned int bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = val[i];
+        const float f = (float)v;
+        out[i] = f;
+        if (!((double)f == v)) bad = 1;                    // also catches NaN
+    }
+    if (__ballot(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(inexact, 1u);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -389,6 +403,8 @@ struct fhx_kr {
     int64_t* d_rptr = nullptr;
     int32_t* d_rcol = nullptr;
     double* d_rval = nullptr;
+    float* d_val32 = nullptr;                          // binary32 copy of the matrix fhx_kr_balance streams (exact or absent)
+    bool val32_reduced = false;
     std::vector<int64_t> removed;
     std::vector<double> row_sums;
     // iteration state
@@ -436,8 +452,12 @@ void launch_spmv(fhx_kr* kr, int64_t n, const int64_t* ptr, const int32_t* col, 
                  double* out1, const double* a0, const double* a1, const double* a2) {
     const int64_t n_blocks = (n + 3) / 4;
     const int64_t per = (n_blocks + 7) / 8;
-    hipLaunchKernelGGL((krd::kr_spmv<MODE>), dim3((unsigned)std::max<int64_t>(1, per * 8)), dim3(krd::THREADS), 0, kr->stream, n, ptr,
-                       col, val, in, out0, out1, a0, a1, a2, n_blocks);
+    const dim3 g((unsigned)std::max<int64_t>(1, per * 8)), t(krd::THREADS);
+    if (kr->d_val32 && val == (kr->val32_reduced ? kr->d_rval : kr->d_val))
+        hipLaunchKernelGGL((krd::kr_spmv<MODE, float>), g, t, 0, kr->stream, n, ptr, col, (const float*)kr->d_val32, in, out0, out1, a0, a1,
+                           a2, n_blocks);
+    else
+        hipLaunchKernelGGL((krd::kr_spmv<MODE, double>), g, t, 0, kr->stream, n, ptr, col, val, in, out0, out1, a0, a1, a2, n_blocks);
 }
 
 int ensure_vectors(fhx_kr* kr, int64_t n) {
@@ -480,6 +500,7 @@ void free_matrix(fhx_kr* kr) {
     kfree(kr->d_rptr);
     kfree(kr->d_rcol);
     kfree(kr->d_rval);
+    kfree(kr->d_val32);
     kr->reduced = false;
     kr->balanced = false;
     kr->n = kr->nnz = kr->nnz_full = 0;
@@ -847,6 +868,21 @@ int fhx_kr_balance(fhx_kr* kr, double tol, fhx_kr_info* out) {
     const int64_t* ptr = mat_ptr(kr);
     const int32_t* col = mat_col(kr);
     const double* val = mat_val(kr);
+    // binary32 copy of the values when that is exact (integer contact counts): 8 B per cell instead of 12
+    if (kr->nnz > 0 && (!kr->d_val32 || kr->val32_reduced != kr->reduced)) {
+        kfree(kr->d_val32);
+        KR_HIP(hipMalloc(&kr->d_val32, (size_t)kr->nnz * sizeof(float)));
+        if (!kr->d_counter) KR_HIP(hipMalloc(&kr->d_counter, 4 * sizeof(unsigned long long)));
+        unsigned int* flag = reinterpret_cast<unsigned int*>(kr->d_counter + 3);
+        KR_HIP(hipMemsetAsync(flag, 0, 4, kr->stream));
+        hipLaunchKernelGGL(krd::kr_to_f32, dim3((unsigned)std::min<int64_t>((kr->nnz + 255) / 256, 256 * 16)), dim3(krd::THREADS), 0,
+                           kr->stream, val, kr->nnz, kr->d_val32, flag);
+        unsigned int inexact = 0;
+        KR_HIP(hipMemcpyAsync(&inexact, flag, 4, hipMemcpyDeviceToHost, kr->stream));
+        KR_HIP(hipStreamSynchronize(kr->stream));
+        kr->val32_reduced = kr->reduced;
+        if (inexact) kfree(kr->d_val32);               // fractional or huge counts: stay with the doubles
+    }
     const dim3 grid(tiles_of(n)), block(krd::THREADS);
     const int OPS_SUM[1] = {0}, OPS_MINMAX[2] = {1, 2}, OPS_MIN[1] = {1};
     kr->spmv_seconds = 0;
@@ -985,6 +1021,7 @@ int fhx_kr_balance(fhx_kr* kr, double tol, fhx_kr_info* out) {
     info.residual = rout;
     info.spmv_seconds = kr->spmv_seconds;
     info.spmv_timed = kr->spmv_calls;
+    info.value_bytes = kr->d_val32 ? 4 : 8;
     kr->info = info;
     kr->balanced = true;
     if (out) *out = info;

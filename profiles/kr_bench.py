@@ -48,9 +48,10 @@ def measure(max_chroms=0, perc=0.05):
     bias = kr.bias()
     n, nnz = info.n, info.nnz
     spmv = info.spmv_seconds / max(info.spmv_timed, 1)
-    algo = 12.0 * nnz + 24.0 * n + 8.0 * (n + 1)        # value 8 + column 4 per cell; in/out/epilogue vectors; indptr
+    vb = info.value_bytes                               # 4 when the counts are exact in binary32 (they are: integers), else 8
+    algo = (vb + 4.0) * nnz + 24.0 * n + 8.0 * (n + 1)   # value + column per cell; in/out/epilogue vectors; indptr
     # isolated SpMV (plain epilogue), many repeats
-    _, spmv_iso = kr.spmv(np.ones(n), which=1, repeats=50)
+    _, spmv_iso = kr.spmv(np.ones(n), which=1, repeats=50)          # uses the same value array as the balance did
     traffic = None
     tp = os.path.join(ROOT, "profiles", "kr_pmc_traffic.json")
     if os.path.exists(tp):
@@ -67,7 +68,8 @@ def measure(max_chroms=0, perc=0.05):
                      "frac": algo / spmv / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "launch_seconds": spmv,
                      "isolated_launch_seconds": spmv_iso, "isolated_frac": algo / spmv_iso / 1e9 / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_launch": algo,
-                     "note": "12 B per stored cell (8 value + 4 column) + 32 B per row (indptr, gathered input, output, epilogue)"},
+                     "value_bytes": vb,
+                     "note": "(value_bytes + 4) B per stored cell + 32 B per row (indptr, gathered input, output, epilogue)"},
     }
     kr.close()
     return out, genome, cols
