@@ -254,6 +254,7 @@ struct K2Params {
     const int32_t* loc2;
     const int32_t* count;
     const double* slot_bias;      // -1 = discarded / missing; all 1.0 without a bias file
+    bool no_bias;                 // no bias table was loaded: slot_bias is all 1.0 and need not be read
     const double* prior_lut;      // newSplineY by distance index (clamp + bisect_left folded in)
     dev::BinomTables intra, inter;
     double inter_chr_prob;
@@ -293,7 +294,8 @@ __device__ __forceinline__ double prior_by_search(const K2Params& P, long long d
 __device__ __forceinline__ bool row_prior(const K2Params& P, int l1, int l2, double& prior, bool& is_inter) {
     const bool inter = l2 < 0;
     const int s2 = inter ? ~l2 : l2;
-    const double b1 = P.slot_bias[l1], b2 = P.slot_bias[s2];
+    // no bias table: every slot holds 1.0 - skip the two gathers
+    const double b1 = P.no_bias ? 1.0 : P.slot_bias[l1], b2 = P.no_bias ? 1.0 : P.slot_bias[s2];
     if ((b1 < 0 || b2 < 0) && !inter) return false;                        // fithic.py:1057-1064
     if (!inter && P.mode != FHX_MODE_INTER_ONLY) {
         if (P.nonfixed) {
@@ -554,7 +556,8 @@ __global__ __launch_bounds__(256) void k2_memo_rows(int n_d, int lo_idx, int cap
 }
 
 __global__ __launch_bounds__(256) void k2_memo_gather(K2Params P, const double* __restrict__ table, int n_d, int cap, int has_intra,
-                                                     int has_inter) {
+                                                     int has_inter, unsigned int* __restrict__ overflow_rows,
+                                                     unsigned long long* __restrict__ n_overflow, unsigned long long overflow_cap) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t intra = has_intra ? (int64_t)n_d * (cap + 1) : 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += stride) {
@@ -565,11 +568,26 @@ __global__ __launch_bounds__(256) void k2_memo_gather(K2Params P, const double* 
         if (row_prior(P, l1, l2, prior, is_inter)) {
             if (c >= 0 && c <= cap && (is_inter ? has_inter : has_intra)) {
                 pv = is_inter ? table[intra + c] : table[(int64_t)(abs(l1 - l2) - P.lo_idx) * (cap + 1) + c];
-            } else {
-                pv = dev::bdtrc_count(c, is_inter ? P.inter : P.intra, prior);     // beyond the table: evaluate here
+            } else {                                        // beyond the table (rare): k2_memo_overflow evaluates these rows
+                const unsigned long long at = atomicAdd(n_overflow, 1ull);
+                if (at < overflow_cap) overflow_rows[at] = (unsigned int)i;
+                pv = -1.0;                                  // never a p-value: marks the row if the list overflowed
             }
         }
         P.p[i] = pv;
+    }
+}
+
+// rows beyond the table: evaluate in place.  from_list = 0: the list overflowed, scan for the -1 marks instead.
+__global__ __launch_bounds__(256) void k2_memo_overflow(K2Params P, const unsigned int* __restrict__ rows, int64_t n_list, int from_list) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n = from_list ? n_list : P.n;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const int64_t i = from_list ? (int64_t)rows[j] : j;
+        if (!from_list && !(P.p[i] == -1.0)) continue;
+        double prior = 1.0;
+        bool is_inter = false;
+        if (row_prior(P, P.loc1[i], P.loc2[i], prior, is_inter)) P.p[i] = dev::bdtrc_count(P.count[i], is_inter ? P.inter : P.intra, prior);
     }
 }
 
@@ -1449,6 +1467,8 @@ struct fhx_ctx {
     unsigned int* d_digit_total = nullptr;
     unsigned long long* d_top_hist = nullptr;
     QEntry* d_queue[2] = {nullptr, nullptr};          // K2's per-class row queues
+    unsigned char* d_memo = nullptr;                  // no-bias table path: virtual rows, table, overflow list (kept across passes)
+    size_t memo_bytes = 0;
     // non-fixed-size mode (-r 0)
     bool nonfixed = false;
     int32_t* d_slot_mid = nullptr;
@@ -1495,6 +1515,7 @@ K2Params make_k2_params(fhx_ctx* c) {
     P.loc2 = c->d_loc2;
     P.count = c->d_count;
     P.slot_bias = c->d_slot_bias;
+    P.no_bias = !c->have_bias;
     P.prior_lut = c->d_lut;
     const double n_intra = (double)c->stats.in_range_sum, n_inter = (double)c->stats.inter_sum;
     P.intra = dev::BinomTables{c->d_lbeta_intra, c->d_invb_intra, n_intra, (n_intra + 1.0) < dev::kMaxGam};
@@ -1928,6 +1949,7 @@ void fhx_destroy(fhx_ctx* ctx) {
         dev_free(ctx->d_top_hist);
         dev_free(ctx->d_queue[0]);
         dev_free(ctx->d_queue[1]);
+        dev_free(ctx->d_memo);
         dev_free(ctx->d_slot_mid);
         dev_free(ctx->d_table_x);
         dev_free(ctx->d_table_y);
@@ -2316,6 +2338,8 @@ int fhx_pvalues(fhx_ctx* ctx) {
     // no bias table, fixed-size loci: evaluate a (distance, count) table instead of every row (see k2_memo_rows)
     int32_t *v_loc1 = nullptr, *v_loc2 = nullptr, *v_count = nullptr;
     double* v_table = nullptr;
+    unsigned int* over_rows = nullptr;
+    unsigned long long over_cap = 0;
     int memo_cap = -1, memo_nd = 0;
     const bool memo_intra = ctx->prm.mode != FHX_MODE_INTER_ONLY, memo_inter = ctx->prm.mode != FHX_MODE_INTRA_ONLY;
     if (!ctx->have_bias && !ctx->nonfixed && !getenv("FHX_NO_MEMO")) {
@@ -2331,10 +2355,19 @@ int fhx_pvalues(fhx_ctx* ctx) {
     int64_t k2_n = ctx->n_rows;
     if (memo_cap >= 0) {
         k2_n = (int64_t)memo_nd * (memo_cap + 1) + (memo_inter ? (memo_cap + 1) : 0);
-        FHX_HIP(hipMalloc(&v_loc1, (size_t)k2_n * 4));
-        FHX_HIP(hipMalloc(&v_loc2, (size_t)k2_n * 4));
-        FHX_HIP(hipMalloc(&v_count, (size_t)k2_n * 4));
-        FHX_HIP(hipMalloc(&v_table, (size_t)k2_n * 8));
+        over_cap = (unsigned long long)std::max<int64_t>(ctx->n_rows / 16, 1024);
+        const size_t need = (size_t)k2_n * (4 + 4 + 4 + 8) + (size_t)over_cap * 4 + 64;
+        if (need > ctx->memo_bytes) {
+            dev_free(ctx->d_memo);
+            ctx->memo_bytes = 0;
+            FHX_HIP(hipMalloc(&ctx->d_memo, need));
+            ctx->memo_bytes = need;
+        }
+        v_table = reinterpret_cast<double*>(ctx->d_memo);                             // 8-byte items first
+        v_loc1 = reinterpret_cast<int32_t*>(ctx->d_memo + (size_t)k2_n * 8);
+        v_loc2 = v_loc1 + k2_n;
+        v_count = v_loc2 + k2_n;
+        over_rows = reinterpret_cast<unsigned int*>(v_count + k2_n);
         hipLaunchKernelGGL(k2_memo_rows, dim3(grid_for(k2_n, 256)), dim3(256), 0, ctx->stream, memo_nd, P.lo_idx, memo_cap, (int)memo_inter,
                            v_loc1, v_loc2, v_count, k2_n);
         P.loc1 = v_loc1;
@@ -2374,14 +2407,22 @@ int fhx_pvalues(fhx_ctx* ctx) {
 #undef FHX_LAUNCH_QUEUE_BY_COUNT
 #undef FHX_LAUNCH_QUEUE
     if (memo_cap >= 0) {
+        unsigned long long* n_over = ctx->d_misc + 5;
+        FHX_HIP(hipMemsetAsync(n_over, 0, sizeof(unsigned long long), ctx->stream));
         hipLaunchKernelGGL(k2_memo_gather, dim3(grid_for(ctx->n_rows, 256, 256 * 16)), dim3(256), 0, ctx->stream, P_rows,
-                           (const double*)v_table, memo_nd, memo_cap, (int)memo_intra, (int)memo_inter);
+                           (const double*)v_table, memo_nd, memo_cap, (int)memo_intra, (int)memo_inter, over_rows, n_over, over_cap);
         FHX_HIP(hipGetLastError());
+        unsigned long long h_over = 0;
+        FHX_HIP(hipMemcpyAsync(&h_over, n_over, sizeof(h_over), hipMemcpyDeviceToHost, ctx->stream));
         FHX_HIP(hipStreamSynchronize(ctx->stream));
-        dev_free(v_loc1);
-        dev_free(v_loc2);
-        dev_free(v_count);
-        dev_free(v_table);
+        if (h_over > 0) {
+            const bool listed = h_over <= over_cap;
+            const int64_t work = listed ? (int64_t)h_over : ctx->n_rows;
+            hipLaunchKernelGGL(k2_memo_overflow, dim3(grid_for(work, 256, 256 * 16)), dim3(256), 0, ctx->stream, P_rows,
+                               (const unsigned int*)over_rows, (int64_t)h_over, listed ? 1 : 0);
+            FHX_HIP(hipGetLastError());
+            FHX_HIP(hipStreamSynchronize(ctx->stream));
+        }
     }
     FHX_HIP(hipGetLastError());
     FHX_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
