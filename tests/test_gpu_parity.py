@@ -344,3 +344,15 @@ def test_mirror_benjamini_hochberg_signature():
     g = np.load(os.path.join(GOLDEN, "f5_bh.npz"))
     assert isinstance(q, list) and bits_equal(np.array(q), g["tiny_q"])
     F.reset_session()
+
+
+def test_ctypes_only_example_runs_and_matches_the_package(tmp_path):
+    """examples/ctypes_minimal.py drives the C ABI with bare ctypes (the binding INTEGRATION.md describes); its p-values
+    are what the package computes on the same rows."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ctypes_minimal", os.path.join(os.path.dirname(GOLDEN), "..", "examples", "ctypes_minimal.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    p, q = mod.main()
+    assert len(p) > 10000 and np.nanmin(p) < 1e-3 and np.all((q[~np.isnan(q)] >= 0) & (q[~np.isnan(q)] <= 1))
+    assert np.all(q[~np.isnan(q)] >= p[~np.isnan(q)] - 1e-18)
