@@ -135,3 +135,11 @@ def test_visual_plots_write_the_reference_figures(tmp_path):
     for name in ("lib.spline_pass1.png", "lib.spline_pass1.qplot.png", "lib.spline_FDR_comparison.png", "lib.spline_comparison.png"):
         f = tmp_path / name
         assert f.exists() and f.read_bytes()[:8] == b"\x89PNG\r\n\x1a\n" and f.stat().st_size > 2000
+
+
+def test_header_is_plain_c():
+    """include/fithic_mi355x.h must be consumable from C (cgo / JNI / FFI bindings read it): C99, pedantic, no warnings."""
+    import subprocess
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fithic_mi355x.h")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
