@@ -211,7 +211,11 @@ def main():
             "whole_pass_hbm_frac": (ALGO_BYTES_K1 + ALGO_BYTES_K2 + ALGO_BYTES_K3) * value / (world * HBM_PEAK_GBS * 1e9),
         }
         if sample_cols:
-            result["cpu_baseline"] = cpu_baseline(genome, sample_cols, res, L, U)
+            try:
+                result["cpu_baseline"] = cpu_baseline(genome, sample_cols, res, L, U)
+            except Exception as e:                           # the GPU line must not be lost to a problem of the CPU leg
+                log("cpu_baseline failed: %r" % (e,))
+                result["cpu_baseline"] = {"value": None, "unit": "contact-pairs/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
     if comm:
         comm.barrier()
     if rank == 0:
