@@ -118,7 +118,7 @@ def main():
         eng.load_bias(*genome.bias_table())
     eng.load_contacts_device([t.data_ptr() for t in cols], n_local)
     sample_cols = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # the CPU leg runs at N = 1 only
         # bounded sample for the CPU oracle: whole chromosomes, smallest first, up to ~3e7 rows (10-15 s of one core)
         by_size = sorted(range(len(mine)), key=lambda j: parts[j][0].numel())
         sample_idx, rows = [], 0
