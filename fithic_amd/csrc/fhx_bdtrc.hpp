@@ -312,6 +312,184 @@ __device__ __forceinline__ double contfrac_lazy(double a, double b, double x) {
     return contfrac_lazy_impl<KIND, 0>(a, b, arg);
 }
 
+// ---- swapped incbcf with WAVE-UNIFORM iteration constants --------------------------------------------------------
+// In the swapped orientation (the "observed < expected" rows: 20 % of the rows and > 90 % of all iterations on Hi-C data)
+// a = n - count + 1 and b = count, so every k1..k8 of incbcf, both denominators D_2i = k3*k4, D_2i+1 = k7*k8 and their
+// reciprocals depend on (n, count) ONLY - never on the row's prior.  When all 64 lanes of a wave hold rows of one
+// (binomial, count), those values come from a table row per iteration (built once per pass by k2h_tables with the
+// same fp64 statements Cephes uses) through scalar loads into SGPR operands, and the lanes execute only what depends
+// on their own x = 1 - prior: 2 products + 3-instruction division + 4 recurrence instructions per half step.
+//
+// Two more statements of Cephes' loop disappear without changing a result bit:
+//   * the big/biginv rescaling multiplies all four recurrence values by 2^-52 or 2^52.  A power-of-two scaling of
+//     (pkm2, pkm1, qkm2, qkm1) commutes with every rounding of the recurrence (no overflow, no subnormals), the value
+//     r = pk/qk and the convergence test are scale-free, so ANY rescaling schedule that keeps the values in range gives
+//     the same bits as Cephes' data-dependent one.  Here every lane renormalises at the same iterations (every 8th, by
+//     the exponent of the largest of its four values): no per-lane exec masking in the loop.
+//     Range proof: x < 1, b <= a  =>  |xk| <= 2 in the first half step and <= 1 in the second, so the largest value grows
+//     by at most 4x per iteration: from <= 2 after a renormalisation to <= 2^17 before the next, products <= 2^34.
+//     Smallness is checked where it matters (below).
+//   * the lazy convergence test of contfrac_lazy_impl (cross-multiplication instead of two divisions) needs Cephes'
+//     previous r = ans.  In the common case that is the pair (pkm1, qkm1) the iteration started with - still live for
+//     the second half step - so no register copy is kept for it.
+// Lanes with unusual inputs or states (b > a, x outside (0, 1), pk or qk zero or tiny, r == 0) are reported through
+// `irregular` and the caller evaluates them with contfrac_lazy (the per-lane loop above).
+struct CfRow {          // one iteration's constants, 64 bytes = one scalar-cache line
+    double k1, k2, k5, k6, d0, y0, d1, y1;
+};
+constexpr int kCfIters = 300;
+
+typedef const CfRow __attribute__((address_space(4))) * CfRowConstPtr;      // constant address space: s_load
+
+__device__ __forceinline__ CfRow cf_load_row(CfRowConstPtr p) {             // eight adjacent scalar loads = one s_load_dwordx16
+    CfRow r;
+    r.k1 = p->k1; r.k2 = p->k2; r.k5 = p->k5; r.k6 = p->k6;
+    r.d0 = p->d0; r.y0 = p->y0; r.d1 = p->d1; r.y1 = p->y1;
+    return r;
+}
+
+// table of one (n_total, count): the values Cephes' loop would hold at iteration i, and lean_div's reciprocals
+__device__ __forceinline__ void cf_swapped_build_rows(double n_total, int count, CfRow* rows) {
+    const double fk = (double)count - 1.0;
+    const double a = n_total - fk, b = fk + 1.0;            // swapped: a = bb, b = aa of incbet
+    double k1 = a, k2 = a + b, k3 = a, k4 = a + 1.0, k5 = 1.0, k6 = b - 1.0, k8 = a + 2.0;
+    for (int i = 0; i < kCfIters; ++i) {
+        CfRow r;
+        r.k1 = k1; r.k2 = k2; r.k5 = k5; r.k6 = k6;
+        r.d0 = k3 * k4;
+        r.d1 = k4 * k8;
+        double d = r.d0;
+        double y = __builtin_amdgcn_rcp(d);
+        double e = __builtin_fma(-d, y, 1.0);
+        y = __builtin_fma(y, e, y);
+        e = __builtin_fma(-d, y, 1.0);
+        r.y0 = __builtin_fma(y, e, y);
+        d = r.d1;
+        y = __builtin_amdgcn_rcp(d);
+        e = __builtin_fma(-d, y, 1.0);
+        y = __builtin_fma(y, e, y);
+        e = __builtin_fma(-d, y, 1.0);
+        r.y1 = __builtin_fma(y, e, y);
+        rows[i] = r;
+        k1 += 1.0; k2 += 1.0; k3 += 2.0; k4 += 2.0; k5 += 1.0; k6 += -1.0; k8 += 2.0;
+    }
+}
+
+// which rows cf_swapped_uniform may evaluate (the rest go through contfrac_lazy): the operand window of lean_div
+// (see contfrac_lazy) and the premises of the range proof above
+__device__ __forceinline__ bool cf_swapped_regular(double a, double b, double x) {
+    return x > 1e-150 && x < 1.0 && a >= 1.0 && a < 4.5e15 && b >= 1.0 && b <= a;
+}
+
+// incbcf(a, b, x) for the rows of one wave that share (a, b); `rows` must be wave-uniform.  Returns Cephes' value for the
+// lanes it leaves regular; lanes that come back irregular must be recomputed.
+struct CfState {
+    double pm, qm, p0, q0;        // pkm2, qkm2, pkm1, qkm1
+    double result;
+    // lane masks, wave-uniform (SGPR pairs): which lanes are finished (converged or given up - they keep iterating and are
+    // ignored) and which must be recomputed by the caller
+    unsigned long long done, irregular;
+};
+
+__device__ __forceinline__ bool cf_lane_bit(unsigned long long m) {
+    return (m >> (threadIdx.x & 63)) & 1ull;
+}
+
+__device__ __forceinline__ void cf_swapped_step(CfState& S, const CfRow c, double arg) {
+    // xk = -(x*k1*k2)/(k3*k4): lean_div with the tabulated reciprocal
+    double n = arg * c.k1 * c.k2;
+    double t0 = n * c.y0;
+    double r0 = __builtin_fma(-c.d0, t0, n);
+    double xk = __builtin_fma(r0, c.y0, t0);
+    const double p1 = S.p0 - S.pm * xk;
+    const double q1 = S.q0 - S.qm * xk;
+    // xk = (x*k5*k6)/(k7*k8)
+    n = arg * c.k5 * c.k6;
+    t0 = n * c.y1;
+    r0 = __builtin_fma(-c.d1, t0, n);
+    xk = __builtin_fma(r0, c.y1, t0);
+    const double p2 = p1 + S.p0 * xk;
+    const double q2 = q1 + S.q0 * xk;
+    // Lazy convergence test.  Cephes' ans is the r of the previous iteration, fl(pk/qk) of the pair this iteration started
+    // with (1.0 = 1/1 before the first) - for every lane that is still regular, because those never met qk == 0 or r == 0.
+    const double c1 = S.p0 * q2;
+    const double c2 = p2 * S.q0;
+    // certainly t > 1e-13 - 5e-16 > thresh (see contfrac_lazy_impl) - provided neither product lost bits to underflow and
+    // pk, qk are not zero: with |p0|, |q0| <= 2^17 both follow from |c1|, |c2| > 2^-600
+    const unsigned long long differ = __builtin_amdgcn_ballot_w64(fabs(c1 - c2) > 1e-13 * fabs(c2)) &
+                                      __builtin_amdgcn_ballot_w64(fmin(fabs(c1), fabs(c2)) > 0x1p-600);
+    const unsigned long long exact = ~(differ | S.done);
+    if (__builtin_expect(exact != 0ull, 0)) {                           // wave-uniform branch; Cephes' statements, literally
+        const bool mine = cf_lane_bit(exact);
+        const bool window = fabs(S.p0) > 0x1p-300 && fabs(S.q0) > 0x1p-300 && fabs(p2) > 0x1p-300 && fabs(q2) > 0x1p-300;
+        const bool go = mine && window;
+        const double ans = go ? S.p0 / S.q0 : 1.0;                      // the pending quotient
+        const double r = go ? p2 / q2 : 1.0;                            // != 0 inside the window
+        const double t = fabs((ans - r) / r);
+        const unsigned long long fin = __builtin_amdgcn_ballot_w64(go && t < 3.0 * kMachEp);
+        const unsigned long long bad = __builtin_amdgcn_ballot_w64(mine && !window);
+        if (cf_lane_bit(fin)) S.result = r;
+        S.done |= fin | bad;
+        S.irregular |= bad;
+    }
+    S.pm = p1; S.qm = q1; S.p0 = p2; S.q0 = q2;
+}
+
+__device__ __forceinline__ void cf_swapped_renorm(CfState& S) {      // same iterations for every lane: no exec masking
+    const double big = fmax(fmax(fabs(S.pm), fabs(S.p0)), fmax(fabs(S.qm), fabs(S.q0)));
+    const int e = -__builtin_amdgcn_frexp_exp(big);
+    S.pm = __builtin_amdgcn_ldexp(S.pm, e);
+    S.p0 = __builtin_amdgcn_ldexp(S.p0, e);
+    S.qm = __builtin_amdgcn_ldexp(S.qm, e);
+    S.q0 = __builtin_amdgcn_ldexp(S.q0, e);
+}
+
+// incbcf(a, b, x) for the rows of one wave that share (a, b); `rows` must be wave-uniform.  Returns Cephes' value for the
+// lanes it leaves regular; lanes that come back irregular must be recomputed.
+__device__ __forceinline__ double cf_swapped_uniform(CfRowConstPtr rows, double arg, bool& irregular) {
+    CfState S;
+    S.pm = 0.0; S.qm = 1.0; S.p0 = 1.0; S.q0 = 1.0;
+    S.result = 1.0;
+    S.irregular = __builtin_amdgcn_ballot_w64(irregular);
+    S.done = S.irregular;
+    static_assert(kCfIters % 8 == 4, "blocks of 8 iterations, then one of 4");
+    int i = 0;
+#pragma unroll 1
+    for (; i + 8 <= kCfIters; i += 8) {
+        // every iteration's constants are requested one iteration ahead (scalar loads into SGPR operands)
+        const CfRow c0 = cf_load_row(rows + i), c1 = cf_load_row(rows + i + 1);
+        cf_swapped_step(S, c0, arg);
+        const CfRow c2 = cf_load_row(rows + i + 2);
+        cf_swapped_step(S, c1, arg);
+        const CfRow c3 = cf_load_row(rows + i + 3);
+        cf_swapped_step(S, c2, arg);
+        const CfRow c4 = cf_load_row(rows + i + 4);
+        cf_swapped_step(S, c3, arg);
+        const CfRow c5 = cf_load_row(rows + i + 5);
+        cf_swapped_step(S, c4, arg);
+        const CfRow c6 = cf_load_row(rows + i + 6);
+        cf_swapped_step(S, c5, arg);
+        const CfRow c7 = cf_load_row(rows + i + 7);
+        cf_swapped_step(S, c6, arg);
+        cf_swapped_step(S, c7, arg);
+        cf_swapped_renorm(S);
+        if (S.done == ~0ull) break;
+    }
+    if (i + 8 > kCfIters) {
+        const CfRow c0 = cf_load_row(rows + i), c1 = cf_load_row(rows + i + 1);
+        cf_swapped_step(S, c0, arg);
+        const CfRow c2 = cf_load_row(rows + i + 2);
+        cf_swapped_step(S, c1, arg);
+        const CfRow c3 = cf_load_row(rows + i + 3);
+        cf_swapped_step(S, c2, arg);
+        cf_swapped_step(S, c3, arg);
+    }
+    irregular = cf_lane_bit(S.irregular);
+    // the loop ran to the cap: Cephes returns the last r = pk/qk
+    if (!cf_lane_bit(S.done)) S.result = S.p0 / S.q0;
+    return S.result;
+}
+
 // branch classes of one incbet evaluation (used to run branch-homogeneous waves)
 enum BranchClass : int {
     BC_TRIVIAL = 0,        // NaN / 0 / 1 / closed form k == 0: no loop at all

@@ -504,6 +504,153 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
     }
 }
 
+// ---- the 300-iteration class in count-homogeneous waves -----------------------------------------------------------
+// The swapped-continued-fraction queue is counting-sorted by (binomial, contact count) so that every wave of k2h_heavy
+// holds 64 rows of ONE count: all per-iteration constants of Cephes' loop then come from a table row per iteration
+// through scalar loads (cf_swapped_uniform, fhx_bdtrc.hpp).  Bucket = count for intra rows, K2H_KCAP + count for
+// rows of the inter-chromosomal binomial, one last bucket for counts >= K2H_KCAP (evaluated by the per-lane k2_queue
+// kernel).  Every bucket starts at a multiple of 64 entries in the sorted queue, so a wave never straddles two counts.
+constexpr int K2H_KCAP = 1023;
+constexpr int K2H_GENERIC = 2 * K2H_KCAP;               // 2046
+constexpr int K2H_BUCKETS = 2048;                       // == RADIX: the radix sort's count matrix and scan are reused
+constexpr int K2H_BLOCKS = 1024;                        // == SORT_BLOCKS
+constexpr int K2H_THREADS = 256;
+
+__device__ __forceinline__ int k2h_bucket(int signed_count) {
+    const bool inter = signed_count < 0;
+    const int c = inter ? -signed_count : signed_count;
+    return c < K2H_KCAP ? (inter ? K2H_KCAP + c : c) : K2H_GENERIC;
+}
+
+__device__ __forceinline__ void k2h_chunk(int64_t n, int64_t& beg, int64_t& end) {
+    const int64_t chunk = ((n + K2H_BLOCKS - 1) / K2H_BLOCKS + 1023) / 1024 * 1024;
+    beg = (int64_t)blockIdx.x * chunk;
+    end = min(n, beg + chunk);
+}
+
+// per-workgroup bucket counts of its contiguous chunk of the queue (digit-major matrix, as rs_count writes it)
+__global__ __launch_bounds__(K2H_THREADS) void k2h_count(const QEntry* __restrict__ q, const unsigned long long* __restrict__ n_ptr,
+                                                         unsigned int* __restrict__ block_hist) {
+    __shared__ unsigned int h[K2H_BUCKETS];
+    for (int d = threadIdx.x; d < K2H_BUCKETS; d += K2H_THREADS) h[d] = 0;
+    __syncthreads();
+    int64_t beg, end;
+    k2h_chunk((int64_t)*n_ptr, beg, end);
+    for (int64_t i = beg + threadIdx.x; i < end; i += K2H_THREADS) atomicAdd(&h[k2h_bucket(q[i].count)], 1u);
+    __syncthreads();
+    for (int d = threadIdx.x; d < K2H_BUCKETS; d += K2H_THREADS) block_hist[(size_t)d * K2H_BLOCKS + blockIdx.x] = h[d];
+}
+
+// bucket starts, each rounded up to a multiple of 64 entries: off[b] for b = 0..K2H_BUCKETS (the last one = padded total)
+__global__ __launch_bounds__(1024) void k2h_offsets(const unsigned int* __restrict__ digit_total, unsigned int* __restrict__ off) {
+    __shared__ unsigned int part[1024];
+    const unsigned int a = (digit_total[2 * threadIdx.x] + 63u) & ~63u, b = (digit_total[2 * threadIdx.x + 1] + 63u) & ~63u;
+    part[threadIdx.x] = a + b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int acc = 0;
+        for (int i = 0; i < 1024; ++i) {
+            const unsigned int c = part[i];
+            part[i] = acc;
+            acc += c;
+        }
+        off[K2H_BUCKETS] = acc;
+    }
+    __syncthreads();
+    off[2 * threadIdx.x] = part[threadIdx.x];
+    off[2 * threadIdx.x + 1] = part[threadIdx.x] + a;
+}
+
+__global__ __launch_bounds__(K2H_THREADS) void k2h_scatter(const QEntry* __restrict__ q, const unsigned long long* __restrict__ n_ptr,
+                                                           const unsigned int* __restrict__ block_hist,
+                                                           const unsigned int* __restrict__ off, QEntry* __restrict__ out) {
+    __shared__ unsigned int cursor[K2H_BUCKETS];
+    for (int d = threadIdx.x; d < K2H_BUCKETS; d += K2H_THREADS) cursor[d] = off[d] + block_hist[(size_t)d * K2H_BLOCKS + blockIdx.x];
+    __syncthreads();
+    int64_t beg, end;
+    k2h_chunk((int64_t)*n_ptr, beg, end);
+    for (int64_t i = beg + threadIdx.x; i < end; i += K2H_THREADS) {
+        const QEntry e = q[i];
+        out[atomicAdd(&cursor[k2h_bucket(e.count)], 1u)] = e;       // order inside a bucket is free: results go to p[row]
+    }
+}
+
+// one thread per non-empty (binomial, count) bucket: the 300 rows of iteration constants
+__global__ __launch_bounds__(64) void k2h_tables(const unsigned int* __restrict__ digit_total, double n_intra, double n_inter,
+                                                 dev::CfRow* __restrict__ tab) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= K2H_GENERIC || digit_total[b] == 0) return;
+    const bool inter = b >= K2H_KCAP;
+    dev::cf_swapped_build_rows(inter ? n_inter : n_intra, inter ? b - K2H_KCAP : b, tab + (size_t)b * dev::kCfIters);
+}
+
+// Lanes cf_swapped_uniform cannot take (unusual inputs or states, see fhx_bdtrc.hpp) are appended to `redo` - the space the
+// unsorted queue occupied, free once k2h_scatter has run - and k2h_generic evaluates them with the per-lane loop; keeping that
+// loop out of this kernel keeps it at 8 waves per SIMD (38 VGPRs instead of 102).
+__global__ __launch_bounds__(K2H_THREADS) void k2h_heavy(
+    K2Params P, const QEntry* __restrict__ sorted, const unsigned int* __restrict__ off,
+    const unsigned int* __restrict__ digit_total, const dev::CfRow* __restrict__ tab, QEntry* __restrict__ redo,
+    unsigned long long* __restrict__ n_redo) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const unsigned int n_tasks = off[K2H_GENERIC] >> 6;          // 64-entry tasks in front of the generic bucket
+    const unsigned int stride = gridDim.x * (K2H_THREADS / 64);
+    for (unsigned int task = blockIdx.x * (K2H_THREADS / 64) + wave; task < n_tasks; task += stride) {
+        const unsigned int first = task << 6;
+        // bucket of this task: the last b with off[b] <= first (empty buckets share their successor's start: skip them)
+        int lo = 0, hi = K2H_GENERIC;                             // invariant: off[lo] <= first < off[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (off[mid] <= first)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const int b = __builtin_amdgcn_readfirstlane(lo);
+        const unsigned int live = off[b] + digit_total[b];        // entries of the bucket end here, padding follows
+        const bool have = first + lane < live;
+        QEntry e;
+        e.row = 0u;
+        e.count = b >= K2H_KCAP ? -(b - K2H_KCAP) : b;
+        e.prior = 0.5;
+        if (have) e = sorted[first + lane];
+        const bool is_inter = b >= K2H_KCAP;
+        const int c = is_inter ? b - K2H_KCAP : b;
+        const dev::BinomTables& T = is_inter ? P.inter : P.intra;
+        // bdtrc_count_class<BC_CF_SWAPPED>: incbet_finish(bb, aa, 1 - xx, xx, incbcf(bb, aa, 1 - xx), flag = 1, ...)
+        const double fk = (double)c - 1.0;
+        const double aa = fk + 1.0, bb = T.n - fk, xx = e.prior;
+        const double w1 = 1.0 - xx;
+        bool irregular = !have || !dev::cf_swapped_regular(bb, aa, w1);
+        const dev::CfRowConstPtr rows = (dev::CfRowConstPtr)(uintptr_t)(tab + (size_t)b * dev::kCfIters);
+        const double cf = dev::cf_swapped_uniform(rows, w1, irregular);      // every lane of the wave takes part
+        if (have) {
+            if (__builtin_expect(irregular, 0))
+                redo[atomicAdd(n_redo, 1ull)] = e;
+            else
+                P.p[e.row] = dev::incbet_finish(bb, aa, w1, xx, cf, 1, T.lbeta[c], T.small_n ? T.inv_beta[c] : 0.0);
+        }
+    }
+}
+
+// counts >= K2H_KCAP (the last bucket) and the rows k2h_heavy handed back: per-lane evaluation, the k2_queue<BC_CF_SWAPPED> body
+__global__ __launch_bounds__(K2_THREADS) void k2h_generic(K2Params P, const QEntry* __restrict__ sorted,
+                                                          const unsigned int* __restrict__ off,
+                                                          const unsigned int* __restrict__ digit_total,
+                                                          const QEntry* __restrict__ redo,
+                                                          const unsigned long long* __restrict__ n_redo) {
+    const QEntry* base = sorted + off[K2H_GENERIC];
+    const int64_t n_generic = (int64_t)digit_total[K2H_GENERIC];
+    const int64_t n = n_generic + (int64_t)*n_redo;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const QEntry e = j < n_generic ? base[j] : redo[j - n_generic];
+        const bool is_inter = e.count < 0;
+        const int c = is_inter ? -e.count : e.count;
+        P.p[e.row] = dev::bdtrc_count_class<dev::BC_CF_SWAPPED>(c, is_inter ? P.inter : P.intra, e.prior);
+    }
+}
+
 // outlier flags (p < 1/N, fithic.py:1215) are derived from p when somebody asks: K2 never writes per-row bytes
 __global__ void k_outlier_flags(const double* __restrict__ p, double thres, int64_t n, uint8_t* __restrict__ flags) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1467,6 +1614,9 @@ struct fhx_ctx {
     unsigned int* d_digit_total = nullptr;
     unsigned long long* d_top_hist = nullptr;
     QEntry* d_queue[2] = {nullptr, nullptr};          // K2's per-class row queues
+    QEntry* d_queue_sorted = nullptr;                 // the 300-iteration class, bucketed by (binomial, count), 64-aligned buckets
+    dev::CfRow* d_cf_tab = nullptr;                   // K2H_GENERIC x 300 rows of iteration constants
+    unsigned int* d_k2h_off = nullptr;                // K2H_BUCKETS + 1 bucket starts
     unsigned char* d_memo = nullptr;                  // no-bias table path: virtual rows, table, overflow list (kept across passes)
     size_t memo_bytes = 0;
     // non-fixed-size mode (-r 0)
@@ -1865,6 +2015,10 @@ int alloc_row_arrays(fhx_ctx* ctx, int64_t n, int64_t n_dist) {
         dev_free(ctx->d_queue[b]);
         FHX_HIP(hipMalloc(&ctx->d_queue[b], cap * sizeof(QEntry)));
     }
+    dev_free(ctx->d_queue_sorted);
+    FHX_HIP(hipMalloc(&ctx->d_queue_sorted, (cap + (size_t)K2H_BUCKETS * 64) * sizeof(QEntry)));
+    if (!ctx->d_cf_tab) FHX_HIP(hipMalloc(&ctx->d_cf_tab, (size_t)K2H_GENERIC * dev::kCfIters * sizeof(dev::CfRow)));
+    if (!ctx->d_k2h_off) FHX_HIP(hipMalloc(&ctx->d_k2h_off, (K2H_BUCKETS + 1) * sizeof(unsigned int)));
     dev_free(ctx->d_tile_max);
     FHX_HIP(hipMalloc(&ctx->d_tile_max, ((size_t)n / BH_TILE + 2) * sizeof(double)));
     FHX_HIP(hipStreamSynchronize(ctx->stream));
@@ -1949,6 +2103,9 @@ void fhx_destroy(fhx_ctx* ctx) {
         dev_free(ctx->d_top_hist);
         dev_free(ctx->d_queue[0]);
         dev_free(ctx->d_queue[1]);
+        dev_free(ctx->d_queue_sorted);
+        dev_free(ctx->d_cf_tab);
+        dev_free(ctx->d_k2h_off);
         dev_free(ctx->d_memo);
         dev_free(ctx->d_slot_mid);
         dev_free(ctx->d_table_x);
@@ -2395,9 +2552,33 @@ int fhx_pvalues(fhx_ctx* ctx) {
 #define FHX_LAUNCH_QUEUE(CLS)                                                                                          \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue<CLS>), qgrid, qblock, 0, ctx->stream, P, (const QEntry*)Q.base[(CLS) - 1], \
                        Q.dir[(CLS) - 1], (const unsigned long long*)(Q.count + ((CLS) - 1) * K2_COUNT_STRIDE))
-    FHX_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
-    FHX_LAUNCH_QUEUE(dev::BC_CF_SWAPPED);            // longest-running class first
-    FHX_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
+    const bool legacy_heavy = getenv("FHX_K2_LEGACY") != nullptr;      // A/B and tests: the per-lane kernel of round 1
+    if (legacy_heavy) {
+        FHX_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
+        FHX_LAUNCH_QUEUE(dev::BC_CF_SWAPPED);            // longest-running class first
+        FHX_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
+    } else {
+        static_assert(K2H_BUCKETS == RADIX && K2H_BLOCKS == SORT_BLOCKS, "the radix sort's count matrix and scan are reused");
+        QEntry* hq = Q.base[dev::BC_CF_SWAPPED - 1];
+        const unsigned long long* hn = Q.count + (dev::BC_CF_SWAPPED - 1) * K2_COUNT_STRIDE;
+        unsigned long long* n_redo = ctx->d_misc + 11;
+        FHX_HIP(hipMemsetAsync(n_redo, 0, sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(k2h_count, dim3(K2H_BLOCKS), dim3(K2H_THREADS), 0, ctx->stream, (const QEntry*)hq, hn, ctx->d_block_hist);
+        hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3(SORT_BLOCKS), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total);
+        hipLaunchKernelGGL(k2h_offsets, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned int*)ctx->d_digit_total, ctx->d_k2h_off);
+        hipLaunchKernelGGL(k2h_tables, dim3((K2H_GENERIC + 63) / 64), dim3(64), 0, ctx->stream, (const unsigned int*)ctx->d_digit_total,
+                           P.intra.n, P.inter.n, ctx->d_cf_tab);
+        hipLaunchKernelGGL(k2h_scatter, dim3(K2H_BLOCKS), dim3(K2H_THREADS), 0, ctx->stream, (const QEntry*)hq, hn,
+                           (const unsigned int*)ctx->d_block_hist, (const unsigned int*)ctx->d_k2h_off, ctx->d_queue_sorted);
+        FHX_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
+        hipLaunchKernelGGL(k2h_heavy, dim3(256 * 8), dim3(K2H_THREADS), 0, ctx->stream, P, (const QEntry*)ctx->d_queue_sorted,
+                           (const unsigned int*)ctx->d_k2h_off, (const unsigned int*)ctx->d_digit_total, (const dev::CfRow*)ctx->d_cf_tab,
+                           hq, n_redo);
+        FHX_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
+        hipLaunchKernelGGL(k2h_generic, dim3(256 * 4), dim3(K2_THREADS), 0, ctx->stream, P, (const QEntry*)ctx->d_queue_sorted,
+                           (const unsigned int*)ctx->d_k2h_off, (const unsigned int*)ctx->d_digit_total, (const QEntry*)hq,
+                           (const unsigned long long*)n_redo);
+    }
 #define FHX_LAUNCH_QUEUE_BY_COUNT(CLS)                                                                                 \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue_by_count<CLS>), qgrid, qblock, 0, ctx->stream, P, (const QEntry*)Q.base[(CLS) - 1], \
                        Q.dir[(CLS) - 1], (const unsigned long long*)(Q.count + ((CLS) - 1) * K2_COUNT_STRIDE))

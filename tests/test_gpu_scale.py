@@ -186,3 +186,52 @@ def test_no_bias_table_path_equals_per_row_evaluation(monkeypatch):
             same = (a[key].view(np.int64) == b[key].view(np.int64)) | (np.isnan(a[key]) & np.isnan(b[key]))
             assert same.all(), key
     assert np.nanmin(out["table"][0]["p"]) < 1e-6
+
+
+def test_count_homogeneous_waves_equal_the_per_lane_kernel(monkeypatch):
+    """The 300-iteration class runs in waves of one (binomial, count) with table-fed iteration constants and a uniform
+    renormalisation schedule (k2h_heavy / cf_swapped_uniform); FHX_K2_LEGACY=1 selects round 1's per-lane kernel, which is
+    itself bit-exact against the oracle's Cephes.  Both must give the same bits: intra + inter binomials, counts beyond the
+    table cap (generic bucket), 2 passes (different totals)."""
+    import torch
+    from fithic_amd import synth
+    from fithic_amd.engine import Engine
+    res = 5000
+    genome = synth.Genome(res, lengths=synth.HG19_AUTOSOMES[19:22])
+    amp = synth.solve_amplitude(0.66, 4, 400)
+    dev = torch.device("cuda", 0)
+    parts = [synth.cis_contacts(genome, c, 4, 400, amp, device=dev) for c in range(3)]
+    cols = [torch.cat([p[k] for p in parts]).cpu().numpy() for k in range(5)]
+    rng = np.random.default_rng(11)
+    n = len(cols[0])
+    cols[4][rng.integers(0, n, 300)] = rng.integers(1000, 5000, 300)            # around and beyond K2H_KCAP = 1023
+    m = 200000                                                                   # inter-chromosomal rows: the second binomial
+    c1 = rng.integers(0, 3, m)
+    c2 = (c1 + rng.integers(1, 3, m)) % 3
+    nl = np.array(genome.n_loci)
+    inter = [c1, rng.integers(0, nl[c1]) * res + res // 2, c2, rng.integers(0, nl[c2]) * res + res // 2, 1 + rng.poisson(0.7, m)]
+    cols = [np.concatenate([a, b]).astype(np.int32) for a, b in zip(cols, inter)]
+    out = {}
+    for tag in ("uniform", "legacy"):
+        if tag == "legacy":
+            monkeypatch.setenv("FHX_K2_LEGACY", "1")
+        else:
+            monkeypatch.delenv("FHX_K2_LEGACY", raising=False)
+        eng = Engine(0)
+        eng.configure(res, 20000, 2000000, n_bins=100, mapp_thres=1, mode="All")
+        eng.load_fragments(*genome.fragments(), genome.sort_rank())
+        eng.load_bias(*genome.bias_table())
+        eng.load_contacts(*cols)
+        res_passes = []
+        for _ in range(2):
+            eng.run_pass(collect=False)
+            res_passes.append(eng.fetch())
+            _, heavy_rows = eng.ctx.k2_heavy_launch()
+            assert heavy_rows > n // 20                                          # the class under test is populated
+            eng.next_pass()
+        out[tag] = res_passes
+        eng.close()
+    for a, b in zip(out["uniform"], out["legacy"]):
+        for key in ("p", "q"):
+            same = (a[key].view(np.int64) == b[key].view(np.int64)) | (np.isnan(a[key]) & np.isnan(b[key]))
+            assert same.all(), (key, int((~same).sum()), float(np.nanmax(np.abs(a[key] - b[key]))))
