@@ -1,19 +1,25 @@
 #!/usr/bin/env python3
 """bench.py - contact-pairs/sec through one full spline pass (K1 classify+histogram -> host fit -> K2 p-values ->
-K3 Benjamini-Hochberg) on synthetic 5 kb human cis contacts, with the inputs resident in HBM.
+K3 Benjamini-Hochberg) on synthetic human contacts, with the inputs resident in HBM.
 
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-One JSON line on stdout (rank 0) with the driver's contract fields plus `roofline` (dominant kernel K2, HIP-event
-timed) and `cpu_baseline` (the oracle timed on this box's host cores on a bounded sample of the same rows).
+One JSON line on stdout (rank 0) with the driver's contract fields plus `roofline` (dominant kernel, HIP-event timed),
+`cpu_baseline` (the oracle timed on this box's host cores on a bounded sample of the same rows, N = 1 only) and
+`parity_check` (N = 1: the p-values of that sample recomputed by the oracle's Cephes from the ENGINE's own fit table, and
+q of EVERY row against the oracle's Benjamini-Hochberg of the engine's p - the run that is timed is the run that is checked).
 
-Workload (BASELINE.json configs[2], "C3"): 22 hg19 autosomes at 5 kb (576 216 loci), -L 20000 -U 2000000 (397
-distance values), ~1.5e8 observed cis pairs, ICE-like bias table, -b 100, 1 pass, intraOnly.  With N GPUs the default
-is weak scaling: the genome is replicated N times (chr1..chr22, chr1_r1.., N x 22 chromosomes), chromosomes are
-sharded over the ranks by size, the distance histogram is all-reduced and the BH ranking is global over all N x 1.5e8
-p-values (RCCL).  `--strong` keeps the single 22-chromosome genome and shards it instead (BASELINE configs[3]).
+Workloads (`--config`, BASELINE.json configs):
+  C3 (default, the configuration the metric is quoted on): 22 hg19 autosomes at 5 kb (576 216 loci), -L 20000 -U 2000000
+      (397 distance values), ~1.5e8 observed cis pairs, ICE-like bias table, -b 100, 1 pass, intraOnly.
+  C2: one chromosome of 249 250 621 bp at 40 kb, no distance bounds, ~1e7 pairs, bias, -b 100, 2 passes (a step = both).
+  C5: 22 autosomes at 1 kb (2 881 044 loci), -L 2000 -U 2000000, ~1.9e9 cis + 1e8 trans pairs, -x All, 1 pass
+      (`--max-chroms k` takes the first k chromosomes; the trans rows scale with the loci).
+With N > 1 GPUs the headline is STRONG scaling (BASELINE configs[3]: the one genome sharded by chromosome over the ranks,
+distance histogram all-reduced, BH ranking global over RCCL); the weak-scaling figure (genome replicated N times, N x the
+rows) is measured afterwards and reported under `weak_scaling` (`--no-weak` skips it, `--weak` makes it the headline).
 """
 import argparse
 import json
@@ -27,10 +33,67 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES_K1, ALGO_BYTES_K2, ALGO_BYTES_K3 = 12, 20, 16          # per pair, SURVEY.md 8d (48 B in total)
 HBM_PEAK_GBS = 8000.0                                              # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6
+HEAVY_FP64_INSTR_PER_ITER = 23.0                                   # ISA count of cf_swapped_step's hot path (fhx_bdtrc.hpp)
+
+CONFIGS = {
+    "C2": dict(res=40000, lengths=[249250621], L=0, U=float("inf"), lo=0, hi=None, amp_lo=1, keep=0.52, passes=2,
+               mode="intraOnly", trans_per_locus=0.0),
+    "C3": dict(res=5000, lengths=None, L=20000, U=2000000, lo=4, hi=400, amp_lo=4, keep=0.66, passes=1, mode="intraOnly",
+               trans_per_locus=0.0),
+    "C5": dict(res=1000, lengths=None, L=2000, U=2000000, lo=2, hi=2000, amp_lo=2, keep=0.33, passes=1, mode="All",
+               trans_per_locus=1.0e8 / 2881044),
+}
+# reference / restatement calibration (BASELINE.md sections 2 and 4.1), bundled hESC chr1 40 kb set, 778 363 rows, 1 core
+CALIBRATION = {"reference_rows_per_s": 25.9e3, "reference_fit_spline_only_rows_per_s": 47e3, "port_rows_per_s": 1.42e6,
+               "input": "bundled Dixon hESC chr1 40 kb, 778 363 rows, -L 50000 -U 5000000 -b 50, 1 pass",
+               "measured_in": "build container (reference = whole fithic.py CLI incl. text I/O; port = oracle on arrays in memory)"}
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def build_rows(synth, torch, cfg, genome, mine, rank, world, device, overdispersion=0.0):
+    """This rank's contact rows as five int32 device columns (one allocation per column, filled chromosome by chromosome)."""
+    n_chr = len(genome)
+    hi = cfg["hi"]
+    amp = synth.solve_amplitude(cfg["keep"], cfg["amp_lo"], hi if hi is not None else genome.n_loci[0] - 1)
+    n_trans = int(round(cfg["trans_per_locus"] * sum(genome.n_loci))) if n_chr > 1 else 0
+    t0, t1 = (n_trans * rank) // world, (n_trans * (rank + 1)) // world
+    est = 0
+    for c in mine:
+        h = min(hi if hi is not None else genome.n_loci[c] - 1, genome.n_loci[c] - 1)
+        est += int(genome.n_loci[c] * max(h - cfg["lo"] + 1, 0) * min(1.0, cfg["keep"] * 1.08)) + 1024
+    est += t1 - t0
+    cols = [torch.empty(est, dtype=torch.int32, device=device) for _ in range(5)]
+    n = 0
+    for c in mine:
+        part = synth.cis_contacts(genome, c, cfg["lo"], hi if hi is not None else genome.n_loci[c] - 1, amp, device=device,
+                                  overdispersion=overdispersion)
+        m = int(part[0].numel())
+        if n + m > est:                                       # estimate too small: grow (rare)
+            grow = [torch.empty(int((n + m) * 1.2), dtype=torch.int32, device=device) for _ in range(5)]
+            for k in range(5):
+                grow[k][:n] = cols[k][:n]
+            cols, est = grow, int((n + m) * 1.2)
+        for k in range(5):
+            cols[k][n:n + m] = part[k]
+        n += m
+        del part
+    n_cis = n
+    if t1 > t0:
+        part = synth.trans_contacts(genome, n_trans, t0, t1, device=device)
+        m = int(part[0].numel())
+        if n + m > est:
+            grow = [torch.empty(n + m, dtype=torch.int32, device=device) for _ in range(5)]
+            for k in range(5):
+                grow[k][:n] = cols[k][:n]
+            cols = grow
+        for k in range(5):
+            cols[k][n:n + m] = part[k]
+        n += m
+        del part
+    return cols, n, n_cis, n_trans
 
 
 def main():
@@ -38,13 +101,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--resolution", type=int, default=5000)
-    ap.add_argument("--keep", type=float, default=0.66, help="fraction of candidate cis pairs observed (sets the depth)")
-    ap.add_argument("--strong", action="store_true", help="shard one genome instead of replicating it per GPU")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="C3", help="workload (BASELINE.json configs); C3 is the headline")
+    ap.add_argument("--keep", type=float, default=0.0, help="fraction of candidate cis pairs observed (0 = the config's depth)")
+    ap.add_argument("--strong", action="store_true", help="N > 1: shard one genome (the default headline)")
+    ap.add_argument("--weak", action="store_true", help="N > 1: make the N-times replicated genome the headline instead")
+    ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the additional weak-scaling measurement")
     ap.add_argument("--overdispersion", type=float, default=0.0,
                     help="0 = synth-v1 (Poisson around the model); s > 0 adds lognormal rate noise: heavier small-p tail, like real maps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--max-chroms", type=int, default=0, help="debug: use only the first k chromosomes")
+    ap.add_argument("--no-parity-check", action="store_true")
+    ap.add_argument("--max-chroms", type=int, default=0, help="use only the first k chromosomes")
     ap.add_argument("--path", choices=["fithic", "kr", "cni"], default="fithic",
                     help="fithic (default): the headline pass.  kr / cni: the neighbouring steps (Knight-Ruiz bias vectors, merging of "
                          "nearby contacts) measured by profiles/kr_bench.py / profiles/cni_bench.py, plus their cpu_baseline")
@@ -88,96 +154,147 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     comm = None
+    rccl = None
     if world > 1 or os.environ.get("FHX_FORCE_DIST"):      # FHX_FORCE_DIST=1: run the RCCL path with a single rank
         import torch.distributed as td
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         td.init_process_group("nccl", device_id=device)          # nccl == RCCL on ROCm
         comm = dist.Comm(td, device)
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            ver = None
+        rccl = {"world": td.get_world_size(), "backend": td.get_backend(), "version": ver, "transport": "xGMI / RCCL via torch.distributed"}
 
-    res = args.resolution
-    L, U = 4 * res, 400 * res
-    lo_idx, hi_idx = 4, 400
-    lengths = synth.HG19_AUTOSOMES[:args.max_chroms] if args.max_chroms else None
-    replicas = args.replicas if args.replicas > 0 else (1 if (args.strong or world == 1) else world)
-    genome = synth.Genome(res, lengths, replicas=replicas)
-    amp = synth.solve_amplitude(args.keep, lo_idx, hi_idx)
-    owner = synth.assign_chromosomes(genome, world)
-    mine = [c for c in range(len(genome)) if owner[c] == rank]
+    cfg = dict(CONFIGS[args.config])
+    if args.keep > 0:
+        cfg["keep"] = args.keep
+    res, L, U = cfg["res"], cfg["L"], cfg["U"]
+    base_lengths = cfg["lengths"] if cfg["lengths"] is not None else synth.HG19_AUTOSOMES
+    if args.max_chroms:
+        base_lengths = base_lengths[:args.max_chroms]
 
-    t_gen = time.time()
-    parts = [synth.cis_contacts(genome, c, lo_idx, hi_idx, amp, device=device, overdispersion=args.overdispersion) for c in mine]
-    cols = [torch.cat([p[k] for p in parts]).contiguous() for k in range(5)]
-    n_local = int(cols[0].numel())
-    torch.cuda.synchronize()
-    log("[rank %d] generated %d rows on %d chromosomes in %.1f s" % (rank, n_local, len(mine), time.time() - t_gen))
+    def measure(replicas, with_cpu_leg):
+        """Generate, load, warm up, time `steps` steps.  Returns the result pieces of this workload."""
+        genome = synth.Genome(res, base_lengths, replicas=replicas)
+        owner = synth.assign_chromosomes(genome, world)
+        mine = [c for c in range(len(genome)) if owner[c] == rank]
+        t_gen = time.time()
+        cols, n_local, n_cis_local, n_trans = build_rows(synth, torch, cfg, genome, mine, rank, world, device, args.overdispersion)
+        torch.cuda.synchronize()
+        log("[rank %d] generated %d rows (%d cis on %d chromosomes, %d of %d trans) in %.1f s" %
+            (rank, n_local, n_cis_local, len(mine), n_local - n_cis_local, n_trans, time.time() - t_gen))
+        eng = Engine(local_rank)
+        eng.configure(res, L, U, n_bins=100, mapp_thres=1, mode=cfg["mode"])
+        eng.load_fragments(*genome.fragments(), genome.sort_rank())
+        if not args.no_bias:
+            eng.load_bias(*genome.bias_table())
+        eng.load_contacts_device([t.data_ptr() for t in cols], n_local)
+        sample = None
+        if with_cpu_leg:
+            # bounded sample for the CPU legs: whole chromosomes, smallest first, up to ~3e7 cis rows (10-15 s of one core),
+            # plus every trans row between two sampled chromosomes; a chromosome that alone exceeds the budget (1 kb loci)
+            # is cut to its first loci - rows with both ends below the cut - so that the sample is a complete small genome
+            c1 = cols[0][:n_local]
+            counts = torch.bincount(c1[:n_cis_local].to(torch.int64), minlength=len(genome)).cpu().numpy()
+            order = sorted(mine, key=lambda c: counts[c])
+            budget = 3.0e7
+            chosen, rows, cut_loci = [], 0, {}
+            for c in order:
+                if chosen and rows + counts[c] > budget:
+                    break
+                chosen.append(c)
+                rows += int(counts[c])
+            sel_chr = torch.zeros(len(genome), dtype=torch.bool, device=device)
+            sel_chr[torch.tensor(sorted(chosen), device=device)] = True
+            keep = sel_chr[cols[0][:n_local].to(torch.int64)] & sel_chr[cols[2][:n_local].to(torch.int64)]
+            if rows > 1.3 * budget:                       # one oversized chromosome: keep its first loci only
+                c = chosen[0]
+                cut = max(int(genome.n_loci[c] * budget / rows), min(genome.n_loci[c], (cfg["hi"] or 0) + 64))
+                cut_loci[c] = cut
+                keep &= (cols[1][:n_local] < cut * res) & (cols[3][:n_local] < cut * res)
+            idx = torch.nonzero(keep).squeeze(1)
+            sample = {"rows": idx.cpu().numpy(), "cols": [cols[k][:n_local][idx].cpu().numpy() for k in range(5)],
+                      "chroms": sorted(chosen), "cut_loci": cut_loci}
+            del keep, idx, sel_chr
+        del cols
+        torch.cuda.empty_cache()
 
-    eng = Engine(local_rank)
-    eng.configure(res, L, U, n_bins=100, mapp_thres=1, mode="intraOnly")
-    eng.load_fragments(*genome.fragments(), genome.sort_rank())
-    if not args.no_bias:
-        eng.load_bias(*genome.bias_table())
-    eng.load_contacts_device([t.data_ptr() for t in cols], n_local)
-    sample_cols = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # the CPU leg runs at N = 1 only
-        # bounded sample for the CPU oracle: whole chromosomes, smallest first, up to ~3e7 rows (10-15 s of one core)
-        by_size = sorted(range(len(mine)), key=lambda j: parts[j][0].numel())
-        sample_idx, rows = [], 0
-        for j in by_size:
-            if sample_idx and rows + parts[j][0].numel() > 3.0e7:
-                break
-            sample_idx.append(j)
-            rows += parts[j][0].numel()
-        sample_cols = [[parts[j][k].cpu().numpy() for k in range(5)] for j in sorted(sample_idx)]
-    del parts, cols
-    torch.cuda.empty_cache()
+        runner = dist.DistributedPass(eng, comm) if comm else None
+        passes = cfg["passes"]
+        pass_ms = np.zeros(passes)
 
-    runner = dist.DistributedPass(eng, comm) if comm else None
+        def one_step(timed=False):
+            info = None
+            for k in range(passes):
+                t_p = time.perf_counter()
+                if runner:
+                    info = (runner.run().as_dict(), runner.stats.as_dict())
+                else:
+                    out = eng.run_pass(collect=False)
+                    info = (out.info, out.stats)
+                if k + 1 < passes:
+                    (runner.next_pass if runner else eng.next_pass)()
+                if timed and passes > 1:
+                    eng.ctx.sync()
+                    pass_ms[k] += 1e3 * (time.perf_counter() - t_p)
+            if passes > 1:
+                eng.reset_passes()
+                if runner:
+                    runner.reset()
+            return info
 
-    def one_step():
+        def barrier():
+            if comm:
+                comm.barrier()
+
+        for _ in range(args.warmup):
+            one_step()
         if runner:
-            return runner.run()
-        eng.run_pass(collect=False)
-        return None
-
-    def barrier():
+            runner.timings.clear()
+        kt = np.zeros(3)
+        heavy = np.zeros(2)                                # seconds, rows of the dominant launch (the 300-iteration class)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        info = None
+        for _ in range(args.steps):
+            info = one_step(timed=True)
+            kt += np.array(eng.kernel_seconds())          # HIP events on the engine's stream (syncs it); last pass of the step
+            heavy += np.array(eng.ctx.k2_heavy_launch(), dtype=np.float64)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
         if comm:
-            comm.barrier()
+            elapsed = comm.max_float(elapsed)
+            n_total = comm.sum_int(n_local)
+        else:
+            n_total = n_local
+        stage_ms = None
+        if runner:
+            stage_ms = {k: 1e3 * v / max(args.steps * passes, 1) for k, v in runner.timings.items()}
+            if rank == 0:
+                log("[rank 0] host wall per pass of the distributed stages (ms): " + ", ".join("%s %.2f" % kv for kv in stage_ms.items()))
+        kt /= max(args.steps, 1)
+        heavy /= max(args.steps, 1)
+        mine_row = list(kt) + [float(n_local)] + list(heavy)
+        k_all = comm.gather_floats(mine_row) if comm else [mine_row]
+        return dict(genome=genome, eng=eng, sample=sample, elapsed=elapsed, n_total=n_total, n_local=n_local, k_all=k_all,
+                    stage_ms=stage_ms, pass_ms=pass_ms / max(args.steps, 1), info=info, n_trans=n_trans, replicas=replicas)
 
-    for _ in range(args.warmup):
-        one_step()
-    if runner:
-        runner.timings.clear()
-    kt = np.zeros(3)
-    heavy = np.zeros(2)                                # seconds, rows of the dominant launch (k2_queue<swapped CF>)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-        kt += np.array(eng.kernel_seconds())          # HIP events on the engine's stream (syncs it)
-        heavy += np.array(eng.ctx.k2_heavy_launch(), dtype=np.float64)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if comm:
-        elapsed = comm.max_float(elapsed)
-        n_total = comm.sum_int(n_local)
-    else:
-        n_total = n_local
-    if runner and rank == 0:
-        log("[rank 0] host wall per pass of the distributed stages (ms): " +
-            ", ".join("%s %.2f" % (k, 1e3 * v / max(args.steps, 1)) for k, v in runner.timings.items()))
-    kt /= max(args.steps, 1)
-    heavy /= max(args.steps, 1)
-    mine_row = list(kt) + [float(n_local)] + list(heavy)
-    k_all = comm.gather_floats(mine_row) if comm else [mine_row]
+    weak_headline = args.weak and world > 1
+    replicas = args.replicas if args.replicas > 0 else (world if weak_headline else 1)
+    M = measure(replicas, with_cpu_leg=(rank == 0 and world == 1 and not (args.no_cpu_baseline and args.no_parity_check)))
+    eng, genome = M["eng"], M["genome"]
+    passes = cfg["passes"]
 
     result = None
     if rank == 0:
+        elapsed, n_total = M["elapsed"], M["n_total"]
         ms = 1000.0 * elapsed / args.steps
-        value = n_total * args.steps / elapsed
+        value = n_total * passes * args.steps / elapsed
         # dominant kernel = the K2 launch over the rows whose continued fraction runs to Cephes' 300-iteration cap
-        worst = max(k_all, key=lambda r: r[4])
+        worst = max(M["k_all"], key=lambda r: r[4])
         hv_s, hv_rows = worst[4], worst[5]
         achieved = ALGO_BYTES_K2 * hv_rows / hv_s / 1e9 if hv_s > 0 else 0.0
         traffic = None
@@ -187,70 +304,127 @@ def main():
                 traffic = json.load(open(prof)).get("hbm_bytes_per_heavy_row") * hv_rows
             except Exception:
                 traffic = None
-        # fp64 view of the same launch: 300 iterations x 46 fp64 VALU instructions per row (ISA count of the hot path of the
-        # one-Newton-step loop: 2 x 7 division, 6 numerator/denominator products, 8 recurrence, 11 tests, 7 counters, 4 masked)
-        fp64_instr = hv_rows * 300.0 * 46.0
+        fp64_instr = hv_rows * 300.0 * HEAVY_FP64_INSTR_PER_ITER
         fp64_issue_peak = 256 * 4 * 16 * 2.4e9          # CUs x SIMDs x fp64 lanes/clk x Hz  (= 78.6 TFLOP/s / 2)
+        n_chr = len(base_lengths)
+        desc = {"C2": "C2-synth: one %d bp chromosome @%d bp, no distance bounds, %d cis pairs, bias, -b 100, 2 passes, intraOnly",
+                "C3": "C3-synth: %d x hg19 %d autosomes @%d bp, -L %d -U %d, %d cis pairs, ICE-like bias, -b 100, 1 pass, intraOnly",
+                "C5": "C5-synth: %d x hg19 %d autosomes @%d bp, -L %d -U %d, %d cis + %d trans pairs, ICE-like bias, -b 100, 1 pass, -x All"}
+        if args.config == "C2":
+            workload = desc["C2"] % (base_lengths[0], res, n_total)
+        elif args.config == "C3":
+            workload = desc["C3"] % (replicas, n_chr, res, L, U, n_total)
+        else:
+            workload = desc["C5"] % (replicas, n_chr, res, L, U, n_total - M["n_trans"], M["n_trans"])
         result = {
             "metric": "contact-pairs/sec through spline+p-value+BH pass (5 kb cis, whole node)",
             "value": value, "unit": "contact-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if (args.strong and world > 1) else "weak",
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak" if (weak_headline or world == 1) else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C3-synth: %d x hg19 22 autosomes @%d bp, -L %d -U %d, %d cis pairs, ICE-like bias, -b 100, "
-                                   "1 pass, intraOnly" % (replicas, res, L, U, n_total),
-                       "pairs": n_total, "resolution": res, "generator": "synth-v1" if args.overdispersion == 0 else
-                       "synth-v1 + lognormal rate noise s=%g" % args.overdispersion, "parallelism": "chromosome-sharded x%d" % world,
-                       "passes": 1},
-            "roofline": {"bound": "hbm", "kernel": "k2_queue<BC_CF_SWAPPED>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "config": {"workload": workload, "name": args.config, "pairs": n_total, "resolution": res,
+                       "generator": "synth-v1" if args.overdispersion == 0 else "synth-v1 + lognormal rate noise s=%g" % args.overdispersion,
+                       "parallelism": "chromosome-sharded x%d" % world, "passes": passes, "mode": cfg["mode"],
+                       "bias": not args.no_bias},
+            "roofline": {"bound": "hbm", "binding_resource": "fp64_valu_issue", "kernel": "k2h_heavy (swapped incbcf, 300 iterations)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "note": "dominant launch = the rows whose Cephes continued fraction runs all 300 iterations; it is "
-                                 "fp64-VALU-issue bound, not HBM bound: algorithmic bytes = 20 B/row (12 read + 8 written)",
+                         "note": "HBM is the designated roofline of the path; the dominant launch (rows whose Cephes continued "
+                                 "fraction runs all 300 iterations) is bound by fp64 VALU issue, see fp64_valu_issue_frac: "
+                                 "algorithmic bytes = 20 B/row (12 read + 8 written), %g fp64 instructions per row-iteration" % HEAVY_FP64_INSTR_PER_ITER,
                          "launch_seconds": hv_s, "rows_per_launch": hv_rows,
                          "fp64_valu_issue_frac": (fp64_instr / hv_s) / fp64_issue_peak if hv_s > 0 else None},
             "kernels_ms": {"k1_classify_hist": 1e3 * worst[0], "k2_pvalue": 1e3 * worst[1], "k3_bh_sort_scan": 1e3 * worst[2]},
             "whole_pass_hbm_frac": (ALGO_BYTES_K1 + ALGO_BYTES_K2 + ALGO_BYTES_K3) * value / (world * HBM_PEAK_GBS * 1e9),
         }
-        if sample_cols:
-            try:
-                result["cpu_baseline"] = cpu_baseline(genome, sample_cols, res, L, U)
-            except Exception as e:                           # the GPU line must not be lost to a problem of the CPU leg
-                log("cpu_baseline failed: %r" % (e,))
-                result["cpu_baseline"] = {"value": None, "unit": "contact-pairs/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+        if passes > 1:
+            result["ms_per_pass"] = [float(v) for v in M["pass_ms"]]
+        if rccl:
+            result["rccl"] = rccl
+            result["stage_ms"] = M["stage_ms"]
+        if M["sample"] is not None:
+            if not args.no_parity_check:
+                try:
+                    if passes > 1:                          # the timed steps end with reset_passes(): check an (untimed) pass 1
+                        out1 = eng.run_pass(collect=False)
+                        M["info"] = (out1.info, out1.stats)
+                    from oracle import run_check
+                    result["parity_check"] = run_check.check_engine_run(eng, genome, M["sample"], cfg, M["info"], not args.no_bias,
+                                                                        p_stride=4)
+                except Exception as e:
+                    log("parity_check failed: %r" % (e,))
+                    result["parity_check"] = {"error": repr(e)}
+            if not args.no_cpu_baseline:
+                try:
+                    result["cpu_baseline"] = cpu_baseline(genome, M["sample"], cfg, not args.no_bias)
+                except Exception as e:                           # the GPU line must not be lost to a problem of the CPU leg
+                    log("cpu_baseline failed: %r" % (e,))
+                    result["cpu_baseline"] = {"value": None, "unit": "contact-pairs/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+    eng.close()
+    del M
+    torch.cuda.empty_cache()
+    if world > 1 and not weak_headline and not args.no_weak and args.replicas == 0:
+        W = measure(world, with_cpu_leg=False)                  # the weak-scaling figure: genome replicated per GPU
+        if rank == 0:
+            result["weak_scaling"] = {"value": W["n_total"] * passes * args.steps / W["elapsed"], "ms_per_step": 1e3 * W["elapsed"] / args.steps,
+                                      "pairs": W["n_total"], "replicas": world, "stage_ms": W["stage_ms"]}
+        W["eng"].close()
     if comm:
         comm.barrier()
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(result) + "\n").encode())
-    eng.close()
     if comm:
         import torch.distributed as td
         td.destroy_process_group()
 
 
-def cpu_baseline(genome, sample_cols, res, L, U):
-    """The oracle (plain C Cephes + numpy stage logic, 1 thread) on a bounded sample of the same rows."""
+def _oracle_tables(genome, chroms, res, with_bias, cut_loci=None):
+    """Fragment rows and the bias dictionary of the sampled chromosomes, in the oracle's input form."""
+    import numpy as np
+    frags, bias_dic = [], {}
+    for c in chroms:
+        n_loci = (cut_loci or {}).get(c, genome.n_loci[c])
+        mids = np.arange(n_loci, dtype=np.int64) * res + res // 2
+        frags += [(genome.names[c], int(m), 1) for m in mids]
+        if with_bias:
+            b = genome.bias(c)[:n_loci]
+            b = np.where((b < 0.5) | (b > 2.0), -1.0, b)
+            bias_dic[genome.names[c]] = dict(zip(mids.tolist(), b.tolist()))
+    return frags, (bias_dic if with_bias else 0)
+
+
+def cpu_baseline(genome, sample, cfg, with_bias):
+    """The oracle (plain C Cephes + numpy stage logic, 1 thread) on a bounded sample of the same rows, own fit on the sample."""
     import numpy as np
     from oracle import fithic_oracle as fo
-    chr_ids = sorted({int(c[0][0]) for c in sample_cols if len(c[0])})
-    names = {c: genome.names[c] for c in chr_ids}
-    local = {c: i for i, c in enumerate(chr_ids)}
-    cat = [np.concatenate([c[k] for c in sample_cols]) for k in range(5)]
-    remap = np.vectorize(local.get)(cat[0]).astype(np.int32)
-    pairs = fo.Pairs(remap, cat[1], remap, cat[3], cat[4], [names[c] for c in chr_ids])
-    frags, bias_dic = [], {}
-    for c in chr_ids:
-        mids = np.arange(genome.n_loci[c], dtype=np.int64) * res + res // 2
-        frags += [(names[c], int(m), 1) for m in mids]
-        b = genome.bias(c)
-        b = np.where((b < 0.5) | (b > 2.0), -1.0, b)
-        bias_dic[names[c]] = dict(zip(mids.tolist(), b.tolist()))
+    chr_ids = sample["chroms"]
+    local = np.full(len(genome), -1, np.int32)
+    local[chr_ids] = np.arange(len(chr_ids), dtype=np.int32)
+    c1, m1, c2, m2, cnt = sample["cols"]
+    pairs = fo.Pairs(local[c1], m1, local[c2], m2, cnt, [genome.names[c] for c in chr_ids])
+    frags, bias_dic = _oracle_tables(genome, chr_ids, cfg["res"], with_bias, sample.get("cut_loci"))
     fo.build()
     t0 = time.perf_counter()
-    fo.run(pairs, frags, None, res, n_bins=100, passes=1, mode="intraOnly", L=L, U=U, bias_dic=bias_dic)
+    fo.run(pairs, frags, None, cfg["res"], n_bins=100, passes=cfg["passes"], mode=cfg["mode"], L=cfg["L"], U=cfg["U"],
+           bias_dic=bias_dic)
     dt = time.perf_counter() - t0
-    return {"value": len(pairs) / dt, "unit": "contact-pairs/s", "cores": 1, "kind": "port",
-            "sample": "%d rows of %s (same synthetic rows, own genome-wide fit on the sample), %.1f s" %
-                      (len(pairs), ",".join(names[c] for c in chr_ids), dt)}
+    cpu_model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": len(pairs) * cfg["passes"] / dt, "unit": "contact-pairs/s", "cores": 1, "kind": "port",
+            "sample": "%d rows of %s%s (same synthetic rows, own genome-wide fit on the sample, %d pass(es)), %.1f s" %
+                      (len(pairs), ",".join(genome.names[c] for c in chr_ids),
+                       "".join(" [first %d loci of %s]" % (v, genome.names[k]) for k, v in (sample.get("cut_loci") or {}).items()),
+                       cfg["passes"], dt),
+            "cpu_model": cpu_model, "host_cores": os.cpu_count(),
+            "calibration": dict(CALIBRATION, reference_over_port=CALIBRATION["reference_rows_per_s"] / CALIBRATION["port_rows_per_s"],
+                                estimated_reference_pairs_per_s_here=len(pairs) * cfg["passes"] / dt *
+                                CALIBRATION["reference_rows_per_s"] / CALIBRATION["port_rows_per_s"])}
 
 
 def cpu_baseline_kr(genome, cols, perc):

@@ -82,6 +82,8 @@ SYMBOLS = {
     "fhx_get_skip_limit": (ctypes.c_int64, [_P]),
     "fhx_set_skip_limit": (ctypes.c_int, [_P, ctypes.c_int64]),
     "fhx_next_pass": (ctypes.c_int, [_P, _I64P]),
+    "fhx_reset_passes": (ctypes.c_int, [_P]),
+    "fhx_get_stats": (ctypes.c_int, [_P, ctypes.POINTER(FhxStats)]),
     "fhx_fetch": (ctypes.c_int, [_P, _F64P, _F64P, _F64P, _F64P, _F64P]),
     "fhx_fetch_flags": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint8)]),
     "fhx_get_array": (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_int64, _I64P]),
@@ -102,6 +104,15 @@ SYMBOLS = {
     "fhx_sort_u64": (ctypes.c_int, [_P, _P, ctypes.c_int64, _P, _P]),
     "fhx_bh_scatter": (ctypes.c_int, [_P, _P]),
     "fhx_memcpy_d2d": (ctypes.c_int, [_P, _P, _P, ctypes.c_int64]),
+    "fhx_comm_unique_id": (ctypes.c_int, [_P, ctypes.c_int64]),
+    "fhx_comm_init": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int]),
+    "fhx_comm_init_custom": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int]),
+    "fhx_comm_destroy": (ctypes.c_int, [_P]),
+    "fhx_comm_info": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "fhx_run_pass_distributed": (ctypes.c_int, [_P, ctypes.POINTER(FhxFitInfo)]),
+    "fhx_next_pass_distributed": (ctypes.c_int, [_P, _I64P]),
+    "fhx_dist_stage_seconds": (ctypes.c_int, [_P, _F64P]),
+    "fhx_copy": (ctypes.c_int, [_P, _P, _P, ctypes.c_int64, ctypes.c_int]),
     "fhx_host_read_table": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_P)]),
     "fhx_table_rows": (ctypes.c_int64, [_P]),
     "fhx_table_n_names": (ctypes.c_int32, [_P]),
@@ -143,7 +154,7 @@ SYMBOLS = {
 
 BUILD_CMD = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
              "-fno-fast-math", "-pthread", "-o", os.path.join(_PKG, "libfithic_mi355x.so"), os.path.join(CSRC, "fhx_device.hip"),
-             os.path.join(CSRC, "fhx_kr.hip"), os.path.join(CSRC, "fhx_cni.hip"), os.path.join(CSRC, "fhx_host.cpp"), os.path.join(CSRC, "fhx_io.cpp"), "-lz"]
+             os.path.join(CSRC, "fhx_kr.hip"), os.path.join(CSRC, "fhx_cni.hip"), os.path.join(CSRC, "fhx_host.cpp"), os.path.join(CSRC, "fhx_io.cpp"), "-lz", "-ldl"]
 
 
 def build(force=False):
@@ -177,6 +188,48 @@ def _share_torch_hip_runtime():
         return ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
     except OSError:
         return None
+
+
+def _share_torch_rccl():
+    """One RCCL per process, for the same reason: PyTorch ships a librccl.so built against its own HIP runtime.  When torch is
+    installed its copy is loaded (globally) before the first communicator is made and the library's run-time lookup finds it;
+    without torch the system's librccl.so.1 is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so")
+    if not os.path.exists(cand):
+        return None
+    try:
+        return ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except OSError:
+        return None
+
+
+UNIQUE_ID_BYTES = 128
+STAGE_NAMES = ("k1_and_stats_exchange", "host_fit", "k2_launch", "cutoff_sort_splitters", "exchange_slice_bh_return")
+
+
+def comm_unique_id():
+    """ncclGetUniqueId as 128 bytes (rank 0 makes it, every rank passes it to Context.comm_init)."""
+    _share_torch_rccl()
+    buf = ctypes.create_string_buffer(UNIQUE_ID_BYTES)
+    rc = lib().fhx_comm_unique_id(ctypes.cast(buf, _P), UNIQUE_ID_BYTES)
+    if rc != FHX_OK:
+        raise FhxError(rc, "fhx_comm_unique_id: RCCL is not available")
+    return bytes(buf.raw)
+
+
+class FhxTransport(ctypes.Structure):
+    """Caller-provided collectives on device pointers (include/fithic_mi355x.h: fhx_transport)."""
+    ALL_REDUCE = ctypes.CFUNCTYPE(ctypes.c_int, _P, _P, ctypes.c_int64, ctypes.c_int)
+    ALL_GATHER = ctypes.CFUNCTYPE(ctypes.c_int, _P, _P, _P, ctypes.c_int64)
+    ALL_TO_ALL_V = ctypes.CFUNCTYPE(ctypes.c_int, _P, _P, _I64P, _I64P, _P, _I64P, _I64P, ctypes.c_int)
+    _fields_ = [("user", _P), ("all_reduce_i64", ALL_REDUCE), ("all_gather", ALL_GATHER), ("all_to_all_v", ALL_TO_ALL_V)]
 
 
 def lib():
@@ -318,6 +371,53 @@ class Context:
         n = ctypes.c_int64(0)
         self._check(self._L.fhx_next_pass(self._h, ctypes.byref(n)))
         return n.value
+
+    def reset_passes(self):
+        self._check(self._L.fhx_reset_passes(self._h))
+
+    # ---- sharded runs (one context per GPU / rank) ----
+    def comm_init(self, unique_id, rank, world):
+        """RCCL communicator on this context's GPU (blocks until every rank has called it)."""
+        _share_torch_rccl()
+        buf = ctypes.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
+        self._check(self._L.fhx_comm_init(self._h, ctypes.cast(buf, _P), int(rank), int(world)))
+
+    def comm_init_custom(self, transport, rank, world):
+        self._transport = transport                      # keeps the callbacks alive
+        self._check(self._L.fhx_comm_init_custom(self._h, ctypes.cast(ctypes.pointer(transport), _P), int(rank), int(world)))
+
+    def comm_destroy(self):
+        self._check(self._L.fhx_comm_destroy(self._h))
+
+    def comm_info(self):
+        r, w, v = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        self._check(self._L.fhx_comm_info(self._h, ctypes.byref(r), ctypes.byref(w), ctypes.byref(v)))
+        return r.value, w.value, v.value
+
+    def run_pass_distributed(self):
+        info = FhxFitInfo()
+        self._check(self._L.fhx_run_pass_distributed(self._h, ctypes.byref(info)))
+        return info
+
+    def next_pass_distributed(self):
+        n = ctypes.c_int64(0)
+        self._check(self._L.fhx_next_pass_distributed(self._h, ctypes.byref(n)))
+        return n.value
+
+    def dist_stage_seconds(self):
+        out = np.zeros(5, np.float64)
+        self._check(self._L.fhx_dist_stage_seconds(self._h, _ptr(out, ctypes.c_double)))
+        return dict(zip(STAGE_NAMES, out.tolist()))
+
+    def copy(self, dst, src, nbytes, kind):
+        """kind 0 = host to device, 1 = device to host, 2 = device to device (addresses as ints)."""
+        self._check(self._L.fhx_copy(self._h, _P(int(dst)), _P(int(src)), int(nbytes), int(kind)))
+
+    def stats(self):
+        """fhx_stats of the last pass as the context holds them (global ones after a sharded pass)."""
+        st = FhxStats()
+        self._check(self._L.fhx_get_stats(self._h, ctypes.byref(st)))
+        return st
 
     def fetch(self, n_rows, p=True, q=True, expcc=False, bias=False):
         out = {}

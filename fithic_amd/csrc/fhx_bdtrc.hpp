@@ -341,10 +341,14 @@ constexpr int kCfIters = 300;
 
 typedef const CfRow __attribute__((address_space(4))) * CfRowConstPtr;      // constant address space: s_load
 
-__device__ __forceinline__ CfRow cf_load_row(CfRowConstPtr p) {             // eight adjacent scalar loads = one s_load_dwordx16
+typedef double cf_d8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ CfRow cf_load_row(CfRowConstPtr p0) {
+    const volatile cf_d8 __attribute__((address_space(4))) * p = (const volatile cf_d8 __attribute__((address_space(4))) *)p0;
+    const cf_d8 v = *p;
     CfRow r;
-    r.k1 = p->k1; r.k2 = p->k2; r.k5 = p->k5; r.k6 = p->k6;
-    r.d0 = p->d0; r.y0 = p->y0; r.d1 = p->d1; r.y1 = p->y1;
+    r.k1 = v[0]; r.k2 = v[1]; r.k5 = v[2]; r.k6 = v[3];
+    r.d0 = v[4]; r.y0 = v[5]; r.d1 = v[6]; r.y1 = v[7];
+    __builtin_amdgcn_sched_barrier(0);
     return r;
 }
 
@@ -411,13 +415,16 @@ __device__ __forceinline__ void cf_swapped_step(CfState& S, const CfRow c, doubl
     const double p2 = p1 + S.p0 * xk;
     const double q2 = q1 + S.q0 * xk;
     // Lazy convergence test.  Cephes' ans is the r of the previous iteration, fl(pk/qk) of the pair this iteration started
-    // with (1.0 = 1/1 before the first) - for every lane that is still regular, because those never met qk == 0 or r == 0.
-    const double c1 = S.p0 * q2;
+    // with (1.0 = 1/1 before the first) - for every lane that is still regular, because those never met pk == 0 or qk == 0.
+    // With C = p2*q0 and E = p0*q2 - C:  c2 = C(1 + e1), d = fl(p0*q2 - c2) = (E - C e1)(1 + e2) (one fused rounding), so
+    // |d| > 1e-13 |c2| gives |E/C| > 1e-13 - 2.3e-16, and Cephes' t = |fl(fl(ans - r)/r)| with ans = fl(p0/q0), r = fl(p2/q2)
+    // is within 3.4e-16 of |E/C|: certainly t > 3 MACHEP, Cephes goes on.  c2 must not have lost bits to underflow and p2,
+    // q0 must not be zero: |c2| > 2^-600 (values are <= 2^17).  q2 == 0 shows up as q0 == 0 one iteration later - or in
+    // the caller's final check - and sends the row to the per-lane loop like every other unusual state.
     const double c2 = p2 * S.q0;
-    // certainly t > 1e-13 - 5e-16 > thresh (see contfrac_lazy_impl) - provided neither product lost bits to underflow and
-    // pk, qk are not zero: with |p0|, |q0| <= 2^17 both follow from |c1|, |c2| > 2^-600
-    const unsigned long long differ = __builtin_amdgcn_ballot_w64(fabs(c1 - c2) > 1e-13 * fabs(c2)) &
-                                      __builtin_amdgcn_ballot_w64(fmin(fabs(c1), fabs(c2)) > 0x1p-600);
+    const double d = __builtin_fma(S.p0, q2, -c2);
+    const unsigned long long differ = __builtin_amdgcn_ballot_w64(fabs(d) > 1e-13 * fabs(c2)) &
+                                      __builtin_amdgcn_ballot_w64(fabs(c2) > 0x1p-600);
     const unsigned long long exact = ~(differ | S.done);
     if (__builtin_expect(exact != 0ull, 0)) {                           // wave-uniform branch; Cephes' statements, literally
         const bool mine = cf_lane_bit(exact);
@@ -454,39 +461,40 @@ __device__ __forceinline__ double cf_swapped_uniform(CfRowConstPtr rows, double 
     S.done = S.irregular;
     static_assert(kCfIters % 8 == 4, "blocks of 8 iterations, then one of 4");
     int i = 0;
+    // Scalar loads return out of order, so the only wait is "all of them": each iteration first waits for its own row (the
+    // empty asm is a use), then requests the next one, then computes - the request has a whole iteration to complete.
+#define FHX_CF_NEXT(cur, nxt, idx)            \
+    asm volatile("" ::"s"(cur.k1));           \
+    const CfRow nxt = cf_load_row(rows + (idx)); \
+    cf_swapped_step(S, cur, arg);
 #pragma unroll 1
     for (; i + 8 <= kCfIters; i += 8) {
-        // every iteration's constants are requested one iteration ahead (scalar loads into SGPR operands)
-        const CfRow c0 = cf_load_row(rows + i), c1 = cf_load_row(rows + i + 1);
-        cf_swapped_step(S, c0, arg);
-        const CfRow c2 = cf_load_row(rows + i + 2);
-        cf_swapped_step(S, c1, arg);
-        const CfRow c3 = cf_load_row(rows + i + 3);
-        cf_swapped_step(S, c2, arg);
-        const CfRow c4 = cf_load_row(rows + i + 4);
-        cf_swapped_step(S, c3, arg);
-        const CfRow c5 = cf_load_row(rows + i + 5);
-        cf_swapped_step(S, c4, arg);
-        const CfRow c6 = cf_load_row(rows + i + 6);
-        cf_swapped_step(S, c5, arg);
-        const CfRow c7 = cf_load_row(rows + i + 7);
-        cf_swapped_step(S, c6, arg);
+        const CfRow c0 = cf_load_row(rows + i);
+        FHX_CF_NEXT(c0, c1, i + 1)
+        FHX_CF_NEXT(c1, c2, i + 2)
+        FHX_CF_NEXT(c2, c3, i + 3)
+        FHX_CF_NEXT(c3, c4, i + 4)
+        FHX_CF_NEXT(c4, c5, i + 5)
+        FHX_CF_NEXT(c5, c6, i + 6)
+        FHX_CF_NEXT(c6, c7, i + 7)
         cf_swapped_step(S, c7, arg);
         cf_swapped_renorm(S);
         if (S.done == ~0ull) break;
     }
     if (i + 8 > kCfIters) {
-        const CfRow c0 = cf_load_row(rows + i), c1 = cf_load_row(rows + i + 1);
-        cf_swapped_step(S, c0, arg);
-        const CfRow c2 = cf_load_row(rows + i + 2);
-        cf_swapped_step(S, c1, arg);
-        const CfRow c3 = cf_load_row(rows + i + 3);
-        cf_swapped_step(S, c2, arg);
+        const CfRow c0 = cf_load_row(rows + i);
+        FHX_CF_NEXT(c0, c1, i + 1)
+        FHX_CF_NEXT(c1, c2, i + 2)
+        FHX_CF_NEXT(c2, c3, i + 3)
         cf_swapped_step(S, c3, arg);
     }
+#undef FHX_CF_NEXT
     irregular = cf_lane_bit(S.irregular);
     // the loop ran to the cap: Cephes returns the last r = pk/qk
-    if (!cf_lane_bit(S.done)) S.result = S.p0 / S.q0;
+    if (!cf_lane_bit(S.done)) {
+        if (!(fabs(S.p0) > 0x1p-300 && fabs(S.q0) > 0x1p-300)) irregular = true;     // a zero in the last iteration
+        S.result = S.p0 / S.q0;
+    }
     return S.result;
 }
 

@@ -822,6 +822,20 @@ __device__ __forceinline__ unsigned long long pvalue_key(double v) {
     return bits;
 }
 
+constexpr unsigned long long KEY_ONE = 0x3FF0000000000000ull;          // bits of 1.0
+constexpr unsigned long long KEY_KEEP_ALL = 0x7FF0000000000001ull;     // above +inf: no value is cut
+
+// Every value that is not NaN is counted (NaN rows take no rank: they sort last and get q = NaN).  p == 1.0 - most rows of
+// a Hi-C run - goes through a per-thread counter instead of 64 lanes hitting one LDS word.  Negative values do not occur
+// (fhx_bh_array rejects them; bdtrc never returns one); a stray sign bit is clamped into the last bin rather than indexing
+// past the table.
+__device__ __forceinline__ void top_hist_one(double v, unsigned int* h, unsigned int& ones) {
+    if (v == 1.0)
+        ++ones;
+    else if (v == v)
+        atomicAdd(&h[min((unsigned int)(pvalue_key(v) >> TOP_SHIFT), (unsigned int)TOP_BINS - 1u)], 1u);
+}
+
 __global__ __launch_bounds__(512) void k3_top_hist(const double* __restrict__ p, int64_t n, unsigned long long* __restrict__ hist) {
     __shared__ unsigned int h[TOP_BINS];
     for (int i = threadIdx.x; i < TOP_BINS; i += 512) h[i] = 0;
@@ -829,15 +843,15 @@ __global__ __launch_bounds__(512) void k3_top_hist(const double* __restrict__ p,
     const int64_t n2 = n >> 1;
     const double2* p2 = reinterpret_cast<const double2*>(p);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned int ones = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
         const double2 v = p2[i];
-        if (v.x < 1.0) atomicAdd(&h[pvalue_key(v.x) >> TOP_SHIFT], 1u);
-        if (v.y < 1.0) atomicAdd(&h[pvalue_key(v.y) >> TOP_SHIFT], 1u);
+        top_hist_one(v.x, h, ones);
+        top_hist_one(v.y, h, ones);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) {
-        const double v = p[n - 1];
-        if (v < 1.0) atomicAdd(&h[pvalue_key(v) >> TOP_SHIFT], 1u);
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) top_hist_one(p[n - 1], h, ones);
+    ones = (unsigned int)wave_sum_i64((long long)ones);
+    if ((threadIdx.x & 63) == 0 && ones) atomicAdd(&h[KEY_ONE >> TOP_SHIFT], ones);
     __syncthreads();
     for (int i = threadIdx.x; i < TOP_BINS; i += 512)
         if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
@@ -883,11 +897,11 @@ __global__ __launch_bounds__(1024) void k3_cutoff(const unsigned long long* __re
     }
     __syncthreads();
     if (threadIdx.x == 0)
-        *cutoff_key = (best < (unsigned int)TOP_BINS) ? ((unsigned long long)best << TOP_SHIFT) : 0x3FF0000000000000ull;
+        *cutoff_key = (best < (unsigned int)TOP_BINS) ? ((unsigned long long)best << TOP_SHIFT) : KEY_KEEP_ALL;
 }
 
-// compaction: keys of the rows with p < 1 (IEEE bit pattern: all such p are >= 0, so unsigned order is
-// numeric order); rows with p == 1 get q = 1 and NaN rows get q = NaN right here.
+// compaction: keys of the rows below the cutoff key (IEEE bit pattern: all p are >= 0, so unsigned order is
+// numeric order); rows at or above it get q = 1 and NaN rows get q = NaN right here.
 __global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restrict__ p, int64_t n,
                                                            unsigned long long* __restrict__ keys,
                                                            unsigned int* __restrict__ vals, double* __restrict__ q,
@@ -914,7 +928,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restr
             v[r] = 1.0;
             if (i < n) {
                 v[r] = p[i];
-                keep = (v[r] < 1.0) && (pvalue_key(v[r]) < cutoff);          // false for NaN
+                keep = (v[r] == v[r]) && (pvalue_key(v[r]) < cutoff);        // false for NaN; p >= 1 stays when nothing saturates
                 if (!keep) q[i] = (v[r] == v[r]) ? 1.0 : v[r];
             }
             const unsigned long long m = __ballot(keep);
@@ -1143,7 +1157,7 @@ __global__ __launch_bounds__(SORT_THREADS) void rs_scatter(const unsigned long l
 __device__ __forceinline__ double bh_value(unsigned long long key_bits, double n_tests, double rank) {
     const double pv = __longlong_as_double((long long)key_bits);
     double v = pv * n_tests / rank;           // (p*N)/(i+1): mul then div, never fused
-    if (1.0 < v) v = 1.0;
+    if (1.0 < v || pv == 1.0) v = 1.0;        // min(bh, 1); p == 1.0 is 1.0 whatever N / rank says (myStats.py:33-34)
     return v;
 }
 
@@ -1221,7 +1235,7 @@ __global__ __launch_bounds__(BH_THREADS) void bh_apply(const unsigned long long*
                                                        const unsigned int* __restrict__ vals,
                                                        const unsigned long long* __restrict__ n_ptr, int64_t n_fixed,
                                                        double n_tests, double rank0, const double* __restrict__ tile_carry,
-                                                       double* __restrict__ q_out) {
+                                                       const double* __restrict__ extra_carry, double* __restrict__ q_out) {
     __shared__ double wtot[BH_THREADS / 64];
     const int64_t n = n_ptr ? (int64_t)*n_ptr : n_fixed;
     const int64_t base = (int64_t)blockIdx.x * BH_TILE;
@@ -1244,6 +1258,7 @@ __global__ __launch_bounds__(BH_THREADS) void bh_apply(const unsigned long long*
     if (lane == 63) wtot[wave] = incl;
     __syncthreads();
     double carry = tile_carry[blockIdx.x];
+    if (extra_carry) carry = fmax(carry, *extra_carry);          // sharded runs: the running max of the lower ranks' slices
     for (int w = 0; w < wave; ++w) carry = fmax(carry, wtot[w]);
     carry = fmax(carry, excl);
 #pragma unroll
@@ -1554,6 +1569,10 @@ __global__ void k_fdr_hist(const double* __restrict__ q, int64_t n, unsigned lon
 // =====================================================================================================
 using namespace fhx;
 
+namespace fhx {
+struct DistState;
+}
+
 struct fhx_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -1613,6 +1632,7 @@ struct fhx_ctx {
     unsigned int* d_block_hist = nullptr;
     unsigned int* d_digit_total = nullptr;
     unsigned long long* d_top_hist = nullptr;
+    unsigned char* d_work = nullptr;                  // the K2 queues and the K3 sort buffers are views into this block
     QEntry* d_queue[2] = {nullptr, nullptr};          // K2's per-class row queues
     QEntry* d_queue_sorted = nullptr;                 // the 300-iteration class, bucketed by (binomial, count), 64-aligned buckets
     dev::CfRow* d_cf_tab = nullptr;                   // K2H_GENERIC x 300 rows of iteration constants
@@ -1632,6 +1652,8 @@ struct fhx_ctx {
     int sorted_buf = 0;
     int64_t n_sorted = -1;
     std::vector<int64_t> fdr_counts;
+    fhx::DistState* dist = nullptr;                 // communicator + exchange buffers of sharded runs (fhx_dist.inc)
+    bool dist_ndist_agreed = false;                   // sharded runs: the histogram length was made equal on all ranks
 };
 
 namespace {
@@ -2001,22 +2023,23 @@ int alloc_row_arrays(fhx_ctx* ctx, int64_t n, int64_t n_dist) {
     FHX_HIP(hipMemsetAsync(ctx->d_out_hist, 0, hist_len * sizeof(unsigned long long), ctx->stream));
     if (!ctx->d_sums) FHX_HIP(hipMalloc(&ctx->d_sums, sizeof(K1Sums)));
     if (!ctx->d_misc) FHX_HIP(hipMalloc(&ctx->d_misc, 128 * sizeof(unsigned long long)));
-    // sort workspace
-    for (int b = 0; b < 2; ++b) {
-        dev_free(ctx->d_keys[b]);
-        dev_free(ctx->d_vals[b]);
-        FHX_HIP(hipMalloc(&ctx->d_keys[b], cap * sizeof(unsigned long long)));
-        FHX_HIP(hipMalloc(&ctx->d_vals[b], cap * sizeof(unsigned int)));
-    }
+    // One workspace, two views that are never live together (K2 and K3 run back to back on one stream):
+    //   K2: queue[0] (16 B/row) | queue[1] (16 B/row) | the bucketed 300-iteration queue (16 B/row + bucket padding)
+    //   K3: keys[0], keys[1] (8 B/row each)            | vals[0], vals[1] (4 B/row each)
+    // (-r 0 sorts distances in K1 and lists outlier distances after K3 through the K3 view.)
+    dev_free(ctx->d_work);
+    const size_t work_bytes = cap * 48 + (size_t)K2H_BUCKETS * 64 * sizeof(QEntry);
+    FHX_HIP(hipMalloc(&ctx->d_work, work_bytes));
+    ctx->d_queue[0] = reinterpret_cast<QEntry*>(ctx->d_work);
+    ctx->d_queue[1] = reinterpret_cast<QEntry*>(ctx->d_work + cap * 16);
+    ctx->d_queue_sorted = reinterpret_cast<QEntry*>(ctx->d_work + cap * 32);
+    ctx->d_keys[0] = reinterpret_cast<unsigned long long*>(ctx->d_work);
+    ctx->d_keys[1] = reinterpret_cast<unsigned long long*>(ctx->d_work + cap * 8);
+    ctx->d_vals[0] = reinterpret_cast<unsigned int*>(ctx->d_work + cap * 16);
+    ctx->d_vals[1] = reinterpret_cast<unsigned int*>(ctx->d_work + cap * 20);
     if (!ctx->d_block_hist) FHX_HIP(hipMalloc(&ctx->d_block_hist, (size_t)RADIX * SORT_BLOCKS * sizeof(unsigned int)));
     if (!ctx->d_digit_total) FHX_HIP(hipMalloc(&ctx->d_digit_total, RADIX * sizeof(unsigned int)));
     if (!ctx->d_top_hist) FHX_HIP(hipMalloc(&ctx->d_top_hist, TOP_BINS * sizeof(unsigned long long)));
-    for (int b = 0; b < 2; ++b) {
-        dev_free(ctx->d_queue[b]);
-        FHX_HIP(hipMalloc(&ctx->d_queue[b], cap * sizeof(QEntry)));
-    }
-    dev_free(ctx->d_queue_sorted);
-    FHX_HIP(hipMalloc(&ctx->d_queue_sorted, (cap + (size_t)K2H_BUCKETS * 64) * sizeof(QEntry)));
     if (!ctx->d_cf_tab) FHX_HIP(hipMalloc(&ctx->d_cf_tab, (size_t)K2H_GENERIC * dev::kCfIters * sizeof(dev::CfRow)));
     if (!ctx->d_k2h_off) FHX_HIP(hipMalloc(&ctx->d_k2h_off, (K2H_BUCKETS + 1) * sizeof(unsigned int)));
     dev_free(ctx->d_tile_max);
@@ -2032,6 +2055,7 @@ int alloc_row_arrays(fhx_ctx* ctx, int64_t n, int64_t n_dist) {
     ctx->h_out_hist.assign((size_t)n_dist, 0);
     ctx->tables_dirty = true;
     ctx->n_sorted = -1;
+    ctx->dist_ndist_agreed = false;
     return FHX_OK;
 }
 
@@ -2069,6 +2093,7 @@ int fhx_create(int device, fhx_ctx** out) {
 
 void fhx_destroy(fhx_ctx* ctx) {
     if (!ctx) return;
+    (void)fhx_comm_destroy(ctx);
     if (ctx->device >= 0) {
         (void)hipSetDevice(ctx->device);
         if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -2094,16 +2119,10 @@ void fhx_destroy(fhx_ctx* ctx) {
         dev_free(ctx->d_invb_inter);
         dev_free(ctx->d_p);
         dev_free(ctx->d_q);
-        for (int b = 0; b < 2; ++b) {
-            dev_free(ctx->d_keys[b]);
-            dev_free(ctx->d_vals[b]);
-        }
+        dev_free(ctx->d_work);
         dev_free(ctx->d_block_hist);
         dev_free(ctx->d_digit_total);
         dev_free(ctx->d_top_hist);
-        dev_free(ctx->d_queue[0]);
-        dev_free(ctx->d_queue[1]);
-        dev_free(ctx->d_queue_sorted);
         dev_free(ctx->d_cf_tab);
         dev_free(ctx->d_k2h_off);
         dev_free(ctx->d_memo);
@@ -2274,12 +2293,8 @@ static int pass_stats_nonfixed(fhx_ctx* ctx, fhx_stats* out) {
     return FHX_OK;
 }
 
-int fhx_pass_stats(fhx_ctx* ctx, fhx_stats* out) {
-    if (!ctx) return FHX_ERR_ARG;
-    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
-    if (!ctx->d_loc1) return fail(ctx, FHX_ERR_ARG, "no contact rows loaded");
-    FHX_HIP(hipSetDevice(ctx->device));
-    if (ctx->nonfixed) return pass_stats_nonfixed(ctx, out);
+// K1 of the fixed-size path on the context's stream: histograms and sums stay in HBM
+static int launch_k1(fhx_ctx* ctx) {
     const int64_t res = ctx->prm.resolution;
     const int64_t lo = (ctx->prm.dist_low + res - 1) / res;
     const int64_t hi = std::min<int64_t>(ctx->prm.dist_up / res, ctx->n_dist - 1);
@@ -2296,6 +2311,19 @@ int fhx_pass_stats(fhx_ctx* ctx, fhx_stats* out) {
     FHX_HIP(hipGetLastError());
     FHX_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     ctx->ev_valid[0] = true;
+    return FHX_OK;
+}
+
+int fhx_pass_stats(fhx_ctx* ctx, fhx_stats* out) {
+    if (!ctx) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (!ctx->d_loc1) return fail(ctx, FHX_ERR_ARG, "no contact rows loaded");
+    FHX_HIP(hipSetDevice(ctx->device));
+    if (ctx->nonfixed) return pass_stats_nonfixed(ctx, out);
+    {
+        const int rc = launch_k1(ctx);
+        if (rc != FHX_OK) return rc;
+    }
     K1Sums s{};
     ctx->h_hist_cc.assign((size_t)ctx->n_dist, 0);
     ctx->h_hist_np.assign((size_t)ctx->n_dist, 0);
@@ -2319,6 +2347,13 @@ int fhx_pass_stats(fhx_ctx* ctx, fhx_stats* out) {
     ctx->have_stats = true;
     ctx->have_fit = ctx->have_bins = ctx->have_p = ctx->have_q = false;
     if (out) *out = st;
+    return FHX_OK;
+}
+
+int fhx_get_stats(fhx_ctx* ctx, fhx_stats* out) {
+    if (!ctx || !out) return FHX_ERR_ARG;
+    if (!ctx->have_stats) return fail(ctx, FHX_ERR_ARG, "no pass statistics yet");
+    *out = ctx->stats;
     return FHX_OK;
 }
 
@@ -2612,7 +2647,7 @@ int fhx_pvalues(fhx_ctx* ctx) {
     ctx->have_q = false;
     ctx->n_sorted = -1;
     {
-        const unsigned long long one = 0x3FF0000000000000ull;      // until a cutoff is computed: keep every p < 1
+        const unsigned long long one = KEY_KEEP_ALL;               // until a cutoff is computed: keep every p
         FHX_HIP(hipMemcpyAsync(ctx->d_misc + 6, &one, sizeof(one), hipMemcpyHostToDevice, ctx->stream));
     }
     return FHX_OK;
@@ -2658,7 +2693,7 @@ static int bh_from_sorted(fhx_ctx* ctx, const unsigned long long* keys, const un
     hipLaunchKernelGGL(bh_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, tile_max, counter, (int64_t)0, 0.0,
                        (double*)nullptr);
     hipLaunchKernelGGL(bh_apply, dim3(tiles), dim3(BH_THREADS), 0, ctx->stream, keys, vals, counter, (int64_t)0,
-                       n_total_tests, 0.0, tile_max, d_q);
+                       n_total_tests, 0.0, tile_max, (const double*)nullptr, d_q);
     FHX_HIP(hipGetLastError());
     return FHX_OK;
 }
@@ -2714,7 +2749,7 @@ int fhx_bh_set_cutoff(fhx_ctx* ctx, const int64_t* global_hist, int64_t n_bins, 
     if (!ctx || !global_hist || n_bins != TOP_BINS || !(n_total_tests > 0)) return FHX_ERR_ARG;
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
     FHX_HIP(hipSetDevice(ctx->device));
-    unsigned long long cutoff = 0x3FF0000000000000ull, cum = 0;
+    unsigned long long cutoff = KEY_KEEP_ALL, cum = 0;
     for (int b = 0; b < TOP_BINS; ++b) {
         cum += (unsigned long long)global_hist[b];
         if (global_hist[b] > 0 && bin_saturates(b, cum, n_total_tests)) {
@@ -2818,6 +2853,9 @@ int fhx_bh_array(fhx_ctx* ctx, const double* p, int64_t n, double n_total_tests,
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
     if (n == 0) return FHX_OK;
     if (n >= (1ll << 32)) return fail(ctx, FHX_ERR_UNSUPPORTED, "more than 2^32 p-values");
+    if (!(n_total_tests > 0)) return fail(ctx, FHX_ERR_ARG, "number of tests must be positive");
+    for (int64_t i = 0; i < n; ++i)
+        if (p[i] < 0.0) return fail(ctx, FHX_ERR_ARG, "negative p-value at index " + std::to_string(i) + " (p-values must be >= 0 or NaN)");
     FHX_HIP(hipSetDevice(ctx->device));
     int rc = ensure_sort_scratch(ctx);
     if (rc != FHX_OK) return rc;
@@ -2894,7 +2932,7 @@ int fhx_bh_apply_sorted(fhx_ctx* ctx, const void* d_sorted_keys, int64_t n, int6
     if (d_q_sorted)
         hipLaunchKernelGGL(bh_apply, dim3(tiles), dim3(BH_THREADS), 0, ctx->stream, keys, (const unsigned int*)nullptr,
                            (const unsigned long long*)nullptr, n, n_total_tests, (double)global_rank0, tile_max,
-                           (double*)d_q_sorted);
+                           (const double*)nullptr, (double*)d_q_sorted);
     double total = 0.0;
     FHX_HIP(hipMemcpyAsync(&total, tile_max + tiles, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     FHX_HIP(hipStreamSynchronize(ctx->stream));
@@ -3040,6 +3078,30 @@ int fhx_next_pass(fhx_ctx* ctx, int64_t* n_outliers_total) {
     ctx->skip_active = true;
     ctx->pass_no += 1;
     if (n_outliers_total) *n_outliers_total = ctx->n_outliers_total;
+    return FHX_OK;
+}
+
+int fhx_reset_passes(fhx_ctx* ctx) {
+    if (!ctx) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (!ctx->d_loc1) return fail(ctx, FHX_ERR_ARG, "no contact rows loaded");
+    FHX_HIP(hipSetDevice(ctx->device));
+    const size_t cap = std::max<size_t>(4, ((size_t)ctx->n_rows + 3) / 4 * 4);
+    FHX_HIP(hipMemsetAsync(ctx->d_skip, 0, cap, ctx->stream));
+    FHX_HIP(hipMemsetAsync(ctx->d_outlier, 0, cap, ctx->stream));
+    FHX_HIP(hipMemsetAsync(ctx->d_seen_twice, 0, cap, ctx->stream));
+    const size_t hist_len = ctx->nonfixed ? cap : (size_t)ctx->n_dist;
+    FHX_HIP(hipMemsetAsync(ctx->d_out_hist, 0, hist_len * sizeof(unsigned long long), ctx->stream));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->pass_no = 0;
+    ctx->skip_active = false;
+    ctx->have_stats = ctx->have_fit = ctx->have_bins = ctx->have_p = ctx->have_q = false;
+    ctx->n_outliers_total = 0;
+    ctx->skip_limit = INT64_MAX;
+    ctx->outlier_hist_nonempty = false;
+    ctx->h_out_hist.assign((size_t)ctx->n_dist, 0);
+    ctx->h_outlier_dists.clear();
+    ctx->n_sorted = -1;
     return FHX_OK;
 }
 
@@ -3205,6 +3267,8 @@ int fhx_kernel_seconds(fhx_ctx* ctx, double* k1, double* k2, double* k3) {
     }
     return FHX_OK;
 }
+
+#include "fhx_dist.inc"
 
 // ---- host numerics exported for tests / host-only callers ----------------------------------------------
 int fhx_host_spline_fit(const double* x, const double* y, int32_t m, double s, double* t, double* c, int32_t* n_knots,

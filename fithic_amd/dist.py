@@ -401,6 +401,11 @@ class DistributedPass:
         self.info, self.stats = info, st
         return info
 
+    def reset(self):
+        """After Engine.reset_passes(): forget the outlier state kept on this side as well."""
+        self.ops._outlier_global = np.zeros(0, np.int64)
+        self.ops._outlier_local = np.zeros(0, np.int64)
+
     def next_pass(self):
         """Fold outliers locally, then make the outlier-distance multiset genome-wide."""
         n_local, hist = self.ops.next_pass_local()

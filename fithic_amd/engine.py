@@ -102,5 +102,10 @@ class Engine:
         """Fold this pass's outliers (p < 1/N) into the skip mask and the outlier-distance multiset."""
         return self.ctx.next_pass()
 
+    def reset_passes(self):
+        """Start over at pass 1 on the loaded tables (the reference: a fresh main() on the same files)."""
+        self.ctx.reset_passes()
+        self.pass_no = 0
+
     def kernel_seconds(self):
         return self.ctx.kernel_seconds()

@@ -178,6 +178,50 @@ def cis_contacts(genome, chrom, lo_idx, hi_idx, amplitude, device="cpu", max_win
     return ch, mid1, ch.clone(), mid2, c_all
 
 
+TRANS_STREAM = 1 << 60          # counter space of the trans rows (cis counters stay below 2^46)
+
+
+def trans_contacts(genome, n_trans, t0=0, t1=None, device="cpu", chunk=1 << 24):
+    """Inter-chromosomal rows t0 <= t < t1 of the genome-wide list of `n_trans` trans pairs: uniform
+    random locus pairs on different chromosomes, count = 1 + Poisson(0.7).  Row t is a function of (SEED, t) alone -
+    splitmix64(SEED ^ (TRANS_STREAM + 4 t + k)), k = 0..2 - so any slicing of [0, n_trans) over ranks, chunks or devices
+    yields the same rows.  Locus a is uniform over all loci; locus b uniform over the loci of the OTHER chromosomes; the
+    pair is written with the lower chromosome index first.  Returned sorted by (chr1, mid1, chr2, mid2) within the slice,
+    as torch int32 tensors (chr1, mid1, chr2, mid2, count)."""
+    import torch
+    t1 = n_trans if t1 is None else t1
+    n_loci = torch.tensor(genome.n_loci, dtype=torch.int64, device=device)
+    if len(genome) < 2 or t1 <= t0:
+        z = torch.zeros(0, dtype=torch.int32, device=device)
+        return z, z, z, z, z
+    start = torch.cumsum(n_loci, 0) - n_loci                                   # first genome-wide locus of each chromosome
+    ends = torch.cumsum(n_loci, 0)
+    total = int(n_loci.sum())
+    lam = torch.tensor(0.7, dtype=torch.float64, device=device)
+    out = []
+    for a0 in range(t0, t1, chunk):
+        t = torch.arange(a0, min(t1, a0 + chunk), device=device, dtype=torch.int64)
+        base = TRANS_STREAM + t * 4
+        la = torch.clamp((_uniform(torch, base) * total).to(torch.int64), max=total - 1)
+        ca = torch.bucketize(la, ends, right=True)
+        rest = total - n_loci[ca]
+        r = torch.minimum((_uniform(torch, base + 1) * rest.to(torch.float64)).to(torch.int64), rest - 1)
+        lb = torch.where(r < start[ca], r, r + n_loci[ca])                     # skip chromosome ca's range
+        cb = torch.bucketize(lb, ends, right=True)
+        cnt = 1 + _poisson_inverse(torch, lam.expand(t.shape), _uniform(torch, base + 2))
+        ia, ib = la - start[ca], lb - start[cb]
+        swap = cb < ca
+        c1, i1 = torch.where(swap, cb, ca), torch.where(swap, ib, ia)
+        c2, i2 = torch.where(swap, ca, cb), torch.where(swap, ia, ib)
+        out.append((c1, i1, c2, i2, cnt))
+    c1, i1, c2, i2, cnt = [torch.cat([o[k] for o in out]) for k in range(5)]
+    order = torch.argsort(((c1 << 22 | i1) << 30) | (c2 << 22 | i2))          # chromosome ids < 2^8, loci < 2^22
+    res = genome.res
+    c1, i1, c2, i2, cnt = c1[order], i1[order], c2[order], i2[order], cnt[order]
+    return (c1.to(torch.int32), (i1 * res + res // 2).to(torch.int32), c2.to(torch.int32), (i2 * res + res // 2).to(torch.int32),
+            cnt.to(torch.int32))
+
+
 def assign_chromosomes(genome, world_size):
     """Greedy size-balanced chromosome -> rank map (largest first), as SURVEY.md 8e describes."""
     load = [0] * world_size

@@ -143,6 +143,7 @@ int fhx_load_pairs_device(fhx_ctx* ctx, const void* d_chr1, const void* d_mid1, 
 
 /* ---- one spline pass ---------------------------------------------------------------------------- */
 int fhx_pass_stats(fhx_ctx* ctx, fhx_stats* out);                       /* K1, then waits for the sums */
+int fhx_get_stats(fhx_ctx* ctx, fhx_stats* out);                        /* the statistics the current fit was made from */
 /* Distributed runs: replace the local histogram / sums by the all-reduced ones before fhx_fit. */
 int fhx_set_global_stats(fhx_ctx* ctx, const fhx_stats* global_stats, const int64_t* hist_sumcc,
                          const int64_t* hist_npairs, int64_t n_dist);
@@ -168,6 +169,10 @@ int fhx_set_global_rows(fhx_ctx* ctx, const int64_t* file_row_of_local_row, int6
 int64_t fhx_get_skip_limit(fhx_ctx* ctx);
 int fhx_set_skip_limit(fhx_ctx* ctx, int64_t limit);
 int fhx_next_pass(fhx_ctx* ctx, int64_t* n_outliers_total);             /* fold this pass's outliers in */
+/* Forget every pass: the outlier line set and distance multiset are emptied, the next fhx_pass_stats is pass 1 again.
+ * The reference equivalent is starting main() over on the same input (fithic/fithic.py:317-331 builds fresh
+ * SortedLists); the loaded tables stay on the device. */
+int fhx_reset_passes(fhx_ctx* ctx);
 
 /* ---- results ------------------------------------------------------------------------------------ */
 /* Any pointer may be NULL.  Arrays have n_rows entries in input row order. */
@@ -222,6 +227,52 @@ int fhx_sort_u64(fhx_ctx* ctx, const void* d_keys_in, int64_t n, void* d_keys_ou
 int fhx_bh_scatter(fhx_ctx* ctx, const void* d_q_sorted_local);
 /* device-to-device copy on the context's stream, then wait (plumbing between the library's buffers and torch's) */
 int fhx_memcpy_d2d(fhx_ctx* ctx, void* dst, const void* src, int64_t bytes);
+
+/* ---- multi-GPU runs behind the boundary (SURVEY 8b last row, 8e) -----------------------------------------------------
+ * One process (or thread) per GPU, one fhx_ctx each, the contact rows sharded over the contexts (by chromosome, or any
+ * other split: every exchange below is row-order free).  The reference is one process, so what must be global is what its
+ * data structures make global: mainDic and the sums of read_Interactions (fithic/fithic.py:434-440) -> ONE all-reduce of
+ * [sums | in-range histogram windows] in HBM; the global ascending order of benjamini_hochberg_correction
+ * (fithic/myStats.py:27-46) -> sample sort: all-reduced 8192-bin key histogram (exact early cutoff), all-gather of
+ * regular samples, splitters, all-to-all of the keys, local sort of the received slice, all-gather of the slice maxima
+ * (carry of the running max), all-to-all of q back; the outlier multiset of pass >= 2 (fithic.py:528-548) -> all-reduce.
+ * All collectives are enqueued on the context's stream between the kernels; the host waits twice per pass (for the summed
+ * statistics the host fit needs, and for the send/receive counts of the key exchange).
+ *
+ * Transport 1 - RCCL over xGMI (production): rank 0 calls fhx_comm_unique_id, hands the bytes to the other ranks by
+ * whatever means started them (environment, file, socket, MPI ...), every rank calls fhx_comm_init.  librccl is loaded at
+ * run time (the copy already in the process, e.g. PyTorch's, else the system's), so single-GPU users need no RCCL.
+ * Transport 2 - caller-provided collectives on device pointers (tests on a one-GPU box, other fabrics): fhx_comm_init_custom.
+ * The library synchronises its stream before each callback; a callback returns when its result is in place. */
+#define FHX_UNIQUE_ID_BYTES 128
+int fhx_comm_unique_id(void* id_out, int64_t capacity);                 /* ncclGetUniqueId */
+int fhx_comm_init(fhx_ctx* ctx, const void* rccl_unique_id, int rank, int nranks);   /* ncclCommInitRank on ctx's device */
+typedef struct fhx_transport {
+    void* user;
+    /* in-place reduction of n int64 values at device address d_buf; op 0 = sum, 1 = max, 2 = min */
+    int (*all_reduce_i64)(void* user, void* d_buf, int64_t n, int op);
+    /* d_recv[r * bytes .. (r + 1) * bytes) = rank r's d_send[0 .. bytes) */
+    int (*all_gather)(void* user, const void* d_send, void* d_recv, int64_t bytes);
+    /* counts and offsets in elements of elem_bytes, one entry per rank */
+    int (*all_to_all_v)(void* user, const void* d_send, const int64_t* send_counts, const int64_t* send_offsets, void* d_recv,
+                        const int64_t* recv_counts, const int64_t* recv_offsets, int elem_bytes);
+} fhx_transport;
+int fhx_comm_init_custom(fhx_ctx* ctx, const fhx_transport* t, int rank, int nranks);
+int fhx_comm_destroy(fhx_ctx* ctx);
+/* rank, world size and the RCCL version code (0 for a custom transport) of an initialised communicator */
+int fhx_comm_info(fhx_ctx* ctx, int* rank, int* nranks, int* rccl_version);
+/* One spline pass over all ranks' rows: K1 -> all-reduce -> host fit (identical on every rank) -> K2 -> global BH; leaves
+ * p and q of the LOCAL rows in row order, as fhx_pass_stats + fhx_fit + fhx_pvalues + fhx_bh do on one GPU.
+ * Fixed-size loci only (-r 0 runs go through the building blocks above). */
+int fhx_run_pass_distributed(fhx_ctx* ctx, fhx_fit_info* out);
+/* fhx_next_pass on every rank + the genome-wide outlier multiset, outlier count and first duplicated line */
+int fhx_next_pass_distributed(fhx_ctx* ctx, int64_t* n_outliers_total);
+/* host wall seconds per stage of the last fhx_run_pass_distributed: k1 + stats exchange, host fit, K2 launch, cutoff +
+ * local sort + splitters (up to the count exchange), key exchange + slice sort + scan + q return */
+int fhx_dist_stage_seconds(fhx_ctx* ctx, double* out5);
+/* plain copies between host and this context's GPU (plumbing for custom transports): kind 0 = host to device,
+ * 1 = device to host, 2 = device to device; waits for completion */
+int fhx_copy(fhx_ctx* ctx, void* dst, const void* src, int64_t bytes, int kind);
 
 /* ---- host numerics, exported for tests and for callers that only need the host side ------------------ */
 int fhx_host_spline_fit(const double* x, const double* y, int32_t m, double s, double* t, double* c,

@@ -484,6 +484,52 @@ def benjamini_hochberg(p, n_tests):
     return q
 
 
+def benjamini_hochberg_pruned(p, n_tests):
+    """The same function as benjamini_hochberg(), evaluated without sorting the rows whose q is provably 1 - for checking
+    q of 10^8-row runs in seconds instead of a minute of argsort.
+
+    Proof of equality.  The reference's q is a FORWARD running max of min(p*N/rank, 1) over ascending p
+    (myStats.py:31-46): once one element reaches 1 every later element has q = 1.  Let c = #{p < tau} and suppose every
+    element with p >= tau is known to be saturated (true for tau = +inf).  The c survivors occupy ranks 1..c, so one with
+    p >= tau2 has fl(fl(p*N)/rank) >= fl(fl(tau2*N)/c) (IEEE rounding is monotone); if that bound is >= 1 it is saturated
+    as well, and so is everything after it.  Iterating tau <- tau2 with exact counts shrinks the survivor set to the
+    enriched tail; only that tail is sorted.  NaN rows sort last in the reference and stay NaN without touching the others.
+    Pinned against benjamini_hochberg() by tests/test_oracle_golden.py."""
+    p = np.asarray(p, np.float64)
+    N = float(n_tests)
+    q = np.ones(len(p), np.float64)
+    nan = np.isnan(p)
+    q[nan] = np.nan
+    c = int(len(p) - nan.sum())
+    tau = np.inf
+    while c > 0:
+        tau2 = c / N
+        while not (tau2 * N / c >= 1.0):              # fl(fl(tau2*N)/c) >= 1, as the reference associates it
+            tau2 = np.nextafter(tau2, np.inf)
+        if tau2 >= tau:
+            break
+        with np.errstate(invalid="ignore"):
+            kept = int(np.count_nonzero(p < tau2))
+        tau = tau2
+        if kept == c:
+            break
+        c = kept
+    with np.errstate(invalid="ignore"):
+        cand = np.flatnonzero(p < tau)
+    vals = p[cand]
+    c = len(vals)
+    if c:
+        order = np.argsort(vals, kind="stable")
+        sp = vals[order]
+        rank = np.arange(1, c + 1, dtype=np.float64)
+        with np.errstate(over="ignore"):
+            bh = sp * N / rank
+        bh = np.where(sp == 1.0, 1.0, np.where(bh > 1.0, 1.0, bh))
+        out = np.maximum.accumulate(bh)
+        q[cand[order]] = out
+    return q
+
+
 def fdr_ticks(q):
     """plot_qvalues (fithic.py:1235-1254): shifted cumulative counts over 0..0.05 step 0.001."""
     ticks = np.arange(0.0, 0.05 + 0.001, 0.001)

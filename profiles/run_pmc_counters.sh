@@ -16,8 +16,8 @@ import sqlite3, sys, re
 con = sqlite3.connect(sys.argv[1])
 rows = con.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection group by kernel_name, counter_name").fetchall()
 for name, counter, total, n in rows:
-    if "k2_queue" in name or "k1_classify" in name or "k2_classify" in name or "k3_compact" in name:
-        m = re.search(r"(k\d_\w+(<[^>]*>)?)", name)
+    if "k2h_" in name or "k2_queue" in name or "k1_classify" in name or "k2_classify" in name or "k3_compact" in name:
+        m = re.search(r"(k\d\w*_\w+(<[^>]*>)?)", name)
         short = re.sub(r"\(fhx::dev::BranchClass\)", "", m.group(1)) if m else name[:40]
         print("%-14s %-40s launches %3d total %.6g per-launch %.6g" % (counter, short, n, total, total / n))
 PY

@@ -1,0 +1,250 @@
+"""The sharded pass BEHIND the C ABI (fhx_comm_init* / fhx_run_pass_distributed / fhx_next_pass_distributed), driven with
+bare ctypes + numpy - no torch in these processes.
+
+  * world 2 and 3 on ONE GPU: RCCL refuses two ranks on one device, so the ranks are separate processes whose collectives
+    are the library's caller-provided transport (fhx_comm_init_custom) implemented here over multiprocessing pipes - the
+    schedule, the kernels and the buffers are exactly the ones the RCCL transport runs.  Each rank's p and q must equal,
+    bit for bit, what a single-GPU run over all rows gives for its rows (1-3 passes, an empty shard, inter rows).
+  * world 1 through REAL RCCL (ncclCommInitRank, all-reduce / all-gather / send-recv to self on the engine's stream): the
+    same bits as fhx_pass_stats + fhx_fit + fhx_pvalues + fhx_bh.
+The 8-GPU RCCL run itself is the driver's (bench.py --gpus N)."""
+import ctypes
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class PipeTransport:
+    """all_reduce / all_gather / all_to_all_v of device buffers over a full mesh of pipes, staged through host memory."""
+
+    def __init__(self, ctx, rank, world, conns):
+        from fithic_amd import _capi
+        self.ctx, self.rank, self.world, self.conns = ctx, rank, world, conns
+        self.struct = _capi.FhxTransport(None, _capi.FhxTransport.ALL_REDUCE(self.all_reduce), _capi.FhxTransport.ALL_GATHER(self.all_gather),
+                                         _capi.FhxTransport.ALL_TO_ALL_V(self.all_to_all_v))
+
+    def _d2h(self, ptr, nbytes):
+        a = np.empty(nbytes, np.uint8)
+        if nbytes:
+            self.ctx.copy(a.ctypes.data, ptr, nbytes, 1)
+        return a
+
+    def _h2d(self, ptr, a):
+        if a.nbytes:
+            self.ctx.copy(ptr, np.ascontiguousarray(a).ctypes.data, a.nbytes, 0)
+
+    def _exchange(self, per_peer):
+        """per_peer[r] = bytes for rank r; returns what every rank sent to me (my own entry passes through)."""
+        for r in range(self.world):
+            if r != self.rank:
+                self.conns[r].send_bytes(per_peer[r].tobytes())
+        got = [None] * self.world
+        got[self.rank] = per_peer[self.rank]
+        for r in range(self.world):
+            if r != self.rank:
+                got[r] = np.frombuffer(self.conns[r].recv_bytes(), np.uint8)
+        return got
+
+    def all_reduce(self, user, d_buf, n, op):
+        try:
+            mine = self._d2h(d_buf, 8 * n)
+            parts = [g.view(np.int64) for g in self._exchange([mine] * self.world)]
+            red = {0: np.sum, 1: np.max, 2: np.min}[op](np.stack(parts), axis=0).astype(np.int64)
+            self._h2d(d_buf, red)
+            return 0
+        except Exception as e:                       # an exception must not unwind through the C caller
+            sys.stderr.write("transport all_reduce: %r\n" % (e,))
+            return 1
+
+    def all_gather(self, user, d_send, d_recv, nbytes):
+        try:
+            mine = self._d2h(d_send, nbytes)
+            self._h2d(d_recv, np.concatenate(self._exchange([mine] * self.world)))
+            return 0
+        except Exception as e:
+            sys.stderr.write("transport all_gather: %r\n" % (e,))
+            return 1
+
+    def all_to_all_v(self, user, d_send, sc, so, d_recv, rc, ro, elem):
+        try:
+            w = self.world
+            sc, so, rc, ro = ([int(v[r]) for r in range(w)] for v in (sc, so, rc, ro))
+            total = max((so[r] + sc[r] for r in range(w)), default=0)
+            send = self._d2h(d_send, total * elem)
+            got = self._exchange([send[so[r] * elem:(so[r] + sc[r]) * elem] for r in range(w)])
+            for r in range(w):
+                assert len(got[r]) == rc[r] * elem
+                if rc[r]:
+                    self._h2d(d_recv + ro[r] * elem, got[r])
+            return 0
+        except Exception as e:
+            sys.stderr.write("transport all_to_all_v: %r\n" % (e,))
+            return 1
+
+
+def _load_case(case):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_case, case_args
+    from fithic_amd import tables
+    meta, _ = load_case(case)
+    kw = case_args(meta)
+    chroms = tables.ChromIndex()
+    con = tables.read_contacts(kw["contacts"], chroms)
+    frag = tables.read_fragments(kw["frags"], chroms)
+    bias = tables.read_bias(kw["bias_path"], chroms) if kw["bias_path"] else None
+    return kw, chroms, con, frag, bias
+
+
+def _make_ctx(kw, chroms, frag, bias, con, rows):
+    from fithic_amd import _capi
+    from fithic_amd.engine import MODES
+    c = _capi.Context(0)
+    c.set_params(kw["resolution"], kw["L"], kw["U"], kw["n_bins"], kw["mapp_thres"], MODES[kw["mode"]], kw["tL"], kw["tU"])
+    c.load_fragments(*frag, chroms.sort_rank())
+    if bias:
+        c.load_bias(*bias)
+    t = con.take(rows)
+    c.load_pairs(t.chr1, t.mid1, t.chr2, t.mid2, t.count)
+    return c
+
+
+def _same(a, b):
+    return bool(((a.view(np.int64) == b.view(np.int64)) | (np.isnan(a) & np.isnan(b))).all())
+
+
+def _single_gpu_passes(ctx, n_rows, passes):
+    out = []
+    for pi in range(passes):
+        ctx.pass_stats()
+        info = ctx.fit()
+        ctx.pvalues()
+        ctx.bh(info.bh_total_tests)
+        v = ctx.fetch(n_rows)
+        out.append((v["p"], v["q"], ctx.next_pass() if pi + 1 < passes else None))
+    return out
+
+
+def _rank_main(rank, world, conns, case, passes, split, result_path):
+    msgs = []
+    try:
+        kw, chroms, con, frag, bias = _load_case(case)
+        n = len(con)
+        if split == "by_chr":
+            mine = np.flatnonzero(con.chr1 % world == rank)
+        elif split == "empty_last":                   # the last rank holds no row at all
+            mine = np.flatnonzero(con.chr1 % (world - 1) == rank) if rank < world - 1 else np.zeros(0, np.int64)
+        else:                                         # contiguous blocks of the file
+            mine = np.arange(n * rank // world, n * (rank + 1) // world)
+        single = _make_ctx(kw, chroms, frag, bias, con, np.arange(n))
+        want = _single_gpu_passes(single, n, passes)
+        single.close()
+        local = _make_ctx(kw, chroms, frag, bias, con, mine)
+        local.set_global_rows(mine)                   # file positions (the -p >= 3 semantics)
+        tr = PipeTransport(local, rank, world, conns)
+        local.comm_init_custom(tr.struct, rank, world)
+        assert local.comm_info()[:2] == (rank, world)
+        for pi in range(passes):
+            info = local.run_pass_distributed()
+            got = local.fetch(len(mine))
+            for key, ref in (("p", want[pi][0]), ("q", want[pi][1])):
+                if not _same(got[key], ref[mine]):
+                    bad = ~((got[key].view(np.int64) == ref[mine].view(np.int64)) | (np.isnan(got[key]) & np.isnan(ref[mine])))
+                    msgs.append("pass %d: %s differs on %d of %d rows" % (pi + 1, key, int(bad.sum()), len(mine)))
+            st = local.stats()
+            if pi == 0 and st.n_skipped != 0:
+                msgs.append("skipped rows in pass 1")
+            if pi + 1 < passes:
+                tot = local.next_pass_distributed()
+                if tot != want[pi][2]:
+                    msgs.append("outliers %d vs %d" % (tot, want[pi][2]))
+        local.close()
+    except Exception as e:
+        import traceback
+        msgs.append("exception: %r\n%s" % (e, traceback.format_exc()))
+    with open(result_path, "w") as f:
+        f.write("OK" if not msgs else "FAIL: " + "; ".join(msgs))
+
+
+def _run_world(world, case, passes, split, tmp_path):
+    ctxmp = mp.get_context("spawn")
+    pipes = {}
+    for a in range(world):
+        for b in range(a + 1, world):
+            pipes[(a, b)] = ctxmp.Pipe(duplex=True)
+    procs = []
+    for r in range(world):
+        conns = {}
+        for (a, b), (ca, cb) in pipes.items():
+            if a == r:
+                conns[b] = ca
+            elif b == r:
+                conns[a] = cb
+        out = os.path.join(str(tmp_path), "rank%d.txt" % r)
+        p = ctxmp.Process(target=_rank_main, args=(r, world, conns, case, passes, split, out))
+        p.start()
+        procs.append((p, out))
+    for p, out in procs:
+        p.join(600)
+        assert p.exitcode == 0, "rank process died (exit code %r)" % (p.exitcode,)
+    for _, out in procs:
+        with open(out) as f:
+            assert f.read() == "OK"
+
+
+@pytest.mark.parametrize("world,case,passes,split", [
+    (2, "f2_all", 2, "by_chr"), (2, "f1_bias", 2, "blocks"), (2, "f6_quirk_all", 3, "by_chr"),
+    (3, "f2_all", 2, "empty_last"), (3, "f2_intra", 2, "blocks")])
+def test_native_sharded_pass_equals_single_gpu(world, case, passes, split, tmp_path):
+    _run_world(world, case, passes, split, tmp_path)
+
+
+def _rccl_single_rank(case, passes, result_path):
+    msgs = []
+    try:
+        from fithic_amd import _capi
+        kw, chroms, con, frag, bias = _load_case(case)
+        n = len(con)
+        single = _make_ctx(kw, chroms, frag, bias, con, np.arange(n))
+        want = _single_gpu_passes(single, n, passes)
+        single.close()
+        local = _make_ctx(kw, chroms, frag, bias, con, np.arange(n))
+        local.comm_init(_capi.comm_unique_id(), 0, 1)
+        rank, world, version = local.comm_info()
+        if (rank, world) != (0, 1) or version <= 0:
+            msgs.append("comm_info %r" % ((rank, world, version),))
+        for pi in range(passes):
+            local.run_pass_distributed()
+            got = local.fetch(n)
+            for key, ref in (("p", want[pi][0]), ("q", want[pi][1])):
+                if not _same(got[key], ref):
+                    msgs.append("pass %d: %s differs" % (pi + 1, key))
+            if pi + 1 < passes and local.next_pass_distributed() != want[pi][2]:
+                msgs.append("outlier totals differ")
+        stages = local.dist_stage_seconds()
+        if not all(v >= 0 for v in stages.values()):
+            msgs.append("stage clocks %r" % (stages,))
+        local.close()
+    except Exception as e:
+        import traceback
+        msgs.append("exception: %r\n%s" % (e, traceback.format_exc()))
+    with open(result_path, "w") as f:
+        f.write("OK" if not msgs else "FAIL: " + "; ".join(msgs))
+
+
+@pytest.mark.parametrize("case,passes", [("f2_all", 2), ("f1_bias", 1)])
+def test_rccl_transport_with_one_rank(case, passes, tmp_path):
+    """Real RCCL, world size 1, in a fresh process without torch (the library loads the system's librccl itself)."""
+    out = os.path.join(str(tmp_path), "rccl.txt")
+    p = mp.get_context("spawn").Process(target=_rccl_single_rank, args=(case, passes, out))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0
+    with open(out) as f:
+        assert f.read() == "OK"

@@ -169,6 +169,32 @@ def test_bh_ragged_sizes_bit_exact(ctx, n):
     assert bits_equal(ctx.bh_array(allone, 5.0), allone)          # nothing to sort at all
 
 
+def test_bh_values_above_one_and_few_tests_follow_the_reference(ctx):
+    """myStats.benjamini_hochberg_correction takes any numbers: with N < rank a p > 1 yields min(p*N/rank, 1) < 1, and only
+    p == 1.0 exactly is pinned to 1.0 (myStats.py:33-38).  Nothing saturates for small N, so every row is ranked."""
+    from oracle import fithic_oracle as fo
+    rng = np.random.default_rng(21)
+    n = 50_001
+    p = rng.uniform(0, 1, n) ** rng.integers(1, 6, n)
+    p[rng.integers(0, n, n // 5)] = 1.0
+    p[rng.integers(0, n, n // 7)] = rng.uniform(1.0, 40.0, n // 7)             # not p-values, but legal inputs
+    p[rng.integers(0, n, 20)] = np.inf
+    p[rng.integers(0, n, 50)] = np.nan
+    for N in (1.0, 10.0, 0.37 * n, float(n), 4.0 * n):
+        assert bits_equal(ctx.bh_array(p, N), fo.benjamini_hochberg(p, N)), N
+
+
+def test_bh_rejects_negative_values_and_bad_test_counts(ctx):
+    """A negative "p-value" would index the key histogram past its end (keys are IEEE bit patterns): refused, loudly."""
+    from fithic_amd._capi import FhxError
+    p = np.array([0.2, -0.1, 0.5])
+    with pytest.raises(FhxError, match="negative p-value at index 1"):
+        ctx.bh_array(p, 10.0)
+    with pytest.raises(FhxError, match="number of tests must be positive"):
+        ctx.bh_array(np.array([0.2, 0.5]), 0.0)
+    assert np.array_equal(ctx.bh_array(np.array([0.2, -0.0, 0.5]), 10.0), np.array([1.0, 0.0, 1.0]))    # -0.0 is zero
+
+
 def _run_case(name, device=0):
     from fithic_amd import tables
     from fithic_amd.engine import Engine

@@ -235,3 +235,76 @@ def test_count_homogeneous_waves_equal_the_per_lane_kernel(monkeypatch):
         for key in ("p", "q"):
             same = (a[key].view(np.int64) == b[key].view(np.int64)) | (np.isnan(a[key]) & np.isnan(b[key]))
             assert same.all(), (key, int((~same).sum()), float(np.nanmax(np.abs(a[key] - b[key]))))
+
+
+def _bench_rows(cfg, lengths, device):
+    import torch
+    import bench
+    from fithic_amd import synth
+    genome = synth.Genome(cfg["res"], lengths)
+    cols, n, n_cis, n_trans = bench.build_rows(synth, torch, cfg, genome, list(range(len(genome))), 0, 1, device)
+    return genome, cols, n, n_cis, n_trans
+
+
+def test_c5_shaped_cis_and_trans_all_mode_vs_oracle():
+    """BASELINE configs[4] at reduced size: 1 kb loci, -L 2000 -U 2000000 (1 999 distance values), cis + trans rows from the
+    synth-v1 generators, -x All (N = possibleIntraInRangeCount + observedInterAllCount, fithic.py:1138-1139; both binomials):
+    every row against the oracle."""
+    import torch
+    import bench
+    from oracle import fithic_oracle as fo
+    cfg = dict(bench.CONFIGS["C5"])
+    genome, cols_t, n, n_cis, n_trans = _bench_rows(cfg, [5_000_000, 4_000_000, 3_000_000], torch.device("cuda", 0))
+    assert n_trans > 300_000 and 6_000_000 < n_cis < 10_000_000
+    cols = [t[:n].cpu().numpy() for t in cols_t]
+    res = cfg["res"]
+    eng = _engine_for(genome, res, cfg["L"], cfg["U"], 100, mode="All")
+    eng.load_contacts_device([t.data_ptr() for t in cols_t], n)
+    out = eng.run_pass()
+    v = eng.fetch(p=True, q=True, expcc=True, bias=True)
+    frags, bias_dic = bench._oracle_tables(genome, list(range(len(genome))), res, True)
+    pairs = fo.Pairs(cols[0], cols[1], cols[2], cols[3], cols[4], genome.names)
+    r = fo.run(pairs, frags, None, res, n_bins=100, passes=1, mode="All", L=cfg["L"], U=cfg["U"], bias_dic=bias_dic)[0]
+    assert [out.stats["inter_count"], out.stats["inter_sum"], out.stats["intra_all_sum"], out.stats["in_range_sum"]] == list(r.sums)
+    assert out.stats["inter_count"] == n_trans
+    assert out.info["bh_total_tests"] == r.N
+    assert bits_equal(out.arrays["x"], np.array(r.x)) and bits_equal(out.arrays["table_y"], r.newSplineY)
+    assert max_abs_diff(v["p"], r.p) <= TOL and max_abs_diff(v["q"], r.q) <= TOL
+    assert bits_equal(v["expcc"], r.expcc)
+    inter = cols[0] != cols[2]
+    assert np.isnan(v["p"][inter]).sum() == np.isnan(r.p[inter]).sum() > 0          # one discarded bias -> NaN (SURVEY A12)
+    assert np.nanmin(v["p"][inter]) < 0.05 and float(np.mean(v["q"] < 1.0)) > 0
+    eng.close()
+
+
+def test_c3_at_full_size():
+    """BASELINE configs[2] at its full size - 22 autosomes at 5 kb, 1.48e8 rows, exactly what bench.py times: K1 against
+    numpy, p of a 1-in-16 sample of six chromosomes against the oracle's bdtrc with the engine's own fit, q of every row
+    against the oracle's Benjamini-Hochberg of the engine's p."""
+    import torch
+    import bench
+    from oracle import run_check
+    cfg = dict(bench.CONFIGS["C3"])
+    dev = torch.device("cuda", 0)
+    genome, cols_t, n, n_cis, _ = _bench_rows(cfg, None, dev)
+    assert 1.40e8 < n < 1.56e8 and n == n_cis
+    res = cfg["res"]
+    eng = _engine_for(genome, res, cfg["L"], cfg["U"], 100)
+    eng.load_contacts_device([t.data_ptr() for t in cols_t], n)
+    d_idx = ((cols_t[3][:n] - cols_t[1][:n]) // res).to(torch.int64)
+    want_np = torch.bincount(d_idx, minlength=512).cpu().numpy()
+    want_cc = torch.bincount(d_idx, weights=cols_t[4][:n].to(torch.float64), minlength=512).cpu().numpy().astype(np.int64)
+    total_cc = int(cols_t[4][:n].to(torch.int64).sum())
+    chroms = [16, 17, 18, 19, 20, 21]
+    sel = torch.nonzero(cols_t[0][:n] >= 16).squeeze(1)
+    sample = {"rows": sel.cpu().numpy(), "cols": [cols_t[k][:n][sel].cpu().numpy() for k in range(5)], "chroms": chroms}
+    del cols_t, d_idx, sel
+    torch.cuda.empty_cache()
+    out = eng.run_pass()
+    assert out.stats["in_range_sum"] == total_cc and out.stats["n_rows"] == n
+    hist_np, hist_cc = out.arrays["hist_npairs"], out.arrays["hist_sumcc"]
+    assert np.array_equal(hist_np[:512], want_np[:512]) and np.array_equal(hist_cc[:512], want_cc[:512]) and hist_np[512:].sum() == 0
+    chk = run_check.check_engine_run(eng, genome, sample, cfg, (out.info, out.stats), True, p_stride=16)
+    assert chk["rows_q"] == n and chk["rows_p"] > 1_000_000
+    assert chk["nan_pattern_equal"] and chk["max_dp"] <= TOL and chk["max_dq"] == 0.0, chk
+    eng.close()

@@ -91,6 +91,34 @@ def test_bh_known_answers_bit_exact():
         assert bits_equal(q, g[name + "_q"]), name
 
 
+def test_pruned_bh_is_the_same_function():
+    """benjamini_hochberg_pruned (used to check q of 10^8-row GPU runs) equals the plain restatement bit for bit: on the
+    reference's own known answers and on random vectors with ties, 1.0s, zeros and NaNs at several N / n ratios."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "f5_bh.npz"))
+    for name in g["names"]:
+        assert bits_equal(fo.benjamini_hochberg_pruned(g[name + "_p"], g[name + "_N"][0]), g[name + "_q"]), name
+    rng = np.random.default_rng(12)
+    for trial in range(120):
+        n = int(rng.integers(1, 4000))
+        kind = trial % 5
+        if kind == 0:
+            p = rng.random(n)
+        elif kind == 1:
+            p = rng.random(n) ** 8
+        elif kind == 2:
+            p = np.round(rng.random(n), 2)
+        elif kind == 3:
+            p = np.where(rng.random(n) < 0.3, 1.0, rng.random(n) ** 4)
+        else:
+            p = rng.random(n) ** 6
+            p[rng.random(n) < 0.05] = np.nan
+            p[rng.random(n) < 0.05] = 0.0
+        for N in (0.5 * n, n, 3.7 * n, 100 * n, 1):
+            assert bits_equal(fo.benjamini_hochberg_pruned(p, N), fo.benjamini_hochberg(p, N)), (trial, N)
+
+
 def test_skip_mask_freezes_at_duplicate():
     m = fo.effective_skip_mask(12, [2, 5, 5, 7, 9])
     assert m.nonzero()[0].tolist() == [2, 5]          # SURVEY A17: nothing after the first duplicate is skipped
