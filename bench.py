@@ -164,7 +164,9 @@ def main():
             ver = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:
             ver = None
-        rccl = {"world": td.get_world_size(), "backend": td.get_backend(), "version": ver, "transport": "xGMI / RCCL via torch.distributed"}
+        rccl = {"world": td.get_world_size(), "backend": td.get_backend(), "torch_rccl_version": ver,
+                "driver": "torch.distributed schedule (fithic_amd.dist)" if os.environ.get("FHX_DIST_PY") else
+                          "library communicator: fhx_comm_init + fhx_run_pass_distributed (collectives on the engine's stream)"}
 
     cfg = dict(CONFIGS[args.config])
     if args.keep > 0:
@@ -220,7 +222,15 @@ def main():
         del cols
         torch.cuda.empty_cache()
 
-        runner = dist.DistributedPass(eng, comm) if comm else None
+        runner = None
+        if comm and os.environ.get("FHX_DIST_PY"):               # the exchange schedule written over torch.distributed
+            runner = dist.DistributedPass(eng, comm)
+        elif comm:                                               # the library's own RCCL communicator on the engine's stream
+            import torch.distributed as td
+            uid = [_capi_mod().comm_unique_id() if rank == 0 else None]
+            td.broadcast_object_list(uid, src=0)                 # torch.distributed only carries the 128-byte id
+            eng.ctx.comm_init(uid[0], rank, world)
+            runner = NativeRunner(eng)
         passes = cfg["passes"]
         pass_ms = np.zeros(passes)
 
@@ -339,6 +349,9 @@ def main():
         if passes > 1:
             result["ms_per_pass"] = [float(v) for v in M["pass_ms"]]
         if rccl:
+            if not os.environ.get("FHX_DIST_PY"):
+                r_, w_, v_ = eng.ctx.comm_info()
+                rccl.update(world_in_library=w_, library_rccl_version_code=v_)
             result["rccl"] = rccl
             result["stage_ms"] = M["stage_ms"]
         if M["sample"] is not None:
@@ -376,6 +389,31 @@ def main():
     if comm:
         import torch.distributed as td
         td.destroy_process_group()
+
+
+def _capi_mod():
+    from fithic_amd import _capi
+    return _capi
+
+
+class NativeRunner:
+    """fhx_run_pass_distributed / fhx_next_pass_distributed with the interface bench.py's step loop expects."""
+
+    def __init__(self, eng):
+        self.eng, self.timings, self.stats = eng, {}, None
+
+    def run(self):
+        info = self.eng.ctx.run_pass_distributed()
+        self.stats = self.eng.ctx.stats()
+        for k, v in self.eng.ctx.dist_stage_seconds().items():
+            self.timings[k] = self.timings.get(k, 0.0) + v
+        return info
+
+    def next_pass(self):
+        return self.eng.ctx.next_pass_distributed()
+
+    def reset(self):
+        pass
 
 
 def _oracle_tables(genome, chroms, res, with_bias, cut_loci=None):

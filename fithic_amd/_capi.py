@@ -111,6 +111,8 @@ SYMBOLS = {
     "fhx_comm_info": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "fhx_run_pass_distributed": (ctypes.c_int, [_P, ctypes.POINTER(FhxFitInfo)]),
     "fhx_next_pass_distributed": (ctypes.c_int, [_P, _I64P]),
+    "fhx_pass_stats_distributed": (ctypes.c_int, [_P, ctypes.POINTER(FhxStats)]),
+    "fhx_bh_distributed": (ctypes.c_int, [_P, ctypes.c_double]),
     "fhx_dist_stage_seconds": (ctypes.c_int, [_P, _F64P]),
     "fhx_copy": (ctypes.c_int, [_P, _P, _P, ctypes.c_int64, ctypes.c_int]),
     "fhx_host_read_table": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_P)]),
@@ -120,6 +122,8 @@ SYMBOLS = {
     "fhx_table_error": (ctypes.c_char_p, [_P]),
     "fhx_table_copy": (ctypes.c_int, [_P, ctypes.c_int32, _P]),
     "fhx_table_free": (None, [_P]),
+    "fhx_host_write_contacts": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int32, _I32P, _I32P, _I32P, _I32P,
+                                               _I32P, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]),
     "fhx_host_write_significances": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int32, _I32P, _I32P, _I32P,
                                                     _I32P, _I32P, _F64P, _F64P, _F64P, _F64P, _F64P, ctypes.c_int64, ctypes.c_int32,
                                                     ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _I64P]),
@@ -399,6 +403,14 @@ class Context:
         self._check(self._L.fhx_run_pass_distributed(self._h, ctypes.byref(info)))
         return info
 
+    def pass_stats_distributed(self):
+        st = FhxStats()
+        self._check(self._L.fhx_pass_stats_distributed(self._h, ctypes.byref(st)))
+        return st
+
+    def bh_distributed(self, n_total_tests):
+        self._check(self._L.fhx_bh_distributed(self._h, float(n_total_tests)))
+
     def next_pass_distributed(self):
         n = ctypes.c_int64(0)
         self._check(self._L.fhx_next_pass_distributed(self._h, ctypes.byref(n)))
@@ -550,6 +562,16 @@ def host_read_table(path, kind, threads=0):
     finally:
         if h:
             L.fhx_table_free(h)
+
+
+def host_write_contacts(path, names, chr1, mid1, chr2, mid2, count, gzip_level=1, threads=0):
+    """chr1 mid1 chr2 mid2 count as the reference reads it, size-tagged gzip members written on all cores (tooling)."""
+    arr_names = (ctypes.c_char_p * len(names))(*[n.encode() for n in names])
+    i32 = [_i32(v) for v in (chr1, mid1, chr2, mid2, count)]
+    rc = lib().fhx_host_write_contacts(os.fsencode(path), arr_names, len(names), *[_ptr(v, ctypes.c_int32) for v in i32], len(i32[0]),
+                                       int(gzip_level), int(threads))
+    if rc != FHX_OK:
+        raise FhxError(rc, "fhx_host_write_contacts(%s)" % path)
 
 
 def host_write_significances(path, names, chr1, mid1, chr2, mid2, count, p, q, b1, b2, expcc, mode, dist_low, dist_up,

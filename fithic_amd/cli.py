@@ -43,6 +43,9 @@ def parse_args(argv=None):
     parser.add_argument("-V", "--version", action="version", version="Fit-Hi-C {} (fithic-mi355x)".format(__version__),
                         help="Print version and exit")
     parser.add_argument("--device", dest="device", type=int, default=0, help="GPU ordinal (engine option, not in the reference)")
+    parser.add_argument("--gpus", dest="gpus", type=int, default=1,
+                        help="engine option, not in the reference: shard the contact rows by chromosome over this many GPUs of the "
+                             "node (RCCL for the genome-wide steps); the output files are the ones a single GPU writes")
     return parser.parse_args(argv)
 
 
@@ -143,6 +146,12 @@ def main(argv=None):
     F.reset_session()
     F.resolution = resolution
     F.device = args.device
+    if args.gpus < 1:
+        print("Invalid Option. --gpus must be at least 1")
+        sys.exit(2)
+    if args.gpus > 1 and resolution == 0:
+        print("--gpus N needs fixed-size data (-r > 0); running on one GPU")
+    F.gpus = args.gpus if resolution > 0 else 1
     F.logfile = os.path.join(outputPath, libName + ".fithic.log")
 
     (mainDic, observedInterAllCount, observedInterAllSum, observedIntraAllSum, observedIntraInRangeSum) = \

@@ -43,6 +43,7 @@ toKb, toMb, toProb = 10 ** -3, 10 ** -6, 10 ** 5
 logfile = None
 resolution = None          # engine-only global, see the module docstring
 device = 0                 # GPU ordinal the engine uses
+gpus = 1                   # > 1: contact rows sharded by chromosome over that many GPUs (fithic_amd.sharded)
 
 
 class _Session:
@@ -69,7 +70,11 @@ class _Session:
 
     def ensure_engine(self):
         if self.engine is None:
-            self.engine = Engine(device)
+            if gpus > 1:
+                from .sharded import ShardedEngine
+                self.engine = ShardedEngine(gpus)
+            else:
+                self.engine = Engine(device)
         return self.engine
 
     def configure(self):

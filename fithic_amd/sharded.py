@@ -1,0 +1,339 @@
+"""`fithic --gpus N`: the reference's one-process run (fithic/fithic.py:317-370) over N MI355X of one node.
+
+Rank 0 is the process the user started: it parses the three tables once, shards the contact rows by chromosome
+(greedy by row count; inter-chromosomal rows follow their first chromosome), keeps shard 0 on its own GPU and hands the
+other shards to N-1 worker processes (one per GPU).  `ShardedEngine` offers the subset of `Engine` the stage functions
+of fithic_amd.fithic use, so the same functions write the same files: every stage is forwarded to all ranks, the
+genome-wide steps go through the library's communicator (fhx_pass_stats_distributed: K1 + one all-reduce;
+fhx_bh_distributed: global ranking; fhx_next_pass_distributed: outlier multiset), and rank 0 gathers p, q, ExpCC and
+the biases back into file order for the one significances file.
+
+Transports: "rccl" (default; fhx_comm_init, RCCL over xGMI) or "pipes" (fhx_comm_init_custom with the collectives
+below, staged through host memory - for boxes where several ranks must share one GPU, which RCCL refuses; used by the
+tests).  No compute happens here: this module moves tables and commands.
+"""
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+
+from . import _capi
+from .engine import Engine, MODES
+
+
+class PipeTransport:
+    """all_reduce / all_gather / all_to_all_v on device buffers over a full mesh of pipes (fhx_transport callbacks)."""
+
+    def __init__(self, ctx, rank, world, conns):
+        self.ctx, self.rank, self.world, self.conns = ctx, rank, world, conns
+        T = _capi.FhxTransport
+        self.struct = T(None, T.ALL_REDUCE(self.all_reduce), T.ALL_GATHER(self.all_gather), T.ALL_TO_ALL_V(self.all_to_all_v))
+
+    def _d2h(self, ptr, nbytes):
+        a = np.empty(nbytes, np.uint8)
+        if nbytes:
+            self.ctx.copy(a.ctypes.data, ptr, nbytes, 1)
+        return a
+
+    def _h2d(self, ptr, a):
+        if a.nbytes:
+            a = np.ascontiguousarray(a)
+            self.ctx.copy(ptr, a.ctypes.data, a.nbytes, 0)
+
+    def _exchange(self, per_peer):
+        """per_peer[r] = bytes for rank r; returns what every rank sent to this one (its own entry passes through)."""
+        for r in range(self.world):
+            if r != self.rank:
+                self.conns[r].send_bytes(per_peer[r].tobytes())
+        got = [None] * self.world
+        got[self.rank] = per_peer[self.rank]
+        for r in range(self.world):
+            if r != self.rank:
+                got[r] = np.frombuffer(self.conns[r].recv_bytes(), np.uint8)
+        return got
+
+    def all_reduce(self, user, d_buf, n, op):
+        try:                                          # an exception must not unwind through the C caller
+            mine = self._d2h(d_buf, 8 * n)
+            parts = [g.view(np.int64) for g in self._exchange([mine] * self.world)]
+            red = {0: np.sum, 1: np.max, 2: np.min}[op](np.stack(parts), axis=0).astype(np.int64)
+            self._h2d(d_buf, red)
+            return 0
+        except Exception as e:
+            sys.stderr.write("transport all_reduce: %r\n" % (e,))
+            return 1
+
+    def all_gather(self, user, d_send, d_recv, nbytes):
+        try:
+            mine = self._d2h(d_send, nbytes)
+            self._h2d(d_recv, np.concatenate(self._exchange([mine] * self.world)))
+            return 0
+        except Exception as e:
+            sys.stderr.write("transport all_gather: %r\n" % (e,))
+            return 1
+
+    def all_to_all_v(self, user, d_send, sc, so, d_recv, rc, ro, elem):
+        try:
+            w = self.world
+            sc, so, rc, ro = ([int(v[r]) for r in range(w)] for v in (sc, so, rc, ro))
+            total = max((so[r] + sc[r] for r in range(w)), default=0)
+            send = self._d2h(d_send, total * elem)
+            got = self._exchange([send[so[r] * elem:(so[r] + sc[r]) * elem] for r in range(w)])
+            for r in range(w):
+                if len(got[r]) != rc[r] * elem:
+                    raise RuntimeError("rank %d sent %d bytes, expected %d" % (r, len(got[r]), rc[r] * elem))
+                if rc[r]:
+                    self._h2d(d_recv + ro[r] * elem, got[r])
+            return 0
+        except Exception as e:
+            sys.stderr.write("transport all_to_all_v: %r\n" % (e,))
+            return 1
+
+
+def make_mesh(ctxmp, world):
+    """conns[r][peer] = this rank's end of the pipe to `peer`."""
+    conns = [dict() for _ in range(world)]
+    for a in range(world):
+        for b in range(a + 1, world):
+            ca, cb = ctxmp.Pipe(duplex=True)
+            conns[a][b] = ca
+            conns[b][a] = cb
+    return conns
+
+
+class _Rank:
+    """One rank's engine + communicator; the same object serves rank 0 (in process) and the workers' command loop."""
+
+    def __init__(self, rank, world, device, transport, unique_id, mesh):
+        self.rank, self.world = rank, world
+        self.eng = Engine(device)
+        self.transport, self.unique_id, self.mesh = transport, unique_id, mesh
+        self.comm_ready = False
+        self.n_rows = 0
+
+    def _ensure_comm(self):
+        if self.comm_ready:
+            return
+        if self.transport == "pipes":
+            self._pt = PipeTransport(self.eng.ctx, self.rank, self.world, self.mesh)
+            self.eng.ctx.comm_init_custom(self._pt.struct, self.rank, self.world)
+        else:
+            self.eng.ctx.comm_init(self.unique_id, self.rank, self.world)
+        self.comm_ready = True
+
+    # every method below is a command; the return value travels back to rank 0
+    def configure(self, *a):
+        self.eng.configure(*a)
+
+    def load_fragments(self, *a):
+        self.eng.load_fragments(*a)
+
+    def load_bias(self, *a):
+        self.eng.load_bias(*a)
+
+    def load_contacts(self, c1, m1, c2, m2, cnt, rows):
+        self.eng.load_contacts(c1, m1, c2, m2, cnt)
+        self.eng.ctx.set_global_rows(rows)               # file positions: the -p >= 3 semantics
+        self.n_rows = len(rows)
+        self._ensure_comm()
+
+    def pass_stats(self):
+        return self.eng.ctx.pass_stats_distributed().as_dict()
+
+    def make_bins(self):
+        return self.eng.ctx.make_bins()
+
+    def fit(self):
+        return self.eng.fit().as_dict()
+
+    def pvalues(self):
+        self.eng.ctx.pvalues()
+
+    def bh(self, n_tests):
+        self.eng.ctx.bh_distributed(n_tests)
+
+    def fetch(self, p, q, expcc, bias):
+        return self.eng.fetch(p=p, q=q, expcc=expcc, bias=bias)
+
+    def fetch_flags(self, outlier, skip):
+        return self.eng.ctx.fetch_flags(self.n_rows, outlier=outlier, skip=skip)
+
+    def fdr_counts(self):
+        return self.eng.fdr_counts()
+
+    def next_pass(self):
+        return self.eng.ctx.next_pass_distributed()
+
+    def close(self):
+        self.eng.close()
+
+
+def _worker_main(rank, world, device, transport, unique_id, mesh, cmd):
+    try:
+        me = _Rank(rank, world, device, transport, unique_id, mesh)
+    except Exception as e:                                # no GPU / no library: report, then leave
+        cmd.send(("error", repr(e)))
+        return
+    cmd.send(("ready", None))
+    while True:
+        name, args = cmd.recv()
+        try:
+            out = getattr(me, name)(*args)
+            cmd.send(("ok", out))
+        except Exception as e:
+            import traceback
+            cmd.send(("error", "%r\n%s" % (e, traceback.format_exc())))
+        if name == "close":
+            return
+
+
+class _Info:
+    """dict with attribute access and as_dict(), like the ctypes structs Engine returns"""
+
+    def __init__(self, d):
+        self.__dict__.update(d)
+        self._d = dict(d)
+
+    def as_dict(self):
+        return dict(self._d)
+
+
+class _CtxFacade:
+    def __init__(self, owner):
+        self._o = owner
+
+    def get_array(self, which):
+        if which == _capi.A_FDR_COUNTS:
+            return self._o.fdr_counts()
+        return self._o.local.eng.ctx.get_array(which)    # host-side arrays are genome-wide and equal on every rank
+
+    def make_bins(self):
+        return self._o._all("make_bins")[0]
+
+    def pvalues(self):
+        self._o._all("pvalues")
+
+    def bh(self, n_total_tests):
+        self._o._all("bh", float(n_total_tests))
+
+    def fetch_flags(self, n_rows, outlier=True, skip=False):
+        parts = self._o._all("fetch_flags", outlier, skip)
+        out = []
+        for k, want in enumerate((outlier, skip)):
+            if not want:
+                out.append(None)
+                continue
+            a = np.empty(self._o.n_rows, np.uint8)
+            for r, part in enumerate(parts):
+                a[self._o.rows_of[r]] = part[k]
+            out.append(a)
+        return out[0], out[1]
+
+    def bh_array(self, p, n_total_tests):
+        return self._o.local.eng.ctx.bh_array(p, n_total_tests)
+
+
+class ShardedEngine:
+    """The Engine methods fithic_amd.fithic uses, over `gpus` ranks (see the module docstring)."""
+
+    def __init__(self, gpus, devices=None, transport=None):
+        transport = transport or os.environ.get("FHX_CLI_TRANSPORT", "rccl")
+        if devices is None:
+            env = os.environ.get("FHX_CLI_DEVICES")
+            devices = [int(v) for v in env.split(",")] if env else list(range(gpus))
+        if len(devices) != gpus:
+            raise ValueError("one device ordinal per rank is needed")
+        self.world, self.transport = gpus, transport
+        ctxmp = mp.get_context("spawn")
+        mesh = make_mesh(ctxmp, gpus) if transport == "pipes" else [None] * gpus
+        uid = _capi.comm_unique_id() if transport != "pipes" else None
+        self.workers = []
+        for r in range(1, gpus):
+            parent, child = ctxmp.Pipe(duplex=True)
+            p = ctxmp.Process(target=_worker_main, args=(r, gpus, devices[r], transport, uid, mesh[r], child), daemon=True)
+            p.start()
+            self.workers.append((p, parent))
+        self.local = _Rank(0, gpus, devices[0], transport, uid, mesh[0])
+        for r, (p, conn) in enumerate(self.workers, start=1):
+            status, msg = conn.recv()
+            if status != "ready":
+                raise RuntimeError("rank %d could not start: %s" % (r, msg))
+        self.ctx = _CtxFacade(self)
+        self.n_rows = 0
+        self.rows_of = [np.zeros(0, np.int64) for _ in range(gpus)]
+        self.resolution = None
+
+    def _all(self, name, *args, per_rank=None):
+        """Run one command on every rank (workers first: collectives need everybody inside the call) -> results by rank."""
+        for r, (_, conn) in enumerate(self.workers, start=1):
+            conn.send((name, per_rank[r] if per_rank else args))
+        out = [getattr(self.local, name)(*(per_rank[0] if per_rank else args))]
+        for r, (_, conn) in enumerate(self.workers, start=1):
+            status, val = conn.recv()
+            if status != "ok":
+                raise RuntimeError("rank %d failed in %s: %s" % (r, name, val))
+            out.append(val)
+        return out
+
+    # ---- Engine surface -------------------------------------------------------------------------------------------
+    def configure(self, resolution, dist_low=0, dist_up=float("inf"), n_bins=100, mapp_thres=1, mode="intraOnly",
+                  bias_low=0.5, bias_up=2.0):
+        if mode not in MODES:
+            raise ValueError("Invalid Option. Only options are 'All', 'interOnly', or 'intraOnly'")
+        if int(resolution) == 0:
+            raise NotImplementedError("--gpus N needs fixed-size loci (-r > 0); -r 0 runs on one GPU")
+        self.resolution = int(resolution)
+        self._all("configure", resolution, dist_low, dist_up, n_bins, mapp_thres, mode, bias_low, bias_up)
+
+    def load_fragments(self, chr_ids, mids, hits, chr_sort_rank):
+        self._all("load_fragments", chr_ids, mids, hits, chr_sort_rank)
+
+    def load_bias(self, chr_ids, mids, bias):
+        self._all("load_bias", chr_ids, mids, bias)
+
+    def load_contacts(self, chr1, mid1, chr2, mid2, count):
+        chr1 = np.asarray(chr1)
+        n = len(chr1)
+        per_chr = np.bincount(chr1, minlength=int(chr1.max()) + 1 if n else 1)
+        load = [0] * self.world
+        owner = np.zeros(len(per_chr), np.int64)
+        for c in np.argsort(-per_chr, kind="stable"):
+            r = min(range(self.world), key=lambda k: load[k])
+            owner[c] = r
+            load[r] += int(per_chr[c])
+        row_owner = owner[chr1] if n else np.zeros(0, np.int64)
+        self.rows_of = [np.flatnonzero(row_owner == r) for r in range(self.world)]
+        cols = [np.asarray(a) for a in (chr1, mid1, chr2, mid2, count)]
+        per_rank = [tuple(a[rows] for a in cols) + (rows,) for rows in self.rows_of]
+        self._all("load_contacts", per_rank=per_rank)
+        self.n_rows = n
+
+    def pass_stats(self):
+        return _Info(self._all("pass_stats")[0])
+
+    def fit(self):
+        return _Info(self._all("fit")[0])
+
+    def fetch(self, p=True, q=True, expcc=False, bias=False):
+        parts = self._all("fetch", p, q, expcc, bias)
+        out = {}
+        for key in parts[0]:
+            a = np.empty(self.n_rows, np.float64)
+            for r, part in enumerate(parts):
+                a[self.rows_of[r]] = part[key]
+            out[key] = a
+        return out
+
+    def fdr_counts(self):
+        return np.sum(self._all("fdr_counts"), axis=0)       # shifted cumulative counts are linear in the rows
+
+    def next_pass(self):
+        return self._all("next_pass")[0]
+
+    def close(self):
+        try:
+            self._all("close")
+        finally:
+            for p, _ in self.workers:
+                p.join(30)

@@ -265,6 +265,11 @@ int fhx_comm_info(fhx_ctx* ctx, int* rank, int* nranks, int* rccl_version);
  * p and q of the LOCAL rows in row order, as fhx_pass_stats + fhx_fit + fhx_pvalues + fhx_bh do on one GPU.
  * Fixed-size loci only (-r 0 runs go through the building blocks above). */
 int fhx_run_pass_distributed(fhx_ctx* ctx, fhx_fit_info* out);
+/* The same pass stage by stage, for callers that keep the reference's stage order (read_Interactions ... fit_Spline):
+ * fhx_pass_stats_distributed (K1 + the one all-reduce; afterwards stats and histograms are the genome-wide ones on every rank)
+ * -> fhx_make_bins / fhx_fit / fhx_pvalues on every rank as on one GPU -> fhx_bh_distributed (global ranking). */
+int fhx_pass_stats_distributed(fhx_ctx* ctx, fhx_stats* out);
+int fhx_bh_distributed(fhx_ctx* ctx, double n_total_tests);
 /* fhx_next_pass on every rank + the genome-wide outlier multiset, outlier count and first duplicated line */
 int fhx_next_pass_distributed(fhx_ctx* ctx, int64_t* n_outliers_total);
 /* host wall seconds per stage of the last fhx_run_pass_distributed: k1 + stats exchange, host fit, K2 launch, cutoff +
@@ -295,6 +300,13 @@ const char* fhx_table_name(const fhx_table* t, int32_t i);
 const char* fhx_table_error(const fhx_table* t);
 int fhx_table_copy(const fhx_table* t, int32_t column, void* dst);
 void fhx_table_free(fhx_table* t);
+/* The contacts table written as the reference reads it ("%s\t%d\t%s\t%d\t%d\n", fithic/fithic.py:413-417) on all cores;
+ * tooling for synthetic workloads.  Like every file this library writes it is a concatenation of gzip members that carry
+ * their compressed size in an "FH" extra subfield - plain gzip to every other reader, inflated in parallel by
+ * fhx_host_read_table (which does the same for bgzip's "BC" blocks). */
+int fhx_host_write_contacts(const char* path, const char* const* chr_names, int32_t n_names, const int32_t* chr1,
+                            const int32_t* mid1, const int32_t* chr2, const int32_t* mid2, const int32_t* count, int64_t n_rows,
+                            int32_t gzip_level, int32_t n_threads);
 /* Writer of <lib>.spline_passN.resR.significances.txt.gz (fithic/fithic.py:1167-1213): header + one
  * "%s\t%d\t%s\t%d\t%d\t%e\t%e\t%e\t%e\t%f" row per emitted contact (inter rows in All / interOnly mode, in-range intra
  * rows in All / intraOnly mode).  Rows are formatted and deflated in parallel, one gzip member per 65 536 rows; the

@@ -2,8 +2,8 @@
 bare ctypes + numpy - no torch in these processes.
 
   * world 2 and 3 on ONE GPU: RCCL refuses two ranks on one device, so the ranks are separate processes whose collectives
-    are the library's caller-provided transport (fhx_comm_init_custom) implemented here over multiprocessing pipes - the
-    schedule, the kernels and the buffers are exactly the ones the RCCL transport runs.  Each rank's p and q must equal,
+    are the library's caller-provided transport (fhx_comm_init_custom) with fithic_amd.sharded.PipeTransport (host-staged
+    exchange over multiprocessing pipes) - the schedule, the kernels and the buffers are exactly the ones the RCCL transport runs.  Each rank's p and q must equal,
     bit for bit, what a single-GPU run over all rows gives for its rows (1-3 passes, an empty shard, inter rows).
   * world 1 through REAL RCCL (ncclCommInitRank, all-reduce / all-gather / send-recv to self on the engine's stream): the
     same bits as fhx_pass_stats + fhx_fit + fhx_pvalues + fhx_bh.
@@ -18,74 +18,6 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-class PipeTransport:
-    """all_reduce / all_gather / all_to_all_v of device buffers over a full mesh of pipes, staged through host memory."""
-
-    def __init__(self, ctx, rank, world, conns):
-        from fithic_amd import _capi
-        self.ctx, self.rank, self.world, self.conns = ctx, rank, world, conns
-        self.struct = _capi.FhxTransport(None, _capi.FhxTransport.ALL_REDUCE(self.all_reduce), _capi.FhxTransport.ALL_GATHER(self.all_gather),
-                                         _capi.FhxTransport.ALL_TO_ALL_V(self.all_to_all_v))
-
-    def _d2h(self, ptr, nbytes):
-        a = np.empty(nbytes, np.uint8)
-        if nbytes:
-            self.ctx.copy(a.ctypes.data, ptr, nbytes, 1)
-        return a
-
-    def _h2d(self, ptr, a):
-        if a.nbytes:
-            self.ctx.copy(ptr, np.ascontiguousarray(a).ctypes.data, a.nbytes, 0)
-
-    def _exchange(self, per_peer):
-        """per_peer[r] = bytes for rank r; returns what every rank sent to me (my own entry passes through)."""
-        for r in range(self.world):
-            if r != self.rank:
-                self.conns[r].send_bytes(per_peer[r].tobytes())
-        got = [None] * self.world
-        got[self.rank] = per_peer[self.rank]
-        for r in range(self.world):
-            if r != self.rank:
-                got[r] = np.frombuffer(self.conns[r].recv_bytes(), np.uint8)
-        return got
-
-    def all_reduce(self, user, d_buf, n, op):
-        try:
-            mine = self._d2h(d_buf, 8 * n)
-            parts = [g.view(np.int64) for g in self._exchange([mine] * self.world)]
-            red = {0: np.sum, 1: np.max, 2: np.min}[op](np.stack(parts), axis=0).astype(np.int64)
-            self._h2d(d_buf, red)
-            return 0
-        except Exception as e:                       # an exception must not unwind through the C caller
-            sys.stderr.write("transport all_reduce: %r\n" % (e,))
-            return 1
-
-    def all_gather(self, user, d_send, d_recv, nbytes):
-        try:
-            mine = self._d2h(d_send, nbytes)
-            self._h2d(d_recv, np.concatenate(self._exchange([mine] * self.world)))
-            return 0
-        except Exception as e:
-            sys.stderr.write("transport all_gather: %r\n" % (e,))
-            return 1
-
-    def all_to_all_v(self, user, d_send, sc, so, d_recv, rc, ro, elem):
-        try:
-            w = self.world
-            sc, so, rc, ro = ([int(v[r]) for r in range(w)] for v in (sc, so, rc, ro))
-            total = max((so[r] + sc[r] for r in range(w)), default=0)
-            send = self._d2h(d_send, total * elem)
-            got = self._exchange([send[so[r] * elem:(so[r] + sc[r]) * elem] for r in range(w)])
-            for r in range(w):
-                assert len(got[r]) == rc[r] * elem
-                if rc[r]:
-                    self._h2d(d_recv + ro[r] * elem, got[r])
-            return 0
-        except Exception as e:
-            sys.stderr.write("transport all_to_all_v: %r\n" % (e,))
-            return 1
 
 
 def _load_case(case):
@@ -147,6 +79,7 @@ def _rank_main(rank, world, conns, case, passes, split, result_path):
         single.close()
         local = _make_ctx(kw, chroms, frag, bias, con, mine)
         local.set_global_rows(mine)                   # file positions (the -p >= 3 semantics)
+        from fithic_amd.sharded import PipeTransport
         tr = PipeTransport(local, rank, world, conns)
         local.comm_init_custom(tr.struct, rank, world)
         assert local.comm_info()[:2] == (rank, world)

@@ -342,6 +342,35 @@ def test_cli_writes_the_reference_files(name, tmp_path, capsys):
     assert mine == want
 
 
+@pytest.mark.parametrize("name,gpus", [("f1_bias", 2), ("f2_all", 3), ("f6_quirk_all", 2)])
+def test_cli_gpus_n_writes_the_same_files(name, gpus, tmp_path, monkeypatch):
+    """`fithic --gpus N`: rows sharded by chromosome over N ranks (worker processes), genome-wide steps through the library's
+    communicator, rank 0 writes the ONE output set - byte-identical to the reference's.  On this one-GPU box the ranks share
+    GPU 0 and the collectives travel over pipes (FHX_CLI_TRANSPORT=pipes; RCCL refuses two ranks on one device)."""
+    import gzip
+    import hashlib
+    from fithic_amd import cli
+    monkeypatch.setenv("FHX_CLI_TRANSPORT", "pipes")
+    monkeypatch.setenv("FHX_CLI_DEVICES", ",".join(["0"] * gpus))
+    meta, g = load_case(name)
+    kw = case_args(meta)
+    argv = ["-i", kw["contacts"], "-f", kw["frags"], "-o", str(tmp_path), "-l", "G", "--gpus", str(gpus)] + meta["argv"]
+    if kw["bias_path"]:
+        argv += ["-t", kw["bias_path"]]
+    cli.main(argv)
+    res = kw["resolution"]
+    for pi in range(1, meta["n_passes"] + 1):
+        with gzip.open(os.path.join(str(tmp_path), "G.spline_pass%d.res%d.significances.txt.gz" % (pi, res)), "rb") as f:
+            text = f.read()
+        assert hashlib.md5(text).hexdigest() == meta["sig_md5_pass%d" % pi]
+        with open(os.path.join(str(tmp_path), "G.fithic_pass%d.res%d.txt" % (pi, res))) as f:
+            assert f.read() == meta["fithic_pass%d_txt" % pi]
+    with open(os.path.join(str(tmp_path), "G.fithic.log")) as f:
+        mine = [ln for ln in f.read().splitlines() if not ln.startswith("Means and error written")]
+    want = [ln for ln in meta["log_txt"].splitlines() if not ln.startswith("Means and error written")]
+    assert mine == want
+
+
 def test_cli_visual_flag_writes_figures_and_same_tables(tmp_path):
     """-v (fithic.py:225-229, 374-376): the figures appear and the significances stay byte-identical."""
     import gzip
