@@ -587,6 +587,16 @@ __device__ __forceinline__ double bdtrc_count_trivial(int count, const BinomTabl
     return p <= 0.0 ? 0.0 : 1.0;              // incbet's domain edges: xx == 0 -> 0, xx == 1 -> 1 (no other p is trivial)
 }
 
+// The one trivial case that costs transcendentals: count == 1 with a proper probability and n > 0, where scipy's bdtrc takes
+// the closed form -expm1(n * log1p(-p)) or 1 - pow(1 - p, n).  bdtrc_count_trivial(1, T, p) == bdtrc_closed_form(T.n, p) there.
+__device__ __forceinline__ bool bdtrc_is_closed_form(int count, double n_total, double p) {
+    return count == 1 && p >= 0.0 && p <= 1.0 && n_total > 0.0;          // false for NaN
+}
+__device__ __forceinline__ double bdtrc_closed_form(double n_total, double p) {
+    if (p < 0.01) return -cephes_expm1(n_total * cephes_log1p(-p));     // dn = n - (count - 1) = n
+    return 1.0 - pow(1.0 - p, n_total);
+}
+
 // cheap classification of which loop bdtrc_count(count, T, p) will run (same predicates as incbet, same rounding)
 __device__ __forceinline__ int bdtrc_class(int count, double n_total, double p) {
     if (isnan(p)) return BC_TRIVIAL;

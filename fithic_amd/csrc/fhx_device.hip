@@ -345,18 +345,25 @@ constexpr int K2_CL_ITEMS = 4;
 constexpr int K2_CL_TILE = K2_THREADS * K2_CL_ITEMS;     // 1024 rows per workgroup step (8 items/thread costs 189 VGPRs -> 2 waves/SIMD and is slower)
 constexpr int K2_COUNT_STRIDE = 16;                      // queue counters 128 B apart: one L2 line each
 
+constexpr int K2_CLOSED = K2_QUEUES + 1;                 // tile-local class: count == 1 rows, evaluated densely from LDS
+
 __global__ __launch_bounds__(K2_THREADS) void k2_classify(K2Params P, K2Queues Q) {
     // Per tile: every wave reserves slots per class with ballots + ONE LDS atomic per (wave, class, item), then each
     // class takes ONE global atomic per tile (a same-address global atomic per wave would cap the kernel at ~88 M
     // atomics/s - MI355X_MICROARCH.md "dequeue" - i.e. slower than the arithmetic it feeds), then the lanes write
     // their own 16-byte entries at base + slot (lanes of one class hold consecutive slots).
-    __shared__ unsigned int cnt[K2_QUEUES];
+    // The closed-form rows (count == 1: a third of a Hi-C run, ~150 fp64 instructions of log1p / expm1 each) are not
+    // evaluated where they are met - with a third of the lanes active that costs every wave the full price four times
+    // per tile - but compacted into LDS and evaluated with all lanes busy at the end of the tile.
+    __shared__ unsigned int cnt[K2_QUEUES + 1];
     __shared__ unsigned long long gbase[K2_QUEUES];
+    __shared__ double cf_prior[K2_CL_TILE];
+    __shared__ unsigned short cf_idx[K2_CL_TILE];          // tile-local row | 0x8000 for the inter-chromosomal binomial
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     const int64_t tiles = (P.n + K2_CL_TILE - 1) / K2_CL_TILE;
     for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
-        if (threadIdx.x < K2_QUEUES) cnt[threadIdx.x] = 0;
+        if (threadIdx.x <= K2_QUEUES) cnt[threadIdx.x] = 0;
         __syncthreads();
         int cls_of[K2_CL_ITEMS];
         unsigned int slot_of[K2_CL_ITEMS];
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_classify(K2Params P, K2Queues Q
 #pragma unroll
         for (int r = 0; r < K2_CL_ITEMS; ++r) {
             const int64_t i = t * K2_CL_TILE + r * K2_THREADS + threadIdx.x;
-            int cls = -1;                                              // -1: no row, 0: done here, 1..4: queued
+            int cls = -1;                                              // -1: no row, 0: done here, 1..4: queued, 5: closed form
             double prior = 1.0;
             int c = 0;
             if (i < P.n) {
@@ -377,7 +384,12 @@ __global__ __launch_bounds__(K2_THREADS) void k2_classify(K2Params P, K2Queues Q
                 if (row_prior(P, l1, l2, prior, is_inter)) {
                     const dev::BinomTables& T = is_inter ? P.inter : P.intra;
                     cls = dev::bdtrc_class(c, T.n, prior);
-                    if (cls == dev::BC_TRIVIAL) pv = dev::bdtrc_count_trivial(c, T, prior);
+                    if (cls == dev::BC_TRIVIAL) {
+                        if (dev::bdtrc_is_closed_form(c, T.n, prior))
+                            cls = K2_CLOSED;
+                        else
+                            pv = dev::bdtrc_count_trivial(c, T, prior);  // constants and NaN only on this path
+                    }
                     if (is_inter) c = -c;
                 }
                 if (cls == 0) P.p[i] = pv;
@@ -386,42 +398,53 @@ __global__ __launch_bounds__(K2_THREADS) void k2_classify(K2Params P, K2Queues Q
             count_of[r] = c;
             prior_of[r] = prior;
         }
-        // slot reservation for the whole wave at once: 16 ballots (4 items x 4 classes), then ONE LDS atomic instruction
-        // (lane k reserves class k's total) and four broadcasts.  One atomic + shuffle per (item, class) made 16 dependent
+        // slot reservation for the whole wave at once: 20 ballots (4 items x 5 classes), then ONE LDS atomic instruction
+        // (lane k reserves class k's total) and five broadcasts.  One atomic + shuffle per (item, class) made 16 dependent
         // LDS round trips per wave and tile, which the 3 waves/SIMD of this kernel cannot hide.
         unsigned int before_cls[K2_CL_ITEMS];          // rank of this lane's item r among the wave's items of its class
-        unsigned int tot[K2_QUEUES] = {0u, 0u, 0u, 0u};
+        unsigned int tot[K2_QUEUES + 1] = {0u, 0u, 0u, 0u, 0u};
 #pragma unroll
         for (int r = 0; r < K2_CL_ITEMS; ++r) {
             before_cls[r] = 0;
 #pragma unroll
-            for (int k = 1; k <= K2_QUEUES; ++k) {
+            for (int k = 1; k <= K2_QUEUES + 1; ++k) {
                 const unsigned long long m = __ballot(cls_of[r] == k);
                 if (cls_of[r] == k) before_cls[r] = tot[k - 1] + (unsigned int)__popcll(m & lane_lt);
                 tot[k - 1] += (unsigned int)__popcll(m);
             }
         }
         static_assert(K2_QUEUES == 4, "lane k reserves class k");
-        const unsigned int my_tot = lane == 0 ? tot[0] : (lane == 1 ? tot[1] : (lane == 2 ? tot[2] : tot[3]));
+        const unsigned int my_tot = lane == 0 ? tot[0] : (lane == 1 ? tot[1] : (lane == 2 ? tot[2] : (lane == 3 ? tot[3] : tot[4])));
         unsigned int my_base = 0;
-        if (lane < K2_QUEUES && my_tot) my_base = atomicAdd(&cnt[lane], my_tot);
-        unsigned int wave_base[K2_QUEUES];
+        if (lane <= K2_QUEUES && my_tot) my_base = atomicAdd(&cnt[lane], my_tot);
+        unsigned int wave_base[K2_QUEUES + 1];
 #pragma unroll
-        for (int k = 0; k < K2_QUEUES; ++k) wave_base[k] = __shfl(my_base, k, 64);
+        for (int k = 0; k <= K2_QUEUES; ++k) wave_base[k] = __shfl(my_base, k, 64);
 #pragma unroll
         for (int r = 0; r < K2_CL_ITEMS; ++r) {
             const int k = cls_of[r] - 1;
-            const unsigned int wb = k == 0 ? wave_base[0] : (k == 1 ? wave_base[1] : (k == 2 ? wave_base[2] : wave_base[3]));
+            const unsigned int wb = k == 0 ? wave_base[0] : (k == 1 ? wave_base[1] : (k == 2 ? wave_base[2] : (k == 3 ? wave_base[3] : wave_base[4])));
             slot_of[r] = k >= 0 ? wb + before_cls[r] : 0u;
+            if (cls_of[r] == K2_CLOSED) {
+                cf_prior[slot_of[r]] = prior_of[r];
+                cf_idx[slot_of[r]] = (unsigned short)((r * K2_THREADS + threadIdx.x) | (count_of[r] < 0 ? 0x8000 : 0));
+            }
         }
         __syncthreads();
         if (threadIdx.x < K2_QUEUES)
             gbase[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&Q.count[threadIdx.x * K2_COUNT_STRIDE], (unsigned long long)cnt[threadIdx.x]) : 0ull;
+        // the closed-form rows of the tile, all lanes busy
+        const unsigned int n_closed = cnt[K2_QUEUES];
+        for (unsigned int j = threadIdx.x; j < n_closed; j += K2_THREADS) {
+            const unsigned int ix = cf_idx[j];
+            const double n_total = (ix & 0x8000u) ? P.inter.n : P.intra.n;
+            P.p[t * K2_CL_TILE + (ix & 0x7FFFu)] = dev::bdtrc_closed_form(n_total, cf_prior[j]);
+        }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < K2_CL_ITEMS; ++r) {
             const int k = cls_of[r] - 1;
-            if (k >= 0) {
+            if (k >= 0 && k < K2_QUEUES) {
                 QEntry e;
                 e.row = (unsigned int)(t * K2_CL_TILE + r * K2_THREADS + threadIdx.x);
                 e.count = count_of[r];
@@ -587,8 +610,13 @@ __global__ __launch_bounds__(64) void k2h_tables(const unsigned int* __restrict_
 // Lanes cf_swapped_uniform cannot take (unusual inputs or states, see fhx_bdtrc.hpp) are appended to `redo` - the space the
 // unsorted queue occupied, free once k2h_scatter has run - and k2h_generic evaluates them with the per-lane loop; keeping that
 // loop out of this kernel keeps it at 8 waves per SIMD (38 VGPRs instead of 102).
-__global__ __launch_bounds__(K2H_THREADS) void k2h_heavy(
-    K2Params P, const QEntry* __restrict__ sorted, const unsigned int* __restrict__ off,
+struct K2HeavyParams {            // the few fields of K2Params this kernel reads: its SGPR count decides how many waves a CU admits
+    dev::BinomTables intra, inter;
+    double* p;
+};
+
+__global__ __launch_bounds__(K2H_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k2h_heavy(
+    K2HeavyParams P, const QEntry* __restrict__ sorted, const unsigned int* __restrict__ off,
     const unsigned int* __restrict__ digit_total, const dev::CfRow* __restrict__ tab, QEntry* __restrict__ redo,
     unsigned long long* __restrict__ n_redo) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1639,8 +1667,11 @@ struct fhx_ctx {
     unsigned int* d_k2h_off = nullptr;                // K2H_BUCKETS + 1 bucket starts
     unsigned char* d_memo = nullptr;                  // no-bias table path: virtual rows, table, overflow list (kept across passes)
     size_t memo_bytes = 0;
-    // non-fixed-size mode (-r 0)
+    // non-fixed-size mode (-r 0), and -r N > 0 on loci that do not share one grid per chromosome (offgrid): arbitrary
+    // midpoints, distinct observed distances as histogram keys, table lookup by search; offgrid keeps the fixed-size
+    // possible-pair enumeration at multiples of the resolution (fithic.py:592-689)
     bool nonfixed = false;
+    bool offgrid = false;
     int32_t* d_slot_mid = nullptr;
     std::vector<unsigned long long> h_slot_keys;      // sorted distinct (chr << 32 | mid) of every locus the rows touch
     std::vector<int64_t> h_dist_keys;                 // distinct in-range distances of the current pass, ascending
@@ -1960,10 +1991,13 @@ int ingest_device_rows(fhx_ctx* ctx, const int32_t* c1, const int32_t* m1, const
     for (int c = 0; c < used; ++c) {
         ctx->grid[c].base = (int32_t)base;
         if (maxidx[c] >= 0) {
-            if (minoff[c] != maxoff[c])
-                return fail(ctx, FHX_ERR_UNSUPPORTED,
-                            "midpoints of one chromosome are not on one fixed-size grid (mid % resolution differs); "
-                            "the accelerated path needs fixed-size loci (reference fast path, fithic.py:592)");
+            if (minoff[c] != maxoff[c]) {
+                // midpoints of one chromosome are not on one grid (mid % resolution differs): the reference still takes
+                // abs(mid1 - mid2) of whatever the files hold (myUtils.py:112-124), so these rows go through the slotting of
+                // the -r 0 path (sort + run detection) while the host keeps the fixed-size possible pairs
+                ctx->offgrid = ctx->nonfixed = true;
+                return ingest_device_rows_nonfixed(ctx, c1, m1, c2, m2, cnt, n);
+            }
             ctx->grid[c].off = minoff[c];
             ctx->grid[c].nslots = maxidx[c] + 1;
             base += ctx->grid[c].nslots;
@@ -2056,6 +2090,7 @@ int alloc_row_arrays(fhx_ctx* ctx, int64_t n, int64_t n_dist) {
     ctx->tables_dirty = true;
     ctx->n_sorted = -1;
     ctx->dist_ndist_agreed = false;
+    if (!ctx->nonfixed) ctx->h_dist_keys.clear();
     return FHX_OK;
 }
 
@@ -2151,7 +2186,7 @@ int fhx_set_params(fhx_ctx* ctx, const fhx_params* p) {
     if (ctx->n_rows > 0 && ctx->have_params && p->resolution != ctx->prm.resolution)
         return fail(ctx, FHX_ERR_ARG, "the resolution cannot change after the contact rows were loaded");
     ctx->prm = *p;
-    ctx->nonfixed = p->resolution == 0;
+    ctx->nonfixed = p->resolution == 0 || ctx->offgrid;
     ctx->have_params = true;
     ctx->tables_dirty = true;
     return FHX_OK;
@@ -2209,6 +2244,8 @@ int fhx_load_pairs_device(fhx_ctx* ctx, const void* c1, const void* m1, const vo
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
     FHX_HIP(hipSetDevice(ctx->device));
     if (stream) FHX_HIP(hipStreamSynchronize((hipStream_t)stream));
+    ctx->offgrid = false;
+    ctx->nonfixed = ctx->have_params && ctx->prm.resolution == 0;
     if (ctx->have_params && ctx->nonfixed)
         return ingest_device_rows_nonfixed(ctx, (const int32_t*)c1, (const int32_t*)m1, (const int32_t*)c2, (const int32_t*)m2,
                                            (const int32_t*)cnt, n);
@@ -2228,6 +2265,8 @@ int fhx_load_pairs(fhx_ctx* ctx, const int32_t* chr1, const int32_t* mid1, const
         if (n) FHX_HIP(hipMemcpyAsync(d[k], h[k], (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     }
     FHX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->offgrid = false;
+    ctx->nonfixed = ctx->have_params && ctx->prm.resolution == 0;
     const int rc = (ctx->have_params && ctx->nonfixed) ? ingest_device_rows_nonfixed(ctx, d[0], d[1], d[2], d[3], d[4], n)
                                                        : ingest_device_rows(ctx, d[0], d[1], d[2], d[3], d[4], n);
     for (int k = 0; k < 5; ++k) dev_free(d[k]);
@@ -2378,7 +2417,10 @@ int fhx_set_global_stats(fhx_ctx* ctx, const fhx_stats* g, const int64_t* hist_s
 
 int fhx_set_dist_keys(fhx_ctx* ctx, const int64_t* keys, int64_t n) {
     if (!ctx || n < 0 || (n > 0 && !keys)) return FHX_ERR_ARG;
-    if (!ctx->nonfixed) return fail(ctx, FHX_ERR_ARG, "distance keys are implicit (index * resolution) in fixed-size mode");
+    if (!ctx->nonfixed) {                          // -r N with explicit distances: loci off the grid (host-side callers)
+        if (!ctx->have_params) return fail(ctx, FHX_ERR_ARG, "fhx_set_params must be called first");
+        ctx->offgrid = ctx->nonfixed = true;
+    }
     ctx->h_dist_keys.assign(keys, keys + n);
     return FHX_OK;
 }
@@ -2606,7 +2648,8 @@ int fhx_pvalues(fhx_ctx* ctx) {
         hipLaunchKernelGGL(k2h_scatter, dim3(K2H_BLOCKS), dim3(K2H_THREADS), 0, ctx->stream, (const QEntry*)hq, hn,
                            (const unsigned int*)ctx->d_block_hist, (const unsigned int*)ctx->d_k2h_off, ctx->d_queue_sorted);
         FHX_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
-        hipLaunchKernelGGL(k2h_heavy, dim3(256 * 8), dim3(K2H_THREADS), 0, ctx->stream, P, (const QEntry*)ctx->d_queue_sorted,
+        const K2HeavyParams HP{P.intra, P.inter, P.p};
+        hipLaunchKernelGGL(k2h_heavy, dim3(256 * 8), dim3(K2H_THREADS), 0, ctx->stream, HP, (const QEntry*)ctx->d_queue_sorted,
                            (const unsigned int*)ctx->d_k2h_off, (const unsigned int*)ctx->d_digit_total, (const dev::CfRow*)ctx->d_cf_tab,
                            hq, n_redo);
         FHX_HIP(hipEventRecord(ctx->ev[7], ctx->stream));

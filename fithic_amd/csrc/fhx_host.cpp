@@ -996,8 +996,9 @@ int run_host_pass(const PassInputs& in, const FragTable& frags, PassFit& out, st
         }
         out.residual = numpy_sum(sq.data(), m);
     }
-    // dense LUT over distance indices: clamp, bisect_left, cap (fithic.py:1066-1069); -r 0 does the same search per row
-    if (res > 0) {
+    // dense LUT over distance indices: clamp, bisect_left, cap (fithic.py:1066-1069); with explicit distance keys (-r 0,
+    // or -r N on off-grid loci) the device does the same search per row
+    if (res > 0 && !in.dist_keys) {
         const size_t nt = tx.size();
         size_t pos = 0;                                       // bisect_left is monotone in the clamped distance
         for (int64_t i = 0; i < in.n_dist; ++i) {

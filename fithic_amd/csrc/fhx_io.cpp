@@ -270,6 +270,7 @@ struct Chunk {
     std::vector<double> dv;
     int64_t bad_line = -1;                        // chunk-relative
     int64_t n_lines = 0;
+    int32_t last_id[2] = {-1, -1};                // id of the previous line's name, per column
 };
 
 inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
@@ -295,6 +296,16 @@ inline bool parse_i32(const char* b, const char* e, int32_t& out) {      // Pyth
 }
 
 inline bool parse_f64(const char* b, const char* e, double& out) {       // Python float()
+    // counts are nearly always plain digits: up to 15 of them are exact in a double and need no strtod
+    if (e - b >= 1 && e - b <= 15) {
+        long long v = 0;
+        const char* q = b;
+        for (; q < e && *q >= '0' && *q <= '9'; ++q) v = v * 10 + (*q - '0');
+        if (q == e) {
+            out = (double)v;
+            return true;
+        }
+    }
     char tmp[64];
     const size_t n = (size_t)(e - b);
     if (n == 0 || n >= sizeof(tmp)) return false;
@@ -326,13 +337,24 @@ void parse_chunk(const char* b, const char* e, int kind, Chunk& c) {
             ++total;
         }
         bool ok = true;
-        auto intern = [&](const char* s, const char* t) -> int32_t {
-            std::string key(s, (size_t)(t - s));
+        // sorted contact files repeat the chromosome of the previous line: compare with the last name of each column first
+        auto intern = [&](const char* s, const char* t, int col) -> int32_t {
+            const size_t len = (size_t)(t - s);
+            if (c.last_id[col] >= 0) {
+                const std::string& last = c.names[(size_t)c.last_id[col]];
+                if (last.size() == len && std::memcmp(last.data(), s, len) == 0) return c.last_id[col];
+            }
+            std::string key(s, len);
             auto it = c.index.find(key);
-            if (it != c.index.end()) return it->second;
-            const int32_t id = (int32_t)c.names.size();
-            c.names.push_back(key);
-            c.index.emplace(std::move(key), id);
+            int32_t id;
+            if (it != c.index.end()) {
+                id = it->second;
+            } else {
+                id = (int32_t)c.names.size();
+                c.names.push_back(key);
+                c.index.emplace(std::move(key), id);
+            }
+            c.last_id[col] = id;
             return id;
         };
         if (kind == 0) {                                   // ch1 mid1 ch2 mid2 count: exactly 5 fields (fithic.py:413)
@@ -344,9 +366,9 @@ void parse_chunk(const char* b, const char* e, int kind, Chunk& c) {
                 const double tr = std::trunc(raw);
                 ok = tr >= INT32_MIN && tr <= INT32_MAX;    // NaN fails both comparisons: int(float('nan')) raises in Python
                 if (ok) {
-                    c.ci[0].push_back(intern(fld_b[0], fld_e[0]));
+                    c.ci[0].push_back(intern(fld_b[0], fld_e[0], 0));
                     c.mi[0].push_back(m1);
-                    c.ci[1].push_back(intern(fld_b[2], fld_e[2]));
+                    c.ci[1].push_back(intern(fld_b[2], fld_e[2], 1));
                     c.mi[1].push_back(m2);
                     c.iv.push_back((int32_t)tr);
                     c.dv.push_back(raw);
@@ -356,7 +378,7 @@ void parse_chunk(const char* b, const char* e, int kind, Chunk& c) {
             int32_t mid, hits;
             ok = total >= 4 && parse_i32(fld_b[2], fld_e[2], mid) && parse_i32(fld_b[3], fld_e[3], hits);
             if (ok) {
-                c.ci[0].push_back(intern(fld_b[0], fld_e[0]));
+                c.ci[0].push_back(intern(fld_b[0], fld_e[0], 0));
                 c.mi[0].push_back(mid);
                 c.iv.push_back(hits);
             }
@@ -365,7 +387,7 @@ void parse_chunk(const char* b, const char* e, int kind, Chunk& c) {
             double bias;
             ok = total >= 3 && parse_i32(fld_b[1], fld_e[1], mid) && parse_f64(fld_b[2], fld_e[2], bias);
             if (ok) {
-                c.ci[0].push_back(intern(fld_b[0], fld_e[0]));
+                c.ci[0].push_back(intern(fld_b[0], fld_e[0], 0));
                 c.mi[0].push_back(mid);
                 c.dv.push_back(bias);
             }

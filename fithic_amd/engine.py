@@ -83,8 +83,9 @@ class Engine:
             names = dict(hist_sumcc=A.A_HIST_SUMCC, hist_npairs=A.A_HIST_NPAIRS, bin_lb=A.A_BIN_LB, bin_ub=A.A_BIN_UB,
                          bin_poss=A.A_BIN_POSS, bin_poss0=A.A_BIN_POSS0, bin_sumcc=A.A_BIN_SUMCC, bin_sumdist=A.A_BIN_SUMDIST,
                          bin_poss7=A.A_BIN_POSS7, x=A.A_X, y=A.A_Y)
-            if self.resolution == 0:
-                names.update(dist_keys=A.A_DIST_KEYS)
+            dist_keys = self.ctx.get_array(A.A_DIST_KEYS)
+            if self.resolution == 0 or len(dist_keys):      # -r 0, or -r N on loci off the grid
+                out.arrays["dist_keys"] = dist_keys
             if self.mode != "interOnly":
                 names.update(knots=A.A_KNOTS, coeffs=A.A_COEFFS, table_x=A.A_TABLE_X, table_y0=A.A_TABLE_Y0, table_y=A.A_TABLE_Y)
             for k, w in names.items():

@@ -157,8 +157,9 @@ def _dist_keys(S):
     """(distinct in-range distances ascending, their summed counts) = the reference's mainDic"""
     hist_cc = S.engine.ctx.get_array(_capi.A_HIST_SUMCC)
     hist_np = S.engine.ctx.get_array(_capi.A_HIST_NPAIRS)
-    if resolution == 0:
-        return S.engine.ctx.get_array(_capi.A_DIST_KEYS), hist_cc
+    keys = S.engine.ctx.get_array(_capi.A_DIST_KEYS)
+    if resolution == 0 or len(keys):               # -r 0, or -r N on loci off the grid: explicit distinct distances
+        return keys, hist_cc[:len(keys)]
     idx = np.flatnonzero(hist_np > 0)
     return idx * resolution, hist_cc[idx]
 

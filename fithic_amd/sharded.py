@@ -42,15 +42,20 @@ class PipeTransport:
             self.ctx.copy(ptr, a.ctypes.data, a.nbytes, 0)
 
     def _exchange(self, per_peer):
-        """per_peer[r] = bytes for rank r; returns what every rank sent to this one (its own entry passes through)."""
-        for r in range(self.world):
-            if r != self.rank:
-                self.conns[r].send_bytes(per_peer[r].tobytes())
+        """per_peer[r] = bytes for rank r; returns what every rank sent to this one (its own entry passes through).
+        Pairwise in rank order - the lower rank of a pair sends first, the higher receives first - so two ranks never sit
+        in send() on full pipe buffers at the same time (messages here reach hundreds of megabytes)."""
         got = [None] * self.world
         got[self.rank] = per_peer[self.rank]
         for r in range(self.world):
-            if r != self.rank:
+            if r == self.rank:
+                continue
+            if self.rank < r:
+                self.conns[r].send_bytes(per_peer[r].tobytes())
                 got[r] = np.frombuffer(self.conns[r].recv_bytes(), np.uint8)
+            else:
+                got[r] = np.frombuffer(self.conns[r].recv_bytes(), np.uint8)
+                self.conns[r].send_bytes(per_peer[r].tobytes())
         return got
 
     def all_reduce(self, user, d_buf, n, op):
@@ -256,6 +261,9 @@ class ShardedEngine:
             self.workers.append((p, parent))
         self.local = _Rank(0, gpus, devices[0], transport, uid, mesh[0])
         for r, (p, conn) in enumerate(self.workers, start=1):
+            while not conn.poll(1.0):
+                if not p.is_alive():
+                    raise RuntimeError("rank %d died while starting (exit code %r)" % (r, p.exitcode))
             status, msg = conn.recv()
             if status != "ready":
                 raise RuntimeError("rank %d could not start: %s" % (r, msg))
@@ -269,7 +277,10 @@ class ShardedEngine:
         for r, (_, conn) in enumerate(self.workers, start=1):
             conn.send((name, per_rank[r] if per_rank else args))
         out = [getattr(self.local, name)(*(per_rank[0] if per_rank else args))]
-        for r, (_, conn) in enumerate(self.workers, start=1):
+        for r, (proc, conn) in enumerate(self.workers, start=1):
+            while not conn.poll(1.0):
+                if not proc.is_alive():
+                    raise RuntimeError("rank %d died in %s (exit code %r)" % (r, name, proc.exitcode))
             status, val = conn.recv()
             if status != "ok":
                 raise RuntimeError("rank %d failed in %s: %s" % (r, name, val))

@@ -46,7 +46,8 @@ def case_args(meta):
 FIXED_CASES = ["f1_nobias", "f1_bias", "f2_all", "f2_inter", "f2_intra", "f2_all_nobias",
                "f6_quirk_all", "f6_quirk_intra_nobounds", "f6_quirk_zero_flags", "f6_quirk_mapp2", "f7_pfal_all"]
 NONFIXED_CASES = ["f8_nonfixed_hESC", "f8_nonfixed_all", "f8_nonfixed_nobounds"]        # -r 0
-ALL_CASES = FIXED_CASES + NONFIXED_CASES
+OFFGRID_CASES = ["f11_offgrid_all", "f11_offgrid_intra"]     # -r N on loci that are not on one grid (fixed-size possible pairs)
+ALL_CASES = FIXED_CASES + NONFIXED_CASES + OFFGRID_CASES
 SMALL_CASES = [c for c in ALL_CASES if not c.startswith("f1_")]
 
 

@@ -690,9 +690,20 @@ def make_f10():
         print("  %s: %d lines" % (name, len(text.decode().split("\n"))))
 
 
+def make_f11():
+    """Fixed-size mode (-r N > 0) on loci that are NOT on one grid: the reference takes abs(mid1 - mid2) of whatever
+    midpoints the files hold (myUtils.py:112-124, fithic.py:425-440) and still enumerates possible pairs at multiples of the
+    resolution (fithic.py:592-689).  Uses the irregular 3-chromosome set of f8 (make_f8 writes the data files)."""
+    print("F11: -r N on off-grid loci")
+    run_case("f11_offgrid_all", "irregular.contacts.gz", "irregular.frags.gz", "irregular.bias.gz", 10000,
+             ["-b", "12", "-p", "2", "-x", "All", "-L", "10000", "-U", "900000"])
+    run_case("f11_offgrid_intra", "irregular.contacts.gz", "irregular.frags.gz", None, 5000,
+             ["-b", "8", "-p", "2", "-x", "intraOnly", "-L", "5000", "-U", "600000"])
+
+
 if __name__ == "__main__":
-    which = [a.lower() for a in sys.argv[1:]] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10"]
+    which = [a.lower() for a in sys.argv[1:]] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11"]
     jobs = dict(f1=make_f1, f2=make_f2, f3=make_f3, f4=make_f4, f5=make_f5, f6=make_f6, f7=make_f7, f8=make_f8, f9=make_f9,
-                f10=make_f10)
+                f10=make_f10, f11=make_f11)
     for w in which:
         jobs[w]()

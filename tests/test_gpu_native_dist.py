@@ -124,7 +124,11 @@ def _run_world(world, case, passes, split, tmp_path):
         p.start()
         procs.append((p, out))
     for p, out in procs:
-        p.join(600)
+        p.join(240)
+        if p.is_alive():
+            for q, _ in procs:
+                q.kill()
+            pytest.fail("a rank hangs")
         assert p.exitcode == 0, "rank process died (exit code %r)" % (p.exitcode,)
     for _, out in procs:
         with open(out) as f:
@@ -177,7 +181,10 @@ def test_rccl_transport_with_one_rank(case, passes, tmp_path):
     out = os.path.join(str(tmp_path), "rccl.txt")
     p = mp.get_context("spawn").Process(target=_rccl_single_rank, args=(case, passes, out))
     p.start()
-    p.join(600)
+    p.join(240)
+    if p.is_alive():
+        p.kill()
+        pytest.fail("the rank hangs")
     assert p.exitcode == 0
     with open(out) as f:
         assert f.read() == "OK"

@@ -230,11 +230,11 @@ def test_pipeline_matches_reference_goldens(name):
         st = out.stats
         # integer results: bit-exact
         assert [st["inter_count"], st["inter_sum"], st["intra_all_sum"], st["in_range_sum"]] == [int(v) for v in g[P + "sums"]]
-        if res:
+        if res and "dist_keys" not in out.arrays:
             keys = np.flatnonzero(out.arrays["hist_npairs"] > 0) * res
             assert np.array_equal(keys, g[P + "dist_keys"])
             assert np.array_equal(out.arrays["hist_sumcc"][keys // res], g[P + "dist_sumcc"])
-        else:                                   # -r 0: explicit distinct distances
+        else:                                   # -r 0, or -r N on off-grid loci: explicit distinct distances
             assert np.array_equal(out.arrays["dist_keys"], g[P + "dist_keys"])
             assert np.array_equal(out.arrays["hist_sumcc"], g[P + "dist_sumcc"])
         for k, mine in (("lb", "bin_lb"), ("ub", "bin_ub"), ("s1", "bin_poss"), ("s2", "bin_sumcc"), ("s7", "bin_poss7")):
@@ -278,13 +278,20 @@ def test_pipeline_matches_oracle_every_row(name):
         assert bits_equal(v["q"], fo.benjamini_hochberg(v["p"], out.info["bh_total_tests"]))
 
 
-def test_off_grid_loci_are_rejected_loudly():
+def test_off_grid_loci_run_through_the_slotting_path():
+    """-r N on midpoints that do not share a grid: accepted (the reference takes abs(mid1 - mid2) of whatever the files hold);
+    the distance histogram is keyed by the distinct distances.  The f11_offgrid_* goldens check the values."""
     from fithic_amd import _capi
     c = _capi.Context(0)
     c.set_params(10000)
-    with pytest.raises(_capi.FhxError) as e:
-        c.load_pairs([0, 0], [5000, 15001], [0, 0], [25000, 35000], [3, 4])
-    assert e.value.code == _capi.FHX_ERR_UNSUPPORTED
+    c.load_pairs([0, 0, 0], [5000, 15001, 5000], [0, 0, 0], [25000, 35000, 35000], [3, 4, 5])
+    st = c.pass_stats()
+    assert st.in_range_sum == 12 and st.n_dist == 3
+    assert np.array_equal(c.get_array(_capi.A_DIST_KEYS), [19999, 20000, 30000])
+    assert np.array_equal(c.get_array(_capi.A_HIST_SUMCC)[:3], [4, 3, 5])
+    c.load_pairs([0, 0], [5000, 15000], [0, 0], [25000, 35000], [3, 4])          # on-grid rows again: the dense path
+    c.pass_stats()
+    assert len(c.get_array(_capi.A_DIST_KEYS)) == 0 and np.array_equal(np.flatnonzero(c.get_array(_capi.A_HIST_NPAIRS)), [2])
     c.close()
 
 

@@ -74,7 +74,7 @@ def test_host_fit_matches_reference(name):
         keys, sumcc = g[P + "dist_keys"], g[P + "dist_sumcc"]
         st = _capi.FhxStats()
         st.inter_count, st.inter_sum, st.intra_all_sum, st.in_range_sum = [int(v) for v in g[P + "sums"]]
-        if res == 0:                                  # -r 0: explicit distance keys and an explicit outlier multiset
+        if res == 0 or name.startswith("f11_offgrid"):   # -r 0 / off-grid loci: explicit distance keys and outlier multiset
             ctx.set_dist_keys(keys)
             ctx.set_global_stats(st, sumcc, np.ones(len(keys), np.int64))
             if pi > 1:
