@@ -263,6 +263,9 @@ struct K2Params {
     int mode;
     int64_t n;
     double* p;
+    // K3's key histogram accumulated where p is stored (4096 bins = key >> 50 of p <= 1): LDS-privatised per workgroup, one
+    // flush per workgroup; nullptr = not collected (k3_top_hist reads p again instead)
+    unsigned long long* top_hist;
     uint8_t* outlier;             // p < 1/N, feeds the next pass
     // non-fixed-size mode (-r 0): loci are ranks into the sorted distinct (chr, mid) list, distances come from slot_mid,
     // and the prior is found by bisect_left over the spline table (fithic.py:1066-1069) instead of a dense LUT
@@ -290,7 +293,10 @@ __device__ __forceinline__ double prior_by_search(const K2Params& P, long long d
     return P.table_y[min(lo, P.n_table - 1)];
 }
 
-// prior and which binomial a row uses; returns false when the row's p-value is the constant 1.0
+// prior and which binomial a row uses; returns false when the row's p-value is the constant 1.0.
+// NF: 0 = fixed-size loci on a grid, 1 = arbitrary loci (-r 0 / off-grid), -1 = decided at run time (P.nonfixed); the
+// specialised forms keep the other mode's fields out of the kernel (SGPRs, and the search loop's code).
+template <int NF = -1>
 __device__ __forceinline__ bool row_prior(const K2Params& P, int l1, int l2, double& prior, bool& is_inter) {
     const bool inter = l2 < 0;
     const int s2 = inter ? ~l2 : l2;
@@ -298,7 +304,7 @@ __device__ __forceinline__ bool row_prior(const K2Params& P, int l1, int l2, dou
     const double b1 = P.no_bias ? 1.0 : P.slot_bias[l1], b2 = P.no_bias ? 1.0 : P.slot_bias[s2];
     if ((b1 < 0 || b2 < 0) && !inter) return false;                        // fithic.py:1057-1064
     if (!inter && P.mode != FHX_MODE_INTER_ONLY) {
-        if (P.nonfixed) {
+        if (NF == 1 || (NF == -1 && P.nonfixed)) {
             const long long dist = llabs((long long)P.slot_mid[l1] - (long long)P.slot_mid[s2]);
             if (dist < P.dist_low || dist > P.dist_up) return false;
             prior = prior_by_search(P, dist) * (b1 * b2);
@@ -316,6 +322,60 @@ __device__ __forceinline__ bool row_prior(const K2Params& P, int l1, int l2, dou
     is_inter = true;
     return true;
 }
+
+// The top-bits histogram of K3's early cutoff (k3_top_hist) gathered by the kernels that store p: bdtrc values are NaN or in
+// [0, 1], so key >> 50 < 4096; p == 1.0 (most rows) goes through a per-thread counter.  One LDS table per workgroup.
+constexpr int K2_HIST_BINS = 4096;
+struct FusedHist {
+    unsigned int* h;
+    unsigned int ones;
+    bool on;
+    __device__ __forceinline__ void init(unsigned int* lds, const unsigned long long* global) {
+        h = lds;
+        ones = 0;
+        on = global != nullptr;
+        if (on) {
+            for (int i = threadIdx.x; i < K2_HIST_BINS; i += blockDim.x) h[i] = 0;
+            __syncthreads();
+        }
+    }
+    __device__ __forceinline__ void add(double v) {
+        if (!on) return;
+        if (v == 1.0)
+            ++ones;
+        else if (v == v) {
+            unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+            if (bits == 0x8000000000000000ull) bits = 0ull;
+            atomicAdd(&h[min((unsigned int)(bits >> 50), (unsigned int)K2_HIST_BINS - 1u)], 1u);
+        }
+    }
+    // All values of the wave counted in the bin of its SMALLEST one: a single LDS atomic instead of 64 on a handful of words
+    // (the 300-iteration class yields p in [0.5, 1): three or four bins for a whole launch).  Counting a value in a lower bin
+    // than its own is exact for the cutoff: cumulative counts only grow, `bin_saturates` is decreasing in the count, so a
+    // bin found saturating this way saturates with the true counts too, and the first true value at or above its edge has a
+    // rank within the inflated count.  At worst a few more rows are sorted.
+    __device__ __forceinline__ void add_wave_min(double v, bool valid) {
+        if (!on) return;
+        valid = valid && v == v;
+        unsigned long long key = valid ? (unsigned long long)__double_as_longlong(v) : ~0ull;
+        if (key == 0x8000000000000000ull) key = 0ull;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) {
+            const unsigned long long o = __shfl_xor(key, s, 64);
+            key = o < key ? o : key;
+        }
+        const unsigned int n = (unsigned int)__popcll(__ballot(valid));
+        if ((threadIdx.x & 63) == 0 && n) atomicAdd(&h[min((unsigned int)(key >> 50), (unsigned int)K2_HIST_BINS - 1u)], n);
+    }
+    __device__ __forceinline__ void flush(unsigned long long* global) {      // every thread of the workgroup must call it
+        if (!on) return;
+        const unsigned int w = (unsigned int)wave_sum_i64((long long)ones);
+        if ((threadIdx.x & 63) == 0 && w) atomicAdd(&h[0x3FF0000000000000ull >> 50], w);
+        __syncthreads();
+        for (int i = threadIdx.x; i < K2_HIST_BINS; i += blockDim.x)
+            if (h[i]) atomicAdd(&global[i], (unsigned long long)h[i]);
+    }
+};
 
 constexpr int K2_THREADS = 256;
 
@@ -347,7 +407,8 @@ constexpr int K2_COUNT_STRIDE = 16;                      // queue counters 128 B
 
 constexpr int K2_CLOSED = K2_QUEUES + 1;                 // tile-local class: count == 1 rows, evaluated densely from LDS
 
-__global__ __launch_bounds__(K2_THREADS) void k2_classify(K2Params P, K2Queues Q) {
+template <int NF>
+__global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k2_classify(K2Params P, K2Queues Q) {
     // Per tile: every wave reserves slots per class with ballots + ONE LDS atomic per (wave, class, item), then each
     // class takes ONE global atomic per tile (a same-address global atomic per wave would cap the kernel at ~88 M
     // atomics/s - MI355X_MICROARCH.md "dequeue" - i.e. slower than the arithmetic it feeds), then the lanes write
@@ -359,6 +420,9 @@ __global__ __launch_bounds__(K2_THREADS) void k2_classify(K2Params P, K2Queues Q
     __shared__ unsigned long long gbase[K2_QUEUES];
     __shared__ double cf_prior[K2_CL_TILE];
     __shared__ unsigned short cf_idx[K2_CL_TILE];          // tile-local row | 0x8000 for the inter-chromosomal binomial
+    __shared__ unsigned int hist_lds[K2_HIST_BINS];
+    FusedHist H;
+    H.init(hist_lds, P.top_hist);
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     const int64_t tiles = (P.n + K2_CL_TILE - 1) / K2_CL_TILE;
@@ -381,7 +445,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_classify(K2Params P, K2Queues Q
                 double pv = 1.0;
                 bool is_inter = false;
                 cls = 0;
-                if (row_prior(P, l1, l2, prior, is_inter)) {
+                if (row_prior<NF>(P, l1, l2, prior, is_inter)) {
                     const dev::BinomTables& T = is_inter ? P.inter : P.intra;
                     cls = dev::bdtrc_class(c, T.n, prior);
                     if (cls == dev::BC_TRIVIAL) {
@@ -392,7 +456,10 @@ __global__ __launch_bounds__(K2_THREADS) void k2_classify(K2Params P, K2Queues Q
                     }
                     if (is_inter) c = -c;
                 }
-                if (cls == 0) P.p[i] = pv;
+                if (cls == 0) {
+                    P.p[i] = pv;
+                    H.add(pv);
+                }
             }
             cls_of[r] = cls;
             count_of[r] = c;
@@ -438,7 +505,9 @@ __global__ __launch_bounds__(K2_THREADS) void k2_classify(K2Params P, K2Queues Q
         for (unsigned int j = threadIdx.x; j < n_closed; j += K2_THREADS) {
             const unsigned int ix = cf_idx[j];
             const double n_total = (ix & 0x8000u) ? P.inter.n : P.intra.n;
-            P.p[t * K2_CL_TILE + (ix & 0x7FFFu)] = dev::bdtrc_closed_form(n_total, cf_prior[j]);
+            const double pv = dev::bdtrc_closed_form(n_total, cf_prior[j]);
+            P.p[t * K2_CL_TILE + (ix & 0x7FFFu)] = pv;
+            H.add(pv);
         }
         __syncthreads();
 #pragma unroll
@@ -455,19 +524,26 @@ __global__ __launch_bounds__(K2_THREADS) void k2_classify(K2Params P, K2Queues Q
         }
         __syncthreads();
     }
+    H.flush(P.top_hist);
 }
 
 template <int CLS>
 __global__ __launch_bounds__(K2_THREADS) void k2_queue(K2Params P, const QEntry* __restrict__ base, int dir,
                                                        const unsigned long long* __restrict__ count) {
+    __shared__ unsigned int hist_lds[K2_HIST_BINS];
+    FusedHist H;
+    H.init(hist_lds, P.top_hist);
     const int64_t n = (int64_t)*count;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
         const QEntry e = base[dir * j];
         const bool is_inter = e.count < 0;
         const int c = is_inter ? -e.count : e.count;
-        P.p[e.row] = dev::bdtrc_count_class<CLS>(c, is_inter ? P.inter : P.intra, e.prior);
+        const double pv = dev::bdtrc_count_class<CLS>(c, is_inter ? P.inter : P.intra, e.prior);
+        P.p[e.row] = pv;
+        H.add(pv);
     }
+    H.flush(P.top_hist);
 }
 
 // The two converging continued-fraction classes need ~5..17 iterations, growing with the contact count: in queue order a
@@ -482,6 +558,9 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
     static_assert(K2_SORT_TILE == 4 * K2_THREADS, "four entries per thread");
     __shared__ QEntry tile[K2_SORT_TILE];
     __shared__ unsigned int bucket_cnt[K2_SORT_BUCKETS], bucket_off[K2_SORT_BUCKETS];
+    __shared__ unsigned int hist_lds[K2_HIST_BINS];
+    FusedHist H;
+    H.init(hist_lds, P.top_hist);
     const int64_t n = (int64_t)*count;
     const int64_t tiles = (n + K2_SORT_TILE - 1) / K2_SORT_TILE;
     for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
@@ -520,11 +599,14 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
                 const QEntry x = tile[idx];
                 const bool is_inter = x.count < 0;
                 const int c = is_inter ? -x.count : x.count;
-                P.p[x.row] = dev::bdtrc_count_class<CLS>(c, is_inter ? P.inter : P.intra, x.prior);
+                const double pv = dev::bdtrc_count_class<CLS>(c, is_inter ? P.inter : P.intra, x.prior);
+                P.p[x.row] = pv;
+                H.add(pv);
             }
         }
         __syncthreads();
     }
+    H.flush(P.top_hist);
 }
 
 // ---- the 300-iteration class in count-homogeneous waves -----------------------------------------------------------
@@ -613,12 +695,16 @@ __global__ __launch_bounds__(64) void k2h_tables(const unsigned int* __restrict_
 struct K2HeavyParams {            // the few fields of K2Params this kernel reads: its SGPR count decides how many waves a CU admits
     dev::BinomTables intra, inter;
     double* p;
+    unsigned long long* top_hist;
 };
 
 __global__ __launch_bounds__(K2H_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k2h_heavy(
     K2HeavyParams P, const QEntry* __restrict__ sorted, const unsigned int* __restrict__ off,
     const unsigned int* __restrict__ digit_total, const dev::CfRow* __restrict__ tab, QEntry* __restrict__ redo,
     unsigned long long* __restrict__ n_redo) {
+    __shared__ unsigned int hist_lds[K2_HIST_BINS];
+    FusedHist H;
+    H.init(hist_lds, P.top_hist);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const unsigned int n_tasks = off[K2H_GENERIC] >> 6;          // 64-entry tasks in front of the generic bucket
@@ -652,13 +738,19 @@ __global__ __launch_bounds__(K2H_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
         bool irregular = !have || !dev::cf_swapped_regular(bb, aa, w1);
         const dev::CfRowConstPtr rows = (dev::CfRowConstPtr)(uintptr_t)(tab + (size_t)b * dev::kCfIters);
         const double cf = dev::cf_swapped_uniform(rows, w1, irregular);      // every lane of the wave takes part
+        double pv = 0.0;
+        const bool mine = have && !irregular;
         if (have) {
             if (__builtin_expect(irregular, 0))
                 redo[atomicAdd(n_redo, 1ull)] = e;
-            else
-                P.p[e.row] = dev::incbet_finish(bb, aa, w1, xx, cf, 1, T.lbeta[c], T.small_n ? T.inv_beta[c] : 0.0);
+            else {
+                pv = dev::incbet_finish(bb, aa, w1, xx, cf, 1, T.lbeta[c], T.small_n ? T.inv_beta[c] : 0.0);
+                P.p[e.row] = pv;
+            }
         }
+        H.add_wave_min(pv, mine);
     }
+    H.flush(P.top_hist);
 }
 
 // counts >= K2H_KCAP (the last bucket) and the rows k2h_heavy handed back: per-lane evaluation, the k2_queue<BC_CF_SWAPPED> body
@@ -670,13 +762,19 @@ __global__ __launch_bounds__(K2_THREADS) void k2h_generic(K2Params P, const QEnt
     const QEntry* base = sorted + off[K2H_GENERIC];
     const int64_t n_generic = (int64_t)digit_total[K2H_GENERIC];
     const int64_t n = n_generic + (int64_t)*n_redo;
+    __shared__ unsigned int hist_lds[K2_HIST_BINS];
+    FusedHist H;
+    H.init(hist_lds, P.top_hist);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
         const QEntry e = j < n_generic ? base[j] : redo[j - n_generic];
         const bool is_inter = e.count < 0;
         const int c = is_inter ? -e.count : e.count;
-        P.p[e.row] = dev::bdtrc_count_class<dev::BC_CF_SWAPPED>(c, is_inter ? P.inter : P.intra, e.prior);
+        const double pv = dev::bdtrc_count_class<dev::BC_CF_SWAPPED>(c, is_inter ? P.inter : P.intra, e.prior);
+        P.p[e.row] = pv;
+        H.add(pv);
     }
+    H.flush(P.top_hist);
 }
 
 // outlier flags (p < 1/N, fithic.py:1215) are derived from p when somebody asks: K2 never writes per-row bytes
@@ -994,7 +1092,8 @@ __global__ __launch_bounds__(SORT_THREADS) void rs_count(const unsigned long lon
                                                          unsigned int* __restrict__ block_hist) {
     __shared__ unsigned int h[RADIX];
     const int64_t n = (int64_t)*n_ptr;
-    const int64_t chunk = ((n + SORT_BLOCKS - 1) / SORT_BLOCKS + SORT_TILE - 1) / SORT_TILE * SORT_TILE;
+    const int64_t nblk = gridDim.x;                   // the launch decides how many chunks there are (sort_blocks_for)
+    const int64_t chunk = ((n + nblk - 1) / nblk + SORT_TILE - 1) / SORT_TILE * SORT_TILE;
     const int64_t beg = (int64_t)blockIdx.x * chunk, end = min(n, beg + chunk);
     for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) h[d] = 0;
     __syncthreads();
@@ -1009,18 +1108,19 @@ __global__ __launch_bounds__(SORT_THREADS) void rs_count(const unsigned long lon
     }
     if (threadIdx.x == 0 && (len & 1)) atomicAdd(&h[(keys[end - 1] >> shift) & (RADIX - 1)], 1u);
     __syncthreads();
-    for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) block_hist[(size_t)d * SORT_BLOCKS + blockIdx.x] = h[d];   // digit-major
+    for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) block_hist[(size_t)d * nblk + blockIdx.x] = h[d];   // digit-major
 }
 
 // exclusive scan of the digit-major (RADIX x SORT_BLOCKS) count matrix along the workgroup axis: one
 // workgroup per digit, one thread per sorting workgroup (coalesced row access); digit totals go to
 // digit_total[], their own exclusive scan is folded into rs_scatter's prologue.
 __global__ __launch_bounds__(SORT_BLOCKS) void rs_scan(unsigned int* __restrict__ block_hist,
-                                                       unsigned int* __restrict__ digit_total) {
+                                                       unsigned int* __restrict__ digit_total, int nblk) {
     __shared__ unsigned int wsum[SORT_BLOCKS / 64];
-    unsigned int* row = block_hist + (size_t)blockIdx.x * SORT_BLOCKS;
+    unsigned int* row = block_hist + (size_t)blockIdx.x * nblk;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned int mine = row[threadIdx.x];
+    const bool live = (int)threadIdx.x < nblk;         // blockDim.x = nblk rounded up to whole waves
+    const unsigned int mine = live ? row[threadIdx.x] : 0u;
     unsigned int incl = mine;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -1031,7 +1131,8 @@ __global__ __launch_bounds__(SORT_BLOCKS) void rs_scan(unsigned int* __restrict_
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned int acc = 0;
-        for (int w = 0; w < SORT_BLOCKS / 64; ++w) {
+        const int waves = (blockDim.x + 63) / 64;
+        for (int w = 0; w < waves; ++w) {
             const unsigned int c = wsum[w];
             wsum[w] = acc;
             acc += c;
@@ -1039,7 +1140,7 @@ __global__ __launch_bounds__(SORT_BLOCKS) void rs_scan(unsigned int* __restrict_
         digit_total[blockIdx.x] = acc;
     }
     __syncthreads();
-    row[threadIdx.x] = wsum[wave] + incl - mine;
+    if (live) row[threadIdx.x] = wsum[wave] + incl - mine;
 }
 
 // RADIX-entry exclusive scan held in LDS by the whole workgroup (RADIX / SORT_THREADS consecutive entries per thread);
@@ -1090,7 +1191,8 @@ __global__ __launch_bounds__(SORT_THREADS) void rs_scatter(const unsigned long l
     __shared__ unsigned int s_vals[SORT_TILE];
     constexpr int PER = RADIX / SORT_THREADS;
     const int64_t n = (int64_t)*n_ptr;
-    const int64_t chunk = ((n + SORT_BLOCKS - 1) / SORT_BLOCKS + SORT_TILE - 1) / SORT_TILE * SORT_TILE;
+    const int64_t nblk = gridDim.x;
+    const int64_t chunk = ((n + nblk - 1) / nblk + SORT_TILE - 1) / SORT_TILE * SORT_TILE;
     const int64_t beg = (int64_t)blockIdx.x * chunk, end = min(n, beg + chunk);
     if (beg >= end) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1099,7 +1201,7 @@ __global__ __launch_bounds__(SORT_THREADS) void rs_scatter(const unsigned long l
     __syncthreads();
     block_exclusive_scan_radix(tile_start, wave_tmp);
     for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS)
-        global_base[d] = tile_start[d] + block_hist[(size_t)d * SORT_BLOCKS + blockIdx.x];
+        global_base[d] = tile_start[d] + block_hist[(size_t)d * nblk + blockIdx.x];
     __syncthreads();
     for (int64_t tile = beg; tile < end; tile += SORT_TILE) {
         for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) {
@@ -1660,6 +1762,8 @@ struct fhx_ctx {
     unsigned int* d_block_hist = nullptr;
     unsigned int* d_digit_total = nullptr;
     unsigned long long* d_top_hist = nullptr;
+    unsigned long long* d_k2_hist = nullptr;          // K3's key histogram as K2 gathered it while storing p (4096 bins)
+    bool k2_hist_valid = false;
     unsigned char* d_work = nullptr;                  // the K2 queues and the K3 sort buffers are views into this block
     QEntry* d_queue[2] = {nullptr, nullptr};          // K2's per-class row queues
     QEntry* d_queue_sorted = nullptr;                 // the 300-iteration class, bucketed by (binomial, count), 64-aligned buckets
@@ -1731,6 +1835,7 @@ K2Params make_k2_params(fhx_ctx* c) {
     P.mode = c->prm.mode;
     P.n = c->n_rows;
     P.p = c->d_p;
+    P.top_hist = nullptr;
     P.outlier = c->d_outlier;
     P.nonfixed = c->nonfixed ? 1 : 0;
     P.slot_mid = c->d_slot_mid;
@@ -1824,15 +1929,25 @@ int ensure_sort_scratch_early(fhx_ctx* ctx) {
 }
 
 // LSD radix sort of (u64 key, u32 payload) pairs over the low `passes`*11 key bits; n lives in *counter (device)
+// Chunks (= workgroups) of a sort of about n keys: a count matrix of RADIX x blocks is scanned in every pass, so a small sort
+// must not pay for 1024 of them (6 passes over ~10^6 keys: 0.26 ms with 1024 blocks, a third of that with 64).  n_hint < 0:
+// the size is only known on the device.
+int sort_blocks_for(int64_t n_hint) {
+    if (n_hint < 0) return SORT_BLOCKS;
+    const int64_t want = (n_hint + 4 * SORT_TILE - 1) / (4 * SORT_TILE);          // >= four tiles per workgroup
+    return (int)std::max<int64_t>(64, std::min<int64_t>(SORT_BLOCKS, (want + 63) / 64 * 64));
+}
+
 int radix_sort_pairs(fhx_ctx* ctx, unsigned long long* keys[2], unsigned int* vals[2], const unsigned long long* counter,
-                     int passes, int* result_buf) {
+                     int passes, int* result_buf, int64_t n_hint = -1) {
+    const int nblk = sort_blocks_for(n_hint);
     int src = 0;
     for (int pass = 0; pass < passes; ++pass) {
         const int shift = pass * RADIX_BITS;
-        hipLaunchKernelGGL(rs_count, dim3(SORT_BLOCKS), dim3(SORT_THREADS), 0, ctx->stream, keys[src], counter, shift,
+        hipLaunchKernelGGL(rs_count, dim3(nblk), dim3(SORT_THREADS), 0, ctx->stream, keys[src], counter, shift,
                            ctx->d_block_hist);
-        hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3(SORT_BLOCKS), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total);
-        hipLaunchKernelGGL(rs_scatter, dim3(SORT_BLOCKS), dim3(SORT_THREADS), 0, ctx->stream, keys[src], vals[src],
+        hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3((nblk + 63) / 64 * 64), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total, nblk);
+        hipLaunchKernelGGL(rs_scatter, dim3(nblk), dim3(SORT_THREADS), 0, ctx->stream, keys[src], vals[src],
                            keys[1 - src], vals[1 - src], counter, shift, ctx->d_block_hist, ctx->d_digit_total);
         src = 1 - src;
     }
@@ -1892,7 +2007,7 @@ int ingest_device_rows_nonfixed(fhx_ctx* ctx, const int32_t* c1, const int32_t* 
     const unsigned long long n2u = (unsigned long long)n2;
     FHX_HIP(hipMemcpyAsync(counter, &n2u, sizeof(n2u), hipMemcpyHostToDevice, ctx->stream));
     int buf = 0;
-    rc = radix_sort_pairs(ctx, keys, vals, counter, SORT_PASSES, &buf);
+    rc = radix_sort_pairs(ctx, keys, vals, counter, SORT_PASSES, &buf, n2);
     int64_t n_slots = 0;
     if (rc == FHX_OK) rc = run_ids(ctx, keys[buf], n2, ids, tiles, &n_slots);
     int h_bad = 0;
@@ -2158,6 +2273,7 @@ void fhx_destroy(fhx_ctx* ctx) {
         dev_free(ctx->d_block_hist);
         dev_free(ctx->d_digit_total);
         dev_free(ctx->d_top_hist);
+        dev_free(ctx->d_k2_hist);
         dev_free(ctx->d_cf_tab);
         dev_free(ctx->d_k2h_off);
         dev_free(ctx->d_memo);
@@ -2585,6 +2701,14 @@ int fhx_pvalues(fhx_ctx* ctx) {
             if (cap >= 8) memo_cap = (int)cap;
         }
     }
+    // K3's key histogram rides on K2's stores of p - except on the table path, whose class kernels store table entries
+    ctx->k2_hist_valid = false;
+    if (memo_cap < 0 && !getenv("FHX_NO_FUSED_HIST")) {
+        if (!ctx->d_k2_hist) FHX_HIP(hipMalloc(&ctx->d_k2_hist, TOP_BINS * sizeof(unsigned long long)));
+        FHX_HIP(hipMemsetAsync(ctx->d_k2_hist, 0, TOP_BINS * sizeof(unsigned long long), ctx->stream));
+        P.top_hist = ctx->d_k2_hist;
+        ctx->k2_hist_valid = true;
+    }
     const K2Params P_rows = P;
     int64_t k2_n = ctx->n_rows;
     if (memo_cap >= 0) {
@@ -2624,7 +2748,10 @@ int fhx_pvalues(fhx_ctx* ctx) {
     Q.dir[dev::BC_CF_BD - 1] = -1;
     Q.count = ctx->d_misc + 64;
     FHX_HIP(hipMemsetAsync(Q.count, 0, K2_QUEUES * K2_COUNT_STRIDE * sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL(k2_classify, dim3(grid_for(k2_n, K2_CL_TILE, 256 * 8)), dim3(K2_THREADS), 0, ctx->stream, P, Q);
+    if (P.nonfixed)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<1>), dim3(grid_for(k2_n, K2_CL_TILE, 256 * 8)), dim3(K2_THREADS), 0, ctx->stream, P, Q);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0>), dim3(grid_for(k2_n, K2_CL_TILE, 256 * 8)), dim3(K2_THREADS), 0, ctx->stream, P, Q);
     const dim3 qgrid(256 * 8), qblock(K2_THREADS);
 #define FHX_LAUNCH_QUEUE(CLS)                                                                                          \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue<CLS>), qgrid, qblock, 0, ctx->stream, P, (const QEntry*)Q.base[(CLS) - 1], \
@@ -2641,14 +2768,14 @@ int fhx_pvalues(fhx_ctx* ctx) {
         unsigned long long* n_redo = ctx->d_misc + 11;
         FHX_HIP(hipMemsetAsync(n_redo, 0, sizeof(unsigned long long), ctx->stream));
         hipLaunchKernelGGL(k2h_count, dim3(K2H_BLOCKS), dim3(K2H_THREADS), 0, ctx->stream, (const QEntry*)hq, hn, ctx->d_block_hist);
-        hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3(SORT_BLOCKS), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total);
+        hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3(SORT_BLOCKS), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total, (int)SORT_BLOCKS);
         hipLaunchKernelGGL(k2h_offsets, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned int*)ctx->d_digit_total, ctx->d_k2h_off);
         hipLaunchKernelGGL(k2h_tables, dim3((K2H_GENERIC + 63) / 64), dim3(64), 0, ctx->stream, (const unsigned int*)ctx->d_digit_total,
                            P.intra.n, P.inter.n, ctx->d_cf_tab);
         hipLaunchKernelGGL(k2h_scatter, dim3(K2H_BLOCKS), dim3(K2H_THREADS), 0, ctx->stream, (const QEntry*)hq, hn,
                            (const unsigned int*)ctx->d_block_hist, (const unsigned int*)ctx->d_k2h_off, ctx->d_queue_sorted);
         FHX_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
-        const K2HeavyParams HP{P.intra, P.inter, P.p};
+        const K2HeavyParams HP{P.intra, P.inter, P.p, P.top_hist};
         hipLaunchKernelGGL(k2h_heavy, dim3(256 * 8), dim3(K2H_THREADS), 0, ctx->stream, HP, (const QEntry*)ctx->d_queue_sorted,
                            (const unsigned int*)ctx->d_k2h_off, (const unsigned int*)ctx->d_digit_total, (const dev::CfRow*)ctx->d_cf_tab,
                            hq, n_redo);
@@ -2698,9 +2825,27 @@ int fhx_pvalues(fhx_ctx* ctx) {
 
 // compact p < 1 and LSD-radix-sort (key, row); returns the index (0/1) of the buffer pair holding the result
 // cutoff key from a device-local histogram of the p-values (single-GPU path; sharded runs all-reduce the histogram)
-static int auto_cutoff(fhx_ctx* ctx, const double* d_p, int64_t n, double n_total_tests, unsigned long long* d_cutoff) {
+// d_top_hist <- key histogram of the context's p: what K2 gathered while storing them, else one more read of p
+static int fill_top_hist(fhx_ctx* ctx) {
+    if (ctx->k2_hist_valid) {
+        FHX_HIP(hipMemcpyAsync(ctx->d_top_hist, ctx->d_k2_hist, TOP_BINS * sizeof(unsigned long long), hipMemcpyDeviceToDevice, ctx->stream));
+        return FHX_OK;
+    }
     FHX_HIP(hipMemsetAsync(ctx->d_top_hist, 0, TOP_BINS * sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL(k3_top_hist, dim3(grid_for((n + 1) / 2, 512, 256 * 4)), dim3(512), 0, ctx->stream, d_p, n, ctx->d_top_hist);
+    hipLaunchKernelGGL(k3_top_hist, dim3(grid_for((ctx->n_rows + 1) / 2, 512, 256 * 4)), dim3(512), 0, ctx->stream, ctx->d_p,
+                       ctx->n_rows, ctx->d_top_hist);
+    FHX_HIP(hipGetLastError());
+    return FHX_OK;
+}
+
+static int auto_cutoff(fhx_ctx* ctx, const double* d_p, int64_t n, double n_total_tests, unsigned long long* d_cutoff) {
+    if (d_p == ctx->d_p) {
+        const int rc = fill_top_hist(ctx);
+        if (rc != FHX_OK) return rc;
+    } else {
+        FHX_HIP(hipMemsetAsync(ctx->d_top_hist, 0, TOP_BINS * sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(k3_top_hist, dim3(grid_for((n + 1) / 2, 512, 256 * 4)), dim3(512), 0, ctx->stream, d_p, n, ctx->d_top_hist);
+    }
     hipLaunchKernelGGL(k3_cutoff, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long*)ctx->d_top_hist, n_total_tests,
                        d_cutoff);
     FHX_HIP(hipGetLastError());
@@ -2708,18 +2853,25 @@ static int auto_cutoff(fhx_ctx* ctx, const double* d_p, int64_t n, double n_tota
 }
 
 static int sort_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned long long* keys[2], unsigned int* vals[2],
-                        double* d_q, unsigned long long* counter, const unsigned long long* d_cutoff, int* sorted_buf) {
+                        double* d_q, unsigned long long* counter, const unsigned long long* d_cutoff, int* sorted_buf,
+                        int64_t* n_sorted_out = nullptr) {
     FHX_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
     hipLaunchKernelGGL(k3_compact, dim3(grid_for(n, SORT_TILE, 256 * 8)), dim3(SORT_THREADS), 0, ctx->stream, d_p, n,
                        keys[0], vals[0], d_q, counter, d_cutoff);
+    // how many keys survived decides the shape of the sort (one 8-byte read back: ~20 us against ~190 us of fixed cost saved)
+    unsigned long long n_kept = 0;
+    FHX_HIP(hipMemcpyAsync(&n_kept, counter, sizeof(n_kept), hipMemcpyDeviceToHost, ctx->stream));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    if (n_sorted_out) *n_sorted_out = (int64_t)n_kept;
+    const int nblk = sort_blocks_for((int64_t)n_kept);
     int src = 0;
     // p < 1 means the IEEE exponent field is <= 1022: bits 62 and 63 are always clear, 62 bits to sort
     for (int pass = 0; pass < SORT_PASSES; ++pass) {
         const int shift = pass * RADIX_BITS;
-        hipLaunchKernelGGL(rs_count, dim3(SORT_BLOCKS), dim3(SORT_THREADS), 0, ctx->stream, keys[src], counter, shift,
+        hipLaunchKernelGGL(rs_count, dim3(nblk), dim3(SORT_THREADS), 0, ctx->stream, keys[src], counter, shift,
                            ctx->d_block_hist);
-        hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3(SORT_BLOCKS), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total);
-        hipLaunchKernelGGL(rs_scatter, dim3(SORT_BLOCKS), dim3(SORT_THREADS), 0, ctx->stream, keys[src], vals[src],
+        hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3((nblk + 63) / 64 * 64), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total, nblk);
+        hipLaunchKernelGGL(rs_scatter, dim3(nblk), dim3(SORT_THREADS), 0, ctx->stream, keys[src], vals[src],
                            keys[1 - src], vals[1 - src], counter, shift, ctx->d_block_hist, ctx->d_digit_total);
         src = 1 - src;
     }
@@ -2754,10 +2906,10 @@ int fhx_bh_top_hist(fhx_ctx* ctx, int64_t* hist_out, int64_t capacity) {
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
     if (!ctx->have_p) return fail(ctx, FHX_ERR_ARG, "fhx_pvalues must run first");
     FHX_HIP(hipSetDevice(ctx->device));
-    FHX_HIP(hipMemsetAsync(ctx->d_top_hist, 0, TOP_BINS * sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL(k3_top_hist, dim3(grid_for((ctx->n_rows + 1) / 2, 512, 256 * 4)), dim3(512), 0, ctx->stream, ctx->d_p,
-                       ctx->n_rows, ctx->d_top_hist);
-    FHX_HIP(hipGetLastError());
+    {
+        const int rc = fill_top_hist(ctx);
+        if (rc != FHX_OK) return rc;
+    }
     FHX_HIP(hipMemcpyAsync(hist_out, ctx->d_top_hist, TOP_BINS * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     FHX_HIP(hipStreamSynchronize(ctx->stream));
     return FHX_OK;
@@ -2770,10 +2922,10 @@ int fhx_bh_top_hist_device(fhx_ctx* ctx) {
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
     if (!ctx->have_p) return fail(ctx, FHX_ERR_ARG, "fhx_pvalues must run first");
     FHX_HIP(hipSetDevice(ctx->device));
-    FHX_HIP(hipMemsetAsync(ctx->d_top_hist, 0, TOP_BINS * sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL(k3_top_hist, dim3(grid_for((ctx->n_rows + 1) / 2, 512, 256 * 4)), dim3(512), 0, ctx->stream, ctx->d_p,
-                       ctx->n_rows, ctx->d_top_hist);
-    FHX_HIP(hipGetLastError());
+    {
+        const int rc = fill_top_hist(ctx);
+        if (rc != FHX_OK) return rc;
+    }
     FHX_HIP(hipStreamSynchronize(ctx->stream));           // the caller's collective runs on another stream
     return FHX_OK;
 }
@@ -2810,10 +2962,11 @@ int fhx_bh_local_sort(fhx_ctx* ctx) {
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
     if (!ctx->have_p) return fail(ctx, FHX_ERR_ARG, "fhx_pvalues must run first");
     FHX_HIP(hipSetDevice(ctx->device));
+    int64_t kept = 0;
     const int rc = sort_pvalues(ctx, ctx->d_p, ctx->n_rows, ctx->d_keys, ctx->d_vals, ctx->d_q, ctx->d_misc, ctx->d_misc + 6,
-                                &ctx->sorted_buf);
+                                &ctx->sorted_buf, &kept);
     if (rc != FHX_OK) return rc;
-    ctx->n_sorted = -2;          // known on the device only until someone asks
+    ctx->n_sorted = kept;
     return FHX_OK;
 }
 
@@ -3002,13 +3155,14 @@ int fhx_sort_u64(fhx_ctx* ctx, const void* d_keys_in, int64_t n, void* d_keys_ou
     // an even number of ping-pong passes: start in the caller's output pair so that the result lands there
     FHX_HIP(hipMemcpyAsync(keys[1], d_keys_in, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, vals[1], n);
+    const int nblk = sort_blocks_for(n);
     int src = 1;
     for (int pass = 0; pass < SORT_PASSES; ++pass) {
         const int shift = pass * RADIX_BITS;
-        hipLaunchKernelGGL(rs_count, dim3(SORT_BLOCKS), dim3(SORT_THREADS), 0, ctx->stream, keys[src], counter, shift,
+        hipLaunchKernelGGL(rs_count, dim3(nblk), dim3(SORT_THREADS), 0, ctx->stream, keys[src], counter, shift,
                            ctx->d_block_hist);
-        hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3(SORT_BLOCKS), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total);
-        hipLaunchKernelGGL(rs_scatter, dim3(SORT_BLOCKS), dim3(SORT_THREADS), 0, ctx->stream, keys[src], vals[src],
+        hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3((nblk + 63) / 64 * 64), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total, nblk);
+        hipLaunchKernelGGL(rs_scatter, dim3(nblk), dim3(SORT_THREADS), 0, ctx->stream, keys[src], vals[src],
                            keys[1 - src], vals[1 - src], counter, shift, ctx->d_block_hist, ctx->d_digit_total);
         src = 1 - src;
     }

@@ -102,13 +102,15 @@ bool deflate_member(const std::string& text, int level, std::string& out) {
     return true;
 }
 
-// blocks 0..n_blocks-1 produced by `produce(block, out)` on n_threads workers, written to `f` in block order while later
-// blocks are still being produced; at most `window` finished blocks wait in memory
+// blocks 0..n_blocks-1 produced by `produce(block, scratch, out)` on n_threads workers, written to `f` in block order while
+// later blocks are still being produced; at most `window` finished blocks wait in memory.  Every buffer is reused: a worker
+// keeps its text scratch, the window keeps its output strings - fresh multi-megabyte allocations per block (mmap, page
+// faults, munmap under one address-space lock) were what 256 threads spent their time on (15.7 s -> see profiles/ for C3).
 template <typename Produce>
 bool ordered_parallel_write(std::FILE* f, int64_t n_blocks, int n_threads, Produce produce) {
     if (n_blocks <= 0) return true;
     n_threads = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, n_blocks));
-    const int64_t window = 4 * (int64_t)n_threads;
+    const int64_t window = 2 * (int64_t)n_threads;
     std::vector<std::string> slot((size_t)window);
     std::vector<char> ready((size_t)window, 0);
     std::mutex mu;
@@ -117,6 +119,7 @@ bool ordered_parallel_write(std::FILE* f, int64_t n_blocks, int n_threads, Produ
     int64_t written = 0;                                   // guarded by mu
     std::atomic<bool> fine{true};
     auto worker = [&]() {
+        std::string scratch;
         for (;;) {
             const int64_t b = next.fetch_add(1);
             if (b >= n_blocks || !fine) return;
@@ -124,11 +127,11 @@ bool ordered_parallel_write(std::FILE* f, int64_t n_blocks, int n_threads, Produ
                 std::unique_lock<std::mutex> lk(mu);
                 cv_space.wait(lk, [&] { return b < written + window || !fine; });
             }
-            std::string z;
-            if (!produce(b, z)) fine = false;
+            if (!fine) return;
+            std::string& out = slot[(size_t)(b % window)];   // free: block b - window has been written
+            if (!produce(b, scratch, out)) fine = false;
             {
                 std::lock_guard<std::mutex> lk(mu);
-                slot[(size_t)(b % window)] = std::move(z);
                 ready[(size_t)(b % window)] = 1;
             }
             cv_ready.notify_all();
@@ -138,7 +141,6 @@ bool ordered_parallel_write(std::FILE* f, int64_t n_blocks, int n_threads, Produ
     for (int k = 0; k < n_threads; ++k) pool.emplace_back(worker);
     bool ok = true;
     for (int64_t b = 0; b < n_blocks; ++b) {
-        std::string z;
         {
             std::unique_lock<std::mutex> lk(mu);
             cv_ready.wait(lk, [&] { return ready[(size_t)(b % window)] || !fine; });
@@ -146,19 +148,21 @@ bool ordered_parallel_write(std::FILE* f, int64_t n_blocks, int n_threads, Produ
                 ok = false;
                 break;
             }
-            z = std::move(slot[(size_t)(b % window)]);
+        }
+        const std::string& z = slot[(size_t)(b % window)];
+        if (!z.empty() && std::fwrite(z.data(), 1, z.size(), f) != z.size()) {
+            ok = false;
+            fine = false;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
             ready[(size_t)(b % window)] = 0;
             written = b + 1;
         }
         cv_space.notify_all();
-        if (!z.empty() && std::fwrite(z.data(), 1, z.size(), f) != z.size()) {
-            ok = false;
-            fine = false;
-            cv_space.notify_all();
-            break;
-        }
+        if (!ok) break;
     }
-    fine = fine && ok;
+    if (!ok) fine = false;
     cv_space.notify_all();
     cv_ready.notify_all();
     for (auto& t : pool) t.join();
@@ -196,10 +200,11 @@ int fhx_host_write_significances(const char* path, const char* const* chr_names,
         ok = deflate_member(hdr, gzip_level, z) && std::fwrite(z.data(), 1, z.size(), f) == z.size();
     }
     std::vector<int64_t> rows((size_t)n_blocks, 0);
-    auto produce = [&](int64_t blk, std::string& zipped) -> bool {
+    auto produce = [&](int64_t blk, std::string& text, std::string& zipped) -> bool {
         const int64_t lo = blk * block, hi = std::min(n_rows, lo + block);
-        std::string text;
-        text.reserve((size_t)(hi - lo) * 110);
+        text.clear();
+        zipped.clear();
+        if (text.capacity() < (size_t)(hi - lo) * 110) text.reserve((size_t)(hi - lo) * 110);
         char buf[1400];                                                   // 2 names <= 512, 3 ints <= 36, 4 x %e <= 100, %f <= 320
         for (int64_t i = lo; i < hi; ++i) {
             const bool inter = chr1[i] != chr2[i];
@@ -253,14 +258,6 @@ int fhx_host_write_significances(const char* path, const char* const* chr_names,
 // =====================================================================================================================
 // reader
 // =====================================================================================================================
-struct fhx_table {
-    int kind = 0;
-    std::vector<std::string> names;
-    std::vector<int32_t> ci[2], mi[2], iv;       // chr ids / mids of locus 1 and 2; iv = count (contacts) or hits (fragments)
-    std::vector<double> dv;                      // raw count (contacts) or bias (bias table)
-    std::string error;
-};
-
 namespace {
 
 struct Chunk {
@@ -272,6 +269,21 @@ struct Chunk {
     int64_t n_lines = 0;
     int32_t last_id[2] = {-1, -1};                // id of the previous line's name, per column
 };
+
+}  // namespace
+
+// the parsed file: per-range chunks in file order; fhx_table_copy gathers a column from them on all cores, straight into the
+// caller's array (no merged intermediate copy)
+struct fhx_table {
+    int kind = 0;
+    std::vector<std::string> names;
+    std::vector<Chunk> chunks;
+    std::vector<std::vector<int32_t>> remap;     // chunk-local chromosome id -> file-wide id (order of first appearance)
+    std::vector<size_t> row0;                    // first row of every chunk, then the total
+    std::string error;
+};
+
+namespace {
 
 inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
 
@@ -659,58 +671,26 @@ int fhx_host_read_table(const char* path, int32_t kind, int32_t n_threads, fhx_t
         }
         line0 += c.n_lines;
     }
-    // ---- merge: names in order of first appearance over the whole file; rows copied on all cores ------------------------
+    // ---- names in order of first appearance over the whole file; the rows stay in their chunks until fhx_table_copy --------
     std::unordered_map<std::string, int32_t> index;
-    std::vector<std::vector<int32_t>> remap(chunks.size());
-    std::vector<size_t> row0(chunks.size() + 1, 0);
+    t->remap.resize(chunks.size());
+    t->row0.assign(chunks.size() + 1, 0);
     for (size_t k = 0; k < chunks.size(); ++k) {
         Chunk& c = chunks[k];
-        remap[k].resize(c.names.size());
+        t->remap[k].resize(c.names.size());
         for (size_t i = 0; i < c.names.size(); ++i) {
             auto it = index.find(c.names[i]);
             if (it == index.end()) {
-                remap[k][i] = (int32_t)t->names.size();
-                index.emplace(c.names[i], remap[k][i]);
+                t->remap[k][i] = (int32_t)t->names.size();
+                index.emplace(c.names[i], t->remap[k][i]);
                 t->names.push_back(c.names[i]);
             } else {
-                remap[k][i] = it->second;
+                t->remap[k][i] = it->second;
             }
         }
-        row0[k + 1] = row0[k] + c.mi[0].size();
+        t->row0[k + 1] = t->row0[k] + c.mi[0].size();
     }
-    const size_t rows = row0[chunks.size()];
-    const bool two = kind == 0, has_iv = kind != 2, has_dv = kind != 1;
-    t->ci[0].resize(rows);
-    t->mi[0].resize(rows);
-    if (two) {
-        t->ci[1].resize(rows);
-        t->mi[1].resize(rows);
-    }
-    if (has_iv) t->iv.resize(rows);
-    if (has_dv) t->dv.resize(rows);
-    {
-        std::atomic<size_t> next{0};
-        auto work = [&]() {
-            for (;;) {
-                const size_t k = next.fetch_add(1);
-                if (k >= chunks.size()) return;
-                Chunk& c = chunks[k];
-                const size_t n = c.mi[0].size(), at = row0[k];
-                for (int s = 0; s < (two ? 2 : 1); ++s) {
-                    for (size_t i = 0; i < n; ++i) t->ci[s][at + i] = remap[k][(size_t)c.ci[s][i]];
-                    if (n) std::memcpy(&t->mi[s][at], c.mi[s].data(), n * sizeof(int32_t));
-                }
-                if (has_iv && n) std::memcpy(&t->iv[at], c.iv.data(), n * sizeof(int32_t));
-                if (has_dv && n) std::memcpy(&t->dv[at], c.dv.data(), n * sizeof(double));
-                c = Chunk();
-            }
-        };
-        const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, chunks.size()));
-        std::vector<std::thread> pool;
-        for (int k = 1; k < nt; ++k) pool.emplace_back(work);
-        work();
-        for (auto& th : pool) th.join();
-    }
+    t->chunks = std::move(chunks);
     return FHX_OK;
 }
 
@@ -732,10 +712,11 @@ int fhx_host_write_contacts(const char* path, const char* const* chr_names, int3
     if (!f) return FHX_ERR_ARG;
     const int64_t block = 1 << 18;
     const int64_t n_blocks = std::max<int64_t>(1, (n_rows + block - 1) / block);
-    auto produce = [&](int64_t blk, std::string& zipped) -> bool {
+    auto produce = [&](int64_t blk, std::string& text, std::string& zipped) -> bool {
         const int64_t lo = blk * block, hi = std::min(n_rows, lo + block);
-        std::string text;
-        text.reserve((size_t)(hi - lo) * 40);
+        text.clear();
+        zipped.clear();
+        if (text.capacity() < (size_t)(hi - lo) * 40) text.reserve((size_t)(hi - lo) * 40);
         char buf[600];
         for (int64_t i = lo; i < hi; ++i) {
             if (chr1[i] < 0 || chr1[i] >= n_names || chr2[i] < 0 || chr2[i] >= n_names) return false;
@@ -761,7 +742,7 @@ int fhx_host_write_contacts(const char* path, const char* const* chr_names, int3
     return ok ? FHX_OK : FHX_ERR_ARG;
 }
 
-int64_t fhx_table_rows(const fhx_table* t) { return t ? (int64_t)t->mi[0].size() : -1; }
+int64_t fhx_table_rows(const fhx_table* t) { return t ? (t->row0.empty() ? 0 : (int64_t)t->row0.back()) : -1; }
 int32_t fhx_table_n_names(const fhx_table* t) { return t ? (int32_t)t->names.size() : -1; }
 const char* fhx_table_name(const fhx_table* t, int32_t i) {
     return (t && i >= 0 && i < (int32_t)t->names.size()) ? t->names[i].c_str() : nullptr;
@@ -770,20 +751,38 @@ const char* fhx_table_error(const fhx_table* t) { return t ? t->error.c_str() : 
 
 // columns: 0 chr1, 1 mid1, 2 chr2, 3 mid2, 4 count / hits (int32); 5 raw count / bias (double)
 int fhx_table_copy(const fhx_table* t, int32_t column, void* dst) {
-    if (!t || !dst) return FHX_ERR_ARG;
-    const std::vector<int32_t>* iv = nullptr;
-    switch (column) {
-        case 0: iv = &t->ci[0]; break;
-        case 1: iv = &t->mi[0]; break;
-        case 2: iv = &t->ci[1]; break;
-        case 3: iv = &t->mi[1]; break;
-        case 4: iv = &t->iv; break;
-        case 5:
-            if (!t->dv.empty()) std::memcpy(dst, t->dv.data(), t->dv.size() * sizeof(double));
-            return FHX_OK;
-        default: return FHX_ERR_ARG;
-    }
-    if (!iv->empty()) std::memcpy(dst, iv->data(), iv->size() * sizeof(int32_t));
+    if (!t || !dst || column < 0 || column > 5) return FHX_ERR_ARG;
+    const int kind = t->kind;
+    if ((column == 2 || column == 3) && kind != 0) return FHX_ERR_ARG;
+    if (column == 4 && kind == 2) return FHX_ERR_ARG;
+    if (column == 5 && kind == 1) return FHX_ERR_ARG;
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const size_t k = next.fetch_add(1);
+            if (k >= t->chunks.size()) return;
+            const Chunk& c = t->chunks[k];
+            const size_t n = c.mi[0].size(), at = t->row0[k];
+            if (!n) continue;
+            if (column == 0 || column == 2) {
+                const std::vector<int32_t>& src = c.ci[column == 0 ? 0 : 1];
+                const std::vector<int32_t>& map = t->remap[k];
+                int32_t* out = static_cast<int32_t*>(dst) + at;
+                for (size_t i = 0; i < n; ++i) out[i] = map[(size_t)src[i]];
+            } else if (column == 1 || column == 3) {
+                std::memcpy(static_cast<int32_t*>(dst) + at, c.mi[column == 1 ? 0 : 1].data(), n * sizeof(int32_t));
+            } else if (column == 4) {
+                std::memcpy(static_cast<int32_t*>(dst) + at, c.iv.data(), n * sizeof(int32_t));
+            } else {
+                std::memcpy(static_cast<double*>(dst) + at, c.dv.data(), n * sizeof(double));
+            }
+        }
+    };
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), t->chunks.size()));
+    std::vector<std::thread> pool;
+    for (int k = 1; k < nt; ++k) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
     return FHX_OK;
 }
 

@@ -129,6 +129,8 @@ def read_Interactions(contactCountsFile, biasFile, outliers=None):
         S.contacts = tables.read_contacts(contactCountsFile, S.chroms)
         S.contacts_path = contactCountsFile
         c = S.contacts
+        if os.environ.get("FHX_TIMING"):
+            print("stage: inflate + parse of %d rows took %.3f s" % (len(c), time.time() - t0))
         S.engine.load_contacts(c.chr1, c.mid1, c.chr2, c.mid2, c.count)
         S.pass_started = 0
     elif outliers is not None and S.pass_started >= 1 and S.values is not None:
@@ -333,26 +335,29 @@ def fit_Spline(mainDic, x, y, yerr, infilename, outfilename, biasDic, outliersli
             from . import plots
             plots.plot_spline_fit(outfilename, passNo, x, y, yerr, splineX, newSplineY, distLowThres, distUpThres)
     eng = S.engine
+    t_stage = time.time()
     eng.ctx.pvalues()                                   # K2
     eng.ctx.bh(info["bh_total_tests"])                  # K3
     print("Outlier threshold is... %s" % (info["outlier_thres"]))
     v = eng.fetch(p=True, q=True, expcc=True, bias=True)
     S.values = v
     con = S.contacts
-    inter = con.chr1 != con.chr2
-    d = np.abs(con.mid1.astype(np.int64) - con.mid2.astype(np.int64))
-    in_rng = (d >= distLowThres) & (d <= distUpThres)
-    emit = (inter & (allReg or interOnly)) | (~inter & (allReg or not interOnly) & in_rng)
+    if os.environ.get("FHX_TIMING"):
+        print("stage: K2 + K3 + fetch of 5 columns took %.3f s" % (time.time() - t_stage))
+        t_stage = time.time()
     name = outfilename + (".res" + str(resolution) if resolution else "") + ".significances.txt.gz"
     print("Writing p-values and q-values to file %s" % (outfilename + ".significances.txt"))
     mode_id = MODES["All" if allReg else ("interOnly" if interOnly else "intraOnly")]
     _capi.host_write_significances(name, S.chroms.names, con.chr1, con.mid1, con.chr2, con.mid2, con.count, v["p"], v["q"],
                                    v["b1"], v["b2"], v["expcc"], mode_id, distLowThres, distUpThres)
+    if os.environ.get("FHX_TIMING"):
+        print("stage: format + deflate + write took %.3f s" % (time.time() - t_stage))
     flags, _ = eng.ctx.fetch_flags(len(con), outlier=True, skip=False)
     rows = np.flatnonzero(flags)
     for r in rows.tolist():
         outliersline.add(r) if hasattr(outliersline, "add") else outliersline.append(r)
-    for dist in d[rows].tolist():
+    # abs(mid1 - mid2) of every outlier line, inter-chromosomal ones included (fithic.py:1217)
+    for dist in np.abs(con.mid1[rows].astype(np.int64) - con.mid2[rows].astype(np.int64)).tolist():
         outliersdist.add(dist) if hasattr(outliersdist, "add") else outliersdist.append(dist)
     if not hasattr(outliersline, "add"):
         outliersline.sort()

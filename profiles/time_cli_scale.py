@@ -1,11 +1,17 @@
 #!/usr/bin/env python3
-"""End-to-end wall time of the drop-in CLI at scale: a synthetic 5 kb map of a few chromosomes written as the
-reference's gz text files (contacts, fragments, bias), then `python -m fithic_amd` on it.  Prints stage times.
+"""End-to-end wall time of the drop-in CLI at scale: the C3-synth map (or its first chromosomes) written as the
+reference's gz text files (contacts, fragments, bias), then `python -m fithic_amd` on it, with the decompressed output
+checked against the oracle's text on a sample of rows.  Prints stage times.
 
-    python profiles/time_cli_scale.py [--chroms 3]
+    python profiles/time_cli_scale.py [--chroms 22] [--plain] [--gpus N]
+
+The contacts file is written by the library's own parallel writer (size-tagged gzip members, which the reader inflates on
+all cores); --plain rewrites it as ONE plain gzip member (what `gzip` produces: a single deflate stream, inflated by one
+thread) to show that case too.
 """
 import argparse
 import gzip
+import hashlib
 import os
 import subprocess
 import sys
@@ -17,42 +23,85 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--chroms", type=int, default=2)
+    ap.add_argument("--chroms", type=int, default=22)
+    ap.add_argument("--plain", action="store_true")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--passes", type=int, nargs="*", default=[1])
+    ap.add_argument("--check-rows", type=int, default=200000)
+    ap.add_argument("--dir", default="/tmp/cli_scale", help="where the input and output files go (/dev/shm/... takes the disk out)")
     args = ap.parse_args()
     import numpy as np
     import torch
-    from fithic_amd import synth
-    res = 5000
-    genome = synth.Genome(res, synth.HG19_AUTOSOMES[16:16 + args.chroms])
-    amp = synth.solve_amplitude(0.66, 4, 400)
+    import bench
+    from fithic_amd import synth, _capi
+    cfg = dict(bench.CONFIGS["C3"])
+    res = cfg["res"]
+    genome = synth.Genome(res, synth.HG19_AUTOSOMES[:args.chroms] if args.chroms < 22 else None)
     dev = torch.device("cuda", 0)
-    parts = [synth.cis_contacts(genome, c, 4, 400, amp, device=dev) for c in range(len(genome))]
-    cols = [torch.cat([p[k] for p in parts]).cpu().numpy() for k in range(5)]
-    n = len(cols[0])
-    out = "/tmp/cli_scale"
+    cols_t, n, _, _ = bench.build_rows(synth, torch, cfg, genome, list(range(len(genome))), 0, 1, dev)
+    cols = [t[:n].cpu().numpy() for t in cols_t]
+    del cols_t
+    torch.cuda.empty_cache()
+    out = args.dir
     os.makedirs(out, exist_ok=True)
     t0 = time.time()
-    names = np.array(genome.names)
+    _capi.host_write_contacts(out + "/contacts.gz", genome.names, *cols, gzip_level=1)
+    t_w = time.time() - t0
+    if args.plain:
+        t0 = time.time()
+        subprocess.run("gzip -dc %s/contacts.gz | gzip -1 > %s/contacts_plain.gz && mv %s/contacts_plain.gz %s/contacts.gz" % (out, out, out, out),
+                       shell=True, check=True)
+        print("rewritten as one plain gzip member in %.1f s" % (time.time() - t0))
     import pandas as pd
-    pd.DataFrame({0: names[cols[0]], 1: cols[1], 2: names[cols[2]], 3: cols[3], 4: cols[4]}).to_csv(
-        out + "/contacts.gz", sep="\t", header=False, index=False, compression={"method": "gzip", "compresslevel": 1})
+    names = np.array(genome.names)
     f_chr, f_mid, f_hits = genome.fragments()
     pd.DataFrame({0: names[f_chr], 1: 0, 2: f_mid, 3: f_hits, 4: 1}).to_csv(out + "/frags.gz", sep="\t", header=False, index=False,
                                                                           compression="gzip")
     b_chr, b_mid, b_val = genome.bias_table()
     pd.DataFrame({0: names[b_chr], 1: b_mid, 2: b_val}).to_csv(out + "/bias.gz", sep="\t", header=False, index=False, compression="gzip")
-    print("wrote %d contact rows (%.1f MB gz) in %.1f s" % (n, os.path.getsize(out + "/contacts.gz") / 1e6, time.time() - t0))
-    for extra in (["-p", "1"], ["-p", "2"]):
+    print("wrote %d contact rows (%.1f MB gz, %s) in %.1f s; host cores %d" %
+          (n, os.path.getsize(out + "/contacts.gz") / 1e6, "one plain member" if args.plain else "size-tagged members", t_w, os.cpu_count()))
+    for passes in args.passes:
         t0 = time.time()
-        r = subprocess.run([sys.executable, "-m", "fithic_amd", "-i", out + "/contacts.gz", "-f", out + "/frags.gz", "-t", out + "/bias.gz",
-                            "-o", out + "/run", "-r", str(res), "-L", "20000", "-U", "2000000"] + extra, cwd=ROOT, capture_output=True, text=True)
+        cmd = [sys.executable, "-m", "fithic_amd", "-i", out + "/contacts.gz", "-f", out + "/frags.gz", "-t", out + "/bias.gz",
+               "-o", out + "/run", "-r", str(res), "-L", str(cfg["L"]), "-U", str(cfg["U"]), "-p", str(passes)]
+        if args.gpus > 1:
+            cmd += ["--gpus", str(args.gpus)]
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, env=dict(os.environ, FHX_TIMING="1"))
         dt = time.time() - t0
-        tail = [ln for ln in r.stdout.splitlines() if "took" in ln or "Time" in ln]
-        sig = out + "/run/FitHiC.spline_pass1.res%d.significances.txt.gz" % res
-        print("fithic %s: wall %.2f s for %d rows (%.2f M rows/s end to end), output %.1f MB gz, cores %d, rc %d" %
-              (" ".join(extra), dt, n, n / dt / 1e6, os.path.getsize(sig) / 1e6, os.cpu_count(), r.returncode))
-        for ln in tail:
-            print("    " + ln)
+        sig = out + "/run/FitHiC.spline_pass%d.res%d.significances.txt.gz" % (passes, res)
+        print("fithic -p %d%s: wall %.2f s for %d rows (%.2f M rows/s end to end), output %.1f MB gz, rc %d" %
+              (passes, " --gpus %d" % args.gpus if args.gpus > 1 else "", dt, n, n / dt / 1e6,
+               os.path.getsize(sig) / 1e6 if os.path.exists(sig) else -1, r.returncode))
+        for ln in r.stdout.splitlines():
+            if "took" in ln or "Time" in ln or "stage" in ln:
+                print("    " + ln)
+        if r.returncode != 0:
+            print(r.stderr[-2000:])
+            continue
+        if passes == 1 and args.check_rows > 0:
+            # the first rows of the output against the oracle's text for the same rows (p, q, biases, ExpCC from the engine's
+            # fetch are formatted by the oracle's Python '%e' / '%f'; the row selection and the order are the reference's)
+            from fithic_amd.engine import Engine
+            t0 = time.time()
+            eng = Engine(0)
+            eng.configure(res, cfg["L"], cfg["U"], n_bins=100, mapp_thres=1, mode="intraOnly")
+            eng.load_fragments(f_chr, f_mid, f_hits, genome.sort_rank())
+            eng.load_bias(b_chr, b_mid, b_val)
+            eng.load_contacts(*cols)
+            eng.run_pass(collect=False)
+            v = eng.fetch(p=True, q=True, expcc=True, bias=True)
+            eng.close()
+            k = min(args.check_rows, n)
+            want = ["chr1\tfragmentMid1\tchr2\tfragmentMid2\tcontactCount\tp-value\tq-value\tbias1\tbias2\tExpCC\n"]
+            for i in range(k):
+                want.append("%s\t%d\t%s\t%d\t%d\t%e\t%e\t%e\t%e\t%f\n" % (names[cols[0][i]], cols[1][i], names[cols[2][i]], cols[3][i],
+                                                                         cols[4][i], v["p"][i], v["q"][i], v["b1"][i], v["b2"][i], v["expcc"][i]))
+            want = "".join(want).encode()
+            with gzip.open(sig, "rb") as f:
+                got = f.read(len(want))
+            print("    first %d output rows %s Python's formatting of the same values (md5 %s), checked in %.1f s" %
+                  (k, "EQUAL" if got == want else "DIFFER FROM", hashlib.md5(got).hexdigest(), time.time() - t0))
 
 
 if __name__ == "__main__":
