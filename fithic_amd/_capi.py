@@ -127,6 +127,8 @@ SYMBOLS = {
     "fhx_host_write_significances": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int32, _I32P, _I32P, _I32P,
                                                     _I32P, _I32P, _F64P, _F64P, _F64P, _F64P, _F64P, ctypes.c_int64, ctypes.c_int32,
                                                     ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _I64P]),
+    "fhx_write_significances_device": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int32, _I32P, _I32P,
+                                                      _I32P, _I32P, _I32P, ctypes.c_int64, _I64P, _I64P]),
     "fhx_host_spline_fit": (ctypes.c_int, [_F64P, _F64P, ctypes.c_int32, ctypes.c_double, _F64P, _F64P, _I32P, _F64P, _I32P, _I32P]),
     "fhx_host_spline_eval": (ctypes.c_int, [_F64P, _F64P, ctypes.c_int32, _F64P, ctypes.c_int64, _F64P]),
     "fhx_host_pava_decreasing": (ctypes.c_int, [_F64P, ctypes.c_int64, _F64P]),
@@ -449,6 +451,17 @@ class Context:
         self._check(self._L.fhx_fetch_flags(self._h, _ptr(o, ctypes.c_uint8) if outlier else None,
                                             _ptr(k, ctypes.c_uint8) if skip else None))
         return o, k
+
+    def write_significances_device(self, path, names, chr1, mid1, chr2, mid2, count):
+        """The significances file formatted and deflated by the GPU from the resident p and q; returns (rows, bytes).  Raises
+        FhxError with code FHX_ERR_UNSUPPORTED when a row does not fit the device formatter (use host_write_significances)."""
+        arr_names = (ctypes.c_char_p * len(names))(*[n.encode() for n in names])
+        i32 = [_i32(v) for v in (chr1, mid1, chr2, mid2, count)]
+        rows, nbytes = ctypes.c_int64(0), ctypes.c_int64(0)
+        self._check(self._L.fhx_write_significances_device(self._h, os.fsencode(path), arr_names, len(names),
+                                                           *[_ptr(v, ctypes.c_int32) for v in i32], len(i32[0]), ctypes.byref(rows),
+                                                           ctypes.byref(nbytes)))
+        return rows.value, nbytes.value
 
     def get_array(self, which):
         n = ctypes.c_int64(0)

@@ -13,6 +13,9 @@
 // MFMA; the whole TU is compiled with -ffp-contract=off (see fhx_bdtrc.hpp for why).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -3466,6 +3469,7 @@ int fhx_kernel_seconds(fhx_ctx* ctx, double* k1, double* k2, double* k3) {
 }
 
 #include "fhx_dist.inc"
+#include "fhx_emit.inc"
 
 // ---- host numerics exported for tests / host-only callers ----------------------------------------------
 int fhx_host_spline_fit(const double* x, const double* y, int32_t m, double s, double* t, double* c, int32_t* n_knots,

@@ -339,17 +339,30 @@ def fit_Spline(mainDic, x, y, yerr, infilename, outfilename, biasDic, outliersli
     eng.ctx.pvalues()                                   # K2
     eng.ctx.bh(info["bh_total_tests"])                  # K3
     print("Outlier threshold is... %s" % (info["outlier_thres"]))
-    v = eng.fetch(p=True, q=True, expcc=True, bias=True)
-    S.values = v
     con = S.contacts
     if os.environ.get("FHX_TIMING"):
-        print("stage: K2 + K3 + fetch of 5 columns took %.3f s" % (time.time() - t_stage))
+        getattr(eng.ctx, "kernel_seconds", lambda: None)()      # synchronises
+        print("stage: K2 + K3 took %.3f s" % (time.time() - t_stage))
         t_stage = time.time()
     name = outfilename + (".res" + str(resolution) if resolution else "") + ".significances.txt.gz"
     print("Writing p-values and q-values to file %s" % (outfilename + ".significances.txt"))
     mode_id = MODES["All" if allReg else ("interOnly" if interOnly else "intraOnly")]
-    _capi.host_write_significances(name, S.chroms.names, con.chr1, con.mid1, con.chr2, con.mid2, con.count, v["p"], v["q"],
-                                   v["b1"], v["b2"], v["expcc"], mode_id, distLowThres, distUpThres)
+    # The GPU formats and deflates the rows from the resident p and q (fhx_write_significances_device); the host writer takes
+    # over for a sharded run (each rank holds a part of the rows), for rows the device formatter does not cover, or on request.
+    on_device = hasattr(eng.ctx, "write_significances_device") and not os.environ.get("FHX_HOST_WRITER")
+    if on_device:
+        try:
+            eng.ctx.write_significances_device(name, S.chroms.names, con.chr1, con.mid1, con.chr2, con.mid2, con.count)
+            S.values = True
+        except _capi.FhxError as e:
+            if e.code != _capi.FHX_ERR_UNSUPPORTED:
+                raise
+            on_device = False
+    if not on_device:
+        v = eng.fetch(p=True, q=True, expcc=True, bias=True)
+        S.values = v
+        _capi.host_write_significances(name, S.chroms.names, con.chr1, con.mid1, con.chr2, con.mid2, con.count, v["p"], v["q"],
+                                       v["b1"], v["b2"], v["expcc"], mode_id, distLowThres, distUpThres)
     if os.environ.get("FHX_TIMING"):
         print("stage: format + deflate + write took %.3f s" % (time.time() - t_stage))
     flags, _ = eng.ctx.fetch_flags(len(con), outlier=True, skip=False)

@@ -316,6 +316,16 @@ int fhx_host_write_significances(const char* path, const char* const* chr_names,
                                  const double* p, const double* q, const double* bias1, const double* bias2,
                                  const double* expcc, int64_t n_rows, int32_t mode, int64_t dist_low, int64_t dist_up,
                                  int32_t gzip_level, int32_t n_threads, int64_t* rows_written);
+/* The same file written BY THE GPU, for the p and q a context holds after fhx_pvalues + fhx_bh: rows are formatted in a
+ * kernel (exact integer arithmetic: the characters C's printf gives), ExpCC and the biases recomputed there, and deflated in
+ * kernels (tokens against the previous row + per-member dynamic Huffman codes built by the host from device histograms);
+ * the host receives finished gzip members (same container as above) and only writes them.  The five identity columns are
+ * the rows given to fhx_load_pairs (n_rows must equal the loaded row count).  Returns FHX_ERR_UNSUPPORTED - nothing usable
+ * written - when a row does not fit the device formatter (a chromosome name longer than 24 bytes, a value of 2^63 or more,
+ * a row of 128 bytes or more): the caller then fetches the columns and uses fhx_host_write_significances. */
+int fhx_write_significances_device(fhx_ctx* ctx, const char* path, const char* const* chr_names, int32_t n_names,
+                                   const int32_t* chr1, const int32_t* mid1, const int32_t* chr2, const int32_t* mid2,
+                                   const int32_t* count, int64_t n_rows, int64_t* rows_written, int64_t* bytes_written);
 
 /* ---- Knight-Ruiz bias vectors (fithic/utils/HiCKRy.py; SURVEY 8f rank 4, the step before Fit-Hi-C) --------------------
  * One fhx_kr per GPU, independent of fhx_ctx.  Call order: load_loci -> load_pairs -> [remove_sparse] -> balance -> bias.

@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--passes", type=int, nargs="*", default=[1])
     ap.add_argument("--check-rows", type=int, default=200000)
+    ap.add_argument("--compare-host-writer", action="store_true",
+                    help="run once more with FHX_HOST_WRITER=1 and compare md5 + line count of the two decompressed files (all rows)")
     ap.add_argument("--dir", default="/tmp/cli_scale", help="where the input and output files go (/dev/shm/... takes the disk out)")
     args = ap.parse_args()
     import numpy as np
@@ -73,12 +75,30 @@ def main():
         print("fithic -p %d%s: wall %.2f s for %d rows (%.2f M rows/s end to end), output %.1f MB gz, rc %d" %
               (passes, " --gpus %d" % args.gpus if args.gpus > 1 else "", dt, n, n / dt / 1e6,
                os.path.getsize(sig) / 1e6 if os.path.exists(sig) else -1, r.returncode))
-        for ln in r.stdout.splitlines():
-            if "took" in ln or "Time" in ln or "stage" in ln:
+        for ln in r.stdout.splitlines() + r.stderr.splitlines():
+            if "took" in ln or "Time" in ln or "stage" in ln or ln.startswith("fhx_"):
                 print("    " + ln)
         if r.returncode != 0:
             print(r.stderr[-2000:])
             continue
+        if args.compare_host_writer:
+            t0 = time.time()
+            cmd_h = [c if c != out + "/run" else out + "/run_host" for c in cmd]
+            rh = subprocess.run(cmd_h, cwd=ROOT, capture_output=True, text=True, env=dict(os.environ, FHX_TIMING="1", FHX_HOST_WRITER="1"))
+            dt_h = time.time() - t0
+            sig_h = sig.replace(out + "/run/", out + "/run_host/")
+            print("same run with the host writer (FHX_HOST_WRITER=1): wall %.2f s, output %.1f MB gz, rc %d" %
+                  (dt_h, os.path.getsize(sig_h) / 1e6 if os.path.exists(sig_h) else -1, rh.returncode))
+            for ln in rh.stdout.splitlines():
+                if "stage" in ln:
+                    print("    " + ln)
+            procs = [subprocess.Popen("gzip -dc %s | tee >(wc -l >&2) | md5sum" % f, shell=True, executable="/bin/bash",
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for f in (sig, sig_h)]
+            res_ = [p.communicate() for p in procs]
+            md5s = [o.split()[0] for o, _ in res_]
+            lines = [int(e.strip()) for _, e in res_]
+            print("    all rows: device writer %d lines md5 %s; host writer %d lines md5 %s -> %s (expected %d lines)" %
+                  (lines[0], md5s[0], lines[1], md5s[1], "EQUAL" if md5s[0] == md5s[1] and lines[0] == lines[1] else "DIFFERENT", n + 1))
         if passes == 1 and args.check_rows > 0:
             # the first rows of the output against the oracle's text for the same rows (p, q, biases, ExpCC from the engine's
             # fetch are formatted by the oracle's Python '%e' / '%f'; the row selection and the order are the reference's)
