@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--passes", type=int, nargs="*", default=[1])
     ap.add_argument("--check-rows", type=int, default=200000)
+    ap.add_argument("--rocprof", default=None, help="directory: run the CLI once more under rocprofv3 --kernel-trace --stats into it")
     ap.add_argument("--compare-host-writer", action="store_true",
                     help="run once more with FHX_HOST_WRITER=1 and compare md5 + line count of the two decompressed files (all rows)")
     ap.add_argument("--dir", default="/tmp/cli_scale", help="where the input and output files go (/dev/shm/... takes the disk out)")
@@ -81,6 +82,11 @@ def main():
         if r.returncode != 0:
             print(r.stderr[-2000:])
             continue
+        if args.rocprof:
+            env = dict(os.environ, TMPDIR="/tmp")
+            rp = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", args.rocprof, "-o", "cli", "--"] + cmd, cwd="/tmp",
+                                capture_output=True, text=True, env=dict(env, PYTHONPATH=ROOT))
+            print("rocprofv3 run of the same command: rc %d" % rp.returncode)
         if args.compare_host_writer:
             t0 = time.time()
             cmd_h = [c if c != out + "/run" else out + "/run_host" for c in cmd]
