@@ -1814,6 +1814,20 @@ void dev_free(T*& p) {
     p = nullptr;
 }
 
+// temporary device allocations of one call: freed on every return path (FHX_HIP returns early on errors)
+struct DeviceScratch {
+    std::vector<void*> v;
+    ~DeviceScratch() {
+        for (void* p : v) (void)hipFree(p);
+    }
+    template <typename T>
+    hipError_t get(T** p, size_t bytes) {
+        const hipError_t e = hipMalloc((void**)p, std::max<size_t>(bytes, 16));
+        if (e == hipSuccess) v.push_back((void*)*p);
+        return e;
+    }
+};
+
 int grid_for(int64_t n, int threads, int max_blocks = 256 * 8) {
     const int64_t b = (n + threads - 1) / threads;
     return (int)std::max<int64_t>(1, std::min<int64_t>(b, max_blocks));
@@ -1989,6 +2003,7 @@ int ingest_device_rows_nonfixed(fhx_ctx* ctx, const int32_t* c1, const int32_t* 
     if (rc != FHX_OK) return rc;
     const int64_t n2 = 2 * n;
     const size_t cap2 = std::max<size_t>(4, (size_t)n2);
+    DeviceScratch tmp;
     unsigned long long* keys[2] = {nullptr, nullptr};
     unsigned int* vals[2] = {nullptr, nullptr};
     unsigned int *ids = nullptr, *tiles = nullptr;
@@ -1996,14 +2011,14 @@ int ingest_device_rows_nonfixed(fhx_ctx* ctx, const int32_t* c1, const int32_t* 
     unsigned long long* slot_key = nullptr;
     int* bad = nullptr;
     for (int b = 0; b < 2; ++b) {
-        FHX_HIP(hipMalloc(&keys[b], cap2 * sizeof(unsigned long long)));
-        FHX_HIP(hipMalloc(&vals[b], cap2 * sizeof(unsigned int)));
+        FHX_HIP(tmp.get(&keys[b], cap2 * sizeof(unsigned long long)));
+        FHX_HIP(tmp.get(&vals[b], cap2 * sizeof(unsigned int)));
     }
-    FHX_HIP(hipMalloc(&ids, cap2 * sizeof(unsigned int)));
-    FHX_HIP(hipMalloc(&tiles, (cap2 / SEG_TILE + 2) * sizeof(unsigned int)));
-    FHX_HIP(hipMalloc(&loc, cap2 * sizeof(int32_t)));
-    FHX_HIP(hipMalloc(&slot_key, cap2 * sizeof(unsigned long long)));
-    FHX_HIP(hipMalloc(&bad, sizeof(int)));
+    FHX_HIP(tmp.get(&ids, cap2 * sizeof(unsigned int)));
+    FHX_HIP(tmp.get(&tiles, (cap2 / SEG_TILE + 2) * sizeof(unsigned int)));
+    FHX_HIP(tmp.get(&loc, cap2 * sizeof(int32_t)));
+    FHX_HIP(tmp.get(&slot_key, cap2 * sizeof(unsigned long long)));
+    FHX_HIP(tmp.get(&bad, sizeof(int)));
     FHX_HIP(hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
     hipLaunchKernelGGL(nf_locus_keys, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, c1, m1, c2, m2, n, keys[0], vals[0], bad);
     unsigned long long* counter = ctx->d_misc + 3;
@@ -2052,15 +2067,6 @@ int ingest_device_rows_nonfixed(fhx_ctx* ctx, const int32_t* c1, const int32_t* 
         ctx->h_outlier_dists.clear();
         ctx->h_dist_keys.clear();
     }
-    for (int b = 0; b < 2; ++b) {
-        dev_free(keys[b]);
-        dev_free(vals[b]);
-    }
-    dev_free(ids);
-    dev_free(tiles);
-    dev_free(loc);
-    dev_free(slot_key);
-    dev_free(bad);
     return rc;
 }
 
@@ -2075,10 +2081,11 @@ int ingest_device_rows(fhx_ctx* ctx, const int32_t* c1, const int32_t* m1, const
     // folded into the extent kernel by giving it a generous table
     n_chr = std::max(n_chr, 4096);
     int32_t *d_maxidx = nullptr, *d_minoff = nullptr, *d_maxoff = nullptr, *d_bad = nullptr;
-    FHX_HIP(hipMalloc(&d_maxidx, n_chr * sizeof(int32_t)));
-    FHX_HIP(hipMalloc(&d_minoff, n_chr * sizeof(int32_t)));
-    FHX_HIP(hipMalloc(&d_maxoff, n_chr * sizeof(int32_t)));
-    FHX_HIP(hipMalloc(&d_bad, sizeof(int32_t)));
+    DeviceScratch tmp;
+    FHX_HIP(tmp.get(&d_maxidx, n_chr * sizeof(int32_t)));
+    FHX_HIP(tmp.get(&d_minoff, n_chr * sizeof(int32_t)));
+    FHX_HIP(tmp.get(&d_maxoff, n_chr * sizeof(int32_t)));
+    FHX_HIP(tmp.get(&d_bad, sizeof(int32_t)));
     FHX_HIP(hipMemsetAsync(d_maxidx, 0xFF, n_chr * sizeof(int32_t), ctx->stream));       // -1
     FHX_HIP(hipMemsetAsync(d_minoff, 0x7F, n_chr * sizeof(int32_t), ctx->stream));       // large
     FHX_HIP(hipMemsetAsync(d_maxoff, 0xFF, n_chr * sizeof(int32_t), ctx->stream));       // -1
@@ -2095,10 +2102,6 @@ int ingest_device_rows(fhx_ctx* ctx, const int32_t* c1, const int32_t* m1, const
     FHX_HIP(hipMemcpyAsync(maxoff.data(), d_maxoff, n_chr * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     FHX_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     FHX_HIP(hipStreamSynchronize(ctx->stream));
-    dev_free(d_maxidx);
-    dev_free(d_minoff);
-    dev_free(d_maxoff);
-    dev_free(d_bad);
     if (bad) return fail(ctx, FHX_ERR_ARG, "contact rows hold a negative midpoint or a chromosome id outside [0, 4096)");
     int used = 0;
     for (int c = 0; c < n_chr; ++c)
@@ -2304,10 +2307,13 @@ int fhx_set_params(fhx_ctx* ctx, const fhx_params* p) {
         return fail(ctx, FHX_ERR_REFERENCE_EXIT, "bias lower bound is greater than bias upper bound (fithic.py:261-263)");
     if (ctx->n_rows > 0 && ctx->have_params && p->resolution != ctx->prm.resolution)
         return fail(ctx, FHX_ERR_ARG, "the resolution cannot change after the contact rows were loaded");
+    // the per-slot bias table depends on the grid and the bias bounds only: the drop-in layer re-sends unchanged parameters
+    // before every stage, which must not cost a rebuild + upload of the table
+    if (!ctx->have_params || p->resolution != ctx->prm.resolution || p->bias_low != ctx->prm.bias_low || p->bias_up != ctx->prm.bias_up)
+        ctx->tables_dirty = true;
     ctx->prm = *p;
     ctx->nonfixed = p->resolution == 0 || ctx->offgrid;
     ctx->have_params = true;
-    ctx->tables_dirty = true;
     return FHX_OK;
 }
 
@@ -2379,8 +2385,9 @@ int fhx_load_pairs(fhx_ctx* ctx, const int32_t* chr1, const int32_t* mid1, const
     FHX_HIP(hipSetDevice(ctx->device));
     int32_t* d[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     const int32_t* h[5] = {chr1, mid1, chr2, mid2, count};
+    DeviceScratch tmp;
     for (int k = 0; k < 5; ++k) {
-        FHX_HIP(hipMalloc(&d[k], (size_t)std::max<int64_t>(n, 1) * sizeof(int32_t)));      // an empty shard is legal
+        FHX_HIP(tmp.get(&d[k], (size_t)std::max<int64_t>(n, 1) * sizeof(int32_t)));         // an empty shard is legal
         if (n) FHX_HIP(hipMemcpyAsync(d[k], h[k], (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     }
     FHX_HIP(hipStreamSynchronize(ctx->stream));
@@ -2388,7 +2395,6 @@ int fhx_load_pairs(fhx_ctx* ctx, const int32_t* chr1, const int32_t* mid1, const
     ctx->nonfixed = ctx->have_params && ctx->prm.resolution == 0;
     const int rc = (ctx->have_params && ctx->nonfixed) ? ingest_device_rows_nonfixed(ctx, d[0], d[1], d[2], d[3], d[4], n)
                                                        : ingest_device_rows(ctx, d[0], d[1], d[2], d[3], d[4], n);
-    for (int k = 0; k < 5; ++k) dev_free(d[k]);
     return rc;
 }
 
@@ -3061,13 +3067,14 @@ int fhx_bh_array(fhx_ctx* ctx, const double* p, int64_t n, double n_total_tests,
     double *d_p = nullptr, *d_q = nullptr, *tile_max = nullptr;
     unsigned long long* keys[2] = {nullptr, nullptr};
     unsigned int* vals[2] = {nullptr, nullptr};
+    DeviceScratch tmp;
     const size_t cap = (size_t)n;
-    FHX_HIP(hipMalloc(&d_p, cap * sizeof(double)));
-    FHX_HIP(hipMalloc(&d_q, cap * sizeof(double)));
-    FHX_HIP(hipMalloc(&tile_max, (cap / BH_TILE + 2) * sizeof(double)));
+    FHX_HIP(tmp.get(&d_p, cap * sizeof(double)));
+    FHX_HIP(tmp.get(&d_q, cap * sizeof(double)));
+    FHX_HIP(tmp.get(&tile_max, (cap / BH_TILE + 2) * sizeof(double)));
     for (int b = 0; b < 2; ++b) {
-        FHX_HIP(hipMalloc(&keys[b], cap * sizeof(unsigned long long)));
-        FHX_HIP(hipMalloc(&vals[b], cap * sizeof(unsigned int)));
+        FHX_HIP(tmp.get(&keys[b], cap * sizeof(unsigned long long)));
+        FHX_HIP(tmp.get(&vals[b], cap * sizeof(unsigned int)));
     }
     FHX_HIP(hipMemcpyAsync(d_p, p, cap * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     int buf = 0;
@@ -3079,13 +3086,6 @@ int fhx_bh_array(fhx_ctx* ctx, const double* p, int64_t n, double n_total_tests,
     if (rc == FHX_OK) {
         FHX_HIP(hipMemcpyAsync(q, d_q, cap * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         FHX_HIP(hipStreamSynchronize(ctx->stream));
-    }
-    dev_free(d_p);
-    dev_free(d_q);
-    dev_free(tile_max);
-    for (int b = 0; b < 2; ++b) {
-        dev_free(keys[b]);
-        dev_free(vals[b]);
     }
     return rc;
 }
@@ -3316,9 +3316,10 @@ int fhx_fetch(fhx_ctx* ctx, double* p, double* q, double* expcc, double* bias1, 
     if (q) FHX_HIP(hipMemcpyAsync(q, ctx->d_q, bytes, hipMemcpyDeviceToHost, ctx->stream));
     double* d_tmp[3] = {nullptr, nullptr, nullptr};
     double* host[3] = {expcc, bias1, bias2};
+    DeviceScratch tmp;
     if (expcc || bias1 || bias2) {
         for (int k = 0; k < 3; ++k)
-            if (host[k]) FHX_HIP(hipMalloc(&d_tmp[k], bytes));
+            if (host[k]) FHX_HIP(tmp.get(&d_tmp[k], bytes));
         const K2Params P = make_k2_params(ctx);
         hipLaunchKernelGGL(k2_extras, dim3(grid_for(ctx->n_rows, 256)), dim3(256), 0, ctx->stream, P, ctx->prm.bias_low,
                            ctx->prm.bias_up, d_tmp[0], d_tmp[1], d_tmp[2]);
@@ -3327,7 +3328,6 @@ int fhx_fetch(fhx_ctx* ctx, double* p, double* q, double* expcc, double* bias1, 
             if (host[k]) FHX_HIP(hipMemcpyAsync(host[k], d_tmp[k], bytes, hipMemcpyDeviceToHost, ctx->stream));
     }
     FHX_HIP(hipStreamSynchronize(ctx->stream));
-    for (int k = 0; k < 3; ++k) dev_free(d_tmp[k]);
     return FHX_OK;
 }
 
