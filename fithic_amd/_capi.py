@@ -452,14 +452,18 @@ class Context:
                                             _ptr(k, ctypes.c_uint8) if skip else None))
         return o, k
 
-    def write_significances_device(self, path, names, chr1, mid1, chr2, mid2, count):
-        """The significances file formatted and deflated by the GPU from the resident p and q; returns (rows, bytes).  Raises
-        FhxError with code FHX_ERR_UNSUPPORTED when a row does not fit the device formatter (use host_write_significances)."""
+    def write_significances_device(self, path, names, chr1=None, mid1=None, chr2=None, mid2=None, count=None):
+        """The significances file formatted and deflated by the GPU from the resident p and q; returns (rows, bytes).  Without
+        the five identity columns they are rebuilt on the device from the rows fhx_load_pairs stored (nothing is uploaded).
+        Raises FhxError with code FHX_ERR_UNSUPPORTED when a row does not fit the device formatter (use host_write_significances)."""
         arr_names = (ctypes.c_char_p * len(names))(*[n.encode() for n in names])
-        i32 = [_i32(v) for v in (chr1, mid1, chr2, mid2, count)]
         rows, nbytes = ctypes.c_int64(0), ctypes.c_int64(0)
-        self._check(self._L.fhx_write_significances_device(self._h, os.fsencode(path), arr_names, len(names),
-                                                           *[_ptr(v, ctypes.c_int32) for v in i32], len(i32[0]), ctypes.byref(rows),
+        if chr1 is None:
+            ptrs, n = [None] * 5, self.stats().n_rows
+        else:
+            i32 = [_i32(v) for v in (chr1, mid1, chr2, mid2, count)]
+            ptrs, n = [_ptr(v, ctypes.c_int32) for v in i32], len(i32[0])
+        self._check(self._L.fhx_write_significances_device(self._h, os.fsencode(path), arr_names, len(names), *ptrs, n, ctypes.byref(rows),
                                                            ctypes.byref(nbytes)))
         return rows.value, nbytes.value
 

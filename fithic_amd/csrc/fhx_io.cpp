@@ -10,6 +10,7 @@
 #include <zlib.h>
 
 #include <charconv>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 
@@ -26,6 +27,7 @@
 #include <vector>
 
 #include "../../include/fithic_mi355x.h"
+#include "fhx_cpus.hpp"
 
 namespace {
 
@@ -181,7 +183,7 @@ int fhx_host_write_significances(const char* path, const char* const* chr_names,
     if (!path || !chr_names || n_names <= 0 || n_rows < 0) return FHX_ERR_ARG;
     if (n_rows > 0 && (!chr1 || !mid1 || !chr2 || !mid2 || !count || !p || !q || !bias1 || !bias2 || !expcc)) return FHX_ERR_ARG;
     if (gzip_level < 0 || gzip_level > 9) gzip_level = 6;
-    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (n_threads <= 0) n_threads = fhx::usable_cpus();
     std::FILE* f = std::fopen(path, "wb");
     if (!f) return FHX_ERR_ARG;
     const bool all_reg = mode == FHX_MODE_ALL, inter_only = mode == FHX_MODE_INTER_ONLY;
@@ -528,7 +530,18 @@ int fhx_host_read_table(const char* path, int32_t kind, int32_t n_threads, fhx_t
     if (!t) return FHX_ERR_NOMEM;
     t->kind = kind;
     *out = t;
-    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (n_threads <= 0) n_threads = fhx::usable_cpus();
+    const bool timing = std::getenv("FHX_TIMING") != nullptr;          // stage clocks on stderr
+    auto t_last = std::chrono::steady_clock::now();
+    std::string t_report;
+    auto mark = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        char b[96];
+        std::snprintf(b, sizeof(b), " %s %.3f s;", what, std::chrono::duration<double>(now - t_last).count());
+        t_report += b;
+        t_last = now;
+    };
     // ---- the compressed file, whole ------------------------------------------------------------------------------
     std::vector<unsigned char> gz;
     {
@@ -552,6 +565,7 @@ int fhx_host_read_table(const char* path, int32_t kind, int32_t n_threads, fhx_t
         t->error = std::string("not a gzip file: ") + path + " (the reference's gzip.open raises on it)";
         return FHX_ERR_REFERENCE_EXIT;
     }
+    mark("file read");
     // ---- inflate: all cores when every member carries its size ("FH" of this library's writers, "BC" of bgzip) ------
     std::vector<std::string> pieces;                       // the text, in order
     std::vector<Member> members;
@@ -602,6 +616,7 @@ int fhx_host_read_table(const char* path, int32_t kind, int32_t n_threads, fhx_t
         }
     }
     std::vector<unsigned char>().swap(gz);
+    mark("inflate");
     // ---- parse ranges, in file order: lines that straddle two pieces are glued, the rest is cut on newlines -------------
     struct Range {
         const char *b, *e;
@@ -662,6 +677,7 @@ int fhx_host_read_table(const char* path, int32_t kind, int32_t n_threads, fhx_t
         work();
         for (auto& th : pool) th.join();
     }
+    mark("parse");
     int64_t line0 = 0;
     for (auto& c : chunks) {
         if (c.bad_line >= 0) {
@@ -691,6 +707,8 @@ int fhx_host_read_table(const char* path, int32_t kind, int32_t n_threads, fhx_t
         t->row0[k + 1] = t->row0[k] + c.mi[0].size();
     }
     t->chunks = std::move(chunks);
+    mark("name index");
+    if (timing) std::fprintf(stderr, "fhx_host_read_table(%s): %d threads:%s\n", path, n_threads, t_report.c_str());
     return FHX_OK;
 }
 
@@ -702,7 +720,7 @@ int fhx_host_write_contacts(const char* path, const char* const* chr_names, int3
     if (!path || !chr_names || n_names <= 0 || n_rows < 0) return FHX_ERR_ARG;
     if (n_rows > 0 && (!chr1 || !mid1 || !chr2 || !mid2 || !count)) return FHX_ERR_ARG;
     if (gzip_level < 0 || gzip_level > 9) gzip_level = 6;
-    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (n_threads <= 0) n_threads = fhx::usable_cpus();
     std::vector<size_t> name_len(n_names);
     for (int i = 0; i < n_names; ++i) {
         name_len[i] = std::strlen(chr_names[i]);
@@ -778,7 +796,7 @@ int fhx_table_copy(const fhx_table* t, int32_t column, void* dst) {
             }
         }
     };
-    const int nt = (int)std::max<size_t>(1, std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), t->chunks.size()));
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)fhx::usable_cpus(), t->chunks.size()));
     std::vector<std::thread> pool;
     for (int k = 1; k < nt; ++k) pool.emplace_back(work);
     work();

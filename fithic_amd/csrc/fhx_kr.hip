@@ -9,13 +9,14 @@
 //   bias       HiCKRy.py:103-115  (1/x) / mean(1/x), -1 at the removed rows
 //
 // HBM layout: CSR with int64 indptr, int32 column, double value (12 B per stored cell); all vectors double.
-// The dominant kernel is kr_spmv: one wave64 per row, lanes stride the row (coalesced 512 B value + 256 B column
-// reads), the input vector is gathered (it is n*8 bytes, L2/MALL resident), partial sums meet in a shuffle tree.
+// The dominant kernel is kr_spmv: one wave64 per row, four consecutive cells per lane (16-byte column and value loads, a wave
+// reads contiguous KBs), the input vector is gathered (it is n*8 bytes, L2/MALL resident), partial sums meet in a shuffle tree.
 // It is HBM bound: 12 B per stored cell + 8 B per row gathered/written.  blockIdx -> row mapping gives every XCD one
 // contiguous band of rows so that the gathers of neighbouring rows hit the same L2.
 //
 // Summation orders are fixed (and restated in oracle/kr_oracle.c, which the tests compare bit for bit):
-//   row sum      lane l adds cells l, l+64, ... in order; then v[l] += v[l+s] for s = 32..1
+//   row sum      chunks of 256 cells from the row start; lane l adds cells 4l..4l+3 of every chunk in cell order, chunks in
+//                order; then v[l] += v[l+s] for s = 32..1
 //   dot / sum    tiles of 1024 elements: thread t adds elements t, t+256, t+512, t+768; wave tree; the four waves and
 //                then the tiles are added left to right
 // The reference's own last bits depend on its BLAS (ddot) build, so this is the parity that can be stated: equal to
@@ -25,6 +26,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -104,7 +106,70 @@ __global__ __launch_bounds__(THREADS) void kr_finish(const double* partials, int
 // ---------------------------------------------------------------------------------------------------------------
 // SpMV: one wave per row.  MODE 0: out0 = A in;  1: out0 = a0*(A in), out1 = 1 - out0  (v, rk; HiCKRy.py:153-154,222-223)
 //                          2: out0 = a0*(A in) + a1*a2                                   (w; HiCKRy.py:192)
+// A row is cut into chunks of 256 cells; lane l owns cells 4l..4l+3 of every chunk and adds them in cell order, chunks in
+// order: one 16-byte column load and one 16-byte (binary32) / two 16-byte (double) value loads per lane and chunk instead
+// of four 4-byte ones (a row of ~500 cells = two chunks: four loads in flight, then eight gathers).  The loads are only dword aligned (rows start anywhere); a wave's 64 loads still cover one contiguous KB.
+// The last chunk reads past the row (the head of the next row - the next wave's data, so not wasted; the arrays carry 256
+// cells of padding behind the last row) and predicates the adds.
 // ---------------------------------------------------------------------------------------------------------------
+typedef int kr_i4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef float kr_f4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef double kr_d2 __attribute__((ext_vector_type(2), aligned(8)));
+constexpr int KR_CHUNK = 256;       // cells per wave step
+constexpr int KR_PAD = 256;         // cells allocated behind the last row of col / val
+
+template <typename VT>
+struct KrCells;
+template <>
+struct KrCells<float> {             // 8 VGPRs per chunk: the values stay binary32 until they are used
+    kr_i4 c;
+    kr_f4 f;
+    __device__ __forceinline__ double v(int i) const { return (double)(i == 0 ? f.x : (i == 1 ? f.y : (i == 2 ? f.z : f.w))); }
+};
+template <>
+struct KrCells<double> {
+    kr_i4 c;
+    kr_d2 a, b;
+    __device__ __forceinline__ double v(int i) const { return i == 0 ? a.x : (i == 1 ? a.y : (i == 2 ? b.x : b.y)); }
+};
+__device__ __forceinline__ KrCells<float> kr_load_cells(const int32_t* __restrict__ col, const float* __restrict__ val, int64_t j) {
+    KrCells<float> k;
+    k.c = *reinterpret_cast<const kr_i4*>(col + j);
+    k.f = *reinterpret_cast<const kr_f4*>(val + j);
+    return k;
+}
+__device__ __forceinline__ KrCells<double> kr_load_cells(const int32_t* __restrict__ col, const double* __restrict__ val, int64_t j) {
+    KrCells<double> k;
+    k.c = *reinterpret_cast<const kr_i4*>(col + j);
+    k.a = *reinterpret_cast<const kr_d2*>(val + j);
+    k.b = *reinterpret_cast<const kr_d2*>(val + j + 2);
+    return k;
+}
+
+// one chunk into the row's partial: cells past the row end gather x[0] (the four gathers go out together, no branch) and
+// skip the add
+template <typename VT>
+__device__ __forceinline__ void kr_gather(const KrCells<VT>& k, int64_t j, int64_t e, const double* __restrict__ in, double (&x)[4]) {
+    x[0] = in[j < e ? k.c.x : 0];
+    x[1] = in[j + 1 < e ? k.c.y : 0];
+    x[2] = in[j + 2 < e ? k.c.z : 0];
+    x[3] = in[j + 3 < e ? k.c.w : 0];
+}
+template <typename VT>
+__device__ __forceinline__ double kr_fold(double acc, const KrCells<VT>& k, const double (&x)[4], int64_t j, int64_t e) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double s = acc + k.v(i) * x[i];
+        acc = j + i < e ? s : acc;
+    }
+    return acc;
+}
+
+// Measured on the C3 matrix (2.96e8 cells, 547 332 rows; profiles/r02_n_kr_variants.txt, r02_o_kr_variants.txt): this form
+// 0.44-0.47 ms = 4.8-5.1 TB/s (the streaming read ceiling seen on this part; K1 reaches 5.2); 4-byte loads with lane-strided
+// cells 0.50; a wave walking 4 / 8 / 16 rows as a software pipeline (next row's cells and the bounds of the row after it
+// requested before the current row is reduced) 0.56-0.58 - the kernel is not latency bound; cells transposed through LDS so that
+// each gather instruction covers 64 consecutive cells 0.47 - nor bound by the number of lines a gather touches.
 template <int MODE, typename VT>
 __global__ __launch_bounds__(THREADS) void kr_spmv(int64_t n, const int64_t* __restrict__ indptr, const int32_t* __restrict__ col,
                                                    const VT* __restrict__ val, const double* __restrict__ in,
@@ -120,25 +185,18 @@ __global__ __launch_bounds__(THREADS) void kr_spmv(int64_t n, const int64_t* __r
     if (row >= n) return;
     const int64_t b = indptr[row], e = indptr[row + 1];
     double acc = 0.0;
-    int64_t j = b + lane;
-    // measured on the C3 matrix: nontemporal loads of col/val -1.6 %; 8-cell unroll -10 %; predicated chunks no gain;
-    // 2 / 4 / 8 / 16 consecutive rows per wave -5 / -10 / -15 / -20 % (fewer waves in flight); binary32 values interleaved
-    // with their columns as 8-byte cells (one load instead of two) -7 %
-#define LD_COL(k) col[k]
-#define LD_VAL(k) ((double)val[k])
-    for (; j + 192 < e; j += 256) {          // four independent loads in flight, adds stay in cell order
-        const double p0 = LD_VAL(j) * in[LD_COL(j)];
-        const double p1 = LD_VAL(j + 64) * in[LD_COL(j + 64)];
-        const double p2 = LD_VAL(j + 128) * in[LD_COL(j + 128)];
-        const double p3 = LD_VAL(j + 192) * in[LD_COL(j + 192)];
-        acc = acc + p0;
-        acc = acc + p1;
-        acc = acc + p2;
-        acc = acc + p3;
+    for (int64_t base = b; base < e; base += 2 * KR_CHUNK) {           // two chunks per step: all four loads go out first
+        const int64_t j0 = base + 4 * lane, j1 = j0 + KR_CHUNK;
+        const bool second = base + KR_CHUNK < e;                        // wave-uniform
+        const KrCells<VT> k0 = kr_load_cells(col, val, j0);
+        KrCells<VT> k1 = k0;
+        if (second) k1 = kr_load_cells(col, val, j1);
+        double x0[4], x1[4];
+        kr_gather(k0, j0, e, in, x0);
+        if (second) kr_gather(k1, j1, e, in, x1);
+        acc = kr_fold(acc, k0, x0, j0, e);
+        if (second) acc = kr_fold(acc, k1, x1, j1, e);
     }
-    for (; j < e; j += 64) acc = acc + LD_VAL(j) * in[LD_COL(j)];
-#undef LD_COL
-#undef LD_VAL
     const double t = wave_tree_sum(acc);
     if (lane == 0) {
         if (MODE == 0) {
@@ -601,8 +659,8 @@ int fhx_kr_load_pairs(fhx_kr* kr, const int32_t* chr1, const int32_t* mid1, cons
     KR_HIP(hipMalloc(&kr->d_indptr, (size_t)(n + 1) * sizeof(int64_t)));
     if (m == 0) {
         KR_HIP(hipMemsetAsync(kr->d_indptr, 0, (size_t)(n + 1) * sizeof(int64_t), kr->stream));
-        KR_HIP(hipMalloc(&kr->d_col, sizeof(int32_t)));
-        KR_HIP(hipMalloc(&kr->d_val, sizeof(double)));
+        KR_HIP(hipMalloc(&kr->d_col, (size_t)(1 + krd::KR_PAD) * sizeof(int32_t)));
+        KR_HIP(hipMalloc(&kr->d_val, (size_t)(1 + krd::KR_PAD) * sizeof(double)));
         KR_HIP(hipStreamSynchronize(kr->stream));
         kr->n = n;
         return FHX_OK;
@@ -677,8 +735,8 @@ int fhx_kr_load_pairs(fhx_kr* kr, const int32_t* chr1, const int32_t* mid1, cons
     KR_TRY(hipMemcpyAsync(&nnz, kr->d_counter + 1, 8, hipMemcpyDeviceToHost, kr->stream));
     KR_TRY(hipStreamSynchronize(kr->stream));
     KR_TRY(hipMalloc(&cell_key, (size_t)nnz * 8));
-    KR_TRY(hipMalloc(&kr->d_col, (size_t)nnz * 4));
-    KR_TRY(hipMalloc(&kr->d_val, (size_t)nnz * 8));
+    KR_TRY(hipMalloc(&kr->d_col, (size_t)(nnz + krd::KR_PAD) * 4));
+    KR_TRY(hipMalloc(&kr->d_val, (size_t)(nnz + krd::KR_PAD) * 8));
     hipLaunchKernelGGL(krd::kr_emit_cells, dim3((unsigned)tiles), dim3(krd::THREADS), 0, kr->stream, skeys, perm, z, m, N, n, tile_off,
                        cell_key, kr->d_col, kr->d_val);
     hipLaunchKernelGGL(krd::kr_indptr, dim3((unsigned)std::min<int64_t>((n + 256) / 256, 4096)), dim3(256), 0, kr->stream, cell_key,
@@ -830,8 +888,8 @@ int fhx_kr_remove_sparse(fhx_kr* kr, double perc, int64_t* n_removed, double* va
     for (int64_t i = 0; i < n2; ++i) rptr[(size_t)i + 1] += rptr[(size_t)i];
     const int64_t nnz2 = rptr[(size_t)n2];
     KR_HIP(hipMalloc(&kr->d_rptr, (size_t)(n2 + 1) * 8));
-    KR_HIP(hipMalloc(&kr->d_rcol, (size_t)std::max<int64_t>(nnz2, 1) * 4));
-    KR_HIP(hipMalloc(&kr->d_rval, (size_t)std::max<int64_t>(nnz2, 1) * 8));
+    KR_HIP(hipMalloc(&kr->d_rcol, (size_t)(std::max<int64_t>(nnz2, 1) + krd::KR_PAD) * 4));
+    KR_HIP(hipMalloc(&kr->d_rval, (size_t)(std::max<int64_t>(nnz2, 1) + krd::KR_PAD) * 8));
     KR_HIP(hipMemcpyAsync(kr->d_rptr, rptr.data(), (size_t)(n2 + 1) * 8, hipMemcpyHostToDevice, kr->stream));
     hipLaunchKernelGGL(krd::kr_compact, dim3(rows_grid), dim3(krd::THREADS), 0, kr->stream, n, kr->d_indptr, kr->d_col, kr->d_val, d_new,
                        kr->d_rptr, kr->d_rcol, kr->d_rval);
@@ -872,7 +930,7 @@ int fhx_kr_balance(fhx_kr* kr, double tol, fhx_kr_info* out) {
     // binary32 copy of the values when that is exact (integer contact counts): 8 B per cell instead of 12
     if (kr->nnz > 0 && (!kr->d_val32 || kr->val32_reduced != kr->reduced)) {
         kfree(kr->d_val32);
-        KR_HIP(hipMalloc(&kr->d_val32, (size_t)kr->nnz * sizeof(float)));
+        KR_HIP(hipMalloc(&kr->d_val32, (size_t)(kr->nnz + krd::KR_PAD) * sizeof(float)));
         if (!kr->d_counter) KR_HIP(hipMalloc(&kr->d_counter, 4 * sizeof(unsigned long long)));
         unsigned int* flag = reinterpret_cast<unsigned int*>(kr->d_counter + 3);
         KR_HIP(hipMemsetAsync(flag, 0, 4, kr->stream));

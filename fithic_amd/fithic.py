@@ -352,7 +352,7 @@ def fit_Spline(mainDic, x, y, yerr, infilename, outfilename, biasDic, outliersli
     on_device = hasattr(eng.ctx, "write_significances_device") and not os.environ.get("FHX_HOST_WRITER")
     if on_device:
         try:
-            eng.ctx.write_significances_device(name, S.chroms.names, con.chr1, con.mid1, con.chr2, con.mid2, con.count)
+            eng.ctx.write_significances_device(name, S.chroms.names)      # identity columns: the rows resident since ingest
             S.values = True
         except _capi.FhxError as e:
             if e.code != _capi.FHX_ERR_UNSUPPORTED:

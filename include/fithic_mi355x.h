@@ -320,7 +320,8 @@ int fhx_host_write_significances(const char* path, const char* const* chr_names,
  * kernel (exact integer arithmetic: the characters C's printf gives), ExpCC and the biases recomputed there, and deflated in
  * kernels (tokens against the previous row + per-member dynamic Huffman codes built by the host from device histograms);
  * the host receives finished gzip members (same container as above) and only writes them.  The five identity columns are
- * the rows given to fhx_load_pairs (n_rows must equal the loaded row count).  Returns FHX_ERR_UNSUPPORTED - nothing usable
+ * the rows given to fhx_load_pairs (n_rows must equal the loaded row count); pass all five as NULL and they are rebuilt on
+ * the device from the resident rows (slot -> chromosome, midpoint), so that nothing but the file leaves the GPU.  Returns FHX_ERR_UNSUPPORTED - nothing usable
  * written - when a row does not fit the device formatter (a chromosome name longer than 24 bytes, a value of 2^63 or more,
  * a row of 128 bytes or more): the caller then fetches the columns and uses fhx_host_write_significances. */
 int fhx_write_significances_device(fhx_ctx* ctx, const char* path, const char* const* chr_names, int32_t n_names,

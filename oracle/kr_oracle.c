@@ -6,7 +6,8 @@
  * GPU == oracle bit for bit while oracle vs reference is pinned by the golden vectors within a stated tolerance.
  *
  *   fho_kr_segsum : duplicates of one (row, col) key are added one by one in file order   (HiCKRy.py:50-51, coo->csr)
- *   fho_kr_spmv   : row sum = 64 lane-strided sequential partials, then a binary tree over the lanes
+ *   fho_kr_spmv   : row sum = 64 sequential partials (chunks of 256 cells, partial l takes cells 4l..4l+3 of each chunk),
+ *                   then a binary tree over the partials
  *   fho_kr_dot/sum: tiles of 1024; 4 sequential terms per thread, tree over each 64-lane wave, 4 waves left to right,
  *                   tile partials left to right
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call this.                              */
@@ -39,7 +40,8 @@ void fho_kr_spmv(int64_t n, const int64_t* indptr, const int32_t* indices, const
         const int64_t b = indptr[i], e = indptr[i + 1];
         for (int64_t j = b; j < e; ++j) {
             const double p = data[j] * x[indices[j]];
-            lane[(j - b) & 63] = lane[(j - b) & 63] + p;
+            const int l = (int)(((j - b) & 255) >> 2);     /* chunks of 256 cells, lane l owns cells 4l..4l+3 of each */
+            lane[l] = lane[l] + p;
         }
         y[i] = wave_tree(lane);
     }

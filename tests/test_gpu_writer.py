@@ -68,7 +68,7 @@ def _engine_with_case(case):
     return eng, kw, chroms, con
 
 
-@pytest.mark.parametrize("case", ["f1_bias", "f2_all", "f2_intra", "f6_quirk_all", "f11_offgrid_all"])
+@pytest.mark.parametrize("case", ["f1_bias", "f2_all", "f2_intra", "f6_quirk_all", "f11_offgrid_all", "f8_nonfixed_all"])
 def test_device_writer_equals_python_formatting_on_the_golden_inputs(case, tmp_path):
     from fithic_amd import _capi
     eng, kw, chroms, con = _engine_with_case(case)
@@ -83,6 +83,11 @@ def test_device_writer_equals_python_formatting_on_the_golden_inputs(case, tmp_p
         got = f.read()
     assert rows == n_emit
     assert got == want
+    # without the identity columns: rebuilt on the device from the rows ingest stored - the same file, byte for byte
+    rebuilt = str(tmp_path / "rebuilt.gz")
+    assert eng.ctx.write_significances_device(rebuilt, chroms.names) == (rows, nbytes)
+    with open(rebuilt, "rb") as f, open(path, "rb") as g:
+        assert f.read() == g.read()
     host = str(tmp_path / "host.gz")
     from fithic_amd.engine import MODES
     _capi.host_write_significances(host, chroms.names, *cols, v["p"], v["q"], v["b1"], v["b2"], v["expcc"], MODES[kw["mode"]], kw["L"], U)
@@ -111,6 +116,9 @@ def test_many_members_with_skipped_rows_and_both_row_kinds(tmp_path):
     v = eng.fetch(p=True, q=True, expcc=True, bias=True)
     dev, host = str(tmp_path / "dev.gz"), str(tmp_path / "host.gz")
     rows, nbytes = eng.ctx.write_significances_device(dev, genome.names, *cols)
+    assert eng.ctx.write_significances_device(str(tmp_path / "rebuilt.gz"), genome.names) == (rows, nbytes)
+    with open(str(tmp_path / "rebuilt.gz"), "rb") as f, open(dev, "rb") as g:
+        assert f.read() == g.read()
     from fithic_amd.engine import MODES
     n_host = _capi.host_write_significances(host, genome.names, *cols, v["p"], v["q"], v["b1"], v["b2"], v["expcc"], MODES["All"], L, U)
     d = np.abs(cols[1].astype(np.int64) - cols[3].astype(np.int64))

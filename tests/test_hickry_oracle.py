@@ -33,7 +33,8 @@ def test_oracle_reproduces_the_reference(name):
 
 
 def test_oracle_summation_orders():
-    """The fixed orders the kernels use: lane-strided partials + tree per row; 1024-element tiles for dot products."""
+    """The fixed orders the kernels use: per row 64 partials (chunks of 256 cells, partial l = cells 4l..4l+3 of each chunk)
+    + tree; 1024-element tiles for dot products."""
     from oracle import hickry_oracle as ho
     rng = np.random.default_rng(3)
     n = 3000
@@ -59,12 +60,12 @@ def test_oracle_summation_orders():
             tile = v[0] if tile is None else tile + v[0]
         total = tile if total is None else total + tile
     assert ho.dot(a, b) == total
-    # a row of 150 cells
-    A = ho.Csr(1, np.array([0, 150], np.int64), np.arange(150, dtype=np.int32), rng.normal(size=150))
-    x = rng.normal(size=150)
+    # a row of 700 cells (two full chunks and a partial one)
+    A = ho.Csr(1, np.array([0, 700], np.int64), np.arange(700, dtype=np.int32), rng.normal(size=700))
+    x = rng.normal(size=700)
     lane = np.zeros(64)
-    for j in range(150):
-        lane[j % 64] = lane[j % 64] + A.data[j] * x[j]
+    for j in range(700):
+        lane[(j % 256) // 4] = lane[(j % 256) // 4] + A.data[j] * x[j]
     s = 32
     while s >= 1:
         lane[:s] = lane[:s] + lane[s:2 * s]
