@@ -40,6 +40,9 @@ CONFIGS = {
                mode="intraOnly", trans_per_locus=0.0),
     "C3": dict(res=5000, lengths=None, L=20000, U=2000000, lo=4, hi=400, amp_lo=4, keep=0.66, passes=1, mode="intraOnly",
                trans_per_locus=0.0),
+    # SURVEY 8(d)'s second C3 variant: no -U, 49 849 distance values (8x the LDS window of K1), ~1.0e9 rows - histogram + sort stress
+    "C3w": dict(res=5000, lengths=None, L=20000, U=float("inf"), lo=4, hi=None, amp_lo=4, keep=0.05, passes=1, mode="intraOnly",
+                trans_per_locus=0.0),
     "C5": dict(res=1000, lengths=None, L=2000, U=2000000, lo=2, hi=2000, amp_lo=2, keep=0.33, passes=1, mode="All",
                trans_per_locus=1.0e8 / 2881044),
 }
@@ -63,7 +66,9 @@ def build_rows(synth, torch, cfg, genome, mine, rank, world, device, overdispers
     est = 0
     for c in mine:
         h = min(hi if hi is not None else genome.n_loci[c] - 1, genome.n_loci[c] - 1)
-        est += int(genome.n_loci[c] * max(h - cfg["lo"] + 1, 0) * min(1.0, cfg["keep"] * 1.08)) + 1024
+        width = max(h - cfg["lo"] + 1, 0)
+        cand = genome.n_loci[c] * width - (width * (width + 1)) // 2 if hi is None else genome.n_loci[c] * width   # window cut by the end
+        est += int(max(cand, 0) * min(1.0, cfg["keep"] * 1.08)) + 1024
     est += t1 - t0
     cols = [torch.empty(est, dtype=torch.int32, device=device) for _ in range(5)]
     n = 0
@@ -317,6 +322,7 @@ def main():
         fp64_instr = hv_rows * 300.0 * HEAVY_FP64_INSTR_PER_ITER
         fp64_issue_peak = 256 * 4 * 16 * 2.4e9          # CUs x SIMDs x fp64 lanes/clk x Hz  (= 78.6 TFLOP/s / 2)
         n_chr = len(base_lengths)
+        genome_loci = [-(-int(v) // res) for v in base_lengths]
         desc = {"C2": "C2-synth: one %d bp chromosome @%d bp, no distance bounds, %d cis pairs, bias, -b 100, 2 passes, intraOnly",
                 "C3": "C3-synth: %d x hg19 %d autosomes @%d bp, -L %d -U %d, %d cis pairs, ICE-like bias, -b 100, 1 pass, intraOnly",
                 "C5": "C5-synth: %d x hg19 %d autosomes @%d bp, -L %d -U %d, %d cis + %d trans pairs, ICE-like bias, -b 100, 1 pass, -x All"}
@@ -324,6 +330,9 @@ def main():
             workload = desc["C2"] % (base_lengths[0], res, n_total)
         elif args.config == "C3":
             workload = desc["C3"] % (replicas, n_chr, res, L, U, n_total)
+        elif args.config == "C3w":
+            workload = ("C3w-synth: %d x hg19 %d autosomes @%d bp, -L %d and no -U (%d distance values), %d cis pairs, ICE-like bias, "
+                        "-b 100, 1 pass, intraOnly" % (replicas, n_chr, res, L, max(genome_loci) - 1 - L // res + 1, n_total))
         else:
             workload = desc["C5"] % (replicas, n_chr, res, L, U, n_total - M["n_trans"], M["n_trans"])
         result = {

@@ -121,6 +121,7 @@ SYMBOLS = {
     "fhx_table_name": (ctypes.c_char_p, [_P, ctypes.c_int32]),
     "fhx_table_error": (ctypes.c_char_p, [_P]),
     "fhx_table_copy": (ctypes.c_int, [_P, ctypes.c_int32, _P]),
+    "fhx_table_map_names": (ctypes.c_int, [_P, _I32P, ctypes.c_int32]),
     "fhx_table_free": (None, [_P]),
     "fhx_host_write_contacts": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int32, _I32P, _I32P, _I32P, _I32P,
                                                _I32P, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]),
@@ -555,8 +556,10 @@ class Context:
 
 
 # ---- native text I/O (no context needed) ---------------------------------------------------------------
-def host_read_table(path, kind, threads=0):
-    """-> (names, int32 columns dict, float64 column or None).  kind: 0 contacts, 1 fragments, 2 bias."""
+def host_read_table(path, kind, threads=0, name_ids=None, want_float=True):
+    """-> (names, int32 columns dict, float64 column or None).  kind: 0 contacts, 1 fragments, 2 bias.
+    name_ids(names) -> the caller's ids of the file's names: the chromosome columns then come out in that id space (mapped inside
+    the parallel copy, not per row in numpy).  want_float=False skips the 8 B/row float column of a contacts file."""
     L = lib()
     h = _P()
     rc = L.fhx_host_read_table(os.fsencode(path), int(kind), int(threads), ctypes.byref(h))
@@ -565,6 +568,11 @@ def host_read_table(path, kind, threads=0):
             raise FhxError(rc, (L.fhx_table_error(h) or b"").decode() if h else "fhx_host_read_table")
         n = L.fhx_table_rows(h)
         names = [L.fhx_table_name(h, i).decode() for i in range(L.fhx_table_n_names(h))]
+        if name_ids is not None and names:
+            ids = np.ascontiguousarray(name_ids(names), np.int32)
+            rc = L.fhx_table_map_names(h, _ptr(ids, ctypes.c_int32), len(ids))
+            if rc != FHX_OK:
+                raise FhxError(rc, "fhx_table_map_names")
         cols = {}
         want = {0: (0, 1, 2, 3, 4), 1: (0, 1, 4), 2: (0, 1)}[kind]
         for c in want:
@@ -572,7 +580,7 @@ def host_read_table(path, kind, threads=0):
             L.fhx_table_copy(h, c, a.ctypes.data_as(_P))
             cols[c] = a
         dv = None
-        if kind in (0, 2):
+        if kind == 2 or (kind == 0 and want_float):
             dv = np.empty(n, np.float64)
             L.fhx_table_copy(h, 5, dv.ctypes.data_as(_P))
         return names, cols, dv

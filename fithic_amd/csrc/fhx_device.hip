@@ -118,18 +118,35 @@ struct K1Sums {           // device accumulator block (int64 each)
     int max_count, pad;
 };
 
-__global__ __launch_bounds__(K1_THREADS) void k1_classify_hist(
+// WIDE = false: the window holds 6144 bins as (u64 sum, u32 rows): every Hi-C run with a distance cap (C3: 397 bins).
+// WIDE = true (more distance values than that, e.g. no -U: 49 847 at 5 kb): one 1024-thread workgroup per CU owns 144 KB =
+// 24 576 bins as (u32 sum, 15-bit row count + guard bit); a sum that wraps adds 2^32 to the bin in HBM (exactly one thread
+// sees the wrap), a row count that reaches 2^15 sets the guard bit, which cannot carry into the neighbouring half-word, and
+// the thread that set it moves 2^15 to HBM and clears it.  With 12 B/bin only a quarter of the bins of that run were in LDS
+// and the rest took two device-scope atomics per row: K1 24.8 ms per 1.06e9 rows (profiles/r02_p_c3w_bench.json).
+constexpr int K1_WIDE_BINS = 24576;
+constexpr int K1_WIDE_THREADS = 1024;
+
+template <int THREADS, bool WIDE>
+__global__ __launch_bounds__(THREADS) void k1_classify_hist(
     const int32_t* __restrict__ loc1, const int32_t* __restrict__ loc2, const int32_t* __restrict__ count,
     const uint8_t* __restrict__ skip, int64_t skip_limit, const long long* __restrict__ grow, int64_t n, int lo_idx,
     int hi_idx,
     unsigned long long* __restrict__ hist_sumcc, unsigned long long* __restrict__ hist_npairs,
     K1Sums* __restrict__ sums) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BINS = WIDE ? K1_WIDE_BINS : K1_LDS_BINS;
     unsigned long long* lds_cc = reinterpret_cast<unsigned long long*>(smem);
     unsigned int* lds_np = reinterpret_cast<unsigned int*>(smem + sizeof(unsigned long long) * K1_LDS_BINS);
-    for (int i = threadIdx.x; i < K1_LDS_BINS; i += K1_THREADS) {
-        lds_cc[i] = 0ull;
-        lds_np[i] = 0u;
+    unsigned int* wide_sum = reinterpret_cast<unsigned int*>(smem);                          // WIDE: BINS x u32
+    unsigned int* wide_cnt = reinterpret_cast<unsigned int*>(smem) + K1_WIDE_BINS;           // WIDE: BINS / 2 x (2 x 16 bit)
+    if (WIDE) {
+        for (int i = threadIdx.x; i < BINS + BINS / 2; i += THREADS) wide_sum[i] = 0u;
+    } else {
+        for (int i = threadIdx.x; i < BINS; i += THREADS) {
+            lds_cc[i] = 0ull;
+            lds_np[i] = 0u;
+        }
     }
     __syncthreads();
 
@@ -154,7 +171,16 @@ __global__ __launch_bounds__(K1_THREADS) void k1_classify_hist(
             ++rng_cnt;
             rng_sum += c;
             const int b = d - lo_idx;
-            if (b < K1_LDS_BINS) {
+            if (WIDE && b < BINS && c >= 0) {
+                const unsigned int old = atomicAdd(&wide_sum[b], (unsigned int)c);
+                if (old + (unsigned int)c < old) atomicAdd(&hist_sumcc[d], 1ull << 32);
+                const int sh = (b & 1) * 16;
+                const unsigned int was = (atomicAdd(&wide_cnt[b >> 1], 1u << sh) >> sh) & 0xFFFFu;
+                if (was == 0x7FFFu) {                       // this add set the guard bit: move 2^15 rows to HBM
+                    atomicSub(&wide_cnt[b >> 1], 0x8000u << sh);
+                    atomicAdd(&hist_npairs[d], 32768ull);
+                }
+            } else if (!WIDE && b < BINS) {
                 atomicAdd(&lds_cc[b], (unsigned long long)(long long)c);
                 atomicAdd(&lds_np[b], 1u);
             } else {
@@ -202,14 +228,20 @@ __global__ __launch_bounds__(K1_THREADS) void k1_classify_hist(
     __syncthreads();
     // flush the LDS window; every workgroup starts at a different bin so that the 512 workgroups, which finish together,
     // do not queue up on the same L2 atomic address (same-address atomics retire at ~88 M/s, MI355X_MICROARCH.md)
-    const int rot = (int)((blockIdx.x * 389u) % (unsigned)K1_LDS_BINS);
-    for (int k = threadIdx.x; k < K1_LDS_BINS; k += K1_THREADS) {
+    const int rot = (int)((blockIdx.x * 389u) % (unsigned)BINS);
+    for (int k = threadIdx.x; k < BINS; k += THREADS) {
         int i = k + rot;
-        if (i >= K1_LDS_BINS) i -= K1_LDS_BINS;
-        const unsigned int np = lds_np[i];
-        if (np) {
-            atomicAdd(&hist_sumcc[lo_idx + i], lds_cc[i]);
-            atomicAdd(&hist_npairs[lo_idx + i], (unsigned long long)np);
+        if (i >= BINS) i -= BINS;
+        if (WIDE) {
+            const unsigned int sum = wide_sum[i], np = (wide_cnt[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu;
+            if (sum) atomicAdd(&hist_sumcc[lo_idx + i], (unsigned long long)sum);
+            if (np) atomicAdd(&hist_npairs[lo_idx + i], (unsigned long long)np);
+        } else {
+            const unsigned int np = lds_np[i];
+            if (np) {
+                atomicAdd(&hist_sumcc[lo_idx + i], lds_cc[i]);
+                atomicAdd(&hist_npairs[lo_idx + i], (unsigned long long)np);
+            }
         }
     }
     // sums: wave reduce, combine the waves in LDS, then ONE atomic per field per workgroup (one per wave was 32 768
@@ -224,7 +256,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_classify_hist(
     max_count = wave_max_i32(max_count);
     __syncthreads();                                   // the histogram window is free now: reuse its first bytes
     long long* part = reinterpret_cast<long long*>(smem);
-    constexpr int WAVES = K1_THREADS / 64;
+    constexpr int WAVES = THREADS / 64;
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
         part[w * 8 + 0] = inter_count;
@@ -2466,12 +2498,29 @@ static int launch_k1(fhx_ctx* ctx) {
     FHX_HIP(hipMemsetAsync(ctx->d_hist_np, 0, ctx->n_dist * sizeof(unsigned long long), ctx->stream));
     FHX_HIP(hipMemsetAsync(ctx->d_sums, 0, sizeof(K1Sums), ctx->stream));
     FHX_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-    const size_t lds = (size_t)K1_LDS_BINS * (sizeof(unsigned long long) + sizeof(unsigned int));
-    const int blocks = grid_for((ctx->n_rows + 3) / 4, K1_THREADS, 512);
-    hipLaunchKernelGGL(k1_classify_hist, dim3(blocks), dim3(K1_THREADS), lds, ctx->stream, ctx->d_loc1, ctx->d_loc2,
-                       ctx->d_count, ctx->skip_active ? ctx->d_skip : (const uint8_t*)nullptr, ctx->skip_limit,
-                       (ctx->skip_limit != INT64_MAX) ? (const long long*)ctx->d_grow : (const long long*)nullptr, ctx->n_rows,
-                       (int)std::min<int64_t>(lo, INT32_MAX), (int)hi, ctx->d_hist_cc, ctx->d_hist_np, ctx->d_sums);
+    const uint8_t* skip = ctx->skip_active ? ctx->d_skip : (const uint8_t*)nullptr;
+    const long long* grow = (ctx->skip_limit != INT64_MAX) ? (const long long*)ctx->d_grow : (const long long*)nullptr;
+    const int lo_i = (int)std::min<int64_t>(lo, INT32_MAX);
+    static const bool force_narrow = std::getenv("FHX_K1_NARROW") != nullptr;      // measurements only
+    if (hi - lo + 1 > K1_LDS_BINS && !force_narrow) {                                // more distance values than the 12-B window holds
+        const size_t lds = (size_t)K1_WIDE_BINS * 6;
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_classify_hist<K1_WIDE_THREADS, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done = true;
+        }
+        const int blocks = grid_for((ctx->n_rows + 3) / 4, K1_WIDE_THREADS, 256);
+        hipLaunchKernelGGL((k1_classify_hist<K1_WIDE_THREADS, true>), dim3(blocks), dim3(K1_WIDE_THREADS), lds, ctx->stream, ctx->d_loc1,
+                           ctx->d_loc2, ctx->d_count, skip, ctx->skip_limit, grow, ctx->n_rows, lo_i, (int)hi, ctx->d_hist_cc,
+                           ctx->d_hist_np, ctx->d_sums);
+    } else {
+        const size_t lds = (size_t)K1_LDS_BINS * (sizeof(unsigned long long) + sizeof(unsigned int));
+        const int blocks = grid_for((ctx->n_rows + 3) / 4, K1_THREADS, 512);
+        hipLaunchKernelGGL((k1_classify_hist<K1_THREADS, false>), dim3(blocks), dim3(K1_THREADS), lds, ctx->stream, ctx->d_loc1,
+                           ctx->d_loc2, ctx->d_count, skip, ctx->skip_limit, grow, ctx->n_rows, lo_i, (int)hi, ctx->d_hist_cc,
+                           ctx->d_hist_np, ctx->d_sums);
+    }
     FHX_HIP(hipGetLastError());
     FHX_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     ctx->ev_valid[0] = true;

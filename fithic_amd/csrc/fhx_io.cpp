@@ -767,6 +767,15 @@ const char* fhx_table_name(const fhx_table* t, int32_t i) {
 }
 const char* fhx_table_error(const fhx_table* t) { return t ? t->error.c_str() : "null table"; }
 
+// ids[i] = the caller's id of name i: columns 0 and 2 of fhx_table_copy then come out in the caller's id space (the
+// file-local order of first appearance is composed away here, once per chunk, instead of per row by the caller)
+int fhx_table_map_names(fhx_table* t, const int32_t* ids, int32_t n_ids) {
+    if (!t || !ids || n_ids != (int32_t)t->names.size()) return FHX_ERR_ARG;
+    for (auto& m : t->remap)
+        for (auto& v : m) v = ids[v];
+    return FHX_OK;
+}
+
 // columns: 0 chr1, 1 mid1, 2 chr2, 3 mid2, 4 count / hits (int32); 5 raw count / bias (double)
 int fhx_table_copy(const fhx_table* t, int32_t column, void* dst) {
     if (!t || !dst || column < 0 || column > 5) return FHX_ERR_ARG;

@@ -77,10 +77,13 @@ class _Session:
                 self.engine = Engine(device)
         return self.engine
 
-    def configure(self):
+    def check_resolution(self):
         if resolution is None or resolution < 0:
             raise RuntimeError("fithic_amd.fithic.resolution must be set before read_Interactions (the -r value; 0 = "
                                "non-fixed-size data): the engine builds its locus grid when the contacts go to the GPU")
+
+    def configure(self):
+        self.check_resolution()
         self.ensure_engine().configure(resolution, distLowThres, distUpThres, self.n_bins, mappThres, self.mode(),
                                        biasLowerBound, biasUpperBound)
 
@@ -125,8 +128,16 @@ def read_Interactions(contactCountsFile, biasFile, outliers=None):
     t0 = time.time()
     S = _S
     if S.contacts is None or S.contacts_path != contactCountsFile:
+        S.check_resolution()
+        # the HIP runtime and the context come up (a few tenths of a second) while the host cores inflate and parse the file
+        import threading
+        starter = threading.Thread(target=S.ensure_engine)
+        starter.start()
+        try:
+            S.contacts = tables.read_contacts(contactCountsFile, S.chroms)
+        finally:
+            starter.join()
         S.configure()
-        S.contacts = tables.read_contacts(contactCountsFile, S.chroms)
         S.contacts_path = contactCountsFile
         c = S.contacts
         if os.environ.get("FHX_TIMING"):

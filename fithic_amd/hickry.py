@@ -77,7 +77,7 @@ def loadfastfithicInteractions(interactionsFile, fragsFile):
         f_chr = np.array([chroms.intern(r[0]) for r in rows], np.int32)
         f_mid = np.array([r[1] for r in rows], np.int64)
     try:
-        con = tables.read_contacts(interactionsFile, chroms)
+        con = tables.read_contacts(interactionsFile, chroms, want_raw=True)
         c1, m1, c2, m2, z = con.chr1, con.mid1, con.chr2, con.mid2, con.raw_count
     except _capi.FhxError:
         rows = _read_python(interactionsFile, [(0, str), (1, int), (2, str), (3, int), (4, float)])

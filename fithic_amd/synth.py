@@ -135,6 +135,7 @@ def cis_contacts(genome, chrom, lo_idx, hi_idx, amplitude, device="cpu", max_win
         gen.manual_seed(SEED * 1000 + chrom)
     b = torch.from_numpy(genome.bias(chrom)).to(device)
     rows = []
+    shift = 13 if hi < (1 << 13) else 17                    # delta field of the counter: 13 bits (synth-v1) unless the window is wider
     # delta bands: the Poisson inversion below runs as many steps as the largest rate of its band needs
     bands, d0 = [], lo
     for edge in (16, 64, hi + 1):
@@ -158,7 +159,7 @@ def cis_contacts(genome, chrom, lo_idx, hi_idx, amplitude, device="cpu", max_win
                 z = torch.randn(lam.shape, device=device, generator=gen, dtype=torch.float32)
                 lam = lam * torch.exp(overdispersion * z - 0.5 * overdispersion * overdispersion).to(lam.dtype)
             # counter-based uniforms: splitmix64(seed ^ index), index unique per (chromosome, i, delta, stream)
-            index = ((chrom * (1 << 22) + i[:, None]) * (1 << 13) + dd[None, :]) * 2
+            index = ((chrom * (1 << 22) + i[:, None]) * (1 << shift) + dd[None, :]) * 2
             cnt = _poisson_inverse(torch, lam, _uniform(torch, index))
             boost = _uniform(torch, index + 1) < 0.001
             cnt = torch.where(boost, cnt * 4, cnt)

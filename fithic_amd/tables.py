@@ -46,44 +46,46 @@ class Contacts:
         return len(self.mid1)
 
     def take(self, sel):
-        return Contacts(self.chr1[sel], self.mid1[sel], self.chr2[sel], self.mid2[sel], self.count[sel], self.raw_count[sel])
+        return Contacts(self.chr1[sel], self.mid1[sel], self.chr2[sel], self.mid2[sel], self.count[sel],
+                        None if self.raw_count is None else self.raw_count[sel])
 
 
-def _intern_native(names, ids, chroms):
-    """file-local chromosome ids (order of first appearance in the file) -> the run's shared id space"""
-    remap = np.empty(max(len(names), 1), np.int32)
-    for k, name in enumerate(names):
-        j = chroms._ids.get(name)
-        if j is None:
-            j = chroms._ids[name] = len(chroms.names)
-            chroms.names.append(name)
-        remap[k] = j
-    return remap[ids] if len(ids) else ids.astype(np.int32)
+def _interner(chroms):
+    """names of a file (order of first appearance) -> ids in the run's shared id space, new names appended in that order"""
+    def ids_of(names):
+        out = np.empty(len(names), np.int32)
+        for k, name in enumerate(names):
+            j = chroms._ids.get(name)
+            if j is None:
+                j = chroms._ids[name] = len(chroms.names)
+                chroms.names.append(name)
+            out[k] = j
+        return out
+    return ids_of
 
 
-def read_contacts(path, chroms, threads=0):
+def read_contacts(path, chroms, threads=0, want_raw=False):
     """Native multi-threaded parser (libfithic_mi355x.so: fhx_host_read_table).  Same semantics as the reference's loop:
-    whitespace split, exactly five fields, int(mid), count = int(float(text)); a malformed line raises like the reference."""
+    whitespace split, exactly five fields, int(mid), count = int(float(text)); a malformed line raises like the reference.
+    Both loci share the file's name table (interned in the reference's order of appearance: row by row, chr1 then chr2).
+    want_raw: also return the float the count was parsed from (HiCKRy's matrix values); 8 B/row, so only on request."""
     from . import _capi
-    names, cols, raw = _capi.host_read_table(path, 0, threads)
-    # both loci share the file's name table; intern in the reference's order of appearance (row by row, chr1 then chr2)
-    c1 = _intern_native(names, cols[0], chroms)
-    c2 = _intern_native(names, cols[2], chroms)
-    return Contacts(c1, cols[1], c2, cols[3], cols[4], raw)
+    names, cols, raw = _capi.host_read_table(path, 0, threads, name_ids=_interner(chroms), want_float=want_raw)
+    return Contacts(cols[0], cols[1], cols[2], cols[3], cols[4], raw)
 
 
 def read_fragments(path, chroms, threads=0):
     """-> (chr ids, mids, hits) as int32 arrays in file order."""
     from . import _capi
-    names, cols, _ = _capi.host_read_table(path, 1, threads)
-    return _intern_native(names, cols[0], chroms), cols[1], cols[4]
+    names, cols, _ = _capi.host_read_table(path, 1, threads, name_ids=_interner(chroms))
+    return cols[0], cols[1], cols[4]
 
 
 def read_bias(path, chroms, threads=0):
     """-> (chr ids, mids, raw bias values); bounds / NaN / first-occurrence rules are applied by the engine."""
     from . import _capi
-    names, cols, bias = _capi.host_read_table(path, 2, threads)
-    return _intern_native(names, cols[0], chroms), cols[1], bias
+    names, cols, bias = _capi.host_read_table(path, 2, threads, name_ids=_interner(chroms))
+    return cols[0], cols[1], bias
 
 
 def bias_quantiles(bias):

@@ -299,6 +299,8 @@ int32_t fhx_table_n_names(const fhx_table* t);
 const char* fhx_table_name(const fhx_table* t, int32_t i);
 const char* fhx_table_error(const fhx_table* t);
 int fhx_table_copy(const fhx_table* t, int32_t column, void* dst);
+/* ids[i] = the caller's id of fhx_table_name(t, i): columns 0 and 2 of later fhx_table_copy calls are in that id space. */
+int fhx_table_map_names(fhx_table* t, const int32_t* ids, int32_t n_ids);
 void fhx_table_free(fhx_table* t);
 /* The contacts table written as the reference reads it ("%s\t%d\t%s\t%d\t%d\n", fithic/fithic.py:413-417) on all cores;
  * tooling for synthetic workloads.  Like every file this library writes it is a concatenation of gzip members that carry

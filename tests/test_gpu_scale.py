@@ -308,3 +308,41 @@ def test_c3_at_full_size():
     assert chk["rows_q"] == n and chk["rows_p"] > 1_000_000
     assert chk["nan_pattern_equal"] and chk["max_dp"] <= TOL and chk["max_dq"] == 0.0, chk
     eng.close()
+
+
+def test_wide_distance_histogram_counters_overflow_into_hbm():
+    """More distance values than K1's 12-byte LDS window holds (no -U): the wide kernel keeps 24 576 bins as (u32 sum, 15-bit
+    row count) per workgroup and moves overflow to HBM - here one distance takes 1.2e7 rows of count 200 000 (every workgroup's
+    sum wraps 2^32 several times, its row count passes 2^15), others sit beyond the window (global atomics), one row has a
+    negative count: sums and row counts must equal numpy's, exactly."""
+    from fithic_amd import _capi
+    from fithic_amd.engine import Engine
+    res, n_loci = 1000, 30000
+    rng = np.random.default_rng(11)
+    f_chr = np.zeros(n_loci, np.int32)
+    f_mid = (np.arange(n_loci, dtype=np.int32) * res + res // 2).astype(np.int32)
+    f_hits = np.ones(n_loci, np.int32)
+    n_big = 12_000_000
+    i_small = rng.integers(0, n_loci - 1, 3_000_000)
+    j_small = np.minimum(i_small + rng.integers(1, 29000, len(i_small)), n_loci - 1)
+    l1 = np.concatenate([np.full(n_big, 10), i_small, [5]]).astype(np.int64)
+    l2 = np.concatenate([np.full(n_big, 6510), j_small, [4005]]).astype(np.int64)
+    cnt = np.concatenate([np.full(n_big, 200_000), rng.integers(1, 50, len(i_small)), [-3]]).astype(np.int32)
+    perm = rng.permutation(len(l1))
+    l1, l2, cnt = l1[perm], l2[perm], cnt[perm]
+    eng = Engine(0)
+    eng.configure(res, 0, float("inf"), n_bins=100, mapp_thres=1, mode="intraOnly")
+    eng.load_fragments(f_chr, f_mid, f_hits, np.zeros(1, np.int32))
+    z = np.zeros(len(l1), np.int32)
+    eng.load_contacts(z, (l1 * res + res // 2).astype(np.int32), z, (l2 * res + res // 2).astype(np.int32), cnt)
+    st = eng.ctx.pass_stats()
+    got_cc = eng.ctx.get_array(_capi.A_HIST_SUMCC)
+    got_np = eng.ctx.get_array(_capi.A_HIST_NPAIRS)
+    d = np.abs(l1 - l2)
+    want_np = np.bincount(d, minlength=len(got_np))
+    want_cc = np.zeros(len(got_cc), np.int64)
+    np.add.at(want_cc, d, cnt.astype(np.int64))
+    assert len(got_np) > 24576 + 1000                       # bins beyond the wide window exist too
+    assert np.array_equal(got_np, want_np[:len(got_np)]) and np.array_equal(got_cc, want_cc[:len(got_cc)])
+    assert st.in_range_sum == int(cnt.astype(np.int64).sum()) and want_np[6500] >= n_big and want_cc[6500] > (1 << 41)
+    eng.close()
