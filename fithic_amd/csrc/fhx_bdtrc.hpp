@@ -597,6 +597,18 @@ __device__ __forceinline__ double bdtrc_closed_form(double n_total, double p) {
     return 1.0 - pow(1.0 - p, n_total);
 }
 
+// bdtrc_count_trivial for the inputs that are BC_TRIVIAL and NOT bdtrc_is_closed_form: with count == 1 those are NaN, p outside
+// [0, 1], or n <= 0, all of which return above the count == 1 statement - so the statement (and its log1p / expm1 / pow, which
+// would set the caller's register budget) is left out.  Same values as bdtrc_count_trivial on that domain.
+__device__ __forceinline__ double bdtrc_count_trivial_open(int count, const BinomTables& T, double p) {
+    if (isnan(p)) return p;
+    const double fk = (double)count - 1.0;
+    if (p < 0.0 || p > 1.0 || T.n < fk) return __builtin_nan("");
+    if (fk < 0) return 1.0;
+    if (fk == T.n) return 0.0;
+    return p <= 0.0 ? 0.0 : 1.0;
+}
+
 // cheap classification of which loop bdtrc_count(count, T, p) will run (same predicates as incbet, same rounding)
 __device__ __forceinline__ int bdtrc_class(int count, double n_total, double p) {
     if (isnan(p)) return BC_TRIVIAL;

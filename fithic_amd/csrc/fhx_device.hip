@@ -430,47 +430,94 @@ struct QEntry {
     double prior;
 };
 
+// Queues are SHARDED: a tile's slots come from one returning atomic per class, and all workgroups adding to ONE address
+// retire at ~88 M atomics/s (MI355X_MICROARCH.md "dequeue") - 144 500 tiles of C3 on one counter per class were 1.64 ms, the
+// whole of k2_classify (r02_s_classify_variants.txt: 2 / 4 / 8 rows per thread = 289 k / 145 k / 72 k tiles = 3.6 / 1.9 /
+// 1.7 ms whatever the occupancy).  So every class has K2_SHARDS counters and K2_SHARDS sub-buffers; workgroup b uses shard
+// b % 8 (the XCD it runs on, for speed only).  A shard's tiles are known in advance (tile t belongs to workgroup t % grid), so
+// a sub-buffer of ceil(grid / 8) * ceil(tiles / grid) tiles can never overflow.  Consumers see one logical queue: entry j of
+// the concatenation of the shards (qspan_at).
+constexpr int K2_SHARDS = 8;
+constexpr int K2_COUNT_STRIDE = 16;                      // counters 128 B apart: one L2 line each
+
+struct QSpan {
+    QEntry* base;                      // slot 0 of shard 0 (queues that grow downwards: the LAST entry of shard 0's sub-buffer)
+    long long cap_s;                   // entries per shard sub-buffer
+    int dir;                           // +1 / -1: two queues share one buffer, growing towards each other inside every shard
+    const unsigned long long* count;   // K2_SHARDS counters, K2_COUNT_STRIDE apart
+};
+struct QIndex {
+    long long start[K2_SHARDS + 1];    // exclusive prefix of the shard counts; start[K2_SHARDS] = entries in the queue
+};
+__device__ __forceinline__ QIndex qindex_of(const unsigned long long* __restrict__ count) {
+    QIndex ix;
+    long long a = 0;
+#pragma unroll
+    for (int s = 0; s < K2_SHARDS; ++s) {
+        ix.start[s] = a;
+        a += (long long)count[s * K2_COUNT_STRIDE];
+    }
+    ix.start[K2_SHARDS] = a;
+    return ix;
+}
+// offset (in elements, from the queue's base) of logical entry j
+__device__ __forceinline__ long long qslot(const QIndex& ix, long long cap_s, int dir, long long j) {
+    int s = 0;
+    long long st = 0;
+#pragma unroll
+    for (int k = 1; k < K2_SHARDS; ++k)
+        if (j >= ix.start[k]) {
+            s = k;
+            st = ix.start[k];
+        }
+    return (long long)s * cap_s + dir * (j - st);
+}
+
 struct K2Queues {
-    QEntry* base[K2_QUEUES];    // two queues share one buffer of n_rows entries: one grows up from its start,
-    int dir[K2_QUEUES];         // the other grows down from its end (+1 / -1)
-    unsigned long long* count;  // K2_QUEUES counters, K2_COUNT_STRIDE apart
+    QSpan q[K2_QUEUES + 1];            // classes 1..4, then the closed-form class (count == 1)
+    unsigned long long* count;         // (K2_QUEUES + 1) x K2_SHARDS counters: [(class * K2_SHARDS + shard) * K2_COUNT_STRIDE]
 };
 
 constexpr int K2_CL_ITEMS = 4;
 constexpr int K2_CL_TILE = K2_THREADS * K2_CL_ITEMS;     // 1024 rows per workgroup step (8 items/thread costs 189 VGPRs -> 2 waves/SIMD and is slower)
-constexpr int K2_COUNT_STRIDE = 16;                      // queue counters 128 B apart: one L2 line each
 
-constexpr int K2_CLOSED = K2_QUEUES + 1;                 // tile-local class: count == 1 rows, evaluated densely from LDS
+constexpr int K2_CLOSED = K2_QUEUES + 1;                 // count == 1 rows with prior >= 0.01 (Cephes takes pow there): queued, k2_closed
+constexpr int K2_CLOSED_LOCAL = K2_QUEUES + 2;           // count == 1 rows with prior < 0.01: tile-local, evaluated densely from LDS
+constexpr int K2_CLASSES = K2_QUEUES + 2;
 
-template <int NF>
-__global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k2_classify(K2Params P, K2Queues Q) {
+template <int NF, int ITEMS, int WPE>
+__global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k2_classify(K2Params P, K2Queues Q) {
+    constexpr int TILE = K2_THREADS * ITEMS;
     // Per tile: every wave reserves slots per class with ballots + ONE LDS atomic per (wave, class, item), then each
     // class takes ONE global atomic per tile (a same-address global atomic per wave would cap the kernel at ~88 M
     // atomics/s - MI355X_MICROARCH.md "dequeue" - i.e. slower than the arithmetic it feeds), then the lanes write
     // their own 16-byte entries at base + slot (lanes of one class hold consecutive slots).
-    // The closed-form rows (count == 1: a third of a Hi-C run, ~150 fp64 instructions of log1p / expm1 each) are not
-    // evaluated where they are met - with a third of the lanes active that costs every wave the full price four times
-    // per tile - but compacted into LDS and evaluated with all lanes busy at the end of the tile.
-    __shared__ unsigned int cnt[K2_QUEUES + 1];
-    __shared__ unsigned long long gbase[K2_QUEUES];
-    __shared__ double cf_prior[K2_CL_TILE];
-    __shared__ unsigned short cf_idx[K2_CL_TILE];          // tile-local row | 0x8000 for the inter-chromosomal binomial
+    // The closed-form rows (count == 1: a third of a Hi-C run) are not evaluated where they are met - with a third of the lanes
+    // active that costs every wave the full price four times per tile - but compacted into LDS and evaluated with all lanes busy
+    // at the end of the tile: -expm1(n * log1p(-prior)), ~150 fp64 instructions and few registers.  Cephes' other branch
+    // (prior >= 0.01: 1 - pow(1 - prior, n); practically never on Hi-C data) would bring pow's ~90 VGPRs into this kernel, which
+    // needs its 8 waves/SIMD (a tile is a chain of dependent round trips): those rows are queued for k2_closed instead.
+    __shared__ unsigned int cnt[K2_CLASSES];
+    __shared__ unsigned long long gbase[K2_QUEUES + 1];
+    __shared__ double cf_prior[TILE];
+    __shared__ unsigned short cf_idx[TILE];          // tile-local row | 0x8000 for the inter-chromosomal binomial
     __shared__ unsigned int hist_lds[K2_HIST_BINS];
     FusedHist H;
     H.init(hist_lds, P.top_hist);
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
-    const int64_t tiles = (P.n + K2_CL_TILE - 1) / K2_CL_TILE;
+    const int shard = (int)(blockIdx.x % K2_SHARDS);
+    const int64_t tiles = (P.n + TILE - 1) / TILE;
     for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
-        if (threadIdx.x <= K2_QUEUES) cnt[threadIdx.x] = 0;
+        if (threadIdx.x < K2_CLASSES) cnt[threadIdx.x] = 0;
         __syncthreads();
-        int cls_of[K2_CL_ITEMS];
-        unsigned int slot_of[K2_CL_ITEMS];
-        int count_of[K2_CL_ITEMS];
-        double prior_of[K2_CL_ITEMS];
+        int cls_of[ITEMS];
+        unsigned int slot_of[ITEMS];
+        int count_of[ITEMS];
+        double prior_of[ITEMS];
 #pragma unroll
-        for (int r = 0; r < K2_CL_ITEMS; ++r) {
-            const int64_t i = t * K2_CL_TILE + r * K2_THREADS + threadIdx.x;
+        for (int r = 0; r < ITEMS; ++r) {
+            const int64_t i = t * TILE + r * K2_THREADS + threadIdx.x;
             int cls = -1;                                              // -1: no row, 0: done here, 1..4: queued, 5: closed form
             double prior = 1.0;
             int c = 0;
@@ -485,9 +532,9 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                     cls = dev::bdtrc_class(c, T.n, prior);
                     if (cls == dev::BC_TRIVIAL) {
                         if (dev::bdtrc_is_closed_form(c, T.n, prior))
-                            cls = K2_CLOSED;
+                            cls = prior < 0.01 ? K2_CLOSED_LOCAL : K2_CLOSED;
                         else
-                            pv = dev::bdtrc_count_trivial(c, T, prior);  // constants and NaN only on this path
+                            pv = dev::bdtrc_count_trivial_open(c, T, prior);  // constants and NaN only
                     }
                     if (is_inter) c = -c;
                 }
@@ -503,75 +550,96 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         // slot reservation for the whole wave at once: 20 ballots (4 items x 5 classes), then ONE LDS atomic instruction
         // (lane k reserves class k's total) and five broadcasts.  One atomic + shuffle per (item, class) made 16 dependent
         // LDS round trips per wave and tile, which the 3 waves/SIMD of this kernel cannot hide.
-        unsigned int before_cls[K2_CL_ITEMS];          // rank of this lane's item r among the wave's items of its class
-        unsigned int tot[K2_QUEUES + 1] = {0u, 0u, 0u, 0u, 0u};
+        unsigned int before_cls[ITEMS];          // rank of this lane's item r among the wave's items of its class
+        unsigned int tot[K2_CLASSES] = {0u, 0u, 0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int r = 0; r < K2_CL_ITEMS; ++r) {
+        for (int r = 0; r < ITEMS; ++r) {
             before_cls[r] = 0;
 #pragma unroll
-            for (int k = 1; k <= K2_QUEUES + 1; ++k) {
+            for (int k = 1; k <= K2_CLASSES; ++k) {
                 const unsigned long long m = __ballot(cls_of[r] == k);
                 if (cls_of[r] == k) before_cls[r] = tot[k - 1] + (unsigned int)__popcll(m & lane_lt);
                 tot[k - 1] += (unsigned int)__popcll(m);
             }
         }
-        static_assert(K2_QUEUES == 4, "lane k reserves class k");
-        const unsigned int my_tot = lane == 0 ? tot[0] : (lane == 1 ? tot[1] : (lane == 2 ? tot[2] : (lane == 3 ? tot[3] : tot[4])));
+        static_assert(K2_CLASSES == 6, "lane k reserves class k");
+        const unsigned int my_tot =
+            lane == 0 ? tot[0] : (lane == 1 ? tot[1] : (lane == 2 ? tot[2] : (lane == 3 ? tot[3] : (lane == 4 ? tot[4] : tot[5]))));
         unsigned int my_base = 0;
-        if (lane <= K2_QUEUES && my_tot) my_base = atomicAdd(&cnt[lane], my_tot);
-        unsigned int wave_base[K2_QUEUES + 1];
+        if (lane < K2_CLASSES && my_tot) my_base = atomicAdd(&cnt[lane], my_tot);
+        unsigned int wave_base[K2_CLASSES];
 #pragma unroll
-        for (int k = 0; k <= K2_QUEUES; ++k) wave_base[k] = __shfl(my_base, k, 64);
+        for (int k = 0; k < K2_CLASSES; ++k) wave_base[k] = __shfl(my_base, k, 64);
 #pragma unroll
-        for (int r = 0; r < K2_CL_ITEMS; ++r) {
+        for (int r = 0; r < ITEMS; ++r) {
             const int k = cls_of[r] - 1;
-            const unsigned int wb = k == 0 ? wave_base[0] : (k == 1 ? wave_base[1] : (k == 2 ? wave_base[2] : (k == 3 ? wave_base[3] : wave_base[4])));
+            const unsigned int wb =
+                k == 0 ? wave_base[0] : (k == 1 ? wave_base[1] : (k == 2 ? wave_base[2] : (k == 3 ? wave_base[3] : (k == 4 ? wave_base[4] : wave_base[5]))));
             slot_of[r] = k >= 0 ? wb + before_cls[r] : 0u;
-            if (cls_of[r] == K2_CLOSED) {
+            if (cls_of[r] == K2_CLOSED_LOCAL) {
                 cf_prior[slot_of[r]] = prior_of[r];
                 cf_idx[slot_of[r]] = (unsigned short)((r * K2_THREADS + threadIdx.x) | (count_of[r] < 0 ? 0x8000 : 0));
             }
         }
         __syncthreads();
-        if (threadIdx.x < K2_QUEUES)
-            gbase[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&Q.count[threadIdx.x * K2_COUNT_STRIDE], (unsigned long long)cnt[threadIdx.x]) : 0ull;
-        // the closed-form rows of the tile, all lanes busy
-        const unsigned int n_closed = cnt[K2_QUEUES];
-        for (unsigned int j = threadIdx.x; j < n_closed; j += K2_THREADS) {
-            const unsigned int ix = cf_idx[j];
-            const double n_total = (ix & 0x8000u) ? P.inter.n : P.intra.n;
-            const double pv = dev::bdtrc_closed_form(n_total, cf_prior[j]);
-            P.p[t * K2_CL_TILE + (ix & 0x7FFFu)] = pv;
-            H.add(pv);
-        }
+        if (threadIdx.x <= K2_QUEUES)
+            gbase[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&Q.count[(threadIdx.x * K2_SHARDS + shard) * K2_COUNT_STRIDE],
+                                                              (unsigned long long)cnt[threadIdx.x]) : 0ull;
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < K2_CL_ITEMS; ++r) {
+        for (int r = 0; r < ITEMS; ++r) {
             const int k = cls_of[r] - 1;
-            if (k >= 0 && k < K2_QUEUES) {
+            if (k >= 0 && k <= K2_QUEUES) {
                 QEntry e;
-                e.row = (unsigned int)(t * K2_CL_TILE + r * K2_THREADS + threadIdx.x);
+                e.row = (unsigned int)(t * TILE + r * K2_THREADS + threadIdx.x);
                 e.count = count_of[r];
                 e.prior = prior_of[r];
                 const long long pos = (long long)(gbase[k] + slot_of[r]);
-                Q.base[k][Q.dir[k] * pos] = e;
+                Q.q[k].base[shard * Q.q[k].cap_s + Q.q[k].dir * pos] = e;
             }
+        }
+        // the small-prior closed-form rows of the tile, all lanes busy; after the entries, so that the per-row state above is dead
+        // while log1p / expm1 need their registers
+        const unsigned int n_local = cnt[K2_CLASSES - 1];
+        for (unsigned int j = threadIdx.x; j < n_local; j += K2_THREADS) {
+            const unsigned int ix = cf_idx[j];
+            const double n_total = (ix & 0x8000u) ? P.inter.n : P.intra.n;
+            const double pv = -dev::cephes_expm1(n_total * dev::cephes_log1p(-cf_prior[j]));        // bdtrc_closed_form, prior < 0.01
+            P.p[t * TILE + (ix & 0x7FFFu)] = pv;
+            H.add(pv);
         }
         __syncthreads();
     }
     H.flush(P.top_hist);
 }
 
-template <int CLS>
-__global__ __launch_bounds__(K2_THREADS) void k2_queue(K2Params P, const QEntry* __restrict__ base, int dir,
-                                                       const unsigned long long* __restrict__ count) {
+// count == 1: p = 1 - (1 - prior)^n through Cephes' log1p / expm1 (or pow): bdtrc_closed_form
+__global__ __launch_bounds__(K2_THREADS) void k2_closed(K2Params P, QSpan q) {
     __shared__ unsigned int hist_lds[K2_HIST_BINS];
     FusedHist H;
     H.init(hist_lds, P.top_hist);
-    const int64_t n = (int64_t)*count;
+    const QIndex ix = qindex_of(q.count);
+    const int64_t n = ix.start[K2_SHARDS];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
-        const QEntry e = base[dir * j];
+        const QEntry e = q.base[qslot(ix, q.cap_s, q.dir, j)];
+        const double pv = dev::bdtrc_closed_form(e.count < 0 ? P.inter.n : P.intra.n, e.prior);
+        P.p[e.row] = pv;
+        H.add(pv);
+    }
+    H.flush(P.top_hist);
+}
+
+template <int CLS>
+__global__ __launch_bounds__(K2_THREADS) void k2_queue(K2Params P, QSpan q) {
+    __shared__ unsigned int hist_lds[K2_HIST_BINS];
+    FusedHist H;
+    H.init(hist_lds, P.top_hist);
+    const QIndex ix = qindex_of(q.count);
+    const int64_t n = ix.start[K2_SHARDS];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const QEntry e = q.base[qslot(ix, q.cap_s, q.dir, j)];
         const bool is_inter = e.count < 0;
         const int c = is_inter ? -e.count : e.count;
         const double pv = dev::bdtrc_count_class<CLS>(c, is_inter ? P.inter : P.intra, e.prior);
@@ -588,15 +656,15 @@ __global__ __launch_bounds__(K2_THREADS) void k2_queue(K2Params P, const QEntry*
 constexpr int K2_SORT_TILE = 1024;
 constexpr int K2_SORT_BUCKETS = 32;
 template <int CLS>
-__global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void k2_queue_by_count(K2Params P, const QEntry* __restrict__ base, int dir,
-                                                                const unsigned long long* __restrict__ count) {
+__global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void k2_queue_by_count(K2Params P, QSpan q) {
     static_assert(K2_SORT_TILE == 4 * K2_THREADS, "four entries per thread");
     __shared__ QEntry tile[K2_SORT_TILE];
     __shared__ unsigned int bucket_cnt[K2_SORT_BUCKETS], bucket_off[K2_SORT_BUCKETS];
     __shared__ unsigned int hist_lds[K2_HIST_BINS];
     FusedHist H;
     H.init(hist_lds, P.top_hist);
-    const int64_t n = (int64_t)*count;
+    const QIndex ix = qindex_of(q.count);
+    const int64_t n = ix.start[K2_SHARDS];
     const int64_t tiles = (n + K2_SORT_TILE - 1) / K2_SORT_TILE;
     for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
         if (threadIdx.x < K2_SORT_BUCKETS) bucket_cnt[threadIdx.x] = 0;
@@ -609,7 +677,7 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
             const int64_t j = t * K2_SORT_TILE + r * K2_THREADS + threadIdx.x;
             bucket[r] = -1;
             if (j < n) {
-                e[r] = base[dir * j];
+                e[r] = q.base[qslot(ix, q.cap_s, q.dir, j)];
                 const int c = e[r].count < 0 ? -e[r].count : e[r].count;
                 bucket[r] = c < K2_SORT_BUCKETS - 1 ? c : K2_SORT_BUCKETS - 1;
                 slot[r] = atomicAdd(&bucket_cnt[bucket[r]], 1u);
@@ -669,14 +737,15 @@ __device__ __forceinline__ void k2h_chunk(int64_t n, int64_t& beg, int64_t& end)
 }
 
 // per-workgroup bucket counts of its contiguous chunk of the queue (digit-major matrix, as rs_count writes it)
-__global__ __launch_bounds__(K2H_THREADS) void k2h_count(const QEntry* __restrict__ q, const unsigned long long* __restrict__ n_ptr,
-                                                         unsigned int* __restrict__ block_hist) {
+__global__ __launch_bounds__(K2H_THREADS) void k2h_count(QSpan q, unsigned int* __restrict__ block_hist) {
     __shared__ unsigned int h[K2H_BUCKETS];
     for (int d = threadIdx.x; d < K2H_BUCKETS; d += K2H_THREADS) h[d] = 0;
     __syncthreads();
+    const QIndex ix = qindex_of(q.count);
     int64_t beg, end;
-    k2h_chunk((int64_t)*n_ptr, beg, end);
-    for (int64_t i = beg + threadIdx.x; i < end; i += K2H_THREADS) atomicAdd(&h[k2h_bucket(q[i].count)], 1u);
+    k2h_chunk(ix.start[K2_SHARDS], beg, end);
+    for (int64_t i = beg + threadIdx.x; i < end; i += K2H_THREADS)
+        atomicAdd(&h[k2h_bucket(q.base[qslot(ix, q.cap_s, q.dir, i)].count)], 1u);
     __syncthreads();
     for (int d = threadIdx.x; d < K2H_BUCKETS; d += K2H_THREADS) block_hist[(size_t)d * K2H_BLOCKS + blockIdx.x] = h[d];
 }
@@ -701,16 +770,16 @@ __global__ __launch_bounds__(1024) void k2h_offsets(const unsigned int* __restri
     off[2 * threadIdx.x + 1] = part[threadIdx.x] + a;
 }
 
-__global__ __launch_bounds__(K2H_THREADS) void k2h_scatter(const QEntry* __restrict__ q, const unsigned long long* __restrict__ n_ptr,
-                                                           const unsigned int* __restrict__ block_hist,
+__global__ __launch_bounds__(K2H_THREADS) void k2h_scatter(QSpan q, const unsigned int* __restrict__ block_hist,
                                                            const unsigned int* __restrict__ off, QEntry* __restrict__ out) {
     __shared__ unsigned int cursor[K2H_BUCKETS];
     for (int d = threadIdx.x; d < K2H_BUCKETS; d += K2H_THREADS) cursor[d] = off[d] + block_hist[(size_t)d * K2H_BLOCKS + blockIdx.x];
     __syncthreads();
+    const QIndex ix = qindex_of(q.count);
     int64_t beg, end;
-    k2h_chunk((int64_t)*n_ptr, beg, end);
+    k2h_chunk(ix.start[K2_SHARDS], beg, end);
     for (int64_t i = beg + threadIdx.x; i < end; i += K2H_THREADS) {
-        const QEntry e = q[i];
+        const QEntry e = q.base[qslot(ix, q.cap_s, q.dir, i)];
         out[atomicAdd(&cursor[k2h_bucket(e.count)], 1u)] = e;       // order inside a bucket is free: results go to p[row]
     }
 }
@@ -1800,7 +1869,9 @@ struct fhx_ctx {
     unsigned long long* d_k2_hist = nullptr;          // K3's key histogram as K2 gathered it while storing p (4096 bins)
     bool k2_hist_valid = false;
     unsigned char* d_work = nullptr;                  // the K2 queues and the K3 sort buffers are views into this block
-    QEntry* d_queue[2] = {nullptr, nullptr};          // K2's per-class row queues
+    QEntry* d_queue[2] = {nullptr, nullptr};          // K2's per-class row queues (sharded, see QSpan)
+    int64_t queue_cap = 0;                            // entries per queue buffer
+    unsigned long long* d_k2_counts = nullptr;        // (K2_QUEUES + 1) x K2_SHARDS queue counters
     QEntry* d_queue_sorted = nullptr;                 // the 300-iteration class, bucketed by (binomial, count), 64-aligned buckets
     dev::CfRow* d_cf_tab = nullptr;                   // K2H_GENERIC x 300 rows of iteration constants
     unsigned int* d_k2h_off = nullptr;                // K2H_BUCKETS + 1 bucket starts
@@ -1863,6 +1934,14 @@ struct DeviceScratch {
 int grid_for(int64_t n, int threads, int max_blocks = 256 * 8) {
     const int64_t b = (n + threads - 1) / threads;
     return (int)std::max<int64_t>(1, std::min<int64_t>(b, max_blocks));
+}
+
+// k2_classify over n rows: workgroup b of `grid` takes tiles b, b + grid, ... and queues into shard b % K2_SHARDS, so a shard
+// receives at most ceil(grid / K2_SHARDS) * ceil(tiles / grid) tiles of rows, whatever their classes
+int k2_classify_grid(int64_t n) { return grid_for(n, K2_CL_TILE, 256 * 8); }
+long long k2_shard_capacity(int64_t n) {
+    const long long tiles = std::max<long long>(1, (n + K2_CL_TILE - 1) / K2_CL_TILE), grid = k2_classify_grid(n);
+    return ((grid + K2_SHARDS - 1) / K2_SHARDS) * ((tiles + grid - 1) / grid) * (long long)K2_CL_TILE;
 }
 
 K2Params make_k2_params(fhx_ctx* c) {
@@ -1972,7 +2051,7 @@ int build_slot_tables(fhx_ctx* ctx) {
 int ensure_sort_scratch_early(fhx_ctx* ctx) {
     if (!ctx->d_block_hist) FHX_HIP(hipMalloc(&ctx->d_block_hist, (size_t)RADIX * SORT_BLOCKS * sizeof(unsigned int)));
     if (!ctx->d_digit_total) FHX_HIP(hipMalloc(&ctx->d_digit_total, RADIX * sizeof(unsigned int)));
-    if (!ctx->d_misc) FHX_HIP(hipMalloc(&ctx->d_misc, 128 * sizeof(unsigned long long)));
+    if (!ctx->d_misc) FHX_HIP(hipMalloc(&ctx->d_misc, 192 * sizeof(unsigned long long)));
     if (!ctx->d_top_hist) FHX_HIP(hipMalloc(&ctx->d_top_hist, TOP_BINS * sizeof(unsigned long long)));
     return FHX_OK;
 }
@@ -2209,17 +2288,19 @@ int alloc_row_arrays(fhx_ctx* ctx, int64_t n, int64_t n_dist) {
     FHX_HIP(hipMalloc(&ctx->d_out_hist, hist_len * sizeof(unsigned long long)));
     FHX_HIP(hipMemsetAsync(ctx->d_out_hist, 0, hist_len * sizeof(unsigned long long), ctx->stream));
     if (!ctx->d_sums) FHX_HIP(hipMalloc(&ctx->d_sums, sizeof(K1Sums)));
-    if (!ctx->d_misc) FHX_HIP(hipMalloc(&ctx->d_misc, 128 * sizeof(unsigned long long)));
+    if (!ctx->d_misc) FHX_HIP(hipMalloc(&ctx->d_misc, 192 * sizeof(unsigned long long)));
     // One workspace, two views that are never live together (K2 and K3 run back to back on one stream):
     //   K2: queue[0] (16 B/row) | queue[1] (16 B/row) | the bucketed 300-iteration queue (16 B/row + bucket padding)
     //   K3: keys[0], keys[1] (8 B/row each)            | vals[0], vals[1] (4 B/row each)
     // (-r 0 sorts distances in K1 and lists outlier distances after K3 through the K3 view.)
     dev_free(ctx->d_work);
-    const size_t work_bytes = cap * 48 + (size_t)K2H_BUCKETS * 64 * sizeof(QEntry);
+    const size_t qcap = std::max<size_t>(cap, (size_t)K2_SHARDS * (size_t)k2_shard_capacity((int64_t)cap));   // sharded queues: k2_classify
+    const size_t work_bytes = qcap * 32 + std::max(qcap, cap + (size_t)K2H_BUCKETS * 64) * sizeof(QEntry);   // queue 0 | queue 1 | sorted heavy queue / closed-form queue
     FHX_HIP(hipMalloc(&ctx->d_work, work_bytes));
+    ctx->queue_cap = (int64_t)qcap;
     ctx->d_queue[0] = reinterpret_cast<QEntry*>(ctx->d_work);
-    ctx->d_queue[1] = reinterpret_cast<QEntry*>(ctx->d_work + cap * 16);
-    ctx->d_queue_sorted = reinterpret_cast<QEntry*>(ctx->d_work + cap * 32);
+    ctx->d_queue[1] = reinterpret_cast<QEntry*>(ctx->d_work + qcap * 16);
+    ctx->d_queue_sorted = reinterpret_cast<QEntry*>(ctx->d_work + qcap * 32);
     ctx->d_keys[0] = reinterpret_cast<unsigned long long*>(ctx->d_work);
     ctx->d_keys[1] = reinterpret_cast<unsigned long long*>(ctx->d_work + cap * 8);
     ctx->d_vals[0] = reinterpret_cast<unsigned int*>(ctx->d_work + cap * 16);
@@ -2314,6 +2395,7 @@ void fhx_destroy(fhx_ctx* ctx) {
         dev_free(ctx->d_k2_hist);
         dev_free(ctx->d_cf_tab);
         dev_free(ctx->d_k2h_off);
+        dev_free(ctx->d_k2_counts);
         dev_free(ctx->d_memo);
         dev_free(ctx->d_slot_mid);
         dev_free(ctx->d_table_x);
@@ -2795,25 +2877,38 @@ int fhx_pvalues(fhx_ctx* ctx) {
     // queues live in the sort workspace, which is idle until K3: 2 x u32[n] + 2 x u64[n]
     // two entry buffers of n_rows each: [swapped CF up | power series down] and [incbcf up | incbd down]
     K2Queues Q;
-    const long long last = (long long)std::max<int64_t>(ctx->n_rows, 1) - 1   /* k2_n <= n_rows / 4 in the table case */;
-    Q.base[dev::BC_CF_SWAPPED - 1] = ctx->d_queue[0];
-    Q.dir[dev::BC_CF_SWAPPED - 1] = 1;
-    Q.base[dev::BC_PSERIES - 1] = ctx->d_queue[0] + last;
-    Q.dir[dev::BC_PSERIES - 1] = -1;
-    Q.base[dev::BC_CF_BCF - 1] = ctx->d_queue[1];
-    Q.dir[dev::BC_CF_BCF - 1] = 1;
-    Q.base[dev::BC_CF_BD - 1] = ctx->d_queue[1] + last;
-    Q.dir[dev::BC_CF_BD - 1] = -1;
-    Q.count = ctx->d_misc + 64;
-    FHX_HIP(hipMemsetAsync(Q.count, 0, K2_QUEUES * K2_COUNT_STRIDE * sizeof(unsigned long long), ctx->stream));
-    if (P.nonfixed)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<1>), dim3(grid_for(k2_n, K2_CL_TILE, 256 * 8)), dim3(K2_THREADS), 0, ctx->stream, P, Q);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0>), dim3(grid_for(k2_n, K2_CL_TILE, 256 * 8)), dim3(K2_THREADS), 0, ctx->stream, P, Q);
+    const long long cap_s = k2_shard_capacity(k2_n);
+    if ((int64_t)K2_SHARDS * cap_s > ctx->queue_cap) return fail(ctx, FHX_ERR_HIP, "internal: queue workspace smaller than the shard layout");
+    if (!ctx->d_k2_counts) FHX_HIP(hipMalloc(&ctx->d_k2_counts, (size_t)(K2_QUEUES + 1) * K2_SHARDS * K2_COUNT_STRIDE * sizeof(unsigned long long)));
+    Q.count = ctx->d_k2_counts;
+    auto span = [&](int cls, QEntry* buf, int dir) {
+        QSpan& q = Q.q[cls - 1];
+        q.base = dir > 0 ? buf : buf + cap_s - 1;
+        q.cap_s = cap_s;
+        q.dir = dir;
+        q.count = Q.count + (size_t)(cls - 1) * K2_SHARDS * K2_COUNT_STRIDE;
+    };
+    span(dev::BC_CF_SWAPPED, ctx->d_queue[0], 1);
+    span(dev::BC_PSERIES, ctx->d_queue[0], -1);
+    span(dev::BC_CF_BCF, ctx->d_queue[1], 1);
+    span(dev::BC_CF_BD, ctx->d_queue[1], -1);
+    span(K2_CLOSED, ctx->d_queue_sorted, 1);             // the sorted heavy queue is written after k2_closed has run
+    FHX_HIP(hipMemsetAsync(Q.count, 0, (size_t)(K2_QUEUES + 1) * K2_SHARDS * K2_COUNT_STRIDE * sizeof(unsigned long long), ctx->stream));
+    {
+        const dim3 cgrid(k2_classify_grid(k2_n)), cblock(K2_THREADS);
+        if (P.nonfixed)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<1, K2_CL_ITEMS, 4>), cgrid, cblock, 0, ctx->stream, P, Q);
+        else {
+            static const int wpe = std::getenv("FHX_CL_WAVES") ? std::atoi(std::getenv("FHX_CL_WAVES")) : 0;    // measurements only
+            if (wpe == 4)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, K2_CL_ITEMS, 4>), cgrid, cblock, 0, ctx->stream, P, Q);
+            else        // 6 waves/SIMD: 80 VGPRs + 20 B of scratch; measured 1.92 ms against 2.01 at 4 (102 VGPRs), r02_v_classify.txt
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, K2_CL_ITEMS, 6>), cgrid, cblock, 0, ctx->stream, P, Q);
+        }
+    }
     const dim3 qgrid(256 * 8), qblock(K2_THREADS);
-#define FHX_LAUNCH_QUEUE(CLS)                                                                                          \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue<CLS>), qgrid, qblock, 0, ctx->stream, P, (const QEntry*)Q.base[(CLS) - 1], \
-                       Q.dir[(CLS) - 1], (const unsigned long long*)(Q.count + ((CLS) - 1) * K2_COUNT_STRIDE))
+    hipLaunchKernelGGL(k2_closed, qgrid, qblock, 0, ctx->stream, P, Q.q[K2_CLOSED - 1]);
+#define FHX_LAUNCH_QUEUE(CLS) hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue<CLS>), qgrid, qblock, 0, ctx->stream, P, Q.q[(CLS) - 1])
     const bool legacy_heavy = getenv("FHX_K2_LEGACY") != nullptr;      // A/B and tests: the per-lane kernel of round 1
     if (legacy_heavy) {
         FHX_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
@@ -2821,17 +2916,19 @@ int fhx_pvalues(fhx_ctx* ctx) {
         FHX_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
     } else {
         static_assert(K2H_BUCKETS == RADIX && K2H_BLOCKS == SORT_BLOCKS, "the radix sort's count matrix and scan are reused");
-        QEntry* hq = Q.base[dev::BC_CF_SWAPPED - 1];
-        const unsigned long long* hn = Q.count + (dev::BC_CF_SWAPPED - 1) * K2_COUNT_STRIDE;
+        const QSpan hs = Q.q[dev::BC_CF_SWAPPED - 1];
+        QEntry* hq = ctx->d_queue[0];                    // the handed-back rows: this buffer is dead once it is scattered and the
+                                                         // power-series class (its other tenant) has run
         unsigned long long* n_redo = ctx->d_misc + 11;
         FHX_HIP(hipMemsetAsync(n_redo, 0, sizeof(unsigned long long), ctx->stream));
-        hipLaunchKernelGGL(k2h_count, dim3(K2H_BLOCKS), dim3(K2H_THREADS), 0, ctx->stream, (const QEntry*)hq, hn, ctx->d_block_hist);
+        hipLaunchKernelGGL(k2h_count, dim3(K2H_BLOCKS), dim3(K2H_THREADS), 0, ctx->stream, hs, ctx->d_block_hist);
         hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3(SORT_BLOCKS), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total, (int)SORT_BLOCKS);
         hipLaunchKernelGGL(k2h_offsets, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned int*)ctx->d_digit_total, ctx->d_k2h_off);
         hipLaunchKernelGGL(k2h_tables, dim3((K2H_GENERIC + 63) / 64), dim3(64), 0, ctx->stream, (const unsigned int*)ctx->d_digit_total,
                            P.intra.n, P.inter.n, ctx->d_cf_tab);
-        hipLaunchKernelGGL(k2h_scatter, dim3(K2H_BLOCKS), dim3(K2H_THREADS), 0, ctx->stream, (const QEntry*)hq, hn,
+        hipLaunchKernelGGL(k2h_scatter, dim3(K2H_BLOCKS), dim3(K2H_THREADS), 0, ctx->stream, hs,
                            (const unsigned int*)ctx->d_block_hist, (const unsigned int*)ctx->d_k2h_off, ctx->d_queue_sorted);
+        FHX_LAUNCH_QUEUE(dev::BC_PSERIES);               // before the redo list reuses the buffer it shares with the heavy queue
         FHX_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
         const K2HeavyParams HP{P.intra, P.inter, P.p, P.top_hist};
         hipLaunchKernelGGL(k2h_heavy, dim3(256 * 8), dim3(K2H_THREADS), 0, ctx->stream, HP, (const QEntry*)ctx->d_queue_sorted,
@@ -2842,12 +2939,11 @@ int fhx_pvalues(fhx_ctx* ctx) {
                            (const unsigned int*)ctx->d_k2h_off, (const unsigned int*)ctx->d_digit_total, (const QEntry*)hq,
                            (const unsigned long long*)n_redo);
     }
-#define FHX_LAUNCH_QUEUE_BY_COUNT(CLS)                                                                                 \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue_by_count<CLS>), qgrid, qblock, 0, ctx->stream, P, (const QEntry*)Q.base[(CLS) - 1], \
-                       Q.dir[(CLS) - 1], (const unsigned long long*)(Q.count + ((CLS) - 1) * K2_COUNT_STRIDE))
+#define FHX_LAUNCH_QUEUE_BY_COUNT(CLS) \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue_by_count<CLS>), qgrid, qblock, 0, ctx->stream, P, Q.q[(CLS) - 1])
     FHX_LAUNCH_QUEUE_BY_COUNT(dev::BC_CF_BD);
     FHX_LAUNCH_QUEUE_BY_COUNT(dev::BC_CF_BCF);
-    FHX_LAUNCH_QUEUE(dev::BC_PSERIES);
+    if (legacy_heavy) FHX_LAUNCH_QUEUE(dev::BC_PSERIES);
 #undef FHX_LAUNCH_QUEUE_BY_COUNT
 #undef FHX_LAUNCH_QUEUE
     if (memo_cap >= 0) {
@@ -2954,7 +3050,7 @@ static int bh_from_sorted(fhx_ctx* ctx, const unsigned long long* keys, const un
 static int ensure_sort_scratch(fhx_ctx* ctx) {
     if (!ctx->d_block_hist) FHX_HIP(hipMalloc(&ctx->d_block_hist, (size_t)RADIX * SORT_BLOCKS * sizeof(unsigned int)));
     if (!ctx->d_digit_total) FHX_HIP(hipMalloc(&ctx->d_digit_total, RADIX * sizeof(unsigned int)));
-    if (!ctx->d_misc) FHX_HIP(hipMalloc(&ctx->d_misc, 128 * sizeof(unsigned long long)));
+    if (!ctx->d_misc) FHX_HIP(hipMalloc(&ctx->d_misc, 192 * sizeof(unsigned long long)));
     if (!ctx->d_top_hist) FHX_HIP(hipMalloc(&ctx->d_top_hist, TOP_BINS * sizeof(unsigned long long)));
     return FHX_OK;
 }
@@ -3493,8 +3589,10 @@ int fhx_k2_heavy_launch(fhx_ctx* ctx, double* seconds, int64_t* rows) {
     FHX_HIP(hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
     FHX_HIP(hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]));
-    unsigned long long n = 0;
-    FHX_HIP(hipMemcpy(&n, ctx->d_misc + 64 + (dev::BC_CF_SWAPPED - 1) * K2_COUNT_STRIDE, sizeof(n), hipMemcpyDeviceToHost));
+    unsigned long long n = 0, part[K2_SHARDS * K2_COUNT_STRIDE];
+    if (!ctx->d_k2_counts) return fail(ctx, FHX_ERR_ARG, "fhx_pvalues has not run");
+    FHX_HIP(hipMemcpy(part, ctx->d_k2_counts + (size_t)(dev::BC_CF_SWAPPED - 1) * K2_SHARDS * K2_COUNT_STRIDE, sizeof(part), hipMemcpyDeviceToHost));
+    for (int sh = 0; sh < K2_SHARDS; ++sh) n += part[sh * K2_COUNT_STRIDE];
     if (seconds) *seconds = ms * 1e-3;
     if (rows) *rows = (int64_t)n;
     return FHX_OK;
