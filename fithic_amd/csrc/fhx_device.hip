@@ -422,6 +422,19 @@ constexpr int K2_THREADS = 256;
 // class at a time with every lane on the same code path and nearly the same trip count.
 constexpr int K2_QUEUES = dev::BC_COUNT - 1;        // classes 1..4
 
+// p of a queued row goes to p[row]: an 8-byte store into a line nobody reads again before K3.  In the queue-order kernels the
+// rows of a wave are neighbours and the L2 merges their stores into whole lines; the bucket-sorted heavy class scatters them over
+// the whole column, and a plain store then makes the L2 FETCH every line it partially writes (PMC, k2h_heavy: 1639 MB read per
+// launch for 427 MB of entries; 713 MB with nontemporal stores, which write through without allocating - and 0.5 ms less per
+// pass, profiles/r02_y_*).  The queue-order kernels keep plain stores (nontemporal ones cost them 10-28 % more write traffic).
+template <bool SCATTERED>
+__device__ __forceinline__ void store_p(double* dst, double v) {
+    if (SCATTERED)
+        __builtin_nontemporal_store(v, dst);
+    else
+        *dst = v;
+}
+
 // one queued row: everything the per-class kernel needs, so that it streams 16 B/row instead of re-gathering the
 // three pair columns, two biases and the prior LUT through a row index (measured 66 B/row of HBM traffic that way)
 struct QEntry {
@@ -624,7 +637,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_closed(K2Params P, QSpan q) {
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
         const QEntry e = q.base[qslot(ix, q.cap_s, q.dir, j)];
         const double pv = dev::bdtrc_closed_form(e.count < 0 ? P.inter.n : P.intra.n, e.prior);
-        P.p[e.row] = pv;
+        store_p<false>(P.p + e.row, pv);
         H.add(pv);
     }
     H.flush(P.top_hist);
@@ -643,7 +656,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_queue(K2Params P, QSpan q) {
         const bool is_inter = e.count < 0;
         const int c = is_inter ? -e.count : e.count;
         const double pv = dev::bdtrc_count_class<CLS>(c, is_inter ? P.inter : P.intra, e.prior);
-        P.p[e.row] = pv;
+        store_p<false>(P.p + e.row, pv);
         H.add(pv);
     }
     H.flush(P.top_hist);
@@ -703,7 +716,7 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
                 const bool is_inter = x.count < 0;
                 const int c = is_inter ? -x.count : x.count;
                 const double pv = dev::bdtrc_count_class<CLS>(c, is_inter ? P.inter : P.intra, x.prior);
-                P.p[x.row] = pv;
+                store_p<false>(P.p + x.row, pv);
                 H.add(pv);
             }
         }
@@ -849,7 +862,7 @@ __global__ __launch_bounds__(K2H_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
                 redo[atomicAdd(n_redo, 1ull)] = e;
             else {
                 pv = dev::incbet_finish(bb, aa, w1, xx, cf, 1, T.lbeta[c], T.small_n ? T.inv_beta[c] : 0.0);
-                P.p[e.row] = pv;
+                store_p<true>(P.p + e.row, pv);
             }
         }
         H.add_wave_min(pv, mine);
@@ -875,7 +888,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2h_generic(K2Params P, const QEnt
         const bool is_inter = e.count < 0;
         const int c = is_inter ? -e.count : e.count;
         const double pv = dev::bdtrc_count_class<dev::BC_CF_SWAPPED>(c, is_inter ? P.inter : P.intra, e.prior);
-        P.p[e.row] = pv;
+        store_p<true>(P.p + e.row, pv);
         H.add(pv);
     }
     H.flush(P.top_hist);
