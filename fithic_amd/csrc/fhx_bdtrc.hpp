@@ -352,33 +352,32 @@ __device__ __forceinline__ CfRow cf_load_row(CfRowConstPtr p0) {
     return r;
 }
 
-// table of one (n_total, count): the values Cephes' loop would hold at iteration i, and lean_div's reciprocals
-__device__ __forceinline__ void cf_swapped_build_rows(double n_total, int count, CfRow* rows) {
+// table of one (n_total, count): the values Cephes' loop would hold at iteration i, and lean_div's reciprocals.  Cephes
+// reaches them by repeated k += 1 or 2 from integer-valued doubles below 2^53 - exact additions - so row i can be written
+// down directly (k1 = a + i, k3 = a + 2i, ...) and the 300 rows of a table are built by 300 threads instead of one.
+__device__ __forceinline__ CfRow cf_swapped_row(double n_total, int count, int i) {
     const double fk = (double)count - 1.0;
     const double a = n_total - fk, b = fk + 1.0;            // swapped: a = bb, b = aa of incbet
-    double k1 = a, k2 = a + b, k3 = a, k4 = a + 1.0, k5 = 1.0, k6 = b - 1.0, k8 = a + 2.0;
-    for (int i = 0; i < kCfIters; ++i) {
-        CfRow r;
-        r.k1 = k1; r.k2 = k2; r.k5 = k5; r.k6 = k6;
-        r.d0 = k3 * k4;
-        r.d1 = k4 * k8;
-        double d = r.d0;
-        double y = __builtin_amdgcn_rcp(d);
-        double e = __builtin_fma(-d, y, 1.0);
-        y = __builtin_fma(y, e, y);
-        e = __builtin_fma(-d, y, 1.0);
-        r.y0 = __builtin_fma(y, e, y);
-        d = r.d1;
-        y = __builtin_amdgcn_rcp(d);
-        e = __builtin_fma(-d, y, 1.0);
-        y = __builtin_fma(y, e, y);
-        e = __builtin_fma(-d, y, 1.0);
-        r.y1 = __builtin_fma(y, e, y);
-        rows[i] = r;
-        k1 += 1.0; k2 += 1.0; k3 += 2.0; k4 += 2.0; k5 += 1.0; k6 += -1.0; k8 += 2.0;
-    }
+    const double di = (double)i, d2 = 2.0 * di;
+    const double k1 = a + di, k2 = (a + b) + di, k3 = a + d2, k4 = (a + 1.0) + d2, k5 = 1.0 + di, k6 = (b - 1.0) - di, k8 = (a + 2.0) + d2;
+    CfRow r;
+    r.k1 = k1; r.k2 = k2; r.k5 = k5; r.k6 = k6;
+    r.d0 = k3 * k4;
+    r.d1 = k4 * k8;
+    double d = r.d0;
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0);
+    r.y0 = __builtin_fma(y, e, y);
+    d = r.d1;
+    y = __builtin_amdgcn_rcp(d);
+    e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0);
+    r.y1 = __builtin_fma(y, e, y);
+    return r;
 }
-
 // which rows cf_swapped_uniform may evaluate (the rest go through contfrac_lazy): the operand window of lean_div
 // (see contfrac_lazy) and the premises of the range proof above
 __device__ __forceinline__ bool cf_swapped_regular(double a, double b, double x) {

@@ -797,13 +797,15 @@ __global__ __launch_bounds__(K2H_THREADS) void k2h_scatter(QSpan q, const unsign
     }
 }
 
-// one thread per non-empty (binomial, count) bucket: the 300 rows of iteration constants
-__global__ __launch_bounds__(64) void k2h_tables(const unsigned int* __restrict__ digit_total, double n_intra, double n_inter,
-                                                 dev::CfRow* __restrict__ tab) {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= K2H_GENERIC || digit_total[b] == 0) return;
+// one workgroup per non-empty (binomial, count) bucket, one thread per iteration: the 300 rows of iteration constants
+constexpr int K2H_TABLE_THREADS = 320;
+static_assert(K2H_TABLE_THREADS >= dev::kCfIters, "one thread per table row");
+__global__ __launch_bounds__(K2H_TABLE_THREADS) void k2h_tables(const unsigned int* __restrict__ digit_total, double n_intra, double n_inter,
+                                                                dev::CfRow* __restrict__ tab) {
+    const int b = blockIdx.x;
+    if (b >= K2H_GENERIC || digit_total[b] == 0 || (int)threadIdx.x >= dev::kCfIters) return;
     const bool inter = b >= K2H_KCAP;
-    dev::cf_swapped_build_rows(inter ? n_inter : n_intra, inter ? b - K2H_KCAP : b, tab + (size_t)b * dev::kCfIters);
+    tab[(size_t)b * dev::kCfIters + threadIdx.x] = dev::cf_swapped_row(inter ? n_inter : n_intra, inter ? b - K2H_KCAP : b, (int)threadIdx.x);
 }
 
 // Lanes cf_swapped_uniform cannot take (unusual inputs or states, see fhx_bdtrc.hpp) are appended to `redo` - the space the
@@ -1869,7 +1871,12 @@ struct fhx_ctx {
     bool have_bins = false;
     double* d_lut = nullptr;
     double *d_lbeta_intra = nullptr, *d_invb_intra = nullptr, *d_lbeta_inter = nullptr, *d_invb_inter = nullptr;
-    int64_t tab_cap = 0;
+    // the tables of one fit (prior LUT | four per-count tables | -r 0: spline table x, y) live in ONE device buffer filled by ONE
+    // copy from a pinned staging buffer: the pointers above point into it
+    double* d_fit_tables = nullptr;
+    double* h_fit_stage = nullptr;              // pinned
+    size_t fit_tables_cap = 0;                  // doubles
+    hipEvent_t ev_fit_copy = nullptr;           // the last copy out of h_fit_stage
     double *d_p = nullptr, *d_q = nullptr;
     bool have_p = false, have_q = false;
 
@@ -2394,11 +2401,9 @@ void fhx_destroy(fhx_ctx* ctx) {
         dev_free(ctx->d_out_hist);
         dev_free(ctx->d_misc);
         dev_free(ctx->d_sums);
-        dev_free(ctx->d_lut);
-        dev_free(ctx->d_lbeta_intra);
-        dev_free(ctx->d_invb_intra);
-        dev_free(ctx->d_lbeta_inter);
-        dev_free(ctx->d_invb_inter);
+        dev_free(ctx->d_fit_tables);            // d_lut, d_lbeta_*, d_invb_*, d_table_x / y point into it
+        if (ctx->h_fit_stage) (void)hipHostFree(ctx->h_fit_stage);
+        if (ctx->ev_fit_copy) (void)hipEventDestroy(ctx->ev_fit_copy);
         dev_free(ctx->d_p);
         dev_free(ctx->d_q);
         dev_free(ctx->d_work);
@@ -2411,8 +2416,6 @@ void fhx_destroy(fhx_ctx* ctx) {
         dev_free(ctx->d_k2_counts);
         dev_free(ctx->d_memo);
         dev_free(ctx->d_slot_mid);
-        dev_free(ctx->d_table_x);
-        dev_free(ctx->d_table_y);
         dev_free(ctx->d_seg_ids);
         dev_free(ctx->d_seg_tiles);
         dev_free(ctx->d_tile_max);
@@ -2765,44 +2768,47 @@ int fhx_fit(fhx_ctx* ctx, fhx_fit_info* out) {
             const int r2 = build_slot_tables(ctx);
             if (r2 != FHX_OK) return r2;
         }
-        // prior LUT (fixed-size) or the spline table itself (-r 0) + the two per-count tables
-        dev_free(ctx->d_lut);
-        FHX_HIP(hipMalloc(&ctx->d_lut, f.prior_lut.size() * sizeof(double)));
-        FHX_HIP(hipMemcpyAsync(ctx->d_lut, f.prior_lut.data(), f.prior_lut.size() * sizeof(double), hipMemcpyHostToDevice,
-                               ctx->stream));
-        std::vector<double> tx(f.table_x.begin(), f.table_x.end());
-        if (ctx->nonfixed) {
-            dev_free(ctx->d_table_x);
-            dev_free(ctx->d_table_y);
-            const size_t nt = std::max<size_t>(tx.size(), 1);
-            FHX_HIP(hipMalloc(&ctx->d_table_x, nt * sizeof(double)));
-            FHX_HIP(hipMalloc(&ctx->d_table_y, nt * sizeof(double)));
-            if (!tx.empty()) {
-                FHX_HIP(hipMemcpyAsync(ctx->d_table_x, tx.data(), tx.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-                FHX_HIP(hipMemcpyAsync(ctx->d_table_y, f.table_y.data(), tx.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-            }
-        }
+        // prior LUT (fixed-size) or the spline table itself (-r 0) + the two pairs of per-count tables: packed into the pinned
+        // staging buffer and sent with one copy; nothing waits for it here (the stream orders it before K2)
         const int64_t mc = std::max<int64_t>(ctx->stats.max_count, 1);
         std::vector<double> lb_a, ib_a, lb_e, ib_e;
         build_lbeta_table((double)ctx->stats.in_range_sum, mc, lb_a, ib_a);
         build_lbeta_table((double)ctx->stats.inter_sum, mc, lb_e, ib_e);
-        if (mc + 1 > ctx->tab_cap) {
-            dev_free(ctx->d_lbeta_intra);
-            dev_free(ctx->d_invb_intra);
-            dev_free(ctx->d_lbeta_inter);
-            dev_free(ctx->d_invb_inter);
-            ctx->tab_cap = mc + 1;
-            FHX_HIP(hipMalloc(&ctx->d_lbeta_intra, ctx->tab_cap * sizeof(double)));
-            FHX_HIP(hipMalloc(&ctx->d_invb_intra, ctx->tab_cap * sizeof(double)));
-            FHX_HIP(hipMalloc(&ctx->d_lbeta_inter, ctx->tab_cap * sizeof(double)));
-            FHX_HIP(hipMalloc(&ctx->d_invb_inter, ctx->tab_cap * sizeof(double)));
+        const size_t n_lut = std::max<size_t>(f.prior_lut.size(), 1), n_tab = (size_t)(mc + 1);
+        const size_t n_xy = ctx->nonfixed ? std::max<size_t>(f.table_x.size(), 1) : 0;
+        const size_t need = n_lut + 4 * n_tab + 2 * n_xy;
+        if (need > ctx->fit_tables_cap) {
+            FHX_HIP(hipStreamSynchronize(ctx->stream));                // kernels of an earlier pass may still read the old buffer
+            dev_free(ctx->d_fit_tables);
+            if (ctx->h_fit_stage) (void)hipHostFree(ctx->h_fit_stage);
+            ctx->h_fit_stage = nullptr;
+            ctx->fit_tables_cap = need + need / 2 + 1024;
+            FHX_HIP(hipMalloc(&ctx->d_fit_tables, ctx->fit_tables_cap * sizeof(double)));
+            FHX_HIP(hipHostMalloc((void**)&ctx->h_fit_stage, ctx->fit_tables_cap * sizeof(double), hipHostMallocDefault));
         }
-        const size_t bytes = (size_t)(mc + 1) * sizeof(double);
-        FHX_HIP(hipMemcpyAsync(ctx->d_lbeta_intra, lb_a.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
-        FHX_HIP(hipMemcpyAsync(ctx->d_invb_intra, ib_a.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
-        FHX_HIP(hipMemcpyAsync(ctx->d_lbeta_inter, lb_e.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
-        FHX_HIP(hipMemcpyAsync(ctx->d_invb_inter, ib_e.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
-        FHX_HIP(hipStreamSynchronize(ctx->stream));      // the host vectors go out of scope
+        if (!ctx->ev_fit_copy) FHX_HIP(hipEventCreateWithFlags(&ctx->ev_fit_copy, hipEventDisableTiming));
+        else FHX_HIP(hipEventSynchronize(ctx->ev_fit_copy));           // the previous fit's copy has left the staging buffer
+        double* h = ctx->h_fit_stage;
+        size_t at = 0;
+        auto put = [&](const double* src, size_t n_src, size_t n_slot) {
+            if (n_src) std::memcpy(h + at, src, n_src * sizeof(double));
+            double* d = ctx->d_fit_tables + at;
+            at += n_slot;
+            return d;
+        };
+        ctx->d_lut = put(f.prior_lut.data(), f.prior_lut.size(), n_lut);
+        ctx->d_lbeta_intra = put(lb_a.data(), lb_a.size(), n_tab);
+        ctx->d_invb_intra = put(ib_a.data(), ib_a.size(), n_tab);
+        ctx->d_lbeta_inter = put(lb_e.data(), lb_e.size(), n_tab);
+        ctx->d_invb_inter = put(ib_e.data(), ib_e.size(), n_tab);
+        ctx->d_table_x = ctx->d_table_y = nullptr;
+        if (ctx->nonfixed) {
+            const std::vector<double> tx(f.table_x.begin(), f.table_x.end());
+            ctx->d_table_x = put(tx.data(), tx.size(), n_xy);
+            ctx->d_table_y = put(f.table_y.data(), std::min(f.table_y.size(), tx.size()), n_xy);
+        }
+        FHX_HIP(hipMemcpyAsync(ctx->d_fit_tables, h, at * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        FHX_HIP(hipEventRecord(ctx->ev_fit_copy, ctx->stream));
     }
     if (out) {
         std::memset(out, 0, sizeof(*out));
@@ -2937,7 +2943,7 @@ int fhx_pvalues(fhx_ctx* ctx) {
         hipLaunchKernelGGL(k2h_count, dim3(K2H_BLOCKS), dim3(K2H_THREADS), 0, ctx->stream, hs, ctx->d_block_hist);
         hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3(SORT_BLOCKS), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total, (int)SORT_BLOCKS);
         hipLaunchKernelGGL(k2h_offsets, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned int*)ctx->d_digit_total, ctx->d_k2h_off);
-        hipLaunchKernelGGL(k2h_tables, dim3((K2H_GENERIC + 63) / 64), dim3(64), 0, ctx->stream, (const unsigned int*)ctx->d_digit_total,
+        hipLaunchKernelGGL(k2h_tables, dim3(K2H_GENERIC), dim3(K2H_TABLE_THREADS), 0, ctx->stream, (const unsigned int*)ctx->d_digit_total,
                            P.intra.n, P.inter.n, ctx->d_cf_tab);
         hipLaunchKernelGGL(k2h_scatter, dim3(K2H_BLOCKS), dim3(K2H_THREADS), 0, ctx->stream, hs,
                            (const unsigned int*)ctx->d_block_hist, (const unsigned int*)ctx->d_k2h_off, ctx->d_queue_sorted);
