@@ -119,6 +119,16 @@ def test_many_members_with_skipped_rows_and_both_row_kinds(tmp_path):
     assert eng.ctx.write_significances_device(str(tmp_path / "rebuilt.gz"), genome.names) == (rows, nbytes)
     with open(str(tmp_path / "rebuilt.gz"), "rb") as f, open(dev, "rb") as g:
         assert f.read() == g.read()
+    # the writer works through the rows in batches of members (bounded device memory): one member per batch = the same file
+    os.environ["FHX_EMIT_BATCH_MEMBERS"] = "1"
+    try:
+        assert eng.ctx.write_significances_device(str(tmp_path / "batched.gz"), genome.names) == (rows, nbytes)
+        assert eng.ctx.write_significances_device(str(tmp_path / "batched_cols.gz"), genome.names, *cols) == (rows, nbytes)
+    finally:
+        del os.environ["FHX_EMIT_BATCH_MEMBERS"]
+    for name in ("batched.gz", "batched_cols.gz"):
+        with open(str(tmp_path / name), "rb") as f, open(dev, "rb") as g:
+            assert f.read() == g.read()
     from fithic_amd.engine import MODES
     n_host = _capi.host_write_significances(host, genome.names, *cols, v["p"], v["q"], v["b1"], v["b2"], v["expcc"], MODES["All"], L, U)
     d = np.abs(cols[1].astype(np.int64) - cols[3].astype(np.int64))
