@@ -562,7 +562,8 @@ def host_read_table(path, kind, threads=0, name_ids=None, want_float=True):
     the parallel copy, not per row in numpy).  want_float=False skips the 8 B/row float column of a contacts file."""
     L = lib()
     h = _P()
-    rc = L.fhx_host_read_table(os.fsencode(path), int(kind), int(threads), ctypes.byref(h))
+    flags = 0x100 if (kind == 0 and not want_float) else 0          # FHX_TABLE_NO_FLOAT
+    rc = L.fhx_host_read_table(os.fsencode(path), int(kind) | flags, int(threads), ctypes.byref(h))
     try:
         if rc != FHX_OK:
             raise FhxError(rc, (L.fhx_table_error(h) or b"").decode() if h else "fhx_host_read_table")

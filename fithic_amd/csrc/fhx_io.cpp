@@ -278,6 +278,7 @@ struct Chunk {
 // caller's array (no merged intermediate copy)
 struct fhx_table {
     int kind = 0;
+    bool has_float = true;                       // contacts read with FHX_TABLE_NO_FLOAT keep no column 5
     std::vector<std::string> names;
     std::vector<Chunk> chunks;
     std::vector<std::vector<int32_t>> remap;     // chunk-local chromosome id -> file-wide id (order of first appearance)
@@ -330,9 +331,20 @@ inline bool parse_f64(const char* b, const char* e, double& out) {       // Pyth
     return end == tmp + n;
 }
 
-void parse_chunk(const char* b, const char* e, int kind, Chunk& c) {
+void parse_chunk(const char* b, const char* e, int kind, bool keep_float, Chunk& c) {
     const char* fld_b[8];
     const char* fld_e[8];
+    {   // one allocation per column instead of a dozen doublings: a contacts line is >= 16 bytes, the others >= 8
+        const size_t est = (size_t)(e - b) / (kind == 0 ? 16 : 8) + 16;
+        c.ci[0].reserve(est);
+        c.mi[0].reserve(est);
+        if (kind == 0) {
+            c.ci[1].reserve(est);
+            c.mi[1].reserve(est);
+        }
+        if (kind != 2) c.iv.reserve(est);
+        if (kind == 2 || (kind == 0 && keep_float)) c.dv.reserve(est);
+    }
     while (b < e) {
         const char* nl = (const char*)std::memchr(b, '\n', (size_t)(e - b));
         const char* le = nl ? nl : e;
@@ -385,7 +397,7 @@ void parse_chunk(const char* b, const char* e, int kind, Chunk& c) {
                     c.ci[1].push_back(intern(fld_b[2], fld_e[2], 1));
                     c.mi[1].push_back(m2);
                     c.iv.push_back((int32_t)tr);
-                    c.dv.push_back(raw);
+                    if (keep_float) c.dv.push_back(raw);
                 }
             }
         } else if (kind == 1) {                            // words[0], int(words[2]), int(words[3]) (fithic.py:583-586)
@@ -524,11 +536,14 @@ bool inflate_stream(const unsigned char* src, size_t n, std::string& text, std::
 extern "C" {
 
 int fhx_host_read_table(const char* path, int32_t kind, int32_t n_threads, fhx_table** out) {
-    if (!path || !out || kind < 0 || kind > 2) return FHX_ERR_ARG;
+    const bool keep_float = !(kind & FHX_TABLE_NO_FLOAT);
+    kind &= ~FHX_TABLE_NO_FLOAT;
+    if (!path || !out || kind < 0 || kind > 2 || (!keep_float && kind != 0)) return FHX_ERR_ARG;
     *out = nullptr;
     fhx_table* t = new (std::nothrow) fhx_table();
     if (!t) return FHX_ERR_NOMEM;
     t->kind = kind;
+    t->has_float = keep_float;
     *out = t;
     if (n_threads <= 0) n_threads = fhx::usable_cpus();
     const bool timing = std::getenv("FHX_TIMING") != nullptr;          // stage clocks on stderr
@@ -668,7 +683,7 @@ int fhx_host_read_table(const char* path, int32_t kind, int32_t n_threads, fhx_t
             for (;;) {
                 const size_t i = next.fetch_add(1);
                 if (i >= ranges.size()) return;
-                parse_chunk(ranges[i].b, ranges[i].e, kind, chunks[i]);
+                parse_chunk(ranges[i].b, ranges[i].e, kind, keep_float, chunks[i]);
             }
         };
         const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, ranges.size()));
@@ -782,7 +797,7 @@ int fhx_table_copy(const fhx_table* t, int32_t column, void* dst) {
     const int kind = t->kind;
     if ((column == 2 || column == 3) && kind != 0) return FHX_ERR_ARG;
     if (column == 4 && kind == 2) return FHX_ERR_ARG;
-    if (column == 5 && kind == 1) return FHX_ERR_ARG;
+    if (column == 5 && (kind == 1 || !t->has_float)) return FHX_ERR_ARG;
     std::atomic<size_t> next{0};
     auto work = [&]() {
         for (;;) {

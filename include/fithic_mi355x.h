@@ -293,6 +293,7 @@ int fhx_host_lbeta_table(double n_total, int64_t max_count, double* lbeta_out, d
  * 4 count = int(float(text)) or hits (int32 each); 5 = the float itself / the bias (double).  A malformed line returns
  * FHX_ERR_REFERENCE_EXIT (the reference raises ValueError there); fhx_table_error gives the line number. */
 typedef struct fhx_table fhx_table;
+#define FHX_TABLE_NO_FLOAT 0x100   /* kind 0 | FHX_TABLE_NO_FLOAT: a contacts table without column 5 (8 B/row less to parse and keep) */
 int fhx_host_read_table(const char* path, int32_t kind, int32_t n_threads, fhx_table** out);
 int64_t fhx_table_rows(const fhx_table* t);
 int32_t fhx_table_n_names(const fhx_table* t);
