@@ -234,8 +234,24 @@ def main():
             import torch.distributed as td
             uid = [_capi_mod().comm_unique_id() if rank == 0 else None]
             td.broadcast_object_list(uid, src=0)                 # torch.distributed only carries the 128-byte id
-            eng.ctx.comm_init(uid[0], rank, world)
-            runner = NativeRunner(eng)
+            ok, why = 1, ""
+            try:
+                if os.environ.get("FHX_BENCH_NO_LIBRARY_COMM"):      # exercise the fallback below
+                    raise RuntimeError("FHX_BENCH_NO_LIBRARY_COMM is set")
+                eng.ctx.comm_init(uid[0], rank, world)
+            except Exception as e:                               # e.g. librccl cannot be loaded a second time on this system
+                ok, why = 0, repr(e)
+            flag = torch.tensor([ok], device=device, dtype=torch.int32)
+            td.all_reduce(flag, op=td.ReduceOp.MIN)              # every rank takes the same path
+            if int(flag.item()) == 1:
+                runner = NativeRunner(eng)
+            else:                                                # say so in the result line and run the torch-driven schedule
+                log("[rank %d] library communicator unavailable (%s): falling back to fithic_amd.dist" % (rank, why or "another rank failed"))
+                if ok:
+                    eng.ctx.comm_destroy()
+                runner = dist.DistributedPass(eng, comm)
+                os.environ["FHX_DIST_PY"] = "fallback"
+                rccl["driver"] = "torch.distributed schedule (fithic_amd.dist); the library communicator did not start: %s" % (why or "on another rank")
         passes = cfg["passes"]
         pass_ms = np.zeros(passes)
 
