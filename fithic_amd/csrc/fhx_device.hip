@@ -1407,6 +1407,10 @@ __device__ __forceinline__ double bh_value(unsigned long long key_bits, double n
     const double pv = __longlong_as_double((long long)key_bits);
     double v = pv * n_tests / rank;           // (p*N)/(i+1): mul then div, never fused
     if (1.0 < v || pv == 1.0) v = 1.0;        // min(bh, 1); p == 1.0 is 1.0 whatever N / rank says (myStats.py:33-34)
+    // The reference's running maximum starts at 0 (myStats.py:30): invisible while N > 0, but fit_Spline can pass a NEGATIVE
+    // number of tests (possible-pair counts go negative with unmappable loci) and then every bh value is negative
+    // and every q is 0 (tests/golden/f12_bh_nonpositive_N.npz).  Clamping the values is the same running maximum.
+    if (v < 0.0) v = 0.0;
     return v;
 }
 
@@ -3222,7 +3226,7 @@ int fhx_bh_array(fhx_ctx* ctx, const double* p, int64_t n, double n_total_tests,
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
     if (n == 0) return FHX_OK;
     if (n >= (1ll << 32)) return fail(ctx, FHX_ERR_UNSUPPORTED, "more than 2^32 p-values");
-    if (!(n_total_tests > 0)) return fail(ctx, FHX_ERR_ARG, "number of tests must be positive");
+    if (!std::isfinite(n_total_tests)) return fail(ctx, FHX_ERR_ARG, "number of tests must be finite");
     for (int64_t i = 0; i < n; ++i)
         if (p[i] < 0.0) return fail(ctx, FHX_ERR_ARG, "negative p-value at index " + std::to_string(i) + " (p-values must be >= 0 or NaN)");
     FHX_HIP(hipSetDevice(ctx->device));
@@ -3258,7 +3262,7 @@ int fhx_bh(fhx_ctx* ctx, double n_total_tests) {
     if (!ctx) return FHX_ERR_ARG;
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
     if (!ctx->have_p) return fail(ctx, FHX_ERR_ARG, "fhx_pvalues must run first");
-    if (!(n_total_tests > 0)) return fail(ctx, FHX_ERR_ARG, "number of tests must be positive");
+    if (!std::isfinite(n_total_tests)) return fail(ctx, FHX_ERR_ARG, "number of tests must be finite");
     FHX_HIP(hipSetDevice(ctx->device));
     FHX_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
     int rc = auto_cutoff(ctx, ctx->d_p, ctx->n_rows, n_total_tests, ctx->d_misc + 6);

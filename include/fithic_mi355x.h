@@ -158,7 +158,8 @@ int fhx_set_outlier_dist_hist(fhx_ctx* ctx, const int64_t* hist, int64_t n_dist)
 int fhx_make_bins(fhx_ctx* ctx, int32_t* n_bins_made);
 int fhx_fit(fhx_ctx* ctx, fhx_fit_info* out);                           /* host; uploads the tables */
 int fhx_pvalues(fhx_ctx* ctx);                                          /* K2 (asynchronous) */
-int fhx_bh(fhx_ctx* ctx, double n_total_tests);                         /* K3 (asynchronous) */
+int fhx_bh(fhx_ctx* ctx, double n_total_tests);                         /* K3 (asynchronous); any finite N: N <= 0 gives
+                                                                          * q = 0 like the reference's loop (running max from 0) */
 int fhx_sync(fhx_ctx* ctx);
 /* Sharded runs with -p >= 3 only.  The reference stops skipping outlier lines after the first line number that
  * is an outlier in two passes (fithic/fithic.py:408-412 on a SortedList with duplicates); that is a

@@ -462,26 +462,34 @@ def benjamini_hochberg(p, n_tests):
     with np.errstate(invalid="ignore", over="ignore"):
         bh = sp * float(n_tests) / rank        # (p*N)/(i+1): same association as the reference
         bh = np.where(sp == 1.0, 1.0, np.where(bh > 1.0, 1.0, bh))     # min(bh, 1): NaN stays NaN
-    # running max with Python max() semantics: max(bh, prev) keeps bh when the comparison is False (NaN)
-    out = np.empty_like(bh)
-    prev = 0.0
+    # running max with Python max() semantics: `bh = max(bh, prev)` returns bh unless prev > bh - NaN propagates, and between
+    # equal values (the two zeros) the LATER one wins; prev starts at the int 0 (myStats.py:30), which only matters when
+    # num_total_tests <= 0 makes the bh values negative (then every q is 0, or -0.0 once a p == 0 has passed)
     nan_at = np.flatnonzero(np.isnan(bh))
-    if len(nan_at) == 0:
-        out = np.maximum.accumulate(bh)
-    else:
-        first = nan_at[0]
-        out[:first] = np.maximum.accumulate(bh[:first]) if first else bh[:0]
-        prev = out[first - 1] if first else 0.0
-        for i in range(first, len(bh)):
-            v = bh[i]
-            # Python: max(v, prev) returns v unless prev > v
-            if prev > v:
-                v = prev
-            out[i] = v
-            prev = v
+    first = int(nan_at[0]) if len(nan_at) else len(bh)
+    out = np.empty_like(bh)
+    out[:first] = _running_python_max(bh[:first])
+    prev = out[first - 1] if first else 0.0
+    for i in range(first, len(bh)):
+        v = bh[i]
+        if prev > v:                            # Python: max(v, prev) returns v unless prev > v
+            v = prev
+        out[i] = v
+        prev = v
     q = np.empty_like(out)
     q[order] = out
     return q
+
+
+def _running_python_max(v):
+    """prev = 0; for x in v: prev = x unless prev > x; yield prev   (no NaN in v) - vectorised, bit for bit"""
+    if len(v) == 0:
+        return v.copy()
+    m = np.maximum.accumulate(np.maximum(v, 0.0))          # the numeric running maximum, the initial 0 included
+    idx = np.arange(len(v))
+    last_zero = np.maximum.accumulate(np.where(v == 0.0, idx, -1))     # between equal values the later one wins: sign of a zero result
+    neg_zero = (last_zero >= 0) & np.signbit(v[np.maximum(last_zero, 0)])
+    return np.where(m == 0.0, np.where(neg_zero, -0.0, 0.0), m)
 
 
 def benjamini_hochberg_pruned(p, n_tests):
@@ -497,6 +505,8 @@ def benjamini_hochberg_pruned(p, n_tests):
     Pinned against benjamini_hochberg() by tests/test_oracle_golden.py."""
     p = np.asarray(p, np.float64)
     N = float(n_tests)
+    if not N > 0.0:                                    # no value ever saturates: nothing to prune
+        return benjamini_hochberg(p, n_tests)
     q = np.ones(len(p), np.float64)
     nan = np.isnan(p)
     q[nan] = np.nan
@@ -525,8 +535,7 @@ def benjamini_hochberg_pruned(p, n_tests):
         with np.errstate(over="ignore"):
             bh = sp * N / rank
         bh = np.where(sp == 1.0, 1.0, np.where(bh > 1.0, 1.0, bh))
-        out = np.maximum.accumulate(bh)
-        q[cand[order]] = out
+        q[cand[order]] = _running_python_max(bh)
     return q
 
 

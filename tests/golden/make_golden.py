@@ -427,6 +427,37 @@ def make_f5():
     print("  %d BH vectors" % len(names))
 
 
+def make_f12():
+    """benjamini_hochberg_correction with a number of tests that is zero or NEGATIVE.  fit_Spline can hand it one: N is the
+    possible-pair count, and `npairs = n - idx` goes negative with unmappable loci (fithic.py:613-615).  The loop
+    starts its running maximum at the int 0 (myStats.py:30), so every negative bh value becomes 0."""
+    print("F12: benjamini_hochberg_correction, N <= 0")
+    rng = np.random.default_rng(12)
+    out = {}
+    names = []
+
+    def add(name, p, N):
+        q = np.array(REF_STATS.benjamini_hochberg_correction(list(p), N), np.float64)
+        out[name + "_p"] = np.asarray(p, np.float64)
+        out[name + "_N"] = np.array([N], np.float64)
+        out[name + "_q"] = q
+        names.append(name)
+
+    add("neg_uniform", rng.uniform(0, 1, 3000), -5000)
+    p = rng.uniform(0, 1, 2000) ** 6
+    p[rng.integers(0, 2000, 200)] = 1.0
+    p[rng.integers(0, 2000, 40)] = np.nan
+    p[rng.integers(0, 2000, 15)] = 0.0
+    add("neg_mixed_nan_one_zero", p, -37)
+    add("neg_fraction", rng.uniform(0, 1, 500) ** 3, -0.25)
+    add("neg_tiny", np.array([0.03, 0.4, 1.0, 0.01]), -10)
+    add("zero_tests", np.array([0.03, 0.4, 1.0, 0.01, 0.0]), 0)
+    add("neg_leading_zero_p", np.array([0.0, 0.2, 0.5, 1.0]), -3)
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "f12_bh_nonpositive_N.npz"), **out)
+    print("  %d BH vectors" % len(names))
+
+
 # ------------------------------------------------------------------------------------------------ F6
 def make_f6():
     print("F6: quirk probes")
@@ -702,8 +733,8 @@ def make_f11():
 
 
 if __name__ == "__main__":
-    which = [a.lower() for a in sys.argv[1:]] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11"]
+    which = [a.lower() for a in sys.argv[1:]] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12"]
     jobs = dict(f1=make_f1, f2=make_f2, f3=make_f3, f4=make_f4, f5=make_f5, f6=make_f6, f7=make_f7, f8=make_f8, f9=make_f9,
-                f10=make_f10, f11=make_f11)
+                f10=make_f10, f11=make_f11, f12=make_f12)
     for w in which:
         jobs[w]()

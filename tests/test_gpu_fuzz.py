@@ -69,7 +69,14 @@ def _make_case(rng, d, nonfixed):
     return paths, kw, len(rows), span
 
 
-@pytest.mark.parametrize("seed", range(36))
+# FHX_FUZZ_SEEDS="lo:hi" runs another range of seeds (campaigns; the default 36 run in every GPU test session)
+_LO, _HI = (int(v) for v in os.environ.get("FHX_FUZZ_SEEDS", "0:36").split(":"))
+
+
+_FOUND = [1413, 2006, 2772, 4554]     # campaign finds, kept: a NEGATIVE number of tests (possible pairs < 0) reaches the BH step
+
+
+@pytest.mark.parametrize("seed", list(range(_LO, _HI)) + ([] if "FHX_FUZZ_SEEDS" in os.environ else _FOUND))
 def test_random_small_runs_match_the_oracle(seed, tmp_path):
     from fithic_amd import _capi, tables
     from fithic_amd.engine import Engine

@@ -184,14 +184,25 @@ def test_bh_values_above_one_and_few_tests_follow_the_reference(ctx):
         assert bits_equal(ctx.bh_array(p, N), fo.benjamini_hochberg(p, N)), N
 
 
+def test_bh_with_zero_or_negative_number_of_tests(ctx):
+    """fit_Spline can pass a negative N (possible-pair counts go negative with unmappable loci; the fuzz campaign
+    found it: seeds 1413, 2006, 2772, 4554): the reference's running maximum starts at 0, so every q is 0 (p == 1.0 stays 1,
+    NaN stays NaN).  Vectors generated by the real myStats.benjamini_hochberg_correction (make_golden.py f12); -0.0 == 0.0."""
+    g = np.load(os.path.join(GOLDEN, "f12_bh_nonpositive_N.npz"))
+    for name in g["names"]:
+        q, want = ctx.bh_array(g[name + "_p"], g[name + "_N"][0]), g[name + "_q"]
+        assert np.array_equal(np.isnan(q), np.isnan(want)), name
+        assert np.array_equal(q[~np.isnan(want)], want[~np.isnan(want)]), name
+
+
 def test_bh_rejects_negative_values_and_bad_test_counts(ctx):
     """A negative "p-value" would index the key histogram past its end (keys are IEEE bit patterns): refused, loudly."""
     from fithic_amd._capi import FhxError
     p = np.array([0.2, -0.1, 0.5])
     with pytest.raises(FhxError, match="negative p-value at index 1"):
         ctx.bh_array(p, 10.0)
-    with pytest.raises(FhxError, match="number of tests must be positive"):
-        ctx.bh_array(np.array([0.2, 0.5]), 0.0)
+    with pytest.raises(FhxError, match="number of tests must be finite"):
+        ctx.bh_array(np.array([0.2, 0.5]), float("nan"))
     assert np.array_equal(ctx.bh_array(np.array([0.2, -0.0, 0.5]), 10.0), np.array([1.0, 0.0, 1.0]))    # -0.0 is zero
 
 

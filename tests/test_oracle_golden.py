@@ -91,6 +91,19 @@ def test_bh_known_answers_bit_exact():
         assert bits_equal(q, g[name + "_q"]), name
 
 
+def test_bh_with_zero_or_negative_number_of_tests():
+    """fit_Spline can pass a negative N (possible-pair counts go negative with unmappable loci): the reference's loop
+    starts its running maximum at 0, so negative bh values give q = 0 (and -0.0 once a p == 0 has passed).  Vectors generated
+    by the real myStats.benjamini_hochberg_correction (make_golden.py f12)."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "f12_bh_nonpositive_N.npz"))
+    assert len(g["names"]) == 6
+    for name in g["names"]:
+        for f in (fo.benjamini_hochberg, fo.benjamini_hochberg_pruned):
+            assert bits_equal(f(g[name + "_p"], g[name + "_N"][0]), g[name + "_q"]), (name, f.__name__)
+
+
 def test_pruned_bh_is_the_same_function():
     """benjamini_hochberg_pruned (used to check q of 10^8-row GPU runs) equals the plain restatement bit for bit: on the
     reference's own known answers and on random vectors with ties, 1.0s, zeros and NaNs at several N / n ratios."""
