@@ -960,7 +960,7 @@ int run_host_pass(const PassInputs& in, const FragTable& frags, PassFit& out, st
         return FHX_ERR_REFERENCE_EXIT;
     }
     const double ymin = *std::min_element(ys.begin(), ys.end());
-    out.spline_s = ymin * ymin;
+    out.spline_s = ymin * ymin;                 // splineError = min(y)*min(y) (fithic.py:948): the product, not pow()
     if (spline_fit(xs.data(), ys.data(), m, out.spline_s, out.spline) != FHX_OK) {
         err = "spline fit rejected its input";
         return FHX_ERR_REFERENCE_EXIT;

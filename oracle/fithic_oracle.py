@@ -574,7 +574,7 @@ def fit_spline(pairs, dist_keys, x, y, b1, b2, mode, L, U, tL, tU, sums, frag, u
         for i in range(1, len(x)):
             if x[i] <= x[i - 1]:
                 raise SystemExit(2)
-        s = min(y) * min(y)
+        s = min(y) * min(y)                                        # fithic.py:948 (a product; Python's ** would be C pow())
         if use_scipy:
             from scipy.interpolate import UnivariateSpline
             ius = UnivariateSpline(x, y, s=s)

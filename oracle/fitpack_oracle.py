@@ -27,9 +27,11 @@ def _givens(piv, ww):
     """fpgivs: returns (cos, sin, new diagonal)."""
     store = abs(piv)
     if store >= ww:
-        dd = store * math.sqrt(1.0 + (ww / piv) ** 2)
+        r = ww / piv
+        dd = store * math.sqrt(1.0 + r * r)        # r*r, not r ** 2: Python's ** is C pow(), < 1 ulp but not the rounded product
     else:
-        dd = ww * math.sqrt(1.0 + (piv / ww) ** 2)
+        r = piv / ww
+        dd = ww * math.sqrt(1.0 + r * r)
     return ww / dd, piv / dd, dd
 
 
@@ -291,7 +293,7 @@ def _fpcurf(iopt, x, y, s, nest, st, ier_in):
             for j in range(K1):
                 l0 += 1
                 term = term + c[l0 - 1] * q[it][j]
-            term = (term - y[it]) ** 2
+            term = (term - y[it]) * (term - y[it])
             fpart = fpart + term
             if new:
                 store = term * 0.5
@@ -358,7 +360,7 @@ def _fpcurf(iopt, x, y, s, nest, st, ier_in):
             for j in range(K1):
                 l0 += 1
                 term = term + c[l0 - 1] * q[it][j]
-            fp = fp + (term - y[it]) ** 2
+            fp = fp + (term - y[it]) * (term - y[it])
         st.c, st.fp = c, fp
         fpms = fp - s
         if abs(fpms) < acc:

@@ -17,7 +17,9 @@ def _write(path, text):
         f.write(text)
 
 
-def _make_case(rng, d, nonfixed):
+def _make_case(rng, d, nonfixed, count_scale=1):
+    """count_scale multiplies every contact count: sums of 1e6..1e10 put the continued fractions into the regimes where K2 seeds
+    its divisions from the previous reciprocal (a >= 1e6, a >= 2e8) and counts beyond the bucket table of the heavy class."""
     res = int(rng.choice([1000, 5000, 40000]))
     n_chr = int(rng.integers(1, 5))
     names = ["chr%s" % s for s in rng.permutation(["1", "2", "10", "X", "M"])[:n_chr]]
@@ -47,12 +49,12 @@ def _make_case(rng, d, nonfixed):
                 lam = 25.0 / (1.0 + dist) ** 1.1
                 c = int(rng.poisson(lam * rng.lognormal(0, 0.5)))
                 if c >= 1 and rng.random() < 0.7:
-                    rows.append("%s\t%d\t%s\t%d\t%d\n" % (ch, m[i], ch, m[j], c))
+                    rows.append("%s\t%d\t%s\t%d\t%d\n" % (ch, m[i], ch, m[j], c * count_scale))
     if n_chr > 1:
         for _ in range(int(rng.integers(0, 300))):
             a, b = rng.choice(n_chr, 2, replace=False)
             rows.append("%s\t%d\t%s\t%d\t%d\n" % (names[a], rng.choice(loci[names[a]]), names[b], rng.choice(loci[names[b]]),
-                                                 1 + int(rng.poisson(0.8))))
+                                                 (1 + int(rng.poisson(0.8))) * count_scale))
     order = rng.permutation(len(rows))
     paths = dict(contacts=os.path.join(d, "c.gz"), frags=os.path.join(d, "f.gz"), bias=os.path.join(d, "b.gz"))
     _write(paths["contacts"], "".join(rows[i] for i in order))
@@ -83,7 +85,9 @@ def test_random_small_runs_match_the_oracle(seed, tmp_path):
     from oracle import fithic_oracle as fo
     rng = np.random.default_rng(9000 + seed)
     nonfixed = seed % 4 == 3
-    paths, kw, n_rows, span = _make_case(rng, str(tmp_path), nonfixed)
+    # seeds from 100 000 on: counts scaled up (the cases of the lower seeds stay what they were)
+    scale = 1 if seed < 100000 else int(np.random.default_rng(seed).choice([1, 37, 2500, 400000]))
+    paths, kw, n_rows, span = _make_case(rng, str(tmp_path), nonfixed, scale)
     try:
         ref = fo.run(paths["contacts"], paths["frags"], kw["bias_path"], kw["resolution"], kw["n_bins"], kw["passes"], kw["mode"],
                      kw["L"], kw["U"], kw["mapp_thres"], kw["tL"], kw["tU"])
@@ -105,6 +109,10 @@ def test_random_small_runs_match_the_oracle(seed, tmp_path):
                     eng.run_pass()
                     eng.next_pass()
             return
+        # Cephes forms p = exp(a log x + b log(1 - x) - lbeta + ...) with a = count: the last bit of the libm's log (glibc on the
+        # reference's side, ocml on the device: both < 1 ulp, not identical) is multiplied by the count.  At Hi-C counts (<= 1e4)
+        # that stays below 1e-11; the scaled-up cases of the campaign seeds reach counts of 1e6 and ~1e-9.
+        tol = max(TOL, 1e-15 * float(np.max(np.abs(con.count)))) if len(con) else TOL
         for pi, r in enumerate(ref):
             out = eng.run_pass()
             v = eng.fetch()
@@ -114,7 +122,7 @@ def test_random_small_runs_match_the_oracle(seed, tmp_path):
                 got = v[key]
                 assert np.array_equal(np.isnan(got), np.isnan(want)), (key, pi)
                 ok = ~np.isnan(want)
-                assert not ok.any() or np.max(np.abs(got[ok] - want[ok])) <= TOL, (key, pi)
+                assert not ok.any() or np.max(np.abs(got[ok] - want[ok])) <= tol, (key, pi)
             assert eng.next_pass() == r.n_outlier_lines_total
     finally:
         eng.close()
