@@ -327,7 +327,7 @@ int fhx_host_write_significances(const char* path, const char* const* chr_names,
  * the rows given to fhx_load_pairs (n_rows must equal the loaded row count); pass all five as NULL and they are rebuilt on
  * the device from the resident rows (slot -> chromosome, midpoint), so that nothing but the file leaves the GPU.  Returns FHX_ERR_UNSUPPORTED - nothing usable
  * written - when a row does not fit the device formatter (a chromosome name longer than 24 bytes, a value of 2^63 or more,
- * a row of 128 bytes or more): the caller then fetches the columns and uses fhx_host_write_significances. */
+ * a row of 192 bytes or more): the caller then fetches the columns and uses fhx_host_write_significances. */
 int fhx_write_significances_device(fhx_ctx* ctx, const char* path, const char* const* chr_names, int32_t n_names,
                                    const int32_t* chr1, const int32_t* mid1, const int32_t* chr2, const int32_t* mid2,
                                    const int32_t* count, int64_t n_rows, int64_t* rows_written, int64_t* bytes_written);

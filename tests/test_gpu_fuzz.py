@@ -115,7 +115,26 @@ def test_random_small_runs_match_the_oracle(seed, tmp_path):
         tol = max(TOL, 1e-15 * float(np.max(np.abs(con.count)))) if len(con) else TOL
         for pi, r in enumerate(ref):
             out = eng.run_pass()
-            v = eng.fetch()
+            v = eng.fetch(p=True, q=True, expcc=True, bias=True)
+            # the significances file as the GPU formats and deflates it: the rows the oracle emits, the characters Python's % gives
+            # for the engine's own values (NaN, 0, 1, denormals, 1e-300 ... all occur here)
+            sig = os.path.join(str(tmp_path), "sig%d.gz" % pi)
+            try:
+                n_written, _ = eng.ctx.write_significances_device(sig, chroms.names)
+            except _capi.FhxError as e:                       # a row of 192 bytes or more: the host writer takes over, as in fit_Spline
+                assert e.code == _capi.FHX_ERR_UNSUPPORTED
+                from fithic_amd.engine import MODES
+                n_written = _capi.host_write_significances(sig, chroms.names, con.chr1, con.mid1, con.chr2, con.mid2, con.count, v["p"], v["q"],
+                                                           v["b1"], v["b2"], v["expcc"], MODES[kw["mode"]], kw["L"], kw["U"])
+            emit = np.flatnonzero(r.emit)
+            assert n_written == len(emit)
+            names = chroms.names
+            want = ["chr1\tfragmentMid1\tchr2\tfragmentMid2\tcontactCount\tp-value\tq-value\tbias1\tbias2\tExpCC\n"]
+            for i in emit.tolist():
+                want.append("%s\t%d\t%s\t%d\t%d\t%e\t%e\t%e\t%e\t%f\n" % (names[con.chr1[i]], con.mid1[i], names[con.chr2[i]], con.mid2[i], con.count[i],
+                                                                         v["p"][i], v["q"][i], v["b1"][i], v["b2"][i], v["expcc"][i]))
+            with gzip.open(sig, "rb") as f:
+                assert f.read() == "".join(want).encode(), ("significances text", pi)
             assert [out.stats["inter_count"], out.stats["inter_sum"], out.stats["intra_all_sum"], out.stats["in_range_sum"]] == list(r.sums)
             assert out.info["bh_total_tests"] == r.N
             for key, want in (("p", r.p), ("q", r.q)):
