@@ -25,8 +25,13 @@ def _load_case(case):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import load_case, case_args
     from fithic_amd import tables
-    meta, _ = load_case(case)
-    kw = case_args(meta)
+    if case.startswith("{"):                            # a random case of the fuzz generator, written by the parent: its kw as JSON
+        import json
+        kw = json.loads(case)
+        kw["U"] = float("inf") if kw["U"] is None else kw["U"]
+    else:
+        meta, _ = load_case(case)
+        kw = case_args(meta)
     chroms = tables.ChromIndex()
     con = tables.read_contacts(kw["contacts"], chroms)
     frag = tables.read_fragments(kw["frags"], chroms)
@@ -70,6 +75,9 @@ def _rank_main(rank, world, conns, case, passes, split, result_path):
         n = len(con)
         if split == "by_chr":
             mine = np.flatnonzero(con.chr1 % world == rank)
+        elif split.startswith("random:"):             # rows dealt at random (the same deal in every rank process)
+            owner = np.random.default_rng(int(split[7:])).integers(0, world, n)
+            mine = np.flatnonzero(owner == rank)
         elif split == "empty_last":                   # the last rank holds no row at all
             mine = np.flatnonzero(con.chr1 % (world - 1) == rank) if rank < world - 1 else np.zeros(0, np.int64)
         else:                                         # contiguous blocks of the file
@@ -140,6 +148,31 @@ def _run_world(world, case, passes, split, tmp_path):
     (3, "f2_all", 2, "empty_last"), (3, "f2_intra", 2, "blocks")])
 def test_native_sharded_pass_equals_single_gpu(world, case, passes, split, tmp_path):
     _run_world(world, case, passes, split, tmp_path)
+
+
+# FHX_FUZZ_SEEDS="lo:hi": random cases of tests/test_gpu_fuzz.py's generator, rows dealt to 2 or 3 ranks at random (one rank may
+# get nothing): every rank's p and q must equal the single-GPU run's bits.  Default: four seeds.
+_LO, _HI = (int(v) for v in os.environ.get("FHX_FUZZ_SEEDS", "0:4").split(":"))
+
+
+@pytest.mark.parametrize("seed", range(_LO, _HI))
+def test_native_sharded_pass_on_random_cases(seed, tmp_path):
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_fuzz as tf
+    rng = np.random.default_rng(77000 + seed)
+    paths, kw, n_rows, _ = tf._make_case(rng, str(tmp_path), False)
+    if kw["mode"] == "interOnly" or n_rows < 8:
+        pytest.skip("no spline pass / too few rows")
+    from oracle import fithic_oracle as fo
+    try:                                                # cases the reference refuses are the single-GPU fuzz test's business
+        fo.run(paths["contacts"], paths["frags"], kw["bias_path"], kw["resolution"], kw["n_bins"], min(kw["passes"], 2), kw["mode"],
+               kw["L"], kw["U"], kw["mapp_thres"], kw["tL"], kw["tU"])
+    except (SystemExit, ZeroDivisionError, TypeError, ValueError, IndexError, KeyError):
+        pytest.skip("the reference refuses this case")
+    case = dict(kw, contacts=paths["contacts"], frags=paths["frags"], U=None if kw["U"] == float("inf") else kw["U"])
+    world = 2 + seed % 2
+    _run_world(world, json.dumps(case), min(kw["passes"], 2), "random:%d" % seed, tmp_path)
 
 
 def _rccl_single_rank(case, passes, result_path):
