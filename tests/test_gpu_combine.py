@@ -55,6 +55,24 @@ def test_large_random_tables_equal_the_oracle(kw, tmp_path):
     assert got == want
 
 
+_CN_LO, _CN_HI = (int(v) for v in os.environ.get("FHX_FUZZ_SEEDS", "0:6").split(":"))      # campaigns: FHX_FUZZ_SEEDS="lo:hi"
+
+
+@pytest.mark.parametrize("seed", range(_CN_LO, _CN_HI))
+def test_random_tables_and_parameters_equal_the_oracle(seed, tmp_path):
+    """Random table sizes, densities, resolutions and every parameter of the merge: the same lines as the oracle."""
+    from fithic_amd import combine
+    from oracle import combine_oracle as co
+    rng = np.random.default_rng(5000 + seed)
+    path = str(tmp_path / "sig.gz")
+    res = int(rng.choice([1000, 5000, 40000]))
+    _random_table(path, rng, int(rng.integers(50, 30000)), int(rng.integers(1, 6)), res, int(rng.integers(40, 1200)))
+    kw = dict(conn=int(rng.choice([4, 8])), pct=int(rng.choice([10, 30, 50, 70, 100])), neigh=int(rng.integers(1, 5)), order=int(rng.integers(0, 2)))
+    want = co.combine_lines(path, res, **kw)
+    names, rec, info = combine.combine_records(combine.read_significances(path, 1), res, **kw)
+    assert combine.format_lines(names, rec, res) == want, kw
+
+
 def test_off_lattice_rows_and_mode_zero_are_refused():
     from fithic_amd import _capi
     cn = _capi.CniContext(0)
