@@ -288,9 +288,32 @@ struct fhx_table {
 
 namespace {
 
-inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
+// str.split() of a line read in text mode: ASCII whitespace as Python's str sees it (\x1c-\x1f are separators too; \n ends the
+// line).  Deviations, documented in INTEGRATION.md: non-ASCII whitespace (NBSP, U+2000...) is not a separator here, and a lone
+// \r is whitespace, not a line end (text mode's universal newlines); \r\n is handled (the \r is trailing whitespace).
+inline bool is_space(char c) { return c == ' ' || (c >= '\t' && c <= '\r') || (c >= '\x1c' && c <= '\x1f'); }
 
-inline bool parse_i32(const char* b, const char* e, int32_t& out) {      // Python int(): optional sign, digits
+// Python's int() / float() grammar on an ASCII token: underscores are allowed singly BETWEEN digits (PEP 515).  Copies the token
+// without them; false if an underscore is misplaced, or the token holds a non-ASCII byte (Python accepts any Unicode decimal
+// digit there - not supported: such a line is refused, which the caller reports).
+inline bool strip_underscores(const char* b, const char* e, char* dst, size_t cap, size_t& n) {
+    n = 0;
+    for (const char* p = b; p < e; ++p) {
+        const unsigned char ch = (unsigned char)*p;
+        if (ch >= 0x80) return false;
+        if (ch == '_') {
+            const bool left = p > b && p[-1] >= '0' && p[-1] <= '9', right = p + 1 < e && p[1] >= '0' && p[1] <= '9';
+            if (!left || !right) return false;
+            continue;
+        }
+        if (n + 1 >= cap) return false;
+        dst[n++] = (char)ch;
+    }
+    dst[n] = 0;
+    return true;
+}
+
+inline bool parse_i32_plain(const char* b, const char* e, int32_t& out) {      // optional sign, ASCII digits
     if (b == e) return false;
     bool neg = false;
     if (*b == '+' || *b == '-') {
@@ -310,6 +333,15 @@ inline bool parse_i32(const char* b, const char* e, int32_t& out) {      // Pyth
     return true;
 }
 
+inline bool parse_i32(const char* b, const char* e, int32_t& out) {      // Python int(): optional sign, digits, single '_' between digits
+    if (parse_i32_plain(b, e, out)) return true;
+    if (std::memchr(b, '_', (size_t)(e - b)) == nullptr) return false;
+    char tmp[64];
+    size_t n = 0;
+    if (!strip_underscores(b, e, tmp, sizeof(tmp), n)) return false;
+    return parse_i32_plain(tmp, tmp + n, out);
+}
+
 inline bool parse_f64(const char* b, const char* e, double& out) {       // Python float()
     // counts are nearly always plain digits: up to 15 of them are exact in a double and need no strtod
     if (e - b >= 1 && e - b <= 15) {
@@ -321,11 +353,12 @@ inline bool parse_f64(const char* b, const char* e, double& out) {       // Pyth
             return true;
         }
     }
-    char tmp[64];
-    const size_t n = (size_t)(e - b);
-    if (n == 0 || n >= sizeof(tmp)) return false;
-    std::memcpy(tmp, b, n);
-    tmp[n] = 0;
+    // the rest through strtod, restricted to what float() takes: no hexadecimal form, no "nan(...)", underscores by PEP 515
+    char tmp[400];
+    size_t n = 0;
+    if (!strip_underscores(b, e, tmp, sizeof(tmp), n) || n == 0) return false;
+    for (size_t i = 0; i < n; ++i)
+        if (tmp[i] == 'x' || tmp[i] == 'X' || tmp[i] == '(' || tmp[i] == 'p' || tmp[i] == 'P') return false;
     char* end = nullptr;
     out = std::strtod(tmp, &end);
     return end == tmp + n;

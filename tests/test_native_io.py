@@ -56,6 +56,65 @@ def test_reader_rejects_what_the_reference_rejects(tmp_path):
         _capi.host_read_table(str(tmp_path / "missing.gz"), 0)
 
 
+def test_reader_follows_python_number_and_split_grammar(tmp_path):
+    """fithic.py:413-417 does `lines.split()`, `int(mid)`, `int(float(count))` on lines read in text mode.  Random lines built from
+    ordinary and adversarial ASCII tokens (signs, underscores by PEP 515, exponents, nan / inf, hexadecimal forms that strtod
+    takes and float() does not, values outside int32, wrong field counts, every ASCII separator str.split() knows) must be
+    accepted or refused exactly as Python does, with the same values.  Non-ASCII digits and spaces (which Python would take)
+    are refused: a documented deviation."""
+    rng = np.random.default_rng(3)
+    int_tok = ["5", "+5", "-5", "0", "007", "1_000", "1__0", "_1", "1_", "2147483647", "2147483648", "-2147483648", "-2147483649", "12a", "1.0",
+               "1e3", "0x10", "+", "-", "+-3"]
+    flt_tok = ["3", "3.9", "-2.5", "1e3", "1E3", "1e-3", ".5", "5.", "nan", "NaN", "inf", "-inf", "Infinity", "infinity", "1_0.5", "1__0", "0x10",
+               "0x1p3", "1e400", "-1e400", "4294967296", "2147483647.9", "2147483648", "abc", "1e", "e5", "+7", "--7", "1.2.3", "1d3", "1,5",
+               "9" * 20, "0" * 30 + "7", "1" + "0" * 70, "nan(1)", "1e+3", "1e+", "-.5e-2", "1_0e1_0", "_1.0", ".", "in", "infin"]
+
+    def python_parse(line):
+        f = line.split()
+        if len(f) != 5:
+            return None
+        try:
+            m1, m2, c = int(f[1]), int(f[3]), int(float(f[4]))
+        except (ValueError, OverflowError):
+            return None
+        if not all(-2 ** 31 <= v < 2 ** 31 for v in (m1, m2, c)):
+            return None                                            # int32 columns: refusing is the documented behaviour
+        return (f[0], m1, f[2], m2, c)
+
+    path = str(tmp_path / "c.gz")
+    checked = accepted = 0
+    for trial in range(1500):
+        t1 = "123" if rng.random() < 0.5 else str(rng.choice(int_tok))
+        t2 = str(rng.choice(int_tok[:4]))
+        tf = "4" if rng.random() < 0.3 else str(rng.choice(flt_tok))
+        sep = str(rng.choice(["\t", " ", "  ", " \t", "\x0b", "\x0c", "\x1c", "\x1f", "\r"]))
+        fields = ["chrA", t1, "chrB", t2, tf]
+        if rng.random() < 0.05:
+            fields = fields[:4]
+        if rng.random() < 0.05:
+            fields.append("x")
+        line = sep.join(fields) + str(rng.choice(["\n", "\r\n", " \n"]))
+        if sep == "\r":
+            continue                                               # a lone \r ends a line in text mode: documented deviation
+        with gzip.open(path, "wt") as f:
+            f.write("chr1\t5\tchr1\t9\t2\n" + line + "chr2\t1\tchr2\t2\t3\n")
+        want = python_parse(line)
+        try:
+            names, cols, _ = _capi.host_read_table(path, 0, 1)
+            got = (names[cols[0][1]], int(cols[1][1]), names[cols[2][1]], int(cols[3][1]), int(cols[4][1])) if len(cols[1]) == 3 else "rows"
+        except _capi.FhxError:
+            got = None
+        assert got == want, repr(line)
+        checked += 1
+        accepted += want is not None
+    assert checked > 1000 and 300 < accepted < checked - 300
+    for line in ("chrA\t\u0663\tchrB\t5\t4\n", "chrA\t3\tchrB\t5\t\u0661\u0662\n"):        # Arabic-Indic digits: Python reads 3 and 12
+        with gzip.open(path, "wt", encoding="utf-8") as f:
+            f.write(line)
+        with pytest.raises(_capi.FhxError):
+            _capi.host_read_table(path, 0, 1)
+
+
 @pytest.mark.parametrize("name", ALL_CASES)
 def test_writer_reproduces_the_reference_file(name, tmp_path):
     """Values from the checker (bit-identical to the reference, see test_oracle_golden) through the PRODUCT's writer:
