@@ -137,6 +137,15 @@ def test_random_small_runs_match_the_oracle(seed, tmp_path):
                 assert f.read() == "".join(want).encode(), ("significances text", pi)
             assert [out.stats["inter_count"], out.stats["inter_sum"], out.stats["intra_all_sum"], out.stats["in_range_sum"]] == list(r.sums)
             assert out.info["bh_total_tests"] == r.N
+            # the host fit, bit for bit: bins, their means, the spline table after the antitonic regression, BH's N above
+            A = out.arrays
+            for k, mine in (("lb", "bin_lb"), ("ub", "bin_ub"), ("s1", "bin_poss"), ("s2", "bin_sumcc"), ("s7", "bin_poss7")):
+                assert np.array_equal(A[mine], np.array([b[k] for b in r.bins])), (k, pi)
+            bits = lambda a, b: len(a) == len(b) and np.array_equal(np.asarray(a, np.float64).view(np.int64), np.asarray(b, np.float64).view(np.int64))
+            assert bits(A["x"], r.x) and bits(A["y"], r.y), pi
+            if r.newSplineY is not None:
+                assert np.array_equal(A["table_x"], r.splineX) and bits(A["table_y"], r.newSplineY) and bits(A["knots"], r.t), pi
+            assert bits(v["expcc"], r.expcc) and bits(v["b1"], r.b1) and bits(v["b2"], r.b2), pi
             for key, want in (("p", r.p), ("q", r.q)):
                 got = v[key]
                 assert np.array_equal(np.isnan(got), np.isnan(want)), (key, pi)
