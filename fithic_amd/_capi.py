@@ -92,6 +92,7 @@ SYMBOLS = {
     "fhx_kernel_seconds": (ctypes.c_int, [_P, _F64P, _F64P, _F64P]),
     "fhx_k2_heavy_launch": (ctypes.c_int, [_P, _F64P, _I64P]),
     "fhx_bdtrc_array": (ctypes.c_int, [_P, ctypes.c_double, _I32P, _F64P, ctypes.c_int64, _F64P]),
+    "fhx_debug_format": (ctypes.c_int, [_P, _F64P, ctypes.c_int64, ctypes.c_int32, ctypes.c_char_p, _I32P]),
     "fhx_debug_contfrac": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _F64P, _F64P, _F64P, ctypes.c_int64, _F64P]),
     "fhx_debug_lean_div": (ctypes.c_int, [_P, _F64P, _F64P, ctypes.c_int64, _F64P]),
     "fhx_bh_array": (ctypes.c_int, [_P, _F64P, ctypes.c_int64, ctypes.c_double, _F64P]),
@@ -502,6 +503,15 @@ class Context:
         self._check(self._L.fhx_debug_contfrac(self._h, int(kind), int(lazy), _ptr(a, ctypes.c_double), _ptr(b, ctypes.c_double),
                                                _ptr(x, ctypes.c_double), len(a), _ptr(out, ctypes.c_double)))
         return out
+
+    def debug_format(self, values, kind):
+        """The device writer's "%e" (kind 0) / "%f" (kind 1) of every value: list of bytes, None where the device does not cover it."""
+        v = np.ascontiguousarray(values, np.float64)
+        text = ctypes.create_string_buffer(len(v) * 32)
+        ln = np.empty(len(v), np.int32)
+        self._check(self._L.fhx_debug_format(self._h, _ptr(v, ctypes.c_double), len(v), int(kind), text, _ptr(ln, ctypes.c_int32)))
+        raw = text.raw
+        return [raw[32 * i:32 * i + ln[i]] if ln[i] > 0 else None for i in range(len(v))]
 
     def debug_lean_div(self, n, d):
         n, d = (np.ascontiguousarray(v, np.float64) for v in (n, d))

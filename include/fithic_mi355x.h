@@ -207,6 +207,9 @@ int fhx_debug_contfrac(fhx_ctx* ctx, int kind, int lazy, const double* a, const 
 
 /* Test hook: out[i] = K2's lean division of n[i] / d[i] (must equal IEEE n/d inside the operand window it is used in). */
 int fhx_debug_lean_div(fhx_ctx* ctx, const double* n, const double* d, int64_t len, double* out);
+/* Test hook: the device writer's number formatting on arbitrary doubles - kind 0 "%e", 1 "%f"; text32 receives 32 bytes per value
+ * (zero padded), len the character count, or -1 where the device formatter hands the row to the host (|v| >= 2^64 / 2^63). */
+int fhx_debug_format(fhx_ctx* ctx, const double* values, int64_t n, int32_t kind, char* text32, int32_t* len);
 
 /* ---- distributed BH building blocks (section 8e): local sort, then rank/scan over a global segment -- */
 /* Early cutoff (exact): the reference's q is a FORWARD running max of min(p*N/rank, 1), so every p at or above the first

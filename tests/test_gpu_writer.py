@@ -186,3 +186,56 @@ def test_members_without_an_emitted_row_are_left_out(tmp_path):
     assert rows == n_emit == n_trans == int((cols[0] != cols[2]).sum()) > 0
     assert len(_members(path)) <= 1 + (n_trans + 65535) // 65536 + 1 < (n + 65535) // 65536
     eng.close()
+
+
+def test_device_number_formatting_equals_python_on_adversarial_doubles():
+    """fmt_e6 / fmt_f6 as the GPU compiles them (fhx_debug_format) against Python's % on 1.2e6 doubles: random bit patterns, p-value-
+    like and ExpCC-like magnitudes, exact decimal ties ((2k+1)/2^j and their 1e-6 multiples), neighbours of every power of ten
+    from 1e-330 to 1e25, denormals, zeros, infinities, NaN.  The CPU build of the same header is checked against libc in
+    tests/test_fmt.py; this is the device build."""
+    from fithic_amd import _capi
+    rng = np.random.default_rng(99)
+    vals = [rng.integers(0, 1 << 64, 400_000, dtype=np.uint64).view(np.float64),
+            rng.random(200_000) ** (1.0 + 40.0 * rng.random(200_000)),
+            rng.random(100_000) * 10.0 ** rng.integers(-3, 9, 100_000),
+            np.exp(rng.normal(0, 0.4, 50_000))]
+    ties = []
+    for j in range(1, 40):
+        k = 2.0 * np.arange(2000) + 1.0
+        ties += [np.ldexp(k, -j), np.ldexp(k, -j) * 1e-6, k * 0.5e-6, np.arange(2000) + 0.5]
+    vals += ties
+    p10 = []
+    for e in range(-330, 26):
+        v = np.float64(10.0) ** e
+        row = [v]
+        for _ in range(3):
+            row += [np.nextafter(row[-1], np.inf)]
+        lo = v
+        for _ in range(3):
+            lo = np.nextafter(lo, 0.0)
+            row.append(lo)
+        row = np.array(row)
+        p10 += [row, row * 9.9999995, row * 1.0000005]
+    vals += p10
+    vals.append(np.array([0.0, -0.0, 1.0, -1.0, 0.5, 9.9999995, 0.9999995, 5e-7, 1.5e-6, 2.5e-6, 123456.5, 1e15, 1e16, 9007199254740993.0, 4.9e-324,
+                          2.2250738585072014e-308, 1.7976931348623157e308, 1e22, 1e23, 1.8446744073709552e19, 9.2233720368547758e18, np.nan, np.inf,
+                          -np.inf, 999999.5, 9999999.5, 0.1 + 0.2, 1.0 / 3.0]))
+    v = np.concatenate([np.asarray(a, np.float64).ravel() for a in vals])
+    v = np.concatenate([v, -v])
+    ctx = _capi.Context(0)
+    checked = 0
+    for kind, spec, limit in ((0, "%e", 2.0 ** 64), (1, "%f", 2.0 ** 63)):
+        got = ctx.debug_format(v, kind)
+        vl = v.tolist()
+        for i, g in enumerate(got):
+            x = vl[i]
+            if g is None:
+                assert abs(x) >= limit, (spec, x)           # only what the header says it does not cover
+                continue
+            want = (spec % x).encode()
+            if want in (b"-nan",):
+                want = b"nan"
+            assert g == want, (spec, repr(x), g, want)
+            checked += 1
+    ctx.close()
+    assert checked > 2_000_000
