@@ -154,3 +154,50 @@ def test_random_small_runs_match_the_oracle(seed, tmp_path):
             assert eng.next_pass() == r.n_outlier_lines_total
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("seed", [100003, 100011, 100021, 100034] if "FHX_FUZZ_SEEDS" not in os.environ else list(range(_LO, _HI)))
+def test_table_fed_heavy_class_equals_the_per_lane_kernel_on_random_cases(seed, tmp_path, monkeypatch):
+    """k2h_heavy (count-homogeneous waves, iteration constants from a table, uniform renormalisation, nontemporal stores) against
+    round 1's per-lane kernel (FHX_K2_LEGACY=1) on the random cases of this file, counts scaled so that the totals range from
+    1e3 to 1e10: p and q bit for bit, every pass."""
+    from fithic_amd import tables
+    from fithic_amd.engine import Engine
+    rng = np.random.default_rng(9000 + seed)
+    scale = 1 if seed < 100000 else int(np.random.default_rng(seed).choice([1, 37, 2500, 400000]))
+    paths, kw, n_rows, _ = _make_case(rng, str(tmp_path), seed % 4 == 3, scale)
+    chroms = tables.ChromIndex()
+    con = tables.read_contacts(paths["contacts"], chroms)
+    frags = tables.read_fragments(paths["frags"], chroms)
+    bias = tables.read_bias(kw["bias_path"], chroms) if kw["bias_path"] else None
+    got = {}
+    for tag in ("table", "per-lane"):
+        if tag == "per-lane":
+            monkeypatch.setenv("FHX_K2_LEGACY", "1")
+        else:
+            monkeypatch.delenv("FHX_K2_LEGACY", raising=False)
+        eng = Engine(0)
+        res_passes = []
+        try:
+            eng.configure(kw["resolution"], kw["L"], kw["U"], kw["n_bins"], kw["mapp_thres"], kw["mode"], kw["tL"], kw["tU"])
+            eng.load_fragments(*frags, chroms.sort_rank())
+            if bias:
+                eng.load_bias(*bias)
+            eng.load_contacts(con.chr1, con.mid1, con.chr2, con.mid2, con.count)
+            for _ in range(kw["passes"]):
+                eng.run_pass(collect=False)
+                res_passes.append(eng.fetch())
+                eng.next_pass()
+        except Exception as e:                                 # cases the reference refuses: both modes must refuse alike
+            res_passes.append(type(e).__name__)
+        finally:
+            eng.close()
+        got[tag] = res_passes
+    assert len(got["table"]) == len(got["per-lane"])
+    for a, b in zip(got["table"], got["per-lane"]):
+        if isinstance(a, str) or isinstance(b, str):
+            assert a == b
+            continue
+        for key in ("p", "q"):
+            same = (a[key].view(np.int64) == b[key].view(np.int64)) | (np.isnan(a[key]) & np.isnan(b[key]))
+            assert same.all(), (key, int((~same).sum()))
