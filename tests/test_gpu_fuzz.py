@@ -201,3 +201,50 @@ def test_table_fed_heavy_class_equals_the_per_lane_kernel_on_random_cases(seed, 
         for key in ("p", "q"):
             same = (a[key].view(np.int64) == b[key].view(np.int64)) | (np.isnan(a[key]) & np.isnan(b[key]))
             assert same.all(), (key, int((~same).sum()))
+
+
+@pytest.mark.parametrize("seed", [3, 8, 14, 21, 27, 33] if "FHX_FUZZ_SEEDS" not in os.environ else list(range(_LO, _HI)))
+def test_command_line_on_random_cases_writes_the_oracle_files(seed, tmp_path, capsys):
+    """`python -m fithic_amd` end to end on the random cases: the .fithic_passN text equals the oracle's byte for byte; every row
+    of the significances file has the oracle's identity columns, biases and ExpCC as text and p / q within tolerance (a p that
+    differs in its 14th digit may print a different 7th once in ~1e7 values, so p and q are compared as numbers)."""
+    from fithic_amd import cli
+    from oracle import fithic_oracle as fo
+    rng = np.random.default_rng(9000 + seed)
+    nonfixed = seed % 4 == 3
+    paths, kw, n_rows, _ = _make_case(rng, str(tmp_path), nonfixed)
+    try:
+        ref = fo.run(paths["contacts"], paths["frags"], kw["bias_path"], kw["resolution"], kw["n_bins"], kw["passes"], kw["mode"],
+                     kw["L"], kw["U"], kw["mapp_thres"], kw["tL"], kw["tU"], keep_text=True)
+    except (SystemExit, ZeroDivisionError, TypeError, ValueError, IndexError, KeyError):
+        ref = None
+    out = os.path.join(str(tmp_path), "out")
+    argv = ["-i", paths["contacts"], "-f", paths["frags"], "-o", out, "-l", "Z", "-r", str(kw["resolution"]), "-b", str(kw["n_bins"]),
+            "-p", str(kw["passes"]), "-x", kw["mode"], "-m", str(kw["mapp_thres"])]
+    if kw["L"]:
+        argv += ["-L", str(kw["L"])]
+    if kw["U"] != float("inf"):
+        argv += ["-U", str(kw["U"])]
+    if kw["bias_path"]:
+        argv += ["-t", kw["bias_path"]]
+    if ref is None:
+        with pytest.raises((SystemExit, Exception)):
+            cli.main(argv)
+        return
+    cli.main(argv)
+    capsys.readouterr()
+    tag = (".res%d" % kw["resolution"]) if kw["resolution"] else ""
+    for pi, r in enumerate(ref, 1):
+        with open(os.path.join(out, "Z.fithic_pass%d%s.txt" % (pi, tag))) as f:
+            assert f.read() == r.pass_txt, pi
+        with gzip.open(os.path.join(out, "Z.spline_pass%d%s.significances.txt.gz" % (pi, tag)), "rt") as f:
+            mine = f.read().splitlines()
+        want = r.sig_txt.splitlines()
+        assert len(mine) == len(want) and mine[0] == want[0], pi
+        for a, b in zip(mine[1:], want[1:]):
+            fa, fb = a.split("\t"), b.split("\t")
+            assert fa[:5] == fb[:5] and fa[7:] == fb[7:], (pi, a, b)
+            for k in (5, 6):
+                if fa[k] != fb[k]:
+                    va, vb = float(fa[k]), float(fb[k])
+                    assert (np.isnan(va) and np.isnan(vb)) or abs(va - vb) <= max(TOL, 2e-6 * abs(vb)), (pi, a, b)
