@@ -144,62 +144,64 @@ def main(argv=None):
     print("\n")
 
     F.reset_session()
-    F.resolution = resolution
-    F.device = args.device
-    if args.gpus < 1:
-        print("Invalid Option. --gpus must be at least 1")
-        sys.exit(2)
-    if args.gpus > 1 and resolution == 0:
-        print("--gpus N needs fixed-size data (-r > 0); running on one GPU")
-    F.gpus = args.gpus if resolution > 0 else 1
-    F.logfile = os.path.join(outputPath, libName + ".fithic.log")
+    try:                                       # the engine (and, with --gpus N, its worker processes) is released on every path
+        F.resolution = resolution
+        F.device = args.device
+        if args.gpus < 1:
+            print("Invalid Option. --gpus must be at least 1")
+            sys.exit(2)
+        if args.gpus > 1 and resolution == 0:
+            print("--gpus N needs fixed-size data (-r > 0); running on one GPU")
+        F.gpus = args.gpus if resolution > 0 else 1
+        F.logfile = os.path.join(outputPath, libName + ".fithic.log")
 
-    (mainDic, observedInterAllCount, observedInterAllSum, observedIntraAllSum, observedIntraInRangeSum) = \
-        F.read_Interactions(contactCountsFile, biasFile)
-    binStats = F.makeBinsFromInteractions(mainDic, noOfBins, observedIntraInRangeSum)
-    (binStats, noOfFrags, maxPossibleGenomicDist, possibleIntraInRangeCount, possibleInterAllCount, interChrProb,
-     baselineIntraChrProb) = F.generate_FragPairs(observedInterAllCount, observedInterAllSum, binStats, fragsFile, resolution)
-    biasDic = F.read_biases(biasFile) if biasFile else 0
-    (x, y, yerr) = F.calculateProbabilities(mainDic, binStats, resolution, os.path.join(outputPath, libName + ".fithic_pass1"),
-                                            observedIntraInRangeSum)
-    t_first = time.time()
-    print("Spline fit Pass 1 starting...")
-    outliersline, outliersdist = [], []
-    (splineXinit, splineYinit, residual, outliersline, outliersdist, FDRXinit, FDRYinit) = F.fit_Spline(
-        mainDic, x, y, yerr, contactCountsFile, os.path.join(outputPath, libName + ".spline_pass1"), biasDic, outliersline,
-        outliersdist, observedIntraInRangeSum, possibleIntraInRangeCount, possibleInterAllCount, observedInterAllCount,
-        observedIntraAllSum, observedInterAllSum, F.biasLowerBound, F.biasUpperBound, resolution, 1)
-    print("Number of outliers is... %s" % len(outliersline))
-    t_first_end = time.time()
-    print("Spline fit Pass 1 completed. Time took %s" % (t_first_end - t_first))
-
-    for i in range(2, 1 + noOfPasses):
-        if F.interOnly:
-            print("Extra spline fits will not help with interOnly spline fit... Bypassing option")
-            break
-        print("\n")
-        print("\n")
         (mainDic, observedInterAllCount, observedInterAllSum, observedIntraAllSum, observedIntraInRangeSum) = \
-            F.read_Interactions(contactCountsFile, biasFile, outliersline)
-        binStats = F.makeBinsFromInteractions(mainDic, noOfBins, observedIntraInRangeSum, outliersdist)
+            F.read_Interactions(contactCountsFile, biasFile)
+        binStats = F.makeBinsFromInteractions(mainDic, noOfBins, observedIntraInRangeSum)
         (binStats, noOfFrags, maxPossibleGenomicDist, possibleIntraInRangeCount, possibleInterAllCount, interChrProb,
          baselineIntraChrProb) = F.generate_FragPairs(observedInterAllCount, observedInterAllSum, binStats, fragsFile, resolution)
-        (x, y, yerr) = F.calculateProbabilities(mainDic, binStats, resolution, os.path.join(outputPath, libName + ".fithic_pass" + str(i)),
+        biasDic = F.read_biases(biasFile) if biasFile else 0
+        (x, y, yerr) = F.calculateProbabilities(mainDic, binStats, resolution, os.path.join(outputPath, libName + ".fithic_pass1"),
                                                 observedIntraInRangeSum)
-        print("Spline fit Pass %s starting..." % i)
-        (splineX, splineY, residual, outliersline, outliersdist, FDRX, FDRY) = F.fit_Spline(
-            mainDic, x, y, yerr, contactCountsFile, os.path.join(outputPath, libName + ".spline_pass" + str(i)), biasDic, outliersline,
+        t_first = time.time()
+        print("Spline fit Pass 1 starting...")
+        outliersline, outliersdist = [], []
+        (splineXinit, splineYinit, residual, outliersline, outliersdist, FDRXinit, FDRYinit) = F.fit_Spline(
+            mainDic, x, y, yerr, contactCountsFile, os.path.join(outputPath, libName + ".spline_pass1"), biasDic, outliersline,
             outliersdist, observedIntraInRangeSum, possibleIntraInRangeCount, possibleInterAllCount, observedInterAllCount,
-            observedIntraAllSum, observedInterAllSum, F.biasLowerBound, F.biasUpperBound, resolution, i)
-        print("Spline fit Pass %s completed. Time took %s" % (i, (t_first_end - t_first)))   # the reference prints pass 1's time (:372)
-        if F.visual:
-            from . import plots
-            plots.compare_Spline_FDR(FDRXinit, FDRYinit, FDRX, FDRY, os.path.join(outputPath, libName + ".spline_FDR_comparison"), str(i))
-            plots.compareFits_Spline(splineXinit, splineYinit, splineX, splineY, os.path.join(outputPath, libName + ".spline_comparison"), str(i))
-    print("=========================")
-    print("Fit-Hi-C completed successfully")
-    print("\n")
-    F.reset_session()
+            observedIntraAllSum, observedInterAllSum, F.biasLowerBound, F.biasUpperBound, resolution, 1)
+        print("Number of outliers is... %s" % len(outliersline))
+        t_first_end = time.time()
+        print("Spline fit Pass 1 completed. Time took %s" % (t_first_end - t_first))
+
+        for i in range(2, 1 + noOfPasses):
+            if F.interOnly:
+                print("Extra spline fits will not help with interOnly spline fit... Bypassing option")
+                break
+            print("\n")
+            print("\n")
+            (mainDic, observedInterAllCount, observedInterAllSum, observedIntraAllSum, observedIntraInRangeSum) = \
+                F.read_Interactions(contactCountsFile, biasFile, outliersline)
+            binStats = F.makeBinsFromInteractions(mainDic, noOfBins, observedIntraInRangeSum, outliersdist)
+            (binStats, noOfFrags, maxPossibleGenomicDist, possibleIntraInRangeCount, possibleInterAllCount, interChrProb,
+             baselineIntraChrProb) = F.generate_FragPairs(observedInterAllCount, observedInterAllSum, binStats, fragsFile, resolution)
+            (x, y, yerr) = F.calculateProbabilities(mainDic, binStats, resolution, os.path.join(outputPath, libName + ".fithic_pass" + str(i)),
+                                                    observedIntraInRangeSum)
+            print("Spline fit Pass %s starting..." % i)
+            (splineX, splineY, residual, outliersline, outliersdist, FDRX, FDRY) = F.fit_Spline(
+                mainDic, x, y, yerr, contactCountsFile, os.path.join(outputPath, libName + ".spline_pass" + str(i)), biasDic, outliersline,
+                outliersdist, observedIntraInRangeSum, possibleIntraInRangeCount, possibleInterAllCount, observedInterAllCount,
+                observedIntraAllSum, observedInterAllSum, F.biasLowerBound, F.biasUpperBound, resolution, i)
+            print("Spline fit Pass %s completed. Time took %s" % (i, (t_first_end - t_first)))   # the reference prints pass 1's time (:372)
+            if F.visual:
+                from . import plots
+                plots.compare_Spline_FDR(FDRXinit, FDRYinit, FDRX, FDRY, os.path.join(outputPath, libName + ".spline_FDR_comparison"), str(i))
+                plots.compareFits_Spline(splineXinit, splineYinit, splineX, splineY, os.path.join(outputPath, libName + ".spline_comparison"), str(i))
+        print("=========================")
+        print("Fit-Hi-C completed successfully")
+        print("\n")
+    finally:
+        F.reset_session()
 
 
 if __name__ == "__main__":

@@ -110,7 +110,10 @@ def reset_session():
     """Forget the loaded tables (a new run in the same interpreter)."""
     global _S
     if _S.engine is not None:
-        _S.engine.close()
+        try:
+            _S.engine.close()
+        except Exception:                      # noqa: BLE001 - a session that failed must not block the next one
+            pass
     _S = _Session()
 
 

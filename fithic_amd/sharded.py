@@ -254,6 +254,7 @@ class ShardedEngine:
         mesh = make_mesh(ctxmp, gpus) if transport == "pipes" else [None] * gpus
         uid = _capi.comm_unique_id() if transport != "pipes" else None
         self.workers = []
+        self.broken = None
         for r in range(1, gpus):
             parent, child = ctxmp.Pipe(duplex=True)
             p = ctxmp.Process(target=_worker_main, args=(r, gpus, devices[r], transport, uid, mesh[r], child), daemon=True)
@@ -273,19 +274,49 @@ class ShardedEngine:
         self.resolution = None
 
     def _all(self, name, *args, per_rank=None):
-        """Run one command on every rank (workers first: collectives need everybody inside the call) -> results by rank."""
-        for r, (_, conn) in enumerate(self.workers, start=1):
-            conn.send((name, per_rank[r] if per_rank else args))
-        out = [getattr(self.local, name)(*(per_rank[0] if per_rank else args))]
+        """Run one command on every rank (workers first: collectives need everybody inside the call) -> results by rank.
+        Every rank's answer is collected before anything is raised, so that a failure (the same refusal on every rank - a spline
+        the reference would exit on -, or one rank's own) leaves the command / answer protocol in step for the next call."""
+        if self.broken:
+            raise RuntimeError("the sharded engine lost a rank earlier (%s): create a new one" % self.broken)
         for r, (proc, conn) in enumerate(self.workers, start=1):
+            try:
+                conn.send((name, per_rank[r] if per_rank else args))
+            except (BrokenPipeError, OSError) as e:
+                self._abandon("rank %d is gone (%r)" % (r, e))
+                raise RuntimeError("rank %d died before %s" % (r, name))
+        local_exc, out = None, [None]
+        try:
+            out[0] = getattr(self.local, name)(*(per_rank[0] if per_rank else args))
+        except Exception as e:                             # noqa: BLE001 - re-raised below, after the other ranks have answered
+            local_exc = e
+        failures = []
+        for r, (proc, conn) in enumerate(self.workers, start=1):
+            waited = 0.0
             while not conn.poll(1.0):
+                waited += 1.0
                 if not proc.is_alive():
-                    raise RuntimeError("rank %d died in %s (exit code %r)" % (r, name, proc.exitcode))
+                    self._abandon("rank %d died in %s (exit code %r)" % (r, name, proc.exitcode))
+                    raise RuntimeError(self.broken)
+                if local_exc is not None and waited >= 30.0:   # rank 0 failed on its own: the others wait for it in a collective
+                    self._abandon("rank 0 failed in %s while rank %d was still inside it" % (name, r))
+                    raise local_exc
             status, val = conn.recv()
             if status != "ok":
-                raise RuntimeError("rank %d failed in %s: %s" % (r, name, val))
+                failures.append("rank %d failed in %s: %s" % (r, name, val))
             out.append(val)
+        if local_exc is not None:
+            raise local_exc
+        if failures:
+            raise RuntimeError("; ".join(failures))
         return out
+
+    def _abandon(self, why):
+        """A rank is lost: no further command can complete.  Stop the remaining workers."""
+        self.broken = why
+        for p, _ in self.workers:
+            if p.is_alive():
+                p.terminate()
 
     # ---- Engine surface -------------------------------------------------------------------------------------------
     def configure(self, resolution, dist_low=0, dist_up=float("inf"), n_bins=100, mapp_thres=1, mode="intraOnly",
@@ -343,8 +374,21 @@ class ShardedEngine:
         return self._all("next_pass")[0]
 
     def close(self):
+        """Never raises: a session is closed on error paths too (and by reset_session before the next run)."""
+        closed_local = False
         try:
-            self._all("close")
+            if not self.broken:
+                self._all("close")
+                closed_local = True
+        except Exception:                                  # noqa: BLE001
+            pass
         finally:
             for p, _ in self.workers:
-                p.join(30)
+                p.join(10)
+                if p.is_alive():
+                    p.terminate()
+            if not closed_local:
+                try:
+                    self.local.close()
+                except Exception:                          # noqa: BLE001
+                    pass

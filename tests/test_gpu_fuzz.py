@@ -205,6 +205,22 @@ def test_table_fed_heavy_class_equals_the_per_lane_kernel_on_random_cases(seed, 
 
 @pytest.mark.parametrize("seed", [3, 8, 14, 21, 27, 33] if "FHX_FUZZ_SEEDS" not in os.environ else list(range(_LO, _HI)))
 def test_command_line_on_random_cases_writes_the_oracle_files(seed, tmp_path, capsys):
+    _cli_case(seed, tmp_path, capsys, gpus=1)
+
+
+@pytest.mark.parametrize("seed", [4, 9] if "FHX_FUZZ_SEEDS" not in os.environ else list(range(_LO, _HI)))
+def test_sharded_command_line_on_random_cases(seed, tmp_path, capsys, monkeypatch):
+    """The same with `--gpus 2` / `--gpus 3` (rows sharded by chromosome over worker processes, collectives over pipes on this
+    one-GPU box; needs -r > 0)."""
+    if seed % 4 == 3:
+        pytest.skip("-r 0 runs on one GPU")
+    monkeypatch.setenv("FHX_CLI_TRANSPORT", "pipes")
+    gpus = 2 + seed % 2
+    monkeypatch.setenv("FHX_CLI_DEVICES", ",".join(["0"] * gpus))
+    _cli_case(seed, tmp_path, capsys, gpus=gpus)
+
+
+def _cli_case(seed, tmp_path, capsys, gpus):
     """`python -m fithic_amd` end to end on the random cases: the .fithic_passN text equals the oracle's byte for byte; every row
     of the significances file has the oracle's identity columns, biases and ExpCC as text and p / q within tolerance (a p that
     differs in its 14th digit may print a different 7th once in ~1e7 values, so p and q are compared as numbers)."""
@@ -227,6 +243,8 @@ def test_command_line_on_random_cases_writes_the_oracle_files(seed, tmp_path, ca
         argv += ["-U", str(kw["U"])]
     if kw["bias_path"]:
         argv += ["-t", kw["bias_path"]]
+    if gpus > 1:
+        argv += ["--gpus", str(gpus)]
     if ref is None:
         with pytest.raises((SystemExit, Exception)):
             cli.main(argv)
