@@ -17,9 +17,11 @@ def _write(path, text):
         f.write(text)
 
 
-def _make_case(rng, d, nonfixed, count_scale=1):
+def _make_case(rng, d, nonfixed, count_scale=1, offgrid=False):
     """count_scale multiplies every contact count: sums of 1e6..1e10 put the continued fractions into the regimes where K2 seeds
-    its divisions from the previous reciprocal (a >= 1e6, a >= 2e8) and counts beyond the bucket table of the heavy class."""
+    its divisions from the previous reciprocal (a >= 1e6, a >= 2e8) and counts beyond the bucket table of the heavy class.
+    offgrid: irregular midpoints (as for -r 0) but run with -r RES: the reference takes |mid1 - mid2| of whatever the files hold
+    and still enumerates possible pairs at multiples of the resolution (the engine slots such input)."""
     res = int(rng.choice([1000, 5000, 40000]))
     n_chr = int(rng.integers(1, 5))
     names = ["chr%s" % s for s in rng.permutation(["1", "2", "10", "X", "M"])[:n_chr]]
@@ -27,7 +29,7 @@ def _make_case(rng, d, nonfixed, count_scale=1):
     frag_lines, bias_lines = [], []
     for ch in names:
         n = int(rng.integers(20, 110))
-        if nonfixed:
+        if nonfixed or offgrid:
             mids = np.cumsum(rng.integers(res // 4 + 1, 3 * res, n))
         else:
             mids = np.arange(n) * res + res // 2
@@ -75,7 +77,9 @@ def _make_case(rng, d, nonfixed, count_scale=1):
 _LO, _HI = (int(v) for v in os.environ.get("FHX_FUZZ_SEEDS", "0:36").split(":"))
 
 
-_FOUND = [1413, 2006, 2772, 4554]     # campaign finds, kept: a NEGATIVE number of tests (possible pairs < 0) reaches the BH step
+_FOUND = [1413, 2006, 2772, 4554,      # campaign finds, kept: a NEGATIVE number of tests (possible pairs < 0) reaches the BH step
+          100024, 110087, 110772,         # counts scaled to 1e4..1e6: libm amplification / the oracle's fitpack squares
+          *range(200000, 200010)]          # -r RES on loci that are not on one grid
 
 
 @pytest.mark.parametrize("seed", list(range(_LO, _HI)) + ([] if "FHX_FUZZ_SEEDS" in os.environ else _FOUND))
@@ -87,7 +91,10 @@ def test_random_small_runs_match_the_oracle(seed, tmp_path):
     nonfixed = seed % 4 == 3
     # seeds from 100 000 on: counts scaled up (the cases of the lower seeds stay what they were)
     scale = 1 if seed < 100000 else int(np.random.default_rng(seed).choice([1, 37, 2500, 400000]))
-    paths, kw, n_rows, span = _make_case(rng, str(tmp_path), nonfixed, scale)
+    offgrid = seed >= 200000                       # seeds from 200 000 on: -r RES on loci that are not on one grid
+    if offgrid:
+        nonfixed, scale = False, 1
+    paths, kw, n_rows, span = _make_case(rng, str(tmp_path), nonfixed, scale, offgrid)
     try:
         ref = fo.run(paths["contacts"], paths["frags"], kw["bias_path"], kw["resolution"], kw["n_bins"], kw["passes"], kw["mode"],
                      kw["L"], kw["U"], kw["mapp_thres"], kw["tL"], kw["tU"])
