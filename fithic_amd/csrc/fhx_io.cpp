@@ -28,6 +28,7 @@
 
 #include "../../include/fithic_mi355x.h"
 #include "fhx_cpus.hpp"
+#include "fhx_io_internal.hpp"
 
 namespace {
 
@@ -566,36 +567,16 @@ bool inflate_stream(const unsigned char* src, size_t n, std::string& text, std::
 
 }  // namespace
 
-extern "C" {
-
-int fhx_host_read_table(const char* path, int32_t kind, int32_t n_threads, fhx_table** out) {
-    const bool keep_float = !(kind & FHX_TABLE_NO_FLOAT);
-    kind &= ~FHX_TABLE_NO_FLOAT;
-    if (!path || !out || kind < 0 || kind > 2 || (!keep_float && kind != 0)) return FHX_ERR_ARG;
-    *out = nullptr;
-    fhx_table* t = new (std::nothrow) fhx_table();
-    if (!t) return FHX_ERR_NOMEM;
-    t->kind = kind;
-    t->has_float = keep_float;
-    *out = t;
-    if (n_threads <= 0) n_threads = fhx::usable_cpus();
-    const bool timing = std::getenv("FHX_TIMING") != nullptr;          // stage clocks on stderr
-    auto t_last = std::chrono::steady_clock::now();
-    std::string t_report;
-    auto mark = [&](const char* what) {
-        if (!timing) return;
-        const auto now = std::chrono::steady_clock::now();
-        char b[96];
-        std::snprintf(b, sizeof(b), " %s %.3f s;", what, std::chrono::duration<double>(now - t_last).count());
-        t_report += b;
-        t_last = now;
-    };
+// The file read whole and inflated into `pieces` (the text, in file order): on n_threads cores when every gzip member carries
+// its size ("FH" of this library's writers, "BC" of bgzip), by one thread otherwise.  seconds[0] = read, seconds[1] = inflate.
+int fhx::io_inflate_file(const char* path, int n_threads, std::vector<std::string>& pieces, std::string& error, double* seconds) {
+    const auto t_begin = std::chrono::steady_clock::now();
     // ---- the compressed file, whole ------------------------------------------------------------------------------
     std::vector<unsigned char> gz;
     {
         std::FILE* f = std::fopen(path, "rb");
         if (!f) {
-            t->error = std::string("cannot open ") + path;
+            error = std::string("cannot open ") + path;
             return FHX_ERR_ARG;
         }
         std::fseek(f, 0, SEEK_END);
@@ -605,17 +586,17 @@ int fhx_host_read_table(const char* path, int32_t kind, int32_t n_threads, fhx_t
         const size_t got = gz.empty() ? 0 : std::fread(gz.data(), 1, gz.size(), f);
         std::fclose(f);
         if (got != gz.size()) {
-            t->error = std::string("read error on ") + path;
+            error = std::string("read error on ") + path;
             return FHX_ERR_ARG;
         }
     }
     if (gz.size() < 18 || gz[0] != 0x1f || gz[1] != 0x8b) {
-        t->error = std::string("not a gzip file: ") + path + " (the reference's gzip.open raises on it)";
+        error = std::string("not a gzip file: ") + path + " (the reference's gzip.open raises on it)";
         return FHX_ERR_REFERENCE_EXIT;
     }
-    mark("file read");
+    if (seconds) seconds[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     // ---- inflate: all cores when every member carries its size ("FH" of this library's writers, "BC" of bgzip) ------
-    std::vector<std::string> pieces;                       // the text, in order
+    pieces.clear();                                        // the text, in order
     std::vector<Member> members;
     if (scan_members(gz.data(), gz.size(), members) && members.size() > 1) {
         const int nt = (int)std::min<size_t>((size_t)n_threads, members.size());
@@ -652,19 +633,57 @@ int fhx_host_read_table(const char* path, int32_t kind, int32_t n_threads, fhx_t
         work(0);
         for (auto& th : pool) th.join();
         if (bad_member >= 0) {
-            t->error = "corrupt gzip member " + std::to_string((long long)bad_member) + " in " + path;
+            error = "corrupt gzip member " + std::to_string((long long)bad_member) + " in " + path;
             return FHX_ERR_REFERENCE_EXIT;
         }
     } else {
         pieces.resize(1);
         std::string err;
         if (!inflate_stream(gz.data(), gz.size(), pieces[0], err)) {
-            t->error = err + " in " + path + " (the reference's gzip module raises on it)";
+            error = err + " in " + path + " (the reference's gzip module raises on it)";
             return FHX_ERR_REFERENCE_EXIT;
         }
     }
-    std::vector<unsigned char>().swap(gz);
-    mark("inflate");
+    if (seconds) seconds[1] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() - seconds[0];
+    return FHX_OK;
+}
+
+extern "C" {
+
+int fhx_host_read_table(const char* path, int32_t kind, int32_t n_threads, fhx_table** out) {
+    const bool keep_float = !(kind & FHX_TABLE_NO_FLOAT);
+    kind &= ~FHX_TABLE_NO_FLOAT;
+    if (!path || !out || kind < 0 || kind > 2 || (!keep_float && kind != 0)) return FHX_ERR_ARG;
+    *out = nullptr;
+    fhx_table* t = new (std::nothrow) fhx_table();
+    if (!t) return FHX_ERR_NOMEM;
+    t->kind = kind;
+    t->has_float = keep_float;
+    *out = t;
+    if (n_threads <= 0) n_threads = fhx::usable_cpus();
+    const bool timing = std::getenv("FHX_TIMING") != nullptr;          // stage clocks on stderr
+    auto t_last = std::chrono::steady_clock::now();
+    std::string t_report;
+    auto mark = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        char b[96];
+        std::snprintf(b, sizeof(b), " %s %.3f s;", what, std::chrono::duration<double>(now - t_last).count());
+        t_report += b;
+        t_last = now;
+    };
+    std::vector<std::string> pieces;                       // the text, in order
+    {
+        double sec[2] = {0, 0};
+        const int rc_in = fhx::io_inflate_file(path, n_threads, pieces, t->error, sec);
+        if (rc_in != FHX_OK) return rc_in;
+        if (timing) {
+            char b[96];
+            std::snprintf(b, sizeof(b), " file read %.3f s; inflate %.3f s;", sec[0], sec[1]);
+            t_report += b;
+            t_last = std::chrono::steady_clock::now();
+        }
+    }
     // ---- parse ranges, in file order: lines that straddle two pieces are glued, the rest is cut on newlines -------------
     struct Range {
         const char *b, *e;
