@@ -65,6 +65,16 @@ SYMBOLS = {
     "fhx_version": (ctypes.c_char_p, []),
     "fhx_set_params": (ctypes.c_int, [_P, ctypes.POINTER(FhxParams)]),
     "fhx_load_fragments": (ctypes.c_int, [_P, _I32P, _I32P, _I32P, ctypes.c_int64, _I32P, ctypes.c_int32]),
+    "fhx_host_inflate": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int32, ctypes.POINTER(_P)]),
+    "fhx_text_bytes": (ctypes.c_int64, [_P]),
+    "fhx_text_error": (ctypes.c_char_p, [_P]),
+    "fhx_host_parse_text": (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_P)]),
+    "fhx_text_free": (None, [_P]),
+    "fhx_ingest_contacts_text": (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32)]),
+    "fhx_ingest_contacts_name": (ctypes.c_char_p, [_P, ctypes.c_int32]),
+    "fhx_ingest_contacts_commit": (ctypes.c_int, [_P, _I32P, ctypes.c_int32]),
+    "fhx_ingest_contacts_discard": (None, [_P]),
+    "fhx_fetch_pairs": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int64), ctypes.c_int64, _I32P, _I32P, _I32P, _I32P, _I32P]),
     "fhx_load_bias": (ctypes.c_int, [_P, _I32P, _I32P, _F64P, ctypes.c_int64]),
     "fhx_load_pairs": (ctypes.c_int, [_P, _I32P, _I32P, _I32P, _I32P, _I32P, ctypes.c_int64]),
     "fhx_load_pairs_device": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int64, _P]),
@@ -323,6 +333,31 @@ class Context:
     def load_pairs_device(self, ptrs, n, stream=None):
         self._check(self._L.fhx_load_pairs_device(self._h, *[_P(int(p)) for p in ptrs], int(n), _P(stream or 0)))
 
+    def ingest_contacts_text(self, text, threads=0):
+        """The inflated contacts file (host_inflate) parsed on the GPU -> (rows, names in order of first appearance).  Raises
+        FhxError(FHX_ERR_UNSUPPORTED) for a file the device parser does not take: host_parse_text(text, ...) then."""
+        n, k = ctypes.c_int64(0), ctypes.c_int32(0)
+        self._check(self._L.fhx_ingest_contacts_text(self._h, text._h, int(threads), ctypes.byref(n), ctypes.byref(k)))
+        return n.value, [self._L.fhx_ingest_contacts_name(self._h, i).decode() for i in range(k.value)]
+
+    def ingest_contacts_commit(self, ids):
+        """ids[i] = the run's chromosome id of name i: the parsed rows become the context's contact rows"""
+        ids = np.ascontiguousarray(ids, np.int32)
+        self._check(self._L.fhx_ingest_contacts_commit(self._h, _ptr(ids, ctypes.c_int32), len(ids)))
+
+    def ingest_contacts_discard(self):
+        self._L.fhx_ingest_contacts_discard(self._h)
+
+    def fetch_pairs(self, rows=None, n=None):
+        """(chr1, mid1, chr2, mid2, count) of the given loaded rows (all n of them when rows is None), rebuilt on the device"""
+        if rows is not None:
+            rows = np.ascontiguousarray(rows, np.int64)
+            n = len(rows)
+        out = [np.empty(int(n), np.int32) for _ in range(5)]
+        self._check(self._L.fhx_fetch_pairs(self._h, _ptr(rows, ctypes.c_int64) if rows is not None else None, int(n),
+                                            *[_ptr(v, ctypes.c_int32) for v in out]))
+        return out
+
     # ---- one pass ----
     def pass_stats(self):
         st = FhxStats()
@@ -566,17 +601,33 @@ class Context:
 
 
 # ---- native text I/O (no context needed) ---------------------------------------------------------------
-def host_read_table(path, kind, threads=0, name_ids=None, want_float=True):
-    """-> (names, int32 columns dict, float64 column or None).  kind: 0 contacts, 1 fragments, 2 bias.
-    name_ids(names) -> the caller's ids of the file's names: the chromosome columns then come out in that id space (mapped inside
-    the parallel copy, not per row in numpy).  want_float=False skips the 8 B/row float column of a contacts file."""
-    L = lib()
-    h = _P()
-    flags = 0x100 if (kind == 0 and not want_float) else 0          # FHX_TABLE_NO_FLOAT
-    rc = L.fhx_host_read_table(os.fsencode(path), int(kind) | flags, int(threads), ctypes.byref(h))
+class HostText:
+    """An inflated file (fhx_host_inflate): input of Ctx.ingest_contacts_text and of host_parse_text."""
+
+    def __init__(self, path, threads=0):
+        L = lib()
+        self._L, self._h = L, _P()
+        rc = L.fhx_host_inflate(os.fsencode(path), int(threads), ctypes.byref(self._h))
+        if rc != FHX_OK:
+            msg = (L.fhx_text_error(self._h) or b"").decode() if self._h else "fhx_host_inflate"
+            self.close()
+            raise FhxError(rc, msg)
+
+    def __len__(self):
+        return int(self._L.fhx_text_bytes(self._h))
+
+    def close(self):
+        if self._h:
+            self._L.fhx_text_free(self._h)
+            self._h = _P()
+
+    __del__ = close
+
+
+def _table_out(L, rc, h, kind, name_ids, want_float, what):
     try:
         if rc != FHX_OK:
-            raise FhxError(rc, (L.fhx_table_error(h) or b"").decode() if h else "fhx_host_read_table")
+            raise FhxError(rc, (L.fhx_table_error(h) or b"").decode() if h else what)
         n = L.fhx_table_rows(h)
         names = [L.fhx_table_name(h, i).decode() for i in range(L.fhx_table_n_names(h))]
         if name_ids is not None and names:
@@ -598,6 +649,26 @@ def host_read_table(path, kind, threads=0, name_ids=None, want_float=True):
     finally:
         if h:
             L.fhx_table_free(h)
+
+
+def host_read_table(path, kind, threads=0, name_ids=None, want_float=True):
+    """-> (names, int32 columns dict, float64 column or None).  kind: 0 contacts, 1 fragments, 2 bias.
+    name_ids(names) -> the caller's ids of the file's names: the chromosome columns then come out in that id space (mapped inside
+    the parallel copy, not per row in numpy).  want_float=False skips the 8 B/row float column of a contacts file."""
+    L = lib()
+    h = _P()
+    flags = 0x100 if (kind == 0 and not want_float) else 0          # FHX_TABLE_NO_FLOAT
+    rc = L.fhx_host_read_table(os.fsencode(path), int(kind) | flags, int(threads), ctypes.byref(h))
+    return _table_out(L, rc, h, kind, name_ids, want_float, "fhx_host_read_table")
+
+
+def host_parse_text(text, kind, threads=0, name_ids=None, want_float=True):
+    """host_read_table's parse stage on an already inflated file (a HostText)"""
+    L = lib()
+    h = _P()
+    flags = 0x100 if (kind == 0 and not want_float) else 0
+    rc = L.fhx_host_parse_text(text._h, int(kind) | flags, int(threads), ctypes.byref(h))
+    return _table_out(L, rc, h, kind, name_ids, want_float, "fhx_host_parse_text")
 
 
 def host_write_contacts(path, names, chr1, mid1, chr2, mid2, count, gzip_level=1, threads=0):

@@ -16,6 +16,7 @@
 #include <atomic>
 #include <chrono>
 #include <thread>
+#include <memory>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -27,6 +28,8 @@
 #include "../../include/fithic_mi355x.h"
 #include "fhx_bdtrc.hpp"
 #include "fhx_host.hpp"
+#include "fhx_io_internal.hpp"
+#include "fhx_scan.hpp"
 
 namespace fhx {
 
@@ -1827,6 +1830,8 @@ struct DistState;
 }
 
 struct fhx_ctx {
+    struct TextIngest;                           // fhx_ingest.inc: a parsed contacts text waiting for its chromosome ids
+    TextIngest* text_ingest = nullptr;
     int device = -1;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [6],[7]: around the heavy K2 launch
@@ -2390,6 +2395,7 @@ void fhx_destroy(fhx_ctx* ctx) {
     if (ctx->device >= 0) {
         (void)hipSetDevice(ctx->device);
         if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        fhx_ingest_contacts_discard(ctx);
         dev_free(ctx->d_loc1);
         dev_free(ctx->d_loc2);
         dev_free(ctx->d_count);
@@ -3640,6 +3646,7 @@ int fhx_kernel_seconds(fhx_ctx* ctx, double* k1, double* k2, double* k3) {
 
 #include "fhx_dist.inc"
 #include "fhx_emit.inc"
+#include "fhx_ingest.inc"
 
 // ---- host numerics exported for tests / host-only callers ----------------------------------------------
 int fhx_host_spline_fit(const double* x, const double* y, int32_t m, double s, double* t, double* c, int32_t* n_knots,

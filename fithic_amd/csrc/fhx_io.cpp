@@ -648,12 +648,12 @@ int fhx::io_inflate_file(const char* path, int n_threads, std::vector<std::strin
     return FHX_OK;
 }
 
-extern "C" {
-
-int fhx_host_read_table(const char* path, int32_t kind, int32_t n_threads, fhx_table** out) {
+// the parse stage of fhx_host_read_table over an inflated text; t_report carries the stage clocks of the stages before it
+static int parse_pieces(const std::vector<std::string>& pieces, const char* path, int32_t kind, int32_t n_threads, fhx_table** out,
+                        std::string t_report) {
     const bool keep_float = !(kind & FHX_TABLE_NO_FLOAT);
     kind &= ~FHX_TABLE_NO_FLOAT;
-    if (!path || !out || kind < 0 || kind > 2 || (!keep_float && kind != 0)) return FHX_ERR_ARG;
+    if (!out || kind < 0 || kind > 2 || (!keep_float && kind != 0)) return FHX_ERR_ARG;
     *out = nullptr;
     fhx_table* t = new (std::nothrow) fhx_table();
     if (!t) return FHX_ERR_NOMEM;
@@ -663,7 +663,6 @@ int fhx_host_read_table(const char* path, int32_t kind, int32_t n_threads, fhx_t
     if (n_threads <= 0) n_threads = fhx::usable_cpus();
     const bool timing = std::getenv("FHX_TIMING") != nullptr;          // stage clocks on stderr
     auto t_last = std::chrono::steady_clock::now();
-    std::string t_report;
     auto mark = [&](const char* what) {
         if (!timing) return;
         const auto now = std::chrono::steady_clock::now();
@@ -672,18 +671,6 @@ int fhx_host_read_table(const char* path, int32_t kind, int32_t n_threads, fhx_t
         t_report += b;
         t_last = now;
     };
-    std::vector<std::string> pieces;                       // the text, in order
-    {
-        double sec[2] = {0, 0};
-        const int rc_in = fhx::io_inflate_file(path, n_threads, pieces, t->error, sec);
-        if (rc_in != FHX_OK) return rc_in;
-        if (timing) {
-            char b[96];
-            std::snprintf(b, sizeof(b), " file read %.3f s; inflate %.3f s;", sec[0], sec[1]);
-            t_report += b;
-            t_last = std::chrono::steady_clock::now();
-        }
-    }
     // ---- parse ranges, in file order: lines that straddle two pieces are glued, the rest is cut on newlines -------------
     struct Range {
         const char *b, *e;
@@ -777,6 +764,54 @@ int fhx_host_read_table(const char* path, int32_t kind, int32_t n_threads, fhx_t
     mark("name index");
     if (timing) std::fprintf(stderr, "fhx_host_read_table(%s): %d threads:%s\n", path, n_threads, t_report.c_str());
     return FHX_OK;
+}
+
+static std::string inflate_report(const fhx_text* x) {
+    char b[96];
+    std::snprintf(b, sizeof(b), " file read %.3f s; inflate %.3f s;", x->seconds[0], x->seconds[1]);
+    return b;
+}
+
+extern "C" {
+
+int fhx_host_inflate(const char* path, int32_t n_threads, fhx_text** out) {
+    if (!path || !out) return FHX_ERR_ARG;
+    *out = nullptr;
+    fhx_text* x = new (std::nothrow) fhx_text();
+    if (!x) return FHX_ERR_NOMEM;
+    *out = x;
+    x->path = path;
+    if (n_threads <= 0) n_threads = fhx::usable_cpus();
+    const int rc = fhx::io_inflate_file(path, n_threads, x->pieces, x->error, x->seconds);
+    if (rc != FHX_OK) return rc;
+    for (const std::string& piece : x->pieces) x->bytes += (int64_t)piece.size();
+    return FHX_OK;
+}
+
+int64_t fhx_text_bytes(const fhx_text* x) { return x ? x->bytes : 0; }
+const char* fhx_text_error(const fhx_text* x) { return x ? x->error.c_str() : "null text"; }
+void fhx_text_free(fhx_text* x) { delete x; }
+
+int fhx_host_parse_text(const fhx_text* text, int32_t kind, int32_t n_threads, fhx_table** out) {
+    if (!text || !out) return FHX_ERR_ARG;
+    return parse_pieces(text->pieces, text->path.c_str(), kind, n_threads, out, inflate_report(text));
+}
+
+int fhx_host_read_table(const char* path, int32_t kind, int32_t n_threads, fhx_table** out) {
+    if (!path || !out) return FHX_ERR_ARG;
+    const int k = kind & ~FHX_TABLE_NO_FLOAT;
+    if (k < 0 || k > 2 || ((kind & FHX_TABLE_NO_FLOAT) && k != 0)) return FHX_ERR_ARG;
+    fhx_text* x = nullptr;
+    int rc = fhx_host_inflate(path, n_threads, &x);
+    if (rc == FHX_OK) {
+        rc = parse_pieces(x->pieces, path, kind, n_threads, out, inflate_report(x));
+    } else if (x) {                                        // the message travels in a table, as before
+        fhx_table* t = new (std::nothrow) fhx_table();
+        if (t) t->error = x->error;
+        *out = t;
+    }
+    fhx_text_free(x);
+    return rc;
 }
 
 // The contacts table as the reference reads it ("%s\t%d\t%s\t%d\t%d\n", fithic/fithic.py:413-417), formatted and deflated

@@ -1,7 +1,17 @@
 // fhx_io_internal.hpp - pieces of the host reader shared with the device-side ingest (not part of the C ABI)
 #pragma once
+#include <cstdint>
 #include <string>
 #include <vector>
+
+// an inflated file (fhx_host_inflate): the text as pieces in file order, one per inflating thread
+struct fhx_text {
+    std::string path;
+    std::vector<std::string> pieces;
+    int64_t bytes = 0;
+    double seconds[2] = {0, 0};                 // file read, inflate
+    std::string error;
+};
 
 namespace fhx {
 

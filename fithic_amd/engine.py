@@ -57,6 +57,12 @@ class Engine:
         self.n_rows = len(mid1)
         self.pass_no = 0
 
+    def commit_contacts_text(self, ids, n):
+        """second half of the device-side ingest (tables.load_contacts): ids of the names ctx.ingest_contacts_text returned"""
+        self.ctx.ingest_contacts_commit(ids)
+        self.n_rows = int(n)
+        self.pass_no = 0
+
     def load_contacts_device(self, ptrs, n, stream=None):
         self.ctx.load_pairs_device(ptrs, n, stream)
         self.n_rows = int(n)

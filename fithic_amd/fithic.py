@@ -132,20 +132,24 @@ def read_Interactions(contactCountsFile, biasFile, outliers=None):
     S = _S
     if S.contacts is None or S.contacts_path != contactCountsFile:
         S.check_resolution()
-        # the HIP runtime and the context come up (a few tenths of a second) while the host cores inflate and parse the file
+        # the HIP runtime and the context come up (a few tenths of a second) while the host cores inflate the file; the GPU
+        # then parses the text (tables.load_contacts; the host parser takes the files the device grammar does not cover)
         import threading
         starter = threading.Thread(target=S.ensure_engine)
         starter.start()
+
+        def engine_of():
+            starter.join()
+            S.configure()
+            return S.engine
         try:
-            S.contacts = tables.read_contacts(contactCountsFile, S.chroms)
+            S.contacts = tables.load_contacts(contactCountsFile, S.chroms, engine_of)
         finally:
             starter.join()
-        S.configure()
         S.contacts_path = contactCountsFile
-        c = S.contacts
         if os.environ.get("FHX_TIMING"):
-            print("stage: inflate + parse of %d rows took %.3f s" % (len(c), time.time() - t0))
-        S.engine.load_contacts(c.chr1, c.mid1, c.chr2, c.mid2, c.count)
+            print("stage: inflate + parse + ingest of %d rows took %.3f s (%s parser)"
+                  % (len(S.contacts), time.time() - t0, "device" if isinstance(S.contacts, tables.DeviceContacts) else "host"))
         S.pass_started = 0
     elif outliers is not None and S.pass_started >= 1 and S.values is not None:
         S.engine.next_pass()                 # fold the previous pass's outliers into the skip mask (K1 skips them)
@@ -384,7 +388,11 @@ def fit_Spline(mainDic, x, y, yerr, infilename, outfilename, biasDic, outliersli
     for r in rows.tolist():
         outliersline.add(r) if hasattr(outliersline, "add") else outliersline.append(r)
     # abs(mid1 - mid2) of every outlier line, inter-chromosomal ones included (fithic.py:1217)
-    for dist in np.abs(con.mid1[rows].astype(np.int64) - con.mid2[rows].astype(np.int64)).tolist():
+    if isinstance(con, tables.DeviceContacts):
+        _, out_mid1, _, out_mid2, _ = con.rows(rows)
+    else:
+        out_mid1, out_mid2 = con.mid1[rows], con.mid2[rows]
+    for dist in np.abs(out_mid1.astype(np.int64) - out_mid2.astype(np.int64)).tolist():
         outliersdist.add(dist) if hasattr(outliersdist, "add") else outliersdist.append(dist)
     if not hasattr(outliersline, "add"):
         outliersline.sort()

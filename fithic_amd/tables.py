@@ -50,6 +50,35 @@ class Contacts:
                         None if self.raw_count is None else self.raw_count[sel])
 
 
+class DeviceContacts:
+    """Contact rows that were parsed on the GPU and never existed as host columns (fhx_ingest_contacts_text): the length is
+    known, the identity columns come back from the device on demand - all of them (the host writer's fallback) or a few rows
+    (the outlier lines)."""
+
+    raw_count = None
+
+    def __init__(self, ctx, n_rows):
+        self._ctx, self._n, self._cols = ctx, int(n_rows), None
+
+    def __len__(self):
+        return self._n
+
+    def rows(self, rows):
+        """(chr1, mid1, chr2, mid2, count) of some rows"""
+        return self._ctx.fetch_pairs(rows=rows)
+
+    def _all(self):
+        if self._cols is None:
+            self._cols = self._ctx.fetch_pairs(n=self._n)
+        return self._cols
+
+    chr1 = property(lambda self: self._all()[0])
+    mid1 = property(lambda self: self._all()[1])
+    chr2 = property(lambda self: self._all()[2])
+    mid2 = property(lambda self: self._all()[3])
+    count = property(lambda self: self._all()[4])
+
+
 def _interner(chroms):
     """names of a file (order of first appearance) -> ids in the run's shared id space, new names appended in that order"""
     def ids_of(names):
@@ -72,6 +101,39 @@ def read_contacts(path, chroms, threads=0, want_raw=False):
     from . import _capi
     names, cols, raw = _capi.host_read_table(path, 0, threads, name_ids=_interner(chroms), want_float=want_raw)
     return Contacts(cols[0], cols[1], cols[2], cols[3], cols[4], raw)
+
+
+def load_contacts(path, chroms, engine_of, threads=0):
+    """The contacts file into the engine, parsed on the GPU when that is possible.  engine_of() -> the engine, configured
+    (called after the file has been inflated, so that the GPU runtime can come up meanwhile).  Returns a DeviceContacts, or a
+    Contacts when the host parser did the work: a sharded engine (its ranks take host columns), a file outside the device
+    parser's grammar (fhx_ingest_contacts_text says FHX_ERR_UNSUPPORTED; the host parser then reports what the reference
+    would), or FHX_HOST_READER=1."""
+    import os
+    from . import _capi
+    text = _capi.HostText(path, threads)
+    try:
+        eng = engine_of()
+        ctx = getattr(eng, "ctx", None)
+        if ctx is not None and hasattr(ctx, "ingest_contacts_text") and not os.environ.get("FHX_HOST_READER"):
+            try:
+                n, names = ctx.ingest_contacts_text(text, threads)
+            except _capi.FhxError as e:
+                if e.code != _capi.FHX_ERR_UNSUPPORTED:
+                    raise
+            else:
+                try:
+                    eng.commit_contacts_text(_interner(chroms)(names), n)
+                except BaseException:
+                    ctx.ingest_contacts_discard()
+                    raise
+                return DeviceContacts(ctx, n)
+        names, cols, _ = _capi.host_parse_text(text, 0, threads, name_ids=_interner(chroms), want_float=False)
+    finally:
+        text.close()
+    c = Contacts(cols[0], cols[1], cols[2], cols[3], cols[4], None)
+    eng.load_contacts(c.chr1, c.mid1, c.chr2, c.mid2, c.count)
+    return c
 
 
 def read_fragments(path, chroms, threads=0):

@@ -141,6 +141,29 @@ int fhx_load_pairs(fhx_ctx* ctx, const int32_t* chr1, const int32_t* mid1, const
 int fhx_load_pairs_device(fhx_ctx* ctx, const void* d_chr1, const void* d_mid1, const void* d_chr2,
                           const void* d_mid2, const void* d_count, int64_t n, void* stream);
 
+/* The contacts file parsed BY THE GPU (csrc/fhx_ingest.inc): the inflated text (fhx_host_inflate) goes to HBM as it is and
+ * kernels find the lines, read the five fields (fithic/fithic.py:404-417: ch1, int(mid1), ch2, int(mid2),
+ * int(float(contactCount))) and collect the chromosome names in the reference's order of first appearance.  Two calls, because
+ * the caller owns the id space the names map into (it is shared with the fragments and bias files):
+ *   fhx_ingest_contacts_text    parse; n_rows, n_names out, fhx_ingest_contacts_name(ctx, i) = name i (valid until the commit)
+ *   fhx_ingest_contacts_commit  ids[i] = the caller's id of name i; the rows enter the context as fhx_load_pairs would have
+ *                               loaded them (fhx_set_params must have been called, as for fhx_load_pairs)
+ * Only the regular file is taken - ASCII, five tokens per line, names of at most 63 bytes, [+-]digits midpoints and a
+ * digits[.digits] count (15 digits at most) within int32.  For every other file (an exponent, an underscore in a number, a malformed line whose
+ * error message must name it, ...) fhx_ingest_contacts_text returns FHX_ERR_UNSUPPORTED with nothing loaded, and the caller
+ * gives the same fhx_text to fhx_host_parse_text, whose grammar is Python's.  fhx_ingest_contacts_discard drops a parsed text
+ * that will not be committed. */
+struct fhx_text;
+int fhx_ingest_contacts_text(fhx_ctx* ctx, const struct fhx_text* text, int32_t n_threads, int64_t* n_rows, int32_t* n_names);
+const char* fhx_ingest_contacts_name(const fhx_ctx* ctx, int32_t i);
+int fhx_ingest_contacts_commit(fhx_ctx* ctx, const int32_t* ids, int32_t n_ids);
+void fhx_ingest_contacts_discard(fhx_ctx* ctx);
+/* The identity columns of loaded rows, rebuilt from the resident rows (slot -> chromosome id, midpoint): rows = n row
+ * numbers, or NULL for all rows in order (n must then be the loaded row count).  What a caller that ingested on the device
+ * uses to look at a few rows (the outlier lines) without ever holding the columns on the host. */
+int fhx_fetch_pairs(fhx_ctx* ctx, const int64_t* rows, int64_t n, int32_t* chr1, int32_t* mid1, int32_t* chr2, int32_t* mid2,
+                    int32_t* count);
+
 /* ---- one spline pass ---------------------------------------------------------------------------- */
 int fhx_pass_stats(fhx_ctx* ctx, fhx_stats* out);                       /* K1, then waits for the sums */
 int fhx_get_stats(fhx_ctx* ctx, fhx_stats* out);                        /* the statistics the current fit was made from */
@@ -307,6 +330,16 @@ int fhx_table_copy(const fhx_table* t, int32_t column, void* dst);
 /* ids[i] = the caller's id of fhx_table_name(t, i): columns 0 and 2 of later fhx_table_copy calls are in that id space. */
 int fhx_table_map_names(fhx_table* t, const int32_t* ids, int32_t n_ids);
 void fhx_table_free(fhx_table* t);
+/* The two stages of fhx_host_read_table on their own.  fhx_host_inflate: the file read and inflated on the host cores (an
+ * object is returned even on failure, for fhx_text_error); fhx_host_parse_text: the table of that text.  The split exists for
+ * fhx_ingest_contacts_text below, which parses the text on the GPU and leaves fhx_host_parse_text as the path for the files
+ * it does not take. */
+typedef struct fhx_text fhx_text;
+int fhx_host_inflate(const char* path, int32_t n_threads, fhx_text** out);
+int64_t fhx_text_bytes(const fhx_text* x);
+const char* fhx_text_error(const fhx_text* x);
+int fhx_host_parse_text(const fhx_text* text, int32_t kind, int32_t n_threads, fhx_table** out);
+void fhx_text_free(fhx_text* x);
 /* The contacts table written as the reference reads it ("%s\t%d\t%s\t%d\t%d\n", fithic/fithic.py:413-417) on all cores;
  * tooling for synthetic workloads.  Like every file this library writes it is a concatenation of gzip members that carry
  * their compressed size in an "FH" extra subfield - plain gzip to every other reader, inflated in parallel by
