@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--rocprof", default=None, help="directory: run the CLI once more under rocprofv3 --kernel-trace --stats into it")
     ap.add_argument("--compare-host-writer", action="store_true",
                     help="run once more with FHX_HOST_WRITER=1 and compare md5 + line count of the two decompressed files (all rows)")
+    ap.add_argument("--compare-host-reader", action="store_true",
+                    help="run once more with FHX_HOST_READER=1 (contacts parsed on the host cores) and compare the output files' md5")
     ap.add_argument("--dir", default="/tmp/cli_scale", help="where the input and output files go (/dev/shm/... takes the disk out)")
     args = ap.parse_args()
     import numpy as np
@@ -105,6 +107,22 @@ def main():
             lines = [int(e.strip()) for _, e in res_]
             print("    all rows: device writer %d lines md5 %s; host writer %d lines md5 %s -> %s (expected %d lines)" %
                   (lines[0], md5s[0], lines[1], md5s[1], "EQUAL" if md5s[0] == md5s[1] and lines[0] == lines[1] else "DIFFERENT", n + 1))
+        if args.compare_host_reader:
+            t0 = time.time()
+            cmd_h = [c if c != out + "/run" else out + "/run_hostreader" for c in cmd]
+            rh = subprocess.run(cmd_h, cwd=ROOT, capture_output=True, text=True, env=dict(os.environ, FHX_TIMING="1", FHX_HOST_READER="1"))
+            dt_h = time.time() - t0
+            sig_h = sig.replace(out + "/run/", out + "/run_hostreader/")
+            print("same run with the host parser (FHX_HOST_READER=1): wall %.2f s, rc %d" % (dt_h, rh.returncode))
+            for ln in rh.stdout.splitlines() + rh.stderr.splitlines():
+                if "stage: inflate" in ln or ln.startswith("fhx_host_read_table") and "contacts" in ln:
+                    print("    " + ln)
+            md5s = []
+            for f in (sig, sig_h):
+                with open(f, "rb") as fh:
+                    md5s.append(hashlib.md5(fh.read()).hexdigest())
+            print("    significances file (compressed bytes) md5: device parser %s, host parser %s -> %s" %
+                  (md5s[0], md5s[1], "EQUAL" if md5s[0] == md5s[1] else "DIFFERENT"))
         if passes == 1 and args.check_rows > 0:
             # the first rows of the output against the oracle's text for the same rows (p, q, biases, ExpCC from the engine's
             # fetch are formatted by the oracle's Python '%e' / '%f'; the row selection and the order are the reference's)
