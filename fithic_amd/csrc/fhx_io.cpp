@@ -7,6 +7,10 @@
 // writers emit carries its own compressed size in a gzip extra subfield ("FH", 8 bytes - the idea of BGZF's "BC"), so a
 // reader can find all member starts without inflating anything; the reader inflates such files - and bgzip output - on all
 // cores.  A plain single-member .gz (what `gzip` writes) has one deflate stream and is inflated by one thread.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <charconv>
@@ -461,9 +465,7 @@ void parse_chunk(const char* b, const char* e, int kind, bool keep_float, Chunk&
     }
 }
 
-struct Member {
-    size_t off, size, isize;                      // position and compressed size in the file, uncompressed size (ISIZE)
-};
+using Member = fhx::GzMember;
 
 // Walks the gzip members of a file whose members all carry their compressed size: "FH" (8 bytes, this library's writers)
 // or "BC" (2 bytes, BGZF: bgzip / htslib).  false: some member has no size field (plain gzip) or the chain does not end
@@ -567,32 +569,64 @@ bool inflate_stream(const unsigned char* src, size_t n, std::string& text, std::
 
 }  // namespace
 
-// The file read whole and inflated into `pieces` (the text, in file order): on n_threads cores when every gzip member carries
-// its size ("FH" of this library's writers, "BC" of bgzip), by one thread otherwise.  seconds[0] = read, seconds[1] = inflate.
-int fhx::io_inflate_file(const char* path, int n_threads, std::vector<std::string>& pieces, std::string& error, double* seconds) {
-    const auto t_begin = std::chrono::steady_clock::now();
-    // ---- the compressed file, whole ------------------------------------------------------------------------------
-    std::vector<unsigned char> gz;
-    {
-        std::FILE* f = std::fopen(path, "rb");
-        if (!f) {
-            error = std::string("cannot open ") + path;
-            return FHX_ERR_ARG;
-        }
-        std::fseek(f, 0, SEEK_END);
-        const long long sz = std::ftell(f);
-        std::fseek(f, 0, SEEK_SET);
-        gz.resize((size_t)std::max<long long>(sz, 0));
-        const size_t got = gz.empty() ? 0 : std::fread(gz.data(), 1, gz.size(), f);
-        std::fclose(f);
-        if (got != gz.size()) {
-            error = std::string("read error on ") + path;
-            return FHX_ERR_ARG;
+bool fhx::io_scan_members(const unsigned char* d, size_t n, std::vector<fhx::GzMember>& out) { return scan_members(d, n, out); }
+
+// The compressed file, whole: mapped, so that the inflating threads page it in themselves (a 600 MB read() into a zero-filled
+// vector was 0.24 s of one core); read() for what cannot be mapped (a pipe, an empty file, a file system without mmap).
+fhx::FileBytes::~FileBytes() {
+    if (map) ::munmap(map, n);
+}
+
+int fhx::io_read_file(const char* path, fhx::FileBytes& gz, std::string& error) {
+    const int fd = ::open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) {
+        error = std::string("cannot open ") + path;
+        return FHX_ERR_ARG;
+    }
+    struct stat st;
+    bool mapped = false;
+    if (::fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+        void* m = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) {
+            (void)::madvise(m, (size_t)st.st_size, MADV_WILLNEED);
+            gz.map = m;
+            gz.p = (const unsigned char*)m;
+            gz.n = (size_t)st.st_size;
+            mapped = true;
         }
     }
-    if (gz.size() < 18 || gz[0] != 0x1f || gz[1] != 0x8b) {
+    if (!mapped) {
+        unsigned char buf[1 << 16];
+        for (;;) {
+            const ssize_t got = ::read(fd, buf, sizeof(buf));
+            if (got < 0 && errno == EINTR) continue;
+            if (got < 0) {
+                ::close(fd);
+                error = std::string("read error on ") + path;
+                return FHX_ERR_ARG;
+            }
+            if (got == 0) break;
+            gz.owned.insert(gz.owned.end(), buf, buf + got);
+        }
+        gz.p = gz.owned.data();
+        gz.n = gz.owned.size();
+    }
+    ::close(fd);
+    if (gz.size() < 18 || gz.data()[0] != 0x1f || gz.data()[1] != 0x8b) {
         error = std::string("not a gzip file: ") + path + " (the reference's gzip.open raises on it)";
         return FHX_ERR_REFERENCE_EXIT;
+    }
+    return FHX_OK;
+}
+
+// The file read whole and inflated into `pieces` (the text, in file order): on n_threads cores when every gzip member carries
+// its size ("FH" of this library's writers, "BC" of bgzip), by one thread otherwise.  seconds[0] = read, seconds[1] = inflate.
+int fhx::io_inflate_file(const char* path, int n_threads, std::vector<fhx::TextPiece>& pieces, std::string& error, double* seconds) {
+    const auto t_begin = std::chrono::steady_clock::now();
+    fhx::FileBytes gz;
+    {
+        const int rc = fhx::io_read_file(path, gz, error);
+        if (rc != FHX_OK) return rc;
     }
     if (seconds) seconds[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     // ---- inflate: all cores when every member carries its size ("FH" of this library's writers, "BC" of bgzip) ------
@@ -617,11 +651,14 @@ int fhx::io_inflate_file(const char* path, int n_threads, std::vector<std::strin
         auto work = [&](int k) {
             size_t bytes = 0;
             for (size_t i = first[k]; i < first[k + 1]; ++i) bytes += members[i].isize;
-            std::string& text = pieces[(size_t)k];
-            text.resize(bytes);
+            fhx::TextPiece& text = pieces[(size_t)k];
+            if (!text.allocate(bytes)) {
+                bad_member = (long long)first[k];
+                return;
+            }
             size_t at = 0;
             for (size_t i = first[k]; i < first[k + 1]; ++i) {
-                if (!inflate_one(gz.data() + members[i].off, members[i].size, &text[0] + at, members[i].isize)) {
+                if (!inflate_one(gz.data() + members[i].off, members[i].size, text.data() + at, members[i].isize)) {
                     bad_member = (long long)i;
                     return;
                 }
@@ -639,7 +676,7 @@ int fhx::io_inflate_file(const char* path, int n_threads, std::vector<std::strin
     } else {
         pieces.resize(1);
         std::string err;
-        if (!inflate_stream(gz.data(), gz.size(), pieces[0], err)) {
+        if (!inflate_stream(gz.data(), gz.size(), pieces[0].grown, err)) {
             error = err + " in " + path + " (the reference's gzip module raises on it)";
             return FHX_ERR_REFERENCE_EXIT;
         }
@@ -649,7 +686,7 @@ int fhx::io_inflate_file(const char* path, int n_threads, std::vector<std::strin
 }
 
 // the parse stage of fhx_host_read_table over an inflated text; t_report carries the stage clocks of the stages before it
-static int parse_pieces(const std::vector<std::string>& pieces, const char* path, int32_t kind, int32_t n_threads, fhx_table** out,
+static int parse_pieces(const std::vector<fhx::TextPiece>& pieces, const char* path, int32_t kind, int32_t n_threads, fhx_table** out,
                         std::string t_report) {
     const bool keep_float = !(kind & FHX_TABLE_NO_FLOAT);
     kind &= ~FHX_TABLE_NO_FLOAT;
@@ -681,12 +718,12 @@ static int parse_pieces(const std::vector<std::string>& pieces, const char* path
     {
         std::string carry;
         const size_t target = 8u << 20;                    // ~8 MB of text per parse task
-        for (const std::string& text : pieces) {
+        for (const fhx::TextPiece& text : pieces) {
             const char* b = text.data();
             const char* e = b + text.size();
             const char* first_nl = (const char*)std::memchr(b, '\n', text.size());
             if (!first_nl) {
-                carry.append(text);
+                carry.append(text.data(), text.size());
                 continue;
             }
             const char* mid_b = b;
@@ -784,7 +821,7 @@ int fhx_host_inflate(const char* path, int32_t n_threads, fhx_text** out) {
     if (n_threads <= 0) n_threads = fhx::usable_cpus();
     const int rc = fhx::io_inflate_file(path, n_threads, x->pieces, x->error, x->seconds);
     if (rc != FHX_OK) return rc;
-    for (const std::string& piece : x->pieces) x->bytes += (int64_t)piece.size();
+    for (const fhx::TextPiece& piece : x->pieces) x->bytes += (int64_t)piece.size();
     return FHX_OK;
 }
 

@@ -110,27 +110,49 @@ def load_contacts(path, chroms, engine_of, threads=0):
     parser's grammar (fhx_ingest_contacts_text says FHX_ERR_UNSUPPORTED; the host parser then reports what the reference
     would), or FHX_HOST_READER=1."""
     import os
+    import time
     from . import _capi
+    timing = os.environ.get("FHX_TIMING")
+    marks = [("start", time.time())]
+
+    def mark(what):
+        if timing:
+            marks.append((what, time.time()))
+
+    def report():
+        if timing:
+            print("stage: contacts:" + "".join(" %s %.3f s;" % (w, t - marks[k][1]) for k, (w, t) in enumerate(marks[1:])))
     text = _capi.HostText(path, threads)
+    mark("read + inflate")
     try:
         eng = engine_of()
+        mark("engine ready")
         ctx = getattr(eng, "ctx", None)
         if ctx is not None and hasattr(ctx, "ingest_contacts_text") and not os.environ.get("FHX_HOST_READER"):
             try:
                 n, names = ctx.ingest_contacts_text(text, threads)
+                mark("device parse")
             except _capi.FhxError as e:
                 if e.code != _capi.FHX_ERR_UNSUPPORTED:
                     raise
             else:
+                text.close()                         # the text is in HBM and not needed again
+                text = None
+                mark("text freed")
                 try:
                     eng.commit_contacts_text(_interner(chroms)(names), n)
+                    mark("rows into the engine")
                 except BaseException:
                     ctx.ingest_contacts_discard()
                     raise
                 return DeviceContacts(ctx, n)
         names, cols, _ = _capi.host_parse_text(text, 0, threads, name_ids=_interner(chroms), want_float=False)
+        mark("host parse")
     finally:
-        text.close()
+        if text is not None:
+            text.close()
+            mark("text freed")
+        report()
     c = Contacts(cols[0], cols[1], cols[2], cols[3], cols[4], None)
     eng.load_contacts(c.chr1, c.mid1, c.chr2, c.mid2, c.count)
     return c

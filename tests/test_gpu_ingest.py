@@ -311,3 +311,38 @@ def test_command_line_uses_the_device_parser_and_either_parser_gives_the_referen
                 assert hashlib.md5(f.read()).hexdigest() == meta["sig_md5_pass%d" % pi]
             with open(os.path.join(str(out), "G.fithic_pass%d%s.txt" % (pi, tag))) as f:
                 assert f.read() == meta["fithic_pass%d_txt" % pi]
+
+
+def test_host_writer_after_device_parser_fetches_the_columns_back(tmp_path, monkeypatch, capsys):
+    """FHX_HOST_WRITER=1 (or a row the device formatter does not take) needs the identity columns on the host: they come back
+    through fhx_fetch_pairs, and the file is the reference's.  A file with integer counts, so that the device parser takes it."""
+    import hashlib
+    from fithic_amd import cli
+    meta, _ = load_case("f1_bias")
+    kw = case_args(meta)
+    # the golden contacts with their counts truncated as the reader would: the same rows for both runs below
+    lines = []
+    with gzip.open(kw["contacts"], "rt") as f:
+        for ln in f:
+            a, b, c, d, e = ln.split()
+            lines.append("%s\t%s\t%s\t%s\t%d\n" % (a, b, c, d, int(float(e))))
+    contacts = _write(tmp_path, "contacts.gz", "".join(lines))
+    monkeypatch.setenv("FHX_TIMING", "1")
+    digests = {}
+    for which in ("device", "host"):
+        out = tmp_path / which
+        out.mkdir()
+        if which == "host":
+            monkeypatch.setenv("FHX_HOST_READER", "1")
+        else:
+            monkeypatch.delenv("FHX_HOST_READER", raising=False)
+        monkeypatch.setenv("FHX_HOST_WRITER", "1")
+        argv = ["-i", contacts, "-f", kw["frags"], "-o", str(out), "-l", "G", "-t", kw["bias_path"]] + meta["argv"]
+        cli.main(argv)
+        assert "(%s parser)" % which in capsys.readouterr().out
+        tag = ".res%d" % kw["resolution"]
+        digests[which] = []
+        for pi in range(1, meta["n_passes"] + 1):
+            with gzip.open(os.path.join(str(out), "G.spline_pass%d%s.significances.txt.gz" % (pi, tag)), "rb") as f:
+                digests[which].append(hashlib.md5(f.read()).hexdigest())
+    assert digests["device"] == digests["host"] == [meta["sig_md5_pass%d" % pi] for pi in range(1, meta["n_passes"] + 1)]
