@@ -72,6 +72,9 @@ SYMBOLS = {
     "fhx_text_free": (None, [_P]),
     "fhx_ingest_contacts_text": (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32)]),
     "fhx_ingest_contacts_name": (ctypes.c_char_p, [_P, ctypes.c_int32]),
+    "fhx_ingest_contacts_file": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32),
+                                                ctypes.POINTER(ctypes.c_int32)]),
+    "fhx_debug_inflate_file": (ctypes.c_int, [_P, ctypes.c_char_p, _P, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
     "fhx_ingest_contacts_commit": (ctypes.c_int, [_P, _I32P, ctypes.c_int32]),
     "fhx_ingest_contacts_discard": (None, [_P]),
     "fhx_fetch_pairs": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int64), ctypes.c_int64, _I32P, _I32P, _I32P, _I32P, _I32P]),
@@ -339,6 +342,24 @@ class Context:
         n, k = ctypes.c_int64(0), ctypes.c_int32(0)
         self._check(self._L.fhx_ingest_contacts_text(self._h, text._h, int(threads), ctypes.byref(n), ctypes.byref(k)))
         return n.value, [self._L.fhx_ingest_contacts_name(self._h, i).decode() for i in range(k.value)]
+
+    def ingest_contacts_file(self, path, threads=0):
+        """The contacts FILE inflated and parsed on the GPU -> (rows, names).  Raises FhxError(FHX_ERR_UNSUPPORTED) with
+        .refused = 1 (container / stream not taken: inflate on the host, the device parser may still take the text) or
+        2 (text outside the device grammar: the host parser)."""
+        n, k, why = ctypes.c_int64(0), ctypes.c_int32(0), ctypes.c_int32(0)
+        rc = self._L.fhx_ingest_contacts_file(self._h, os.fsencode(path), int(threads), ctypes.byref(n), ctypes.byref(k), ctypes.byref(why))
+        if rc != FHX_OK:
+            e = FhxError(rc, (self._L.fhx_last_error(self._h) or b"").decode())
+            e.refused = why.value
+            raise e
+        return n.value, [self._L.fhx_ingest_contacts_name(self._h, i).decode() for i in range(k.value)]
+
+    def debug_inflate_file(self, path, cap):
+        out = np.empty(int(cap), np.uint8)
+        n = ctypes.c_int64(0)
+        self._check(self._L.fhx_debug_inflate_file(self._h, os.fsencode(path), out.ctypes.data_as(_P), int(cap), ctypes.byref(n)))
+        return out[:n.value].tobytes()
 
     def ingest_contacts_commit(self, ids):
         """ids[i] = the run's chromosome id of name i: the parsed rows become the context's contact rows"""

@@ -17,6 +17,9 @@
 #include <chrono>
 #include <thread>
 #include <memory>
+#include <deque>
+#include <mutex>
+#include <condition_variable>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -3646,6 +3649,7 @@ int fhx_kernel_seconds(fhx_ctx* ctx, double* k1, double* k2, double* k3) {
 
 #include "fhx_dist.inc"
 #include "fhx_emit.inc"
+#include "fhx_inflate.inc"
 #include "fhx_ingest.inc"
 
 // ---- host numerics exported for tests / host-only callers ----------------------------------------------

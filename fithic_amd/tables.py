@@ -104,11 +104,13 @@ def read_contacts(path, chroms, threads=0, want_raw=False):
 
 
 def load_contacts(path, chroms, engine_of, threads=0):
-    """The contacts file into the engine, parsed on the GPU when that is possible.  engine_of() -> the engine, configured
-    (called after the file has been inflated, so that the GPU runtime can come up meanwhile).  Returns a DeviceContacts, or a
-    Contacts when the host parser did the work: a sharded engine (its ranks take host columns), a file outside the device
-    parser's grammar (fhx_ingest_contacts_text says FHX_ERR_UNSUPPORTED; the host parser then reports what the reference
-    would), or FHX_HOST_READER=1."""
+    """The contacts file into the engine, on the GPU as far as the file allows.  engine_of() -> the engine, configured.
+      1. a file of size-tagged gzip members (this library's writers, bgzip): the compressed bytes are uploaded, the GPU inflates
+         and parses them (fhx_ingest_contacts_file) - the text never exists on the host;
+      2. any other gzip file: inflated on the host cores, the text parsed by the GPU (fhx_ingest_contacts_text);
+      3. a text outside the device parser's grammar (it says FHX_ERR_UNSUPPORTED), a sharded engine (its ranks take host
+         columns) or FHX_HOST_READER=1: the host parser, which reports a malformed line as the reference would.
+    Returns a DeviceContacts (1, 2) or a Contacts (3)."""
     import os
     import time
     from . import _capi
@@ -122,13 +124,35 @@ def load_contacts(path, chroms, engine_of, threads=0):
     def report():
         if timing:
             print("stage: contacts:" + "".join(" %s %.3f s;" % (w, t - marks[k][1]) for k, (w, t) in enumerate(marks[1:])))
-    text = _capi.HostText(path, threads)
-    mark("read + inflate")
+
+    def commit(eng, ctx, names, n):
+        try:
+            eng.commit_contacts_text(_interner(chroms)(names), n)
+            mark("rows into the engine")
+        except BaseException:
+            ctx.ingest_contacts_discard()
+            raise
+        return DeviceContacts(ctx, n)
+    eng = engine_of()
+    mark("engine ready")
+    ctx = getattr(eng, "ctx", None)
+    on_device = ctx is not None and hasattr(ctx, "ingest_contacts_text") and not os.environ.get("FHX_HOST_READER")
+    text = None
     try:
-        eng = engine_of()
-        mark("engine ready")
-        ctx = getattr(eng, "ctx", None)
-        if ctx is not None and hasattr(ctx, "ingest_contacts_text") and not os.environ.get("FHX_HOST_READER"):
+        if on_device and not os.environ.get("FHX_HOST_INFLATE"):
+            try:
+                n, names = ctx.ingest_contacts_file(path, threads)
+                mark("device inflate + parse")
+                return commit(eng, ctx, names, n)
+            except _capi.FhxError as e:
+                if e.code != _capi.FHX_ERR_UNSUPPORTED:
+                    raise
+                mark("device refused")
+                if getattr(e, "refused", 1) == 2:
+                    on_device = False
+        text = _capi.HostText(path, threads)
+        mark("read + inflate")
+        if on_device:
             try:
                 n, names = ctx.ingest_contacts_text(text, threads)
                 mark("device parse")
@@ -139,13 +163,7 @@ def load_contacts(path, chroms, engine_of, threads=0):
                 text.close()                         # the text is in HBM and not needed again
                 text = None
                 mark("text freed")
-                try:
-                    eng.commit_contacts_text(_interner(chroms)(names), n)
-                    mark("rows into the engine")
-                except BaseException:
-                    ctx.ingest_contacts_discard()
-                    raise
-                return DeviceContacts(ctx, n)
+                return commit(eng, ctx, names, n)
         names, cols, _ = _capi.host_parse_text(text, 0, threads, name_ids=_interner(chroms), want_float=False)
         mark("host parse")
     finally:

@@ -156,6 +156,15 @@ int fhx_load_pairs_device(fhx_ctx* ctx, const void* d_chr1, const void* d_mid1, 
 struct fhx_text;
 int fhx_ingest_contacts_text(fhx_ctx* ctx, const struct fhx_text* text, int32_t n_threads, int64_t* n_rows, int32_t* n_names);
 const char* fhx_ingest_contacts_name(const fhx_ctx* ctx, int32_t i);
+/* The same straight from the FILE, for a file of size-tagged gzip members ("FH" of this library's writers, "BC" of bgzip):
+ * the compressed bytes are uploaded and every member is inflated by the GPU (csrc/fhx_inflate.inc: one wave per member, CRC-32
+ * and ISIZE checked), so the text exists in HBM only.  FHX_ERR_UNSUPPORTED with *refused = 1: not such a container, or a
+ * stream the device decoder does not accept - fhx_host_inflate (zlib; it reports what the reference's gzip module would) and
+ * fhx_ingest_contacts_text may still take it; *refused = 2: the text is outside the device parser's grammar -
+ * fhx_host_read_table is the path. */
+int fhx_ingest_contacts_file(fhx_ctx* ctx, const char* path, int32_t n_threads, int64_t* n_rows, int32_t* n_names, int32_t* refused);
+/* test hook: the text of such a file as the device decoder produces it (n_out = its size; cap = room in out) */
+int fhx_debug_inflate_file(fhx_ctx* ctx, const char* path, void* out, int64_t cap, int64_t* n_out);
 int fhx_ingest_contacts_commit(fhx_ctx* ctx, const int32_t* ids, int32_t n_ids);
 void fhx_ingest_contacts_discard(fhx_ctx* ctx);
 /* The identity columns of loaded rows, rebuilt from the resident rows (slot -> chromosome id, midpoint): rows = n row
