@@ -134,3 +134,39 @@ def test_writer_reproduces_the_reference_file(name, tmp_path):
             text = f.read()
         assert n == meta["sig_rows_pass%d" % pi] == text.count(b"\n") - 1
         assert hashlib.md5(text).hexdigest() == meta["sig_md5_pass%d" % pi]
+
+
+def test_inflate_and_parse_as_separate_stages(tmp_path):
+    """fhx_host_inflate + fhx_host_parse_text (the fallback of the device parser) = fhx_host_read_table: rows, names, and the
+    message of a malformed line; a file that is not gzip fails in the inflate stage with the reader's message"""
+    path = os.path.join(DATA, "hESC_chr1_w40000.contacts.gz")
+    text = _capi.HostText(path, 3)
+    assert len(text) == len(gzip.open(path, "rb").read())
+    for want_float in (True, False):
+        a = _capi.host_parse_text(text, 0, 2, want_float=want_float)
+        b = _capi.host_read_table(path, 0, 2, want_float=want_float)
+        assert a[0] == b[0] and all(np.array_equal(a[1][k], b[1][k]) for k in b[1])
+        assert (a[2] is None and b[2] is None) or np.array_equal(a[2], b[2])
+    text.close()
+    text.close()                                                            # idempotent
+    bad = tmp_path / "bad.gz"
+    with gzip.open(bad, "wt") as f:
+        f.write("chr1\t5000\tchr1\t15000\t3\nchr1\t5000\tchr1\t25000\n")
+    text = _capi.HostText(str(bad))
+    with pytest.raises(_capi.FhxError) as e1:
+        _capi.host_parse_text(text, 0)
+    with pytest.raises(_capi.FhxError) as e2:
+        _capi.host_read_table(str(bad), 0)
+    assert str(e1.value) == str(e2.value) and "line 2" in str(e1.value)
+    text.close()
+    notgz = tmp_path / "plain.txt"
+    notgz.write_text("chr1\t1\tchr1\t2\t3\n")
+    with pytest.raises(_capi.FhxError) as e1:
+        _capi.HostText(str(notgz))
+    with pytest.raises(_capi.FhxError) as e2:
+        _capi.host_read_table(str(notgz), 0)
+    assert e1.value.code == e2.value.code == _capi.FHX_ERR_REFERENCE_EXIT and str(e1.value) == str(e2.value)
+    empty = tmp_path / "empty.gz"
+    empty.write_bytes(b"")
+    with pytest.raises(_capi.FhxError):
+        _capi.HostText(str(empty))
