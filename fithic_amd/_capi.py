@@ -9,8 +9,10 @@ import subprocess
 
 import numpy as np
 
+from . import _loader
+
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("FHX_LIB") or os.path.join(_PKG, "libfithic_mi355x.so")   # FHX_LIB: A/B experiments only
+LIB_PATH = _loader.LIB_PATH
 CSRC = os.path.join(_PKG, "csrc")
 
 FHX_OK = 0
@@ -63,6 +65,7 @@ SYMBOLS = {
     "fhx_destroy": (None, [_P]),
     "fhx_last_error": (ctypes.c_char_p, [_P]),
     "fhx_version": (ctypes.c_char_p, []),
+    "fhx_warmup": (ctypes.c_int, [ctypes.c_int]),
     "fhx_set_params": (ctypes.c_int, [_P, ctypes.POINTER(FhxParams)]),
     "fhx_load_fragments": (ctypes.c_int, [_P, _I32P, _I32P, _I32P, ctypes.c_int64, _I32P, ctypes.c_int32]),
     "fhx_host_inflate": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int32, ctypes.POINTER(_P)]),
@@ -190,27 +193,6 @@ def build(force=False):
 _lib = None
 
 
-def _share_torch_hip_runtime():
-    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so.7 (+ HSA, comgr) next to libtorch and can only
-    work with that copy; if the system copy (/opt/rocm, what this library is linked against, same soname) is loaded first, a
-    later `import torch` finds no device.  So when torch is installed, its copy is loaded first - without importing torch -
-    and this library binds to it; without torch the system runtime is used."""
-    import importlib.util
-    try:
-        spec = importlib.util.find_spec("torch")
-    except (ImportError, ValueError):
-        spec = None
-    if spec is None or not spec.origin:
-        return None
-    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
-    if not os.path.exists(cand):
-        return None
-    try:
-        return ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
-    except OSError:
-        return None
-
-
 def _share_torch_rccl():
     """One RCCL per process, for the same reason: PyTorch ships a librccl.so built against its own HIP runtime.  When torch is
     installed its copy is loaded (globally) before the first communicator is made and the library's run-time lookup finds it;
@@ -257,11 +239,7 @@ def lib():
     """The loaded library; raises (loudly) when it has not been built - there is no fallback."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError("libfithic_mi355x.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; "
-                               "g.build()'` or fithic_amd._capi.build(); fithic_amd has no CPU fallback." % LIB_PATH)
-        _share_torch_hip_runtime()
-        L = ctypes.CDLL(LIB_PATH)
+        L = _loader.load()
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)        # AttributeError if the .so does not export a declared symbol
             fn.restype = res

@@ -2392,6 +2392,12 @@ int fhx_create(int device, fhx_ctx** out) {
     return FHX_OK;
 }
 
+int fhx_warmup(int device) {
+    if (device < 0) return FHX_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return FHX_ERR_NO_DEVICE;
+    return hipFree(nullptr) == hipSuccess ? FHX_OK : FHX_ERR_HIP;
+}
+
 void fhx_destroy(fhx_ctx* ctx) {
     if (!ctx) return;
     (void)fhx_comm_destroy(ctx);

@@ -125,6 +125,9 @@ int fhx_create(int device, fhx_ctx** out);      /* device >= 0: HIP device ordin
 void fhx_destroy(fhx_ctx* ctx);
 const char* fhx_last_error(fhx_ctx* ctx);
 const char* fhx_version(void);
+/* The HIP runtime and the device's primary context brought up ahead of fhx_create (0.15-0.25 s the first time in a process);
+ * a launcher calls it on a thread while it does other start-up work.  Optional: fhx_create does the same when needed. */
+int fhx_warmup(int device);
 int fhx_set_params(fhx_ctx* ctx, const fhx_params* p);
 
 /* ---- tables (host SoA in, copied) --------------------------------------------------------------- */

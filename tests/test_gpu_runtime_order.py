@@ -1,4 +1,4 @@
-"""The engine and PyTorch share one HIP runtime whichever is loaded first (fithic_amd/_capi.py:_share_torch_hip_runtime)."""
+"""The engine and PyTorch share one HIP runtime whichever is loaded first (fithic_amd/_loader.py:_share_torch_hip_runtime)."""
 import subprocess
 import sys
 import os
