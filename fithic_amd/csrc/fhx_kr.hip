@@ -225,6 +225,81 @@ __global__ __launch_bounds__(THREADS) void kr_to_f32(const double* __restrict__ 
     if (__ballot(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(inexact, 1u);
 }
 
+// The 4-byte cell.  A Hi-C map at one resolution is a band: the columns of a row lie within a few hundred of each other, and
+// the counts are small integers.  When every row spans fewer than 65 536 columns and every value is an integer below 65 536
+// the matrix is streamed as one dword per cell - (column - first column of the row) | value << 16 - plus the row's first
+// column: 4 B per cell instead of 8 (binary32 values) or 12.  The same doubles enter the same products in the same order, so
+// the results are the same bits; any row or value that does not fit leaves the matrix in the wider format.
+typedef unsigned int kr_u4 __attribute__((ext_vector_type(4), aligned(4)));
+
+__global__ __launch_bounds__(THREADS) void kr_pack16(int64_t n, const int64_t* __restrict__ indptr, const int32_t* __restrict__ col,
+                                                     const double* __restrict__ val, unsigned int* __restrict__ pack,
+                                                     int32_t* __restrict__ rowbase, unsigned int* __restrict__ misfit) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int64_t b = indptr[row], e = indptr[row + 1];
+    int lo = 0x7fffffff;
+    for (int64_t j = b + lane; j < e; j += 64) lo = min(lo, col[j]);
+    for (int s = 32; s >= 1; s >>= 1) lo = min(lo, __shfl_xor(lo, s, 64));
+    if (e == b) lo = 0;
+    if (lane == 0) rowbase[row] = lo;
+    bool bad = false;
+    for (int64_t j = b + lane; j < e; j += 64) {
+        const long long off = (long long)col[j] - lo;
+        const double v = val[j];
+        const unsigned int q = v >= 0.0 && v < 65536.0 ? (unsigned int)v : 0u;
+        bad |= off > 65535 || !((double)q == v);
+        pack[j] = (unsigned int)(off & 0xFFFF) | (q << 16);
+    }
+    if (__ballot(bad) && lane == 0) atomicOr(misfit, 1u);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(THREADS) void kr_spmv_packed(int64_t n, const int64_t* __restrict__ indptr, const unsigned int* __restrict__ pack,
+                                                          const int32_t* __restrict__ rowbase, const double* __restrict__ in,
+                                                          double* __restrict__ out0, double* __restrict__ out1, const double* __restrict__ a0,
+                                                          const double* __restrict__ a1, const double* __restrict__ a2, int64_t n_blocks) {
+    const int64_t per = (n_blocks + 7) / 8;                             // XCD-aware, as kr_spmv
+    const int64_t blk = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (blk >= n_blocks) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = blk * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int64_t b = indptr[row], e = indptr[row + 1];
+    const int base_col = rowbase[row];
+    double acc = 0.0;
+    for (int64_t base = b; base < e; base += 2 * KR_CHUNK) {           // same cells per lane, same order of the adds as kr_spmv
+        const int64_t j0 = base + 4 * lane, j1 = j0 + KR_CHUNK;
+        const bool second = base + KR_CHUNK < e;                        // wave-uniform
+        const kr_u4 w0 = *reinterpret_cast<const kr_u4*>(pack + j0);
+        kr_u4 w1 = w0;
+        if (second) w1 = *reinterpret_cast<const kr_u4*>(pack + j1);
+        KrCells<float> k0, k1;
+        k0.c = kr_i4{base_col + (int)(w0.x & 0xFFFFu), base_col + (int)(w0.y & 0xFFFFu), base_col + (int)(w0.z & 0xFFFFu), base_col + (int)(w0.w & 0xFFFFu)};
+        k0.f = kr_f4{(float)(w0.x >> 16), (float)(w0.y >> 16), (float)(w0.z >> 16), (float)(w0.w >> 16)};
+        k1.c = kr_i4{base_col + (int)(w1.x & 0xFFFFu), base_col + (int)(w1.y & 0xFFFFu), base_col + (int)(w1.z & 0xFFFFu), base_col + (int)(w1.w & 0xFFFFu)};
+        k1.f = kr_f4{(float)(w1.x >> 16), (float)(w1.y >> 16), (float)(w1.z >> 16), (float)(w1.w >> 16)};
+        double x0[4], x1[4];
+        kr_gather(k0, j0, e, in, x0);
+        if (second) kr_gather(k1, j1, e, in, x1);
+        acc = kr_fold(acc, k0, x0, j0, e);
+        if (second) acc = kr_fold(acc, k1, x1, j1, e);
+    }
+    const double t = wave_tree_sum(acc);
+    if (lane == 0) {
+        if (MODE == 0) {
+            out0[row] = t;
+        } else if (MODE == 1) {
+            const double v = a0[row] * t;
+            out0[row] = v;
+            out1[row] = 1.0 - v;
+        } else {
+            out0[row] = a0[row] * t + a1[row] * a2[row];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // n-sized vector kernels of the KR iteration; block = tile of 1024 elements, thread t owns t, t+256, t+512, t+768
 // ---------------------------------------------------------------------------------------------------------------
@@ -464,6 +539,8 @@ struct fhx_kr {
     double* d_rval = nullptr;
     float* d_val32 = nullptr;                          // binary32 copy of the matrix fhx_kr_balance streams (exact or absent)
     bool val32_reduced = false;
+    unsigned int* d_pack = nullptr;                    // 4-byte cells (kr_pack16) of the same matrix, or absent
+    int32_t* d_rowbase = nullptr;
     std::vector<int64_t> removed;
     std::vector<double> row_sums;
     // iteration state
@@ -512,7 +589,10 @@ void launch_spmv(fhx_kr* kr, int64_t n, const int64_t* ptr, const int32_t* col, 
     const int64_t n_blocks = (n + 3) / 4;
     const int64_t per = (n_blocks + 7) / 8;
     const dim3 g((unsigned)std::max<int64_t>(1, per * 8)), t(krd::THREADS);
-    if (kr->d_val32 && val == (kr->val32_reduced ? kr->d_rval : kr->d_val))
+    if (kr->d_pack && val == (kr->val32_reduced ? kr->d_rval : kr->d_val))
+        hipLaunchKernelGGL((krd::kr_spmv_packed<MODE>), g, t, 0, kr->stream, n, ptr, (const unsigned int*)kr->d_pack, (const int32_t*)kr->d_rowbase, in,
+                           out0, out1, a0, a1, a2, n_blocks);
+    else if (kr->d_val32 && val == (kr->val32_reduced ? kr->d_rval : kr->d_val))
         hipLaunchKernelGGL((krd::kr_spmv<MODE, float>), g, t, 0, kr->stream, n, ptr, col, (const float*)kr->d_val32, in, out0, out1, a0, a1,
                            a2, n_blocks);
     else
@@ -560,6 +640,8 @@ void free_matrix(fhx_kr* kr) {
     kfree(kr->d_rcol);
     kfree(kr->d_rval);
     kfree(kr->d_val32);
+    kfree(kr->d_pack);
+    kfree(kr->d_rowbase);
     kr->reduced = false;
     kr->balanced = false;
     kr->n = kr->nnz = kr->nnz_full = 0;
@@ -568,7 +650,7 @@ void free_matrix(fhx_kr* kr) {
 }
 
 // numpy's pairwise np.sum of a contiguous double array (computeBiasVector, HiCKRy.py:106)
-double numpy_sum(const double* a, int64_t n) {
+double numpy_pairwise(const double* a, int64_t n) {
     if (n < 8) {
         double r = -0.0;
         for (int64_t i = 0; i < n; ++i) r += a[i];
@@ -586,7 +668,18 @@ double numpy_sum(const double* a, int64_t n) {
     }
     int64_t n2 = n / 2;
     n2 -= n2 % 8;
-    return numpy_sum(a, n2) + numpy_sum(a + n2, n - n2);
+    return numpy_pairwise(a, n2) + numpy_pairwise(a + n2, n - n2);
+}
+
+// np.sum of a contiguous double array: the reduction runs over buffers of 8192 elements (numpy's default buffer size), each
+// summed pairwise, the buffer sums added from left to right (checked against numpy 2.2 up to 10^6 elements; a single pairwise
+// pass over the whole array differs in the last bit for about half of the arrays beyond 8192 elements)
+double numpy_sum(const double* a, int64_t n) {
+    const int64_t B = 8192;
+    if (n <= B) return numpy_pairwise(a, n);
+    double acc = numpy_pairwise(a, B);
+    for (int64_t i = B; i < n; i += B) acc += numpy_pairwise(a + i, std::min<int64_t>(B, n - i));
+    return acc;
 }
 
 }  // namespace
@@ -941,6 +1034,24 @@ int fhx_kr_balance(fhx_kr* kr, double tol, fhx_kr_info* out) {
         KR_HIP(hipStreamSynchronize(kr->stream));
         kr->val32_reduced = kr->reduced;
         if (inexact) kfree(kr->d_val32);               // fractional or huge counts: stay with the doubles
+        // 4-byte cells when the rows are narrow and the counts small (kr_pack16)
+        kfree(kr->d_pack);
+        kfree(kr->d_rowbase);
+        if (kr->d_val32 && !std::getenv("FHX_KR_NO_PACK")) {
+            KR_HIP(hipMalloc(&kr->d_pack, (size_t)(kr->nnz + krd::KR_PAD) * sizeof(unsigned int)));
+            KR_HIP(hipMalloc(&kr->d_rowbase, (size_t)std::max<int64_t>(n, 1) * sizeof(int32_t)));
+            KR_HIP(hipMemsetAsync(kr->d_pack + kr->nnz, 0, (size_t)krd::KR_PAD * sizeof(unsigned int), kr->stream));
+            KR_HIP(hipMemsetAsync(flag, 0, 4, kr->stream));
+            hipLaunchKernelGGL(krd::kr_pack16, dim3((unsigned)((n + 3) / 4)), dim3(krd::THREADS), 0, kr->stream, n, ptr, col, val, kr->d_pack,
+                               kr->d_rowbase, flag);
+            unsigned int misfit = 0;
+            KR_HIP(hipMemcpyAsync(&misfit, flag, 4, hipMemcpyDeviceToHost, kr->stream));
+            KR_HIP(hipStreamSynchronize(kr->stream));
+            if (misfit) {                              // a row wider than 65 535 columns or a count of 65 536 or more
+                kfree(kr->d_pack);
+                kfree(kr->d_rowbase);
+            }
+        }
     }
     const dim3 grid(tiles_of(n)), block(krd::THREADS);
     const int OPS_SUM[1] = {0}, OPS_MINMAX[2] = {1, 2}, OPS_MIN[1] = {1};
@@ -1080,7 +1191,7 @@ int fhx_kr_balance(fhx_kr* kr, double tol, fhx_kr_info* out) {
     info.residual = rout;
     info.spmv_seconds = kr->spmv_seconds;
     info.spmv_timed = kr->spmv_calls;
-    info.value_bytes = kr->d_val32 ? 4 : 8;
+    info.value_bytes = kr->d_pack ? 2 : (kr->d_val32 ? 4 : 8);
     kr->info = info;
     kr->balanced = true;
     if (out) *out = info;

@@ -393,7 +393,8 @@ typedef struct fhx_kr_info {
     double residual;                /* rout = |1 - x*(A x)|^2 at exit */
     double spmv_seconds;            /* HIP-event time of the timed SpMV launches */
     int64_t spmv_timed;
-    int64_t value_bytes;            /* 4: the values were streamed as binary32 (exact for integer counts), 8: as doubles */
+    int64_t value_bytes;            /* bytes per value streamed by the SpMV: 8 doubles; 4 binary32 (exact for integer counts), with 4-byte
+                                     * columns either way; 2: the 4-byte cell (16-bit count + 16-bit column offset in its row) */
 } fhx_kr_info;
 int fhx_kr_create(int device, fhx_kr** out);
 void fhx_kr_destroy(fhx_kr* kr);

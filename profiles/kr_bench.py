@@ -49,7 +49,8 @@ def measure(max_chroms=0, perc=0.05):
     n, nnz = info.n, info.nnz
     spmv = info.spmv_seconds / max(info.spmv_timed, 1)
     vb = info.value_bytes                               # 4 when the counts are exact in binary32 (they are: integers), else 8
-    algo = (vb + 4.0) * nnz + 24.0 * n + 8.0 * (n + 1)   # value + column per cell; in/out/epilogue vectors; indptr
+    cell = 4.0 if vb == 2 else vb + 4.0                 # the 4-byte cell (16-bit count + 16-bit column offset), else value + 4-byte column
+    algo = cell * nnz + (28.0 if vb == 2 else 24.0) * n + 8.0 * (n + 1)   # cells; in/out/epilogue vectors (+ the row's first column); indptr
     # isolated SpMV (plain epilogue), many repeats
     _, spmv_iso = kr.spmv(np.ones(n), which=1, repeats=50)          # uses the same value array as the balance did
     traffic = None
@@ -69,7 +70,9 @@ def measure(max_chroms=0, perc=0.05):
                      "isolated_launch_seconds": spmv_iso, "isolated_frac": algo / spmv_iso / 1e9 / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_launch": algo,
                      "value_bytes": vb,
-                     "note": "(value_bytes + 4) B per stored cell + 32 B per row (indptr, gathered input, output, epilogue)"},
+                     "cell_bytes": cell,
+                     "note": "cell_bytes per stored cell (4 = 16-bit count + 16-bit column offset in its row; else value_bytes + 4) + 32-36 B per row "
+                             "(indptr, gathered input, output, epilogue, first column)"},
     }
     kr.close()
     return out, genome, cols
