@@ -1832,7 +1832,11 @@ namespace fhx {
 struct DistState;
 }
 
+struct FhxPinnedPair;                            // fhx_emit.inc: two pinned 64 MB buffers + events, kept for the context's life
+void fhx_pinned_pair_free(FhxPinnedPair* p);
+
 struct fhx_ctx {
+    FhxPinnedPair* pinned = nullptr;
     struct TextIngest;                           // fhx_ingest.inc: a parsed contacts text waiting for its chromosome ids
     TextIngest* text_ingest = nullptr;
     int device = -1;
@@ -2405,6 +2409,8 @@ void fhx_destroy(fhx_ctx* ctx) {
         (void)hipSetDevice(ctx->device);
         if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
         fhx_ingest_contacts_discard(ctx);
+        fhx_pinned_pair_free(ctx->pinned);
+        ctx->pinned = nullptr;
         dev_free(ctx->d_loc1);
         dev_free(ctx->d_loc2);
         dev_free(ctx->d_count);
