@@ -226,3 +226,36 @@ def test_contacts_file_inflated_and_parsed_on_the_device(tmp_path):
         eng.ctx.ingest_contacts_file(plain)
     assert e.value.code == _capi.FHX_ERR_UNSUPPORTED and e.value.refused == 1
     eng.close()
+
+
+def test_command_line_on_a_bgzf_contacts_file_writes_the_reference_files(tmp_path, monkeypatch, capsys):
+    """the golden hESC contacts recompressed as BGZF blocks (what bgzip writes): the CLI inflates and parses them on the GPU and
+    writes the reference's files; the stage line says which path ran"""
+    import hashlib
+    from conftest import load_case, case_args
+    from fithic_amd import cli
+    meta, _ = load_case("f1_bias")
+    kw = case_args(meta)
+    with gzip.open(kw["contacts"], "rb") as f:
+        text = f.read()
+    rng = random.Random(3)
+    members, at = [], 0
+    while at < len(text):
+        n = rng.choice([65280, 65280, 30000, 1000])
+        members.append(bgzf_member(text[at:at + n]))                  # blocks end anywhere, also inside a line
+        at += n
+    members.append(bgzf_member(b""))
+    contacts = str(tmp_path / "contacts.bgzf.gz")
+    with open(contacts, "wb") as f:
+        f.write(b"".join(members))
+    monkeypatch.setenv("FHX_TIMING", "1")
+    out = tmp_path / "out"
+    cli.main(["-i", contacts, "-f", kw["frags"], "-o", str(out), "-l", "G", "-t", kw["bias_path"]] + meta["argv"])
+    printed = capsys.readouterr().out
+    assert "device inflate + parse" in printed and "(device parser)" in printed
+    tag = ".res%d" % kw["resolution"]
+    for pi in range(1, meta["n_passes"] + 1):
+        with gzip.open(os.path.join(str(out), "G.spline_pass%d%s.significances.txt.gz" % (pi, tag)), "rb") as f:
+            assert hashlib.md5(f.read()).hexdigest() == meta["sig_md5_pass%d" % pi]
+        with open(os.path.join(str(out), "G.fithic_pass%d%s.txt" % (pi, tag))) as f:
+            assert f.read() == meta["fithic_pass%d_txt" % pi]
