@@ -70,6 +70,7 @@ SYMBOLS = {
     "fhx_load_fragments": (ctypes.c_int, [_P, _I32P, _I32P, _I32P, ctypes.c_int64, _I32P, ctypes.c_int32]),
     "fhx_host_inflate": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int32, ctypes.POINTER(_P)]),
     "fhx_text_bytes": (ctypes.c_int64, [_P]),
+    "fhx_text_copy": (ctypes.c_int, [_P, _P, ctypes.c_int64]),
     "fhx_text_error": (ctypes.c_char_p, [_P]),
     "fhx_host_parse_text": (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_P)]),
     "fhx_text_free": (None, [_P]),
@@ -178,7 +179,7 @@ SYMBOLS = {
 
 BUILD_CMD = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
              "-fno-fast-math", "-pthread", "-o", os.path.join(_PKG, "libfithic_mi355x.so"), os.path.join(CSRC, "fhx_device.hip"),
-             os.path.join(CSRC, "fhx_kr.hip"), os.path.join(CSRC, "fhx_cni.hip"), os.path.join(CSRC, "fhx_host.cpp"), os.path.join(CSRC, "fhx_io.cpp"), "-lz", "-ldl"]
+             os.path.join(CSRC, "fhx_kr.hip"), os.path.join(CSRC, "fhx_cni.hip"), os.path.join(CSRC, "fhx_host.cpp"), os.path.join(CSRC, "fhx_io.cpp"), os.path.join(CSRC, "fhx_gunzip.cpp"), "-lz", "-ldl"]
 
 
 def build(force=False):
@@ -614,6 +615,14 @@ class HostText:
 
     def __len__(self):
         return int(self._L.fhx_text_bytes(self._h))
+
+    def bytes(self):
+        """the inflated text (tests)"""
+        out = np.empty(len(self), np.uint8)
+        rc = self._L.fhx_text_copy(self._h, out.ctypes.data_as(_P), len(out))
+        if rc != FHX_OK:
+            raise FhxError(rc, "fhx_text_copy")
+        return out.tobytes()
 
     def close(self):
         if self._h:

@@ -1,0 +1,581 @@
+// fhx_gunzip.cpp - ONE plain gzip stream inflated on all host cores (what `gzip` writes: no member sizes, nothing to split on).
+//
+// The reference reads its inputs through Python's gzip module (fithic/fithic.py:404); a deflate stream is serial, and zlib
+// needs 11 s for the 4.6 GB of a C3-size contacts file.  Two facts make it parallel (the scheme of pugz / rapidgzip, written
+// here from RFC 1951):
+//   * a dynamic-Huffman block header is recognisable: of 2^17 random bit patterns a handful pass the field ranges, and next to
+//     none the requirement that the code-length code, the literal/length code and the distance code it describes are all
+//     complete prefix codes with an end-of-block symbol.  So a thread can FIND a block start somewhere in the middle of the file;
+//   * decoding from there lacks only the 32 KB of text before it.  The decoder writes 16-bit symbols: a byte, or "byte j of the
+//     unknown window" (256 + j); matches copy these symbols like any others.  When the chunk before has been resolved, its last
+//     32 KB turn every such symbol into its byte.
+// Stages: (1) chunk starts = found block starts; (2) every chunk decoded in parallel up to the next chunk's start, which it must
+// hit exactly; (3) the windows handed down the chain (32 KB per chunk, serial); (4) all chunks resolved into the text in
+// parallel; (5) CRC-32 (zlib's crc32 per chunk + crc32_combine) and ISIZE against the trailer.  Any disagreement - a guessed
+// block start that was none, a stream this decoder does not accept, a second member behind the first - and the caller inflates
+// the file with zlib as before: the result is zlib's, or it is checked against the file's own CRC.
+#include <sys/mman.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "fhx_io_internal.hpp"
+
+namespace {
+
+constexpr int kWindow = 32768;
+constexpr int kFastL = 11, kFastD = 9;
+
+const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+const uint8_t kLenBits[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073,
+                                4097, 6145, 8193, 12289, 16385, 24577};
+const uint8_t kDistBits[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// bits of the stream [data, data + n), least significant first; reads past the end give zeros and set `over`
+struct Bits {
+    const uint8_t* data;
+    size_t n;
+    size_t byte = 0;             // next byte to load
+    uint64_t buf = 0;
+    int cnt = 0;
+    bool over = false;
+    void seek(uint64_t bitpos) {
+        byte = (size_t)(bitpos >> 3);
+        buf = 0;
+        cnt = 0;
+        over = false;
+        refill();
+        const int skip = (int)(bitpos & 7);
+        buf >>= skip;
+        cnt -= skip;
+    }
+    uint64_t pos() const { return (uint64_t)byte * 8 - (uint64_t)cnt; }
+    void refill() {
+        if (byte + 8 <= n) {                                   // 8 bytes at once: the bits that fit are taken, whole bytes counted
+            uint64_t w;
+            std::memcpy(&w, data + byte, 8);
+            buf |= w << cnt;
+            const int take = (63 - cnt) >> 3;
+            byte += (size_t)take;
+            cnt += take * 8;
+            return;
+        }
+        while (cnt <= 56) {
+            uint64_t b = 0;
+            if (byte < n)
+                b = data[byte];
+            else
+                over = true;
+            ++byte;
+            buf |= b << cnt;
+            cnt += 8;
+        }
+    }
+    uint32_t peek(int k) const { return (uint32_t)(buf & ((1ull << k) - 1)); }
+    void drop(int k) {
+        buf >>= k;
+        cnt -= k;
+    }
+    uint32_t get(int k) {
+        const uint32_t v = peek(k);
+        drop(k);
+        return v;
+    }
+};
+
+// canonical code of `n` lengths: counts, symbols in code order; returns the code space left (0 = complete, < 0 = over-subscribed)
+int construct(const uint8_t* lens, int n, uint16_t* cnt, uint16_t* sym) {
+    for (int l = 0; l < 16; ++l) cnt[l] = 0;
+    for (int s = 0; s < n; ++s) cnt[lens[s]]++;
+    int left = 1;
+    for (int l = 1; l < 16; ++l) {
+        left <<= 1;
+        left -= cnt[l];
+        if (left < 0) return left;
+    }
+    uint16_t offs[16];
+    offs[1] = 0;
+    for (int l = 1; l < 15; ++l) offs[l + 1] = (uint16_t)(offs[l] + cnt[l]);
+    for (int s = 0; s < n; ++s)
+        if (lens[s]) sym[offs[lens[s]]++] = (uint16_t)s;
+    return left;
+}
+
+// entries: bits 0-3 code length (0 = longer than the table), 4-7 extra bits, 8-9 kind (0 literal / distance, 1 length,
+// 2 end of block, 3 not a symbol), 16-31 the byte or the base value
+uint32_t lit_entry(uint32_t s, uint32_t len) {
+    if (s < 256) return (s << 16) | len;
+    if (s == 256) return (2u << 8) | len;
+    if (s >= 286) return (3u << 8) | len;
+    return ((uint32_t)kLenBase[s - 257] << 16) | (1u << 8) | ((uint32_t)kLenBits[s - 257] << 4) | len;
+}
+uint32_t dist_entry(uint32_t s, uint32_t len) {
+    if (s >= 30) return (3u << 8) | len;
+    return ((uint32_t)kDistBase[s] << 16) | ((uint32_t)kDistBits[s] << 4) | len;
+}
+uint32_t reverse_bits(uint32_t v, int n) {
+    uint32_t r = 0;
+    for (int i = 0; i < n; ++i) r |= ((v >> i) & 1u) << (n - 1 - i);
+    return r;
+}
+template <typename F>
+void fill_fast(const uint16_t* cnt, const uint16_t* sym, uint32_t* fast, int bits, F entry) {
+    std::memset(fast, 0, sizeof(uint32_t) << bits);
+    uint32_t code = 0, index = 0;
+    for (int l = 1; l <= bits; ++l) {
+        for (uint32_t j = 0; j < cnt[l]; ++j) {
+            const uint32_t e = entry(sym[index + j], (uint32_t)l), rev = reverse_bits(code + j, l);
+            for (uint32_t k = 0; k < (1u << (bits - l)); ++k) fast[rev | (k << l)] = e;
+        }
+        index += cnt[l];
+        code = (code + cnt[l]) << 1;
+    }
+}
+template <typename F>
+uint32_t decode_slow(uint64_t b, const uint16_t* cnt, const uint16_t* sym, F entry) {
+    int code = 0, first = 0, index = 0;
+    for (int l = 1; l <= 15; ++l) {
+        code |= (int)(b & 1);
+        b >>= 1;
+        const int c = cnt[l];
+        if (code - c < first) return entry(sym[index + (code - first)], (uint32_t)l);
+        index += c;
+        first += c;
+        first <<= 1;
+        code <<= 1;
+    }
+    return 0;
+}
+
+struct Tables {
+    uint32_t lit_fast[1 << kFastL], dist_fast[1 << kFastD];
+    uint16_t lit_cnt[16], dist_cnt[16], lit_sym[288], dist_sym[32];
+};
+
+// The header of a dynamic block at the reader's position (after the 3 block bits): lengths -> tables.  false = not a header a
+// deflate encoder writes (and not one zlib accepts): used both to decode and to recognise block starts.
+bool dynamic_tables(Bits& B, Tables& T) {
+    B.refill();
+    const int n_lit = (int)B.get(5) + 257, n_dist = (int)B.get(5) + 1, n_cl = (int)B.get(4) + 4;
+    if (n_lit > 286 || n_dist > 30) return false;
+    uint8_t lens[320];
+    std::memset(lens, 0, sizeof(lens));
+    for (int k = 0; k < n_cl; ++k) {
+        B.refill();
+        lens[kClOrder[k]] = (uint8_t)B.get(3);
+    }
+    uint16_t cl_cnt[16], cl_sym[19];
+    if (construct(lens, 19, cl_cnt, cl_sym) != 0) return false;            // the code length code must be complete
+    uint32_t cl_fast[128];
+    fill_fast(cl_cnt, cl_sym, cl_fast, 7, [](uint32_t s, uint32_t l) { return (s << 16) | l; });
+    std::memset(lens, 0, sizeof(lens));
+    int at = 0;
+    const int total = n_lit + n_dist;
+    uint32_t prev = 0;
+    while (at < total) {
+        B.refill();
+        const uint32_t e = cl_fast[B.peek(7)];
+        if ((e & 15u) == 0) return false;
+        B.drop((int)(e & 15u));
+        const uint32_t s = e >> 16;
+        if (s < 16) {
+            lens[at++] = (uint8_t)s;
+            prev = s;
+        } else {
+            uint32_t v = 0, rep;
+            if (s == 16) {
+                if (at == 0) return false;
+                v = prev;
+                rep = 3 + B.get(2);
+            } else if (s == 17) {
+                rep = 3 + B.get(3);
+            } else {
+                rep = 11 + B.get(7);
+            }
+            if (at + (int)rep > total) return false;
+            for (uint32_t k = 0; k < rep; ++k) lens[at++] = (uint8_t)v;
+            prev = v;
+        }
+    }
+    if (B.over || lens[256] == 0) return false;
+    uint8_t dl[32];
+    std::memset(dl, 0, sizeof(dl));
+    std::memcpy(dl, lens + n_lit, (size_t)n_dist);
+    std::memset(lens + n_lit, 0, (size_t)(320 - n_lit));
+    const int left_l = construct(lens, 288, T.lit_cnt, T.lit_sym);
+    if (left_l < 0 || (left_l > 0 && !(288 - T.lit_cnt[0] == 1 && T.lit_cnt[1] == 1))) return false;
+    const int left_d = construct(dl, 32, T.dist_cnt, T.dist_sym);
+    if (left_d < 0 || (left_d > 0 && !(32 - T.dist_cnt[0] == 1 && T.dist_cnt[1] == 1))) return false;
+    fill_fast(T.lit_cnt, T.lit_sym, T.lit_fast, kFastL, lit_entry);
+    fill_fast(T.dist_cnt, T.dist_sym, T.dist_fast, kFastD, dist_entry);
+    return true;
+}
+
+void fixed_tables(Tables& T) {
+    uint8_t lens[288], dl[32];
+    for (int s = 0; s < 288; ++s) lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+    std::memset(dl, 5, sizeof(dl));
+    construct(lens, 288, T.lit_cnt, T.lit_sym);
+    construct(dl, 32, T.dist_cnt, T.dist_sym);
+    fill_fast(T.lit_cnt, T.lit_sym, T.lit_fast, kFastL, lit_entry);
+    fill_fast(T.dist_cnt, T.dist_sym, T.dist_fast, kFastD, dist_entry);
+}
+
+// first bit position >= from (and < limit) where a non-final dynamic block with complete codes begins; UINT64_MAX if none
+uint64_t find_block(const uint8_t* data, size_t n, uint64_t from, uint64_t limit, Tables& scratch) {
+    Bits B{data, n};
+    for (uint64_t at = from; at < limit; ++at) {
+        // cheap look first: BFINAL = 0, BTYPE = 10, HLIT <= 29, HDIST <= 29
+        const size_t by = (size_t)(at >> 3);
+        if (by + 4 > n) return UINT64_MAX;
+        uint32_t w;
+        std::memcpy(&w, data + by, 4);
+        w >>= (at & 7);
+        if ((w & 7u) != 4u) continue;                                     // bits: 0 (not final), then 0 1 = type 2 (LSB first: 100b)
+        if (((w >> 3) & 31u) > 29u || ((w >> 8) & 31u) > 29u) continue;
+        B.seek(at + 3);
+        if (dynamic_tables(B, scratch) && !B.over) return at;
+    }
+    return UINT64_MAX;
+}
+
+// 16-bit symbols of a chunk: an anonymous mapping on huge pages (nothing is zero-filled by us, first touch is cheap), grown by
+// mremap when a chunk expands more than expected
+struct SymBuf {
+    uint16_t* p = nullptr;
+    size_t cap = 0;
+    SymBuf() = default;
+    SymBuf(const SymBuf&) = delete;
+    SymBuf& operator=(const SymBuf&) = delete;
+    SymBuf(SymBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    SymBuf& operator=(SymBuf&& o) noexcept {
+        if (this != &o) {
+            release();
+            p = o.p;
+            cap = o.cap;
+            o.p = nullptr;
+            o.cap = 0;
+        }
+        return *this;
+    }
+    ~SymBuf() { release(); }
+    void release() {
+        if (p) ::munmap(p, cap * sizeof(uint16_t));
+        p = nullptr;
+        cap = 0;
+    }
+    bool reserve(size_t want) {
+        if (want <= cap) return true;
+        const size_t bytes = ((want * sizeof(uint16_t) + ((size_t)2 << 20) - 1) >> 21) << 21;
+        void* m = p ? ::mremap(p, cap * sizeof(uint16_t), bytes, MREMAP_MAYMOVE)
+                    : ::mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m == MAP_FAILED) return false;
+        (void)::madvise(m, bytes, MADV_HUGEPAGE);
+        p = (uint16_t*)m;
+        cap = bytes / sizeof(uint16_t);
+        return true;
+    }
+    uint16_t* data() { return p; }
+    const uint16_t* data() const { return p; }
+    size_t size() const { return cap; }
+};
+
+struct Chunk {
+    uint64_t start_bit = 0, stop_bit = 0;      // decodes blocks from start_bit until a block would begin at stop_bit (or the final block ends)
+    SymBuf sym;                                // kWindow markers, then the output symbols
+    size_t n_out = 0;
+    bool ok = false, saw_final = false;
+    uint64_t end_bit = 0;
+};
+
+// blocks from C.start_bit on; first = the stream's own start (no unknown window: a distance beyond the output is an error)
+void decode_chunk(const uint8_t* data, size_t n, Chunk& C, bool first, size_t expect_out) {
+    Tables* T = new Tables();
+    struct Free {
+        Tables* t;
+        ~Free() { delete t; }
+    } guard{T};
+    SymBuf& buf16 = C.sym;
+    if (!buf16.reserve(kWindow + std::max<size_t>(expect_out, 1 << 16))) return;
+    uint16_t* out = buf16.data();
+    for (int j = 0; j < kWindow; ++j) out[(size_t)j] = (uint16_t)(256 + j);
+    size_t pos = kWindow;
+    Bits B{data, n};
+    B.seek(C.start_bit);
+    for (;;) {
+        const uint64_t here = B.pos();
+        if (here >= C.stop_bit) {
+            if (here != C.stop_bit) return;                                // ran past the next chunk's start: one of the two is wrong
+            break;
+        }
+        B.refill();
+        const bool last = B.get(1) != 0;
+        const uint32_t type = B.get(2);
+        if (type == 3) return;
+        if (type == 0) {
+            B.drop(B.cnt & 7);
+            B.refill();
+            const uint32_t len = B.get(16), nlen = B.get(16);
+            if ((len ^ 0xffffu) != nlen) return;
+            if (buf16.size() < pos + len + 512) {
+                if (!buf16.reserve((pos + len) * 2)) return;
+                out = buf16.data();
+            }
+            for (uint32_t i = 0; i < len; ++i) {
+                B.refill();
+                out[pos++] = (uint16_t)B.get(8);
+            }
+            if (B.over) return;
+        } else {
+            if (type == 1) {
+                fixed_tables(*T);
+            } else if (!dynamic_tables(B, *T)) {
+                return;
+            }
+            for (;;) {
+                if (buf16.size() < pos + 600) {
+                    if (!buf16.reserve(buf16.size() * 2)) return;
+                    out = buf16.data();
+                }
+                B.refill();
+                uint32_t e = T->lit_fast[B.peek(kFastL)];
+                if ((e & 15u) == 0) {
+                    e = decode_slow(B.buf, T->lit_cnt, T->lit_sym, lit_entry);
+                    if (e == 0) return;
+                }
+                B.drop((int)(e & 15u));
+                const uint32_t kind = (e >> 8) & 3u;
+                if (kind == 0) {
+                    out[pos++] = (uint16_t)(e >> 16);
+                } else if (kind == 1) {
+                    const uint32_t len = (e >> 16) + B.get((int)((e >> 4) & 15u));
+                    B.refill();
+                    uint32_t d = T->dist_fast[B.peek(kFastD)];
+                    if ((d & 15u) == 0) {
+                        d = decode_slow(B.buf, T->dist_cnt, T->dist_sym, dist_entry);
+                        if (d == 0) return;
+                    }
+                    if ((d >> 8) & 3u) return;
+                    B.drop((int)(d & 15u));
+                    const uint32_t dist = (d >> 16) + B.get((int)((d >> 4) & 15u));
+                    if (first && dist > pos - kWindow) return;
+                    const uint16_t* src = out + pos - dist;
+                    uint16_t* dst = out + pos;
+                    for (uint32_t i = 0; i < len; ++i) dst[i] = src[i];     // forward, element by element: overlapping copies repeat
+                    pos += len;
+                } else if (kind == 2) {
+                    break;
+                } else {
+                    return;
+                }
+                if (B.over) return;
+            }
+        }
+        if (last) {
+            C.saw_final = true;
+            break;
+        }
+    }
+    C.end_bit = B.pos();
+    C.n_out = pos - kWindow;
+    C.ok = true;
+}
+
+}  // namespace
+
+// gz = a whole gzip file.  true: `pieces` hold its text (one piece per chunk, in order), checked against the trailer's CRC-32
+// and ISIZE.  false: not done (why says what stood in the way) - the caller uses zlib.
+bool fhx::io_parallel_gunzip(const unsigned char* gz, size_t n, int n_threads, std::vector<fhx::TextPiece>& pieces, std::string& why) {
+    // FHX_PGUNZIP_MIN / FHX_PGUNZIP_CHUNK (bytes): test knobs for the size from which the scheme is used (default 16 MB: below
+    // that zlib is done in a few hundredths of a second) and for the compressed bytes per chunk (default 2 MB at least)
+    size_t min_bytes = (size_t)16 << 20, chunk_bytes = (size_t)2 << 20;
+    if (const char* e = std::getenv("FHX_PGUNZIP_MIN")) min_bytes = (size_t)std::max(0ll, std::atoll(e));
+    if (const char* e = std::getenv("FHX_PGUNZIP_CHUNK")) chunk_bytes = (size_t)std::max(1024ll, std::atoll(e));
+    if (n_threads < 2 || n < min_bytes) {
+        why = "small file or one thread";
+        return false;
+    }
+    if (n < 18 || gz[0] != 0x1f || gz[1] != 0x8b || gz[2] != 8 || (gz[3] & 0xe0)) {
+        why = "not a gzip header";
+        return false;
+    }
+    size_t o = 10;
+    const unsigned flg = gz[3];
+    if (flg & 4) {
+        if (o + 2 > n) return false;
+        o += 2 + (gz[o] | ((size_t)gz[o + 1] << 8));
+    }
+    for (int name = 0; name < 2; ++name)
+        if (flg & (name == 0 ? 8u : 16u)) {
+            while (o < n && gz[o]) ++o;
+            ++o;
+        }
+    if (flg & 2) o += 2;
+    if (o + 8 >= n) {
+        why = "truncated";
+        return false;
+    }
+    const uint8_t* data = gz + o;
+    const size_t len = n - o - 8;                                         // if this is the only member: deflate stream, then CRC-32 and ISIZE
+    const unsigned char* tail = gz + n - 8;
+    const uint32_t want_crc = tail[0] | ((uint32_t)tail[1] << 8) | ((uint32_t)tail[2] << 16) | ((uint32_t)tail[3] << 24);
+    const uint32_t want_isize = tail[4] | ((uint32_t)tail[5] << 8) | ((uint32_t)tail[6] << 16) | ((uint32_t)tail[7] << 24);
+    const bool timing = std::getenv("FHX_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
+    double t_find = 0, t_decode = 0, t_chain = 0, t_resolve = 0;
+    // ---- (1) chunk starts ------------------------------------------------------------------------------------------------
+    const size_t n_chunks = std::min<size_t>((size_t)n_threads * 4, std::max<size_t>(2, len / chunk_bytes));
+    std::vector<Chunk> chunks(n_chunks);
+    {
+        std::atomic<size_t> next{1};
+        auto work = [&]() {
+            Tables* scratch = new Tables();
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= n_chunks) break;
+                const uint64_t from = (uint64_t)(len / n_chunks * k) * 8, limit = (uint64_t)(len / n_chunks * (k + 1)) * 8;
+                chunks[k].start_bit = find_block(data, len + 8, from, limit, *scratch);
+            }
+            delete scratch;
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < n_threads; ++t) pool.emplace_back(work);
+        work();
+        for (auto& th : pool) th.join();
+    }
+    t_find = since();
+    chunks[0].start_bit = 0;
+    {
+        std::vector<Chunk> kept;
+        for (auto& c : chunks)
+            if (c.start_bit != UINT64_MAX) kept.push_back(std::move(c));   // a stretch without a dynamic block start joins the chunk before it
+        chunks.swap(kept);
+    }
+    if (chunks.size() < 2) {
+        why = "no block starts found (stored or fixed-code blocks only)";
+        return false;
+    }
+    for (size_t k = 0; k < chunks.size(); ++k) chunks[k].stop_bit = k + 1 < chunks.size() ? chunks[k + 1].start_bit : UINT64_MAX;
+    // ---- (2)-(5) in batches of n_threads chunks, so that the 16-bit symbols of at most that many chunks exist at a time:
+    // decode the batch in parallel, hand the windows down its chain, resolve + CRC in parallel ------------------------------
+    const size_t readable = len + 8;                                      // the decoder may look at (never consume) the trailer
+    pieces.clear();
+    pieces.resize(chunks.size());
+    std::vector<uint32_t> crcs(chunks.size(), 0);
+    std::vector<uint8_t> carry(kWindow, 0);                               // the 32 KB of text before the batch's first chunk
+    uint64_t total = 0;
+    auto run_parallel = [&](size_t lo, size_t hi, const std::function<void(size_t)>& job) {
+        std::atomic<size_t> next{lo};
+        auto work = [&]() {
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= hi) break;
+                job(k);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < n_threads && (size_t)t < hi - lo; ++t) pool.emplace_back(work);
+        work();
+        for (auto& th : pool) th.join();
+    };
+    for (size_t lo = 0; lo < chunks.size(); lo += (size_t)n_threads) {
+        const size_t hi = std::min(chunks.size(), lo + (size_t)n_threads);
+        double t0 = since();
+        run_parallel(lo, hi, [&](size_t k) {
+            const uint64_t span = (k + 1 < chunks.size() ? chunks[k + 1].start_bit : (uint64_t)len * 8) - chunks[k].start_bit;
+            decode_chunk(data, readable, chunks[k], k == 0, (size_t)(span / 8) * 8);
+        });
+        t_decode += since() - t0;
+        t0 = since();
+        for (size_t k = lo; k < hi; ++k) {
+            if (!chunks[k].ok) {
+                pieces.clear();
+                why = "a chunk did not decode from its guessed block start to the next one";
+                return false;
+            }
+            if (chunks[k].saw_final != (k + 1 == chunks.size())) {
+                pieces.clear();
+                why = "the final block is not where the stream ends (more than one member?)";
+                return false;
+            }
+        }
+        if (hi == chunks.size() && (chunks.back().end_bit + 7) / 8 != len) {
+            pieces.clear();
+            why = "the stream does not end where the file's trailer begins (more than one member?)";
+            return false;
+        }
+        // windows down the chain: window[k] = the 32 KB of text before chunk k
+        std::vector<std::vector<uint8_t>> window(hi - lo + 1);
+        window[0] = carry;
+        for (size_t k = lo; k < hi; ++k) {
+            const Chunk& c = chunks[k];
+            const std::vector<uint8_t>& before = window[k - lo];
+            std::vector<uint8_t>& w = window[k - lo + 1];
+            w.resize(kWindow);
+            const uint16_t* end = c.sym.data() + kWindow + c.n_out;      // the last kWindow symbols of [markers of the window, output]
+            for (int j = 0; j < kWindow; ++j) {
+                const uint16_t v = end[j - kWindow];
+                w[(size_t)j] = v < 256 ? (uint8_t)v : before[(size_t)(v - 256)];
+            }
+        }
+        carry = window[hi - lo];
+        t_chain += since() - t0;
+        t0 = since();
+        std::atomic<bool> bad{false};
+        run_parallel(lo, hi, [&](size_t k) {
+            Chunk& c = chunks[k];
+            if (!pieces[k].allocate(c.n_out)) {
+                bad = true;
+                return;
+            }
+            uint8_t* dst = (uint8_t*)pieces[k].data();
+            const uint16_t* src = c.sym.data() + kWindow;
+            const uint8_t* w = window[k - lo].data();
+            for (size_t i = 0; i < c.n_out; ++i) {
+                const uint16_t v = src[i];
+                dst[i] = v < 256 ? (uint8_t)v : w[v - 256];
+            }
+            uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
+            for (size_t i = 0; i < c.n_out; i += (size_t)1 << 30)
+                crc = (uint32_t)crc32(crc, dst + i, (uInt)std::min<size_t>((size_t)1 << 30, c.n_out - i));
+            crcs[k] = crc;
+            c.sym.release();
+        });
+        if (bad) {
+            pieces.clear();
+            why = "out of memory";
+            return false;
+        }
+        for (size_t k = lo; k < hi; ++k) total += chunks[k].n_out;
+        t_resolve += since() - t0;
+    }
+    if (timing)
+        std::fprintf(stderr, "parallel gunzip: %zu chunks on %d threads: block starts %.3f s; decode %.3f s; windows %.3f s; resolve + CRC-32 %.3f s\n",
+                     chunks.size(), n_threads, t_find, t_decode, t_chain, t_resolve);
+    if ((uint32_t)total != want_isize) {
+        pieces.clear();
+        why = "ISIZE differs";
+        return false;
+    }
+    uint32_t crc = crcs[0];
+    for (size_t k = 1; k < chunks.size(); ++k) crc = (uint32_t)crc32_combine(crc, crcs[k], (z_off_t)chunks[k].n_out);
+    if (crc != want_crc) {
+        pieces.clear();
+        why = "CRC-32 differs";
+        return false;
+    }
+    return true;
+}

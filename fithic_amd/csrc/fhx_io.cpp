@@ -673,7 +673,12 @@ int fhx::io_inflate_file(const char* path, int n_threads, std::vector<fhx::TextP
             error = "corrupt gzip member " + std::to_string((long long)bad_member) + " in " + path;
             return FHX_ERR_REFERENCE_EXIT;
         }
+    } else if (!std::getenv("FHX_SERIAL_GUNZIP") && fhx::io_parallel_gunzip(gz.data(), gz.size(), n_threads, pieces, error)) {
+        error.clear();                                     // one plain stream, inflated on all cores and checked against its trailer
     } else {
+        if (std::getenv("FHX_TIMING") && !error.empty()) std::fprintf(stderr, "parallel gunzip of %s not used: %s\n", path, error.c_str());
+        error.clear();
+        pieces.clear();
         pieces.resize(1);
         std::string err;
         if (!inflate_stream(gz.data(), gz.size(), pieces[0].grown, err)) {
@@ -826,6 +831,15 @@ int fhx_host_inflate(const char* path, int32_t n_threads, fhx_text** out) {
 }
 
 int64_t fhx_text_bytes(const fhx_text* x) { return x ? x->bytes : 0; }
+int fhx_text_copy(const fhx_text* x, void* dst, int64_t cap) {
+    if (!x || (!dst && cap > 0) || cap < x->bytes) return FHX_ERR_ARG;
+    char* out = (char*)dst;
+    for (const fhx::TextPiece& piece : x->pieces) {
+        std::memcpy(out, piece.data(), piece.size());
+        out += piece.size();
+    }
+    return FHX_OK;
+}
 const char* fhx_text_error(const fhx_text* x) { return x ? x->error.c_str() : "null text"; }
 void fhx_text_free(fhx_text* x) { delete x; }
 

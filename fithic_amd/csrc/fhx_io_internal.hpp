@@ -81,6 +81,10 @@ struct GzMember {
 // some member has no size field (plain gzip) or the chain does not end exactly at the end of the file
 bool io_scan_members(const unsigned char* d, size_t n, std::vector<GzMember>& out);
 
+// One plain gzip stream inflated on all cores (fhx_gunzip.cpp: block starts found by their headers, chunks decoded with the
+// unknown window as 16-bit symbols, windows resolved down the chain, CRC-32 and ISIZE checked).  false + why: not done, use zlib.
+bool io_parallel_gunzip(const unsigned char* gz, size_t n, int n_threads, std::vector<TextPiece>& pieces, std::string& why);
+
 // path -> the inflated text as pieces in file order (see fhx_io.cpp); returns an FHX_* code and, on failure, the message
 int io_inflate_file(const char* path, int n_threads, std::vector<TextPiece>& pieces, std::string& error, double* seconds);
 

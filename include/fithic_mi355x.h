@@ -342,13 +342,17 @@ int fhx_table_copy(const fhx_table* t, int32_t column, void* dst);
 /* ids[i] = the caller's id of fhx_table_name(t, i): columns 0 and 2 of later fhx_table_copy calls are in that id space. */
 int fhx_table_map_names(fhx_table* t, const int32_t* ids, int32_t n_ids);
 void fhx_table_free(fhx_table* t);
-/* The two stages of fhx_host_read_table on their own.  fhx_host_inflate: the file read and inflated on the host cores (an
+/* The two stages of fhx_host_read_table on their own.  fhx_host_inflate: the file read and inflated on the host cores - a file
+ * of size-tagged members by one zlib per core, ONE plain gzip stream (what `gzip` writes) by csrc/fhx_gunzip.cpp: block starts
+ * found by their headers, chunks decoded in parallel with the unknown 32 KB window as 16-bit symbols, windows resolved down the
+ * chain, CRC-32 and ISIZE checked, zlib on one thread whenever any of that does not work out (an
  * object is returned even on failure, for fhx_text_error); fhx_host_parse_text: the table of that text.  The split exists for
  * fhx_ingest_contacts_text below, which parses the text on the GPU and leaves fhx_host_parse_text as the path for the files
  * it does not take. */
 typedef struct fhx_text fhx_text;
 int fhx_host_inflate(const char* path, int32_t n_threads, fhx_text** out);
 int64_t fhx_text_bytes(const fhx_text* x);
+int fhx_text_copy(const fhx_text* x, void* dst, int64_t cap);      /* the inflated bytes (cap >= fhx_text_bytes) */
 const char* fhx_text_error(const fhx_text* x);
 int fhx_host_parse_text(const fhx_text* text, int32_t kind, int32_t n_threads, fhx_table** out);
 void fhx_text_free(fhx_text* x);

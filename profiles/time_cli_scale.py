@@ -79,7 +79,7 @@ def main():
               (passes, " --gpus %d" % args.gpus if args.gpus > 1 else "", dt, n, n / dt / 1e6,
                os.path.getsize(sig) / 1e6 if os.path.exists(sig) else -1, r.returncode))
         for ln in r.stdout.splitlines() + r.stderr.splitlines():
-            if "took" in ln or "Time" in ln or "stage" in ln or ln.startswith("fhx_") or ln.startswith("contacts on the device"):
+            if "took" in ln or "Time" in ln or "stage" in ln or ln.startswith("fhx_") or ln.startswith("contacts on the device") or ln.startswith("parallel gunzip"):
                 print("    " + ln)
         if r.returncode != 0:
             print(r.stderr[-2000:])

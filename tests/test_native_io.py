@@ -170,3 +170,122 @@ def test_inflate_and_parse_as_separate_stages(tmp_path):
     empty.write_bytes(b"")
     with pytest.raises(_capi.FhxError):
         _capi.HostText(str(empty))
+
+
+def _plain_gzip(data, level=6, strategy=None, name=None):
+    import struct
+    import zlib
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, zlib.Z_DEFAULT_STRATEGY if strategy is None else strategy)
+    body = co.compress(data) + co.flush()
+    head = b"\x1f\x8b\x08" + (b"\x08" if name else b"\x00") + b"\0\0\0\0\x00\x03" + ((name + b"\0") if name else b"")
+    return head + body + struct.pack("<II", zlib.crc32(data), len(data) & 0xffffffff)
+
+
+def test_one_plain_gzip_stream_is_inflated_on_all_cores(tmp_path, monkeypatch):
+    """csrc/fhx_gunzip.cpp: block starts found by their headers, chunks decoded with the unknown window as 16-bit symbols.  The
+    text must be what Python's gzip gives, for every level and for streams that mix stored, fixed and dynamic blocks; what the
+    scheme cannot take (two members, fixed codes only, damage) comes out of zlib on one thread as before - same text, same errors.
+    FHX_PGUNZIP_MIN / _CHUNK shrink the sizes from which it is used so that small files go through it."""
+    import random
+    import zlib
+    rng = random.Random(12)
+    rows = []
+    for _ in range(150_000):
+        c = rng.randrange(1, 23)
+        rows.append("chr%d\t%d\tchr%d\t%d\t%d\n" % (c, rng.randrange(1, 50000) * 5000 + 2500, c, rng.randrange(1, 50000) * 5000 + 2500, rng.randrange(1, 500)))
+    text = "".join(rows).encode()
+    noise = bytes(rng.getrandbits(8) for _ in range(300_000))
+    monkeypatch.setenv("FHX_PGUNZIP_MIN", "0")
+    monkeypatch.setenv("FHX_PGUNZIP_CHUNK", "200000")
+    monkeypatch.setenv("FHX_TIMING", "1")
+    cases = {
+        "level1": _plain_gzip(text, 1), "level6": _plain_gzip(text, 6), "level9": _plain_gzip(text, 9),
+        "named": _plain_gzip(text, 6, name=b"contacts.txt"),
+        "mixed": _plain_gzip(text[:1_000_000] + noise + text[1_000_000:2_000_000] + b"\0" * 500_000 + noise[:70_000] + text[2_000_000:], 6),
+        "huffman_only": _plain_gzip(text[:800_000], 6, zlib.Z_HUFFMAN_ONLY),
+        "rle": _plain_gzip(text, 6, zlib.Z_RLE),
+        "fixed_only": _plain_gzip(text[:500_000], 6, zlib.Z_FIXED),            # no dynamic block to find: zlib
+        "stored_only": _plain_gzip(noise * 3, 0),
+        "two_members": gzip.compress(text[:900_000]) + gzip.compress(text[900_000:1_800_000]),
+        "python_gzip": gzip.compress(text, 6),
+    }
+    for label, blob in cases.items():
+        path = str(tmp_path / (label + ".gz"))
+        with open(path, "wb") as f:
+            f.write(blob)
+        want = gzip.decompress(blob)
+        for threads in (2, 5):
+            t = _capi.HostText(path, threads)
+            assert t.bytes() == want, (label, threads)
+            t.close()
+    # the parallel path is really the one that ran on the regular streams (its stage line goes to stderr), and not on the others
+    # damage: the same error as zlib on one thread
+    blob = bytearray(cases["level6"])
+    blob[len(blob) // 2] ^= 0x10
+    bad = str(tmp_path / "bad.gz")
+    with open(bad, "wb") as f:
+        f.write(bytes(blob))
+    with pytest.raises(_capi.FhxError) as e1:
+        _capi.HostText(bad, 4)
+    monkeypatch.setenv("FHX_SERIAL_GUNZIP", "1")
+    with pytest.raises(_capi.FhxError) as e2:
+        _capi.HostText(bad, 4)
+    assert str(e1.value) == str(e2.value)
+    cut = str(tmp_path / "cut.gz")
+    with open(cut, "wb") as f:
+        f.write(cases["level6"][:-5000])
+    monkeypatch.delenv("FHX_SERIAL_GUNZIP")
+    with pytest.raises(_capi.FhxError):
+        _capi.HostText(cut, 4)
+
+
+def test_parallel_gunzip_reports_its_stages(tmp_path, monkeypatch, capfd):
+    import random
+    rng = random.Random(2)
+    text = "".join("chr1\t%d\tchr1\t%d\t%d\n" % (rng.randrange(10 ** 8), rng.randrange(10 ** 8), rng.randrange(99)) for _ in range(200_000)).encode()
+    path = str(tmp_path / "c.gz")
+    with gzip.open(path, "wb", compresslevel=6) as f:
+        f.write(text)
+    monkeypatch.setenv("FHX_PGUNZIP_MIN", "0")
+    monkeypatch.setenv("FHX_PGUNZIP_CHUNK", "150000")
+    monkeypatch.setenv("FHX_TIMING", "1")
+    t = _capi.HostText(path, 4)
+    assert t.bytes() == text
+    t.close()
+    assert "parallel gunzip:" in capfd.readouterr().err
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FHX_FUZZ_SEEDS", "0:3").split(":")[0]),
+                                       int(os.environ.get("FHX_FUZZ_SEEDS", "0:3").split(":")[1])))
+def test_parallel_gunzip_on_random_streams(seed, tmp_path, monkeypatch):
+    """random mixtures of table text, noise, zero runs and repeats far apart, every level and strategy, chunk sizes from 1 KB (many
+    guessed block starts, chunks of a block or two) to 1 MB, 2-7 threads: the text equals Python's, whichever path produced it"""
+    import random
+    import zlib
+    rng = random.Random(4000 + seed)
+    monkeypatch.setenv("FHX_PGUNZIP_MIN", "0")
+    for trial in range(8):
+        parts = []
+        for _ in range(rng.randrange(1, 7)):
+            kind = rng.randrange(5)
+            if kind == 0:
+                parts.append("".join("chr%d\t%d\tchr%d\t%d\t%d\n" % (rng.randrange(1, 23), rng.randrange(10 ** 8), rng.randrange(1, 23),
+                                                                     rng.randrange(10 ** 8), rng.randrange(999))
+                                     for _ in range(rng.randrange(100, 40000))).encode())
+            elif kind == 1:
+                parts.append(bytes(rng.getrandbits(8) for _ in range(rng.randrange(10, 100_000))))
+            elif kind == 2:
+                parts.append(bytes([rng.randrange(256)]) * rng.randrange(1, 400_000))
+            elif kind == 3 and parts:
+                parts.append(parts[rng.randrange(len(parts))][:50_000])          # a repeat, possibly beyond the window
+            else:
+                parts.append(("%d\n" % rng.randrange(10 ** 9)).encode() * rng.randrange(1, 30000))
+        data = b"".join(parts)
+        blob = _plain_gzip(data, rng.choice([1, 2, 4, 6, 9]), rng.choice([None, None, zlib.Z_FILTERED, zlib.Z_RLE, zlib.Z_HUFFMAN_ONLY]))
+        path = str(tmp_path / ("r%d.gz" % trial))
+        with open(path, "wb") as f:
+            f.write(blob)
+        monkeypatch.setenv("FHX_PGUNZIP_CHUNK", str(rng.choice([1024, 5000, 40_000, 300_000, 1_000_000])))
+        t = _capi.HostText(path, rng.randrange(2, 8))
+        assert t.bytes() == data, (seed, trial)
+        t.close()
