@@ -294,7 +294,7 @@ struct SymBuf {
 
 struct Chunk {
     uint64_t start_bit = 0, stop_bit = 0;      // decodes blocks from start_bit until a block would begin at stop_bit (or the final block ends)
-    SymBuf sym;                                // kWindow markers, then the output symbols
+    SymBuf* sym = nullptr;                     // kWindow markers, then the output symbols (a buffer of the batch's pool)
     size_t n_out = 0;
     bool ok = false, saw_final = false;
     uint64_t end_bit = 0;
@@ -307,7 +307,7 @@ void decode_chunk(const uint8_t* data, size_t n, Chunk& C, bool first, size_t ex
         Tables* t;
         ~Free() { delete t; }
     } guard{T};
-    SymBuf& buf16 = C.sym;
+    SymBuf& buf16 = *C.sym;
     if (!buf16.reserve(kWindow + std::max<size_t>(expect_out, 1 << 16))) return;
     uint16_t* out = buf16.data();
     for (int j = 0; j < kWindow; ++j) out[(size_t)j] = (uint16_t)(256 + j);
@@ -491,8 +491,10 @@ bool fhx::io_parallel_gunzip(const unsigned char* gz, size_t n, int n_threads, s
         work();
         for (auto& th : pool) th.join();
     };
+    std::vector<SymBuf> pool((size_t)n_threads);                         // reused by every batch: mapping and unmapping GBs is not free
     for (size_t lo = 0; lo < chunks.size(); lo += (size_t)n_threads) {
         const size_t hi = std::min(chunks.size(), lo + (size_t)n_threads);
+        for (size_t k = lo; k < hi; ++k) chunks[k].sym = &pool[k - lo];
         double t0 = since();
         run_parallel(lo, hi, [&](size_t k) {
             const uint64_t span = (k + 1 < chunks.size() ? chunks[k + 1].start_bit : (uint64_t)len * 8) - chunks[k].start_bit;
@@ -525,7 +527,7 @@ bool fhx::io_parallel_gunzip(const unsigned char* gz, size_t n, int n_threads, s
             const std::vector<uint8_t>& before = window[k - lo];
             std::vector<uint8_t>& w = window[k - lo + 1];
             w.resize(kWindow);
-            const uint16_t* end = c.sym.data() + kWindow + c.n_out;      // the last kWindow symbols of [markers of the window, output]
+            const uint16_t* end = c.sym->data() + kWindow + c.n_out;      // the last kWindow symbols of [markers of the window, output]
             for (int j = 0; j < kWindow; ++j) {
                 const uint16_t v = end[j - kWindow];
                 w[(size_t)j] = v < 256 ? (uint8_t)v : before[(size_t)(v - 256)];
@@ -542,9 +544,25 @@ bool fhx::io_parallel_gunzip(const unsigned char* gz, size_t n, int n_threads, s
                 return;
             }
             uint8_t* dst = (uint8_t*)pieces[k].data();
-            const uint16_t* src = c.sym.data() + kWindow;
+            const uint16_t* src = c.sym->data() + kWindow;
             const uint8_t* w = window[k - lo].data();
-            for (size_t i = 0; i < c.n_out; ++i) {
+            size_t i = 0;
+            for (; i + 4 <= c.n_out; i += 4) {                          // four symbols at a time when none of them is a window reference
+                uint64_t q;
+                std::memcpy(&q, src + i, 8);
+                if ((q & 0xff00ff00ff00ff00ull) == 0) {
+                    dst[i] = (uint8_t)q;
+                    dst[i + 1] = (uint8_t)(q >> 16);
+                    dst[i + 2] = (uint8_t)(q >> 32);
+                    dst[i + 3] = (uint8_t)(q >> 48);
+                } else {
+                    for (int j = 0; j < 4; ++j) {
+                        const uint16_t v = src[i + j];
+                        dst[i + j] = v < 256 ? (uint8_t)v : w[v - 256];
+                    }
+                }
+            }
+            for (; i < c.n_out; ++i) {
                 const uint16_t v = src[i];
                 dst[i] = v < 256 ? (uint8_t)v : w[v - 256];
             }
@@ -552,7 +570,6 @@ bool fhx::io_parallel_gunzip(const unsigned char* gz, size_t n, int n_threads, s
             for (size_t i = 0; i < c.n_out; i += (size_t)1 << 30)
                 crc = (uint32_t)crc32(crc, dst + i, (uInt)std::min<size_t>((size_t)1 << 30, c.n_out - i));
             crcs[k] = crc;
-            c.sym.release();
         });
         if (bad) {
             pieces.clear();
