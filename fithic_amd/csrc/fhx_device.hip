@@ -1954,15 +1954,58 @@ void dev_free(T*& p) {
 }
 
 // temporary device allocations of one call: freed on every return path (FHX_HIP returns early on errors)
+// Device blocks kept between the batches of one call: allocating and freeing GBs per batch stalls behind the other thread's
+// hipFree (a batch of the device writer waited up to 0.5 s in its allocations); a block goes back here instead and the next
+// batch, which asks for the same sizes in the same order, takes it again.  Freed when the pool goes out of scope.
+struct ScratchPool {
+    std::mutex mu;
+    std::vector<std::pair<void*, size_t>> idle;
+    ~ScratchPool() {
+        for (auto& b : idle) (void)hipFree(b.first);
+    }
+    void* take(size_t bytes, size_t* real) {           // the smallest idle block that is large enough, or nullptr
+        std::lock_guard<std::mutex> g(mu);
+        size_t best = idle.size();
+        for (size_t i = 0; i < idle.size(); ++i)
+            if (idle[i].second >= bytes && (best == idle.size() || idle[i].second < idle[best].second)) best = i;
+        if (best == idle.size()) return nullptr;
+        void* p = idle[best].first;
+        *real = idle[best].second;
+        idle.erase(idle.begin() + (long)best);
+        return p;
+    }
+    void give(void* p, size_t bytes) {
+        std::lock_guard<std::mutex> g(mu);
+        idle.emplace_back(p, bytes);
+    }
+};
+
 struct DeviceScratch {
-    std::vector<void*> v;
+    std::vector<std::pair<void*, size_t>> v;
+    ScratchPool* pool = nullptr;                       // where the blocks go at the end instead of hipFree
+    DeviceScratch() = default;
+    explicit DeviceScratch(ScratchPool* p) : pool(p) {}
     ~DeviceScratch() {
-        for (void* p : v) (void)hipFree(p);
+        for (auto& b : v) {
+            if (pool)
+                pool->give(b.first, b.second);
+            else
+                (void)hipFree(b.first);
+        }
     }
     template <typename T>
     hipError_t get(T** p, size_t bytes) {
-        const hipError_t e = hipMalloc((void**)p, std::max<size_t>(bytes, 16));
-        if (e == hipSuccess) v.push_back((void*)*p);
+        bytes = std::max<size_t>(bytes, 16);
+        if (pool) {
+            size_t real = 0;
+            if (void* q = pool->take(bytes, &real)) {
+                *p = (T*)q;
+                v.emplace_back(q, real);
+                return hipSuccess;
+            }
+        }
+        const hipError_t e = hipMalloc((void**)p, bytes);
+        if (e == hipSuccess) v.emplace_back((void*)*p, bytes);
         return e;
     }
 };
