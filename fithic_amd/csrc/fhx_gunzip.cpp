@@ -301,7 +301,10 @@ struct Chunk {
 };
 
 // blocks from C.start_bit on; first = the stream's own start (no unknown window: a distance beyond the output is an error)
+// expect_out: the first reservation; a chunk that grows beyond 8 x that (text compresses 3-10 x; 64 x its compressed bytes) is
+// given up - sixteen chunks of a file of zeros would otherwise ask for hundreds of GB of symbols - and zlib streams the file
 void decode_chunk(const uint8_t* data, size_t n, Chunk& C, bool first, size_t expect_out) {
+    const size_t out_limit = kWindow + std::max<size_t>(expect_out * 8, (size_t)64 << 20);
     Tables* T = new Tables();
     struct Free {
         Tables* t;
@@ -330,7 +333,7 @@ void decode_chunk(const uint8_t* data, size_t n, Chunk& C, bool first, size_t ex
             const uint32_t len = B.get(16), nlen = B.get(16);
             if ((len ^ 0xffffu) != nlen) return;
             if (buf16.size() < pos + len + 512) {
-                if (!buf16.reserve((pos + len) * 2)) return;
+                if (pos + len > out_limit || !buf16.reserve((pos + len) * 2)) return;
                 out = buf16.data();
             }
             for (uint32_t i = 0; i < len; ++i) {
@@ -346,7 +349,7 @@ void decode_chunk(const uint8_t* data, size_t n, Chunk& C, bool first, size_t ex
             }
             for (;;) {
                 if (buf16.size() < pos + 600) {
-                    if (!buf16.reserve(buf16.size() * 2)) return;
+                    if (pos > out_limit || !buf16.reserve(buf16.size() * 2)) return;
                     out = buf16.data();
                 }
                 B.refill();
