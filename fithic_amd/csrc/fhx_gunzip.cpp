@@ -401,9 +401,9 @@ void decode_chunk(const uint8_t* data, size_t n, Chunk& C, bool first, size_t ex
 // gz = a whole gzip file.  true: `pieces` hold its text (one piece per chunk, in order), checked against the trailer's CRC-32
 // and ISIZE.  false: not done (why says what stood in the way) - the caller uses zlib.
 bool fhx::io_parallel_gunzip(const unsigned char* gz, size_t n, int n_threads, std::vector<fhx::TextPiece>& pieces, std::string& why) {
-    // FHX_PGUNZIP_MIN / FHX_PGUNZIP_CHUNK (bytes): test knobs for the size from which the scheme is used (default 16 MB: below
-    // that zlib is done in a few hundredths of a second) and for the compressed bytes per chunk (default 2 MB at least)
-    size_t min_bytes = (size_t)16 << 20, chunk_bytes = (size_t)2 << 20;
+    // FHX_PGUNZIP_MIN / FHX_PGUNZIP_CHUNK (bytes): test knobs for the size from which the scheme is used (default 4 MB: below
+    // that zlib is done in a few hundredths of a second) and for the compressed bytes per chunk (default 512 KB at least)
+    size_t min_bytes = (size_t)4 << 20, chunk_bytes = (size_t)512 << 10;
     if (const char* e = std::getenv("FHX_PGUNZIP_MIN")) min_bytes = (size_t)std::max(0ll, std::atoll(e));
     if (const char* e = std::getenv("FHX_PGUNZIP_CHUNK")) chunk_bytes = (size_t)std::max(1024ll, std::atoll(e));
     if (n_threads < 2 || n < min_bytes) {

@@ -722,7 +722,10 @@ static int parse_pieces(const std::vector<fhx::TextPiece>& pieces, const char* p
     glued.reserve(pieces.size() + 1);
     {
         std::string carry;
-        const size_t target = 8u << 20;                    // ~8 MB of text per parse task
+        size_t total_text = 0;
+        for (const fhx::TextPiece& text : pieces) total_text += text.size();
+        // ~8 MB of text per parse task; a small table (fragments, biases: 10-20 MB) is still cut into a few tasks per thread
+        const size_t target = std::min<size_t>(8u << 20, std::max<size_t>(256u << 10, total_text / (size_t)(4 * std::max(n_threads, 1))));
         for (const fhx::TextPiece& text : pieces) {
             const char* b = text.data();
             const char* e = b + text.size();
