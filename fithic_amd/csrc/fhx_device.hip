@@ -17,6 +17,8 @@
 #include <chrono>
 #include <thread>
 #include <memory>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <deque>
 #include <mutex>
 #include <condition_variable>
