@@ -103,6 +103,7 @@ SYMBOLS = {
     "fhx_get_stats": (ctypes.c_int, [_P, ctypes.POINTER(FhxStats)]),
     "fhx_fetch": (ctypes.c_int, [_P, _F64P, _F64P, _F64P, _F64P, _F64P]),
     "fhx_fetch_flags": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint8)]),
+    "fhx_fetch_outlier_rows": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int64), ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
     "fhx_get_array": (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_int64, _I64P]),
     "fhx_device_ptr": (_P, [_P, ctypes.c_int]),
     "fhx_n_sorted": (ctypes.c_int64, [_P]),
@@ -481,6 +482,15 @@ class Context:
                 bufs.append(None)
         self._check(self._L.fhx_fetch(self._h, *bufs))
         return out
+
+    def fetch_outlier_rows(self):
+        """row numbers of the outlier lines, ascending (int64), compacted on the device"""
+        n = ctypes.c_int64(0)
+        self._check(self._L.fhx_fetch_outlier_rows(self._h, None, 0, ctypes.byref(n)))
+        rows = np.empty(n.value, np.int64)
+        if n.value:
+            self._check(self._L.fhx_fetch_outlier_rows(self._h, _ptr(rows, ctypes.c_int64), len(rows), ctypes.byref(n)))
+        return rows
 
     def fetch_flags(self, n_rows, outlier=True, skip=False):
         o = np.empty(n_rows, np.uint8) if outlier else None

@@ -383,20 +383,25 @@ def fit_Spline(mainDic, x, y, yerr, infilename, outfilename, biasDic, outliersli
                                        v["b1"], v["b2"], v["expcc"], mode_id, distLowThres, distUpThres)
     if os.environ.get("FHX_TIMING"):
         print("stage: format + deflate + write took %.3f s" % (time.time() - t_stage))
-    flags, _ = eng.ctx.fetch_flags(len(con), outlier=True, skip=False)
-    rows = np.flatnonzero(flags)
-    for r in rows.tolist():
-        outliersline.add(r) if hasattr(outliersline, "add") else outliersline.append(r)
+    t_stage = time.time()
+    if hasattr(eng.ctx, "fetch_outlier_rows"):
+        rows = eng.ctx.fetch_outlier_rows()                  # compacted on the device
+    else:                                                    # a sharded run: flags of all ranks in file order
+        flags, _ = eng.ctx.fetch_flags(len(con), outlier=True, skip=False)
+        rows = np.flatnonzero(flags)
+    (outliersline.update if hasattr(outliersline, "add") else outliersline.extend)(rows.tolist())
     # abs(mid1 - mid2) of every outlier line, inter-chromosomal ones included (fithic.py:1217)
     if isinstance(con, tables.DeviceContacts):
         _, out_mid1, _, out_mid2, _ = con.rows(rows)
     else:
         out_mid1, out_mid2 = con.mid1[rows], con.mid2[rows]
-    for dist in np.abs(out_mid1.astype(np.int64) - out_mid2.astype(np.int64)).tolist():
-        outliersdist.add(dist) if hasattr(outliersdist, "add") else outliersdist.append(dist)
+    dists = np.abs(out_mid1.astype(np.int64) - out_mid2.astype(np.int64)).tolist()
+    (outliersdist.update if hasattr(outliersdist, "add") else outliersdist.extend)(dists)
     if not hasattr(outliersline, "add"):
         outliersline.sort()
         outliersdist.sort()
+    if os.environ.get("FHX_TIMING"):
+        print("stage: %d outlier lines collected in %.3f s" % (len(rows), time.time() - t_stage))
     FDRx = np.arange(0.0, 0.05 + 0.001, 0.001)
     FDRy = [int(c) for c in eng.fdr_counts()]                # plot_qvalues' counts (fithic.py:1235-1254), device histogram
     if visual:

@@ -216,6 +216,9 @@ int fhx_fetch(fhx_ctx* ctx, double* p, double* q, double* expcc, double* bias1, 
 /* Per-row byte flags: outlier[i] = (p_i < 1/N) of the last fhx_pvalues; skip[i] = row is skipped by fhx_pass_stats
  * (outlier of an earlier pass, fithic/fithic.py:408-412).  Either pointer may be NULL. */
 int fhx_fetch_flags(fhx_ctx* ctx, uint8_t* outlier, uint8_t* skip);
+/* The row numbers (file order, ascending) of the rows fhx_fetch_flags would flag as outliers, compacted on the device.
+ * rows == NULL or cap < *n_out: only the count is returned. */
+int fhx_fetch_outlier_rows(fhx_ctx* ctx, int64_t* rows, int64_t cap, int64_t* n_out);
 int fhx_get_array(fhx_ctx* ctx, int which, void* dst, int64_t capacity_elems, int64_t* n_out);
 /* Raw device pointers for plumbing (torch / RCCL exchange): 0 = p, 1 = q, 2 = sorted keys, 3 = sorted idx */
 void* fhx_device_ptr(fhx_ctx* ctx, int which);

@@ -429,3 +429,15 @@ def test_ctypes_only_example_runs_and_matches_the_package(tmp_path):
     p, q = mod.main()
     assert len(p) > 10000 and np.nanmin(p) < 1e-3 and np.all((q[~np.isnan(q)] >= 0) & (q[~np.isnan(q)] <= 1))
     assert np.all(q[~np.isnan(q)] >= p[~np.isnan(q)] - 1e-18)
+
+
+@pytest.mark.parametrize("name", ["f1_bias", "f2_all", "f8_nonfixed_all"])
+def test_outlier_rows_compacted_on_the_device_equal_the_flag_bytes(name):
+    """fhx_fetch_outlier_rows = the ascending positions of the bytes fhx_fetch_flags sets (fithic.py:1215: p < 1/N)"""
+    from test_gpu_writer import _engine_with_case
+    eng, kw, chroms, con = _engine_with_case(name)
+    eng.run_pass(collect=False)
+    flags, _ = eng.ctx.fetch_flags(len(con), outlier=True, skip=False)
+    rows = eng.ctx.fetch_outlier_rows()
+    assert rows.dtype == np.int64 and np.array_equal(rows, np.flatnonzero(flags))
+    eng.close()
