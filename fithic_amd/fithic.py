@@ -287,7 +287,67 @@ def generate_FragPairs(observedInterAllCount, observedInterAllSum, binStats, fra
 
 
 class _BiasDic(dict):
-    """Truthiness and chromosome membership like the reference's nested dict; values are resolved on the GPU."""
+    """{chrom: {mid: bias}} like the reference's nested dict (fithic.py:798-837), filled when somebody looks: the engine reads the
+    biases from its own table, and building 6e5 Python entries costs the command line 0.07 s.  Truthiness, len(), iteration,
+    indexing, membership, get/keys/values/items, equality and repr all see the filled dict."""
+
+    def __init__(self, fill=None, n_loci=0):
+        super().__init__()
+        self._fill_from, self._n_loci = fill, n_loci
+
+    def _fill(self):
+        fill, self._fill_from = self._fill_from, None
+        if fill is not None:
+            names, bc, bm, vals = fill
+            for c, m, v in zip(bc.tolist(), bm.tolist(), vals.tolist()):
+                d = dict.setdefault(self, names[c], {})
+                if m not in d:
+                    d[m] = -1 if v == -1.0 else v
+        return self
+
+    def __bool__(self):
+        return self._n_loci > 0 if self._fill_from is not None else dict.__len__(self) > 0
+
+    def __len__(self):
+        return dict.__len__(self._fill())
+
+    def __iter__(self):
+        return dict.__iter__(self._fill())
+
+    def __contains__(self, key):
+        return dict.__contains__(self._fill(), key)
+
+    def __getitem__(self, key):
+        return dict.__getitem__(self._fill(), key)
+
+    def __eq__(self, other):
+        return dict.__eq__(self._fill(), other)
+
+    def __ne__(self, other):
+        return dict.__ne__(self._fill(), other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        return dict.__repr__(self._fill())
+
+    def get(self, key, default=None):
+        return dict.get(self._fill(), key, default)
+
+    def keys(self):
+        return dict.keys(self._fill())
+
+    def values(self):
+        return dict.values(self._fill())
+
+    def items(self):
+        return dict.items(self._fill())
+
+    def setdefault(self, key, default=None):
+        return dict.setdefault(self._fill(), key, default)
+
+    def copy(self):
+        return dict(self.items())
 
 
 def read_biases(infilename):
@@ -300,14 +360,9 @@ def read_biases(infilename):
     S.bias_path, S.bias_loaded = infilename, True
     bot, med, top = tables.bias_quantiles(bv)
     _log("5th quantile of biases: %s\n50th quantile of biases: %s\n95th quantile of biases: %s\n" % (bot, med, top))
-    out = _BiasDic()
-    names = S.chroms.names
     vals = np.where((bv < biasLowerBound) | np.isnan(bv) | (bv > biasUpperBound), -1.0, bv)
     discard = int(((bv < biasLowerBound) | np.isnan(bv) | (bv > biasUpperBound)).sum())
-    for c, m, v in zip(bc.tolist(), bm.tolist(), vals.tolist()):
-        d = out.setdefault(names[c], {})
-        if m not in d:
-            d[m] = -1 if v == -1.0 else v
+    out = _BiasDic((list(S.chroms.names), bc, bm, vals), len(bv))
     _log("Out of %s loci %s were discarded with biases not in range [%s-%s]\n\n" % (len(bv), discard, biasLowerBound, biasUpperBound))
     print("Bias file read. Time took %s" % (time.time() - t0))
     return out

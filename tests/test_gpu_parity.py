@@ -441,3 +441,26 @@ def test_outlier_rows_compacted_on_the_device_equal_the_flag_bytes(name):
     rows = eng.ctx.fetch_outlier_rows()
     assert rows.dtype == np.int64 and np.array_equal(rows, np.flatnonzero(flags))
     eng.close()
+
+
+def test_mirror_read_biases_returns_the_reference_dictionary_lazily():
+    """read_biases gives {chrom: {mid: bias}} (fithic.py:798-837; first occurrence wins, out-of-range -> -1): the engine does not
+    need it, so it is built when first looked at - and must then be the oracle's dictionary"""
+    from fithic_amd import fithic as F
+    from oracle import fithic_oracle as fo
+    meta, _ = load_case("f1_bias")
+    kw = case_args(meta)
+    F.reset_session()
+    F.resolution = kw["resolution"]
+    F.biasLowerBound, F.biasUpperBound = kw["tL"], kw["tU"]
+    F.distLowThres, F.distUpThres = kw["L"], kw["U"]
+    d = F.read_biases(kw["bias_path"])
+    assert d and dict.__len__(d) == 0                         # truthy like the reference's dict, nothing built yet
+    want = fo.read_biases(kw["bias_path"], kw["tL"], kw["tU"])
+    chrom = next(iter(want))
+    assert chrom in d and dict.__len__(d) == len(want)        # the first look fills it
+    assert d == want and len(d) == len(want) and sorted(d.keys()) == sorted(want.keys())
+    mid = next(iter(want[chrom]))
+    assert d[chrom][mid] == want[chrom][mid] and d.get("no such chromosome") is None
+    assert {k: len(v) for k, v in d.items()} == {k: len(v) for k, v in want.items()}
+    F.reset_session()
