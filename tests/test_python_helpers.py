@@ -1,0 +1,51 @@
+"""CPU tests of the small Python pieces around the C ABI: the numpy-free loader the command line starts first, and the lazily
+built bias dictionary read_biases returns (fithic/fithic.py:798-837)."""
+import threading
+
+import numpy as np
+
+
+def test_loader_is_numpy_free_and_warmup_never_raises():
+    import subprocess
+    import sys
+    code = ("import sys; from fithic_amd import _loader; t = _loader.warm_in_background(0); t.join(60); "
+            "print('numpy' in sys.modules, t.is_alive())")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ["False", "False"]            # numpy not imported by the loader; the thread ended (GPU or not)
+
+
+def test_loader_and_capi_share_one_library_object():
+    from fithic_amd import _capi, _loader
+    assert _capi.lib() is _loader.load() and _capi.LIB_PATH == _loader.LIB_PATH
+    got = []
+    ts = [threading.Thread(target=lambda: got.append(_loader.load())) for _ in range(8)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert all(g is got[0] for g in got)
+
+
+def test_bias_dictionary_fills_itself_on_first_use():
+    from fithic_amd.fithic import _BiasDic
+    names = ["chr1", "chr2", "chrX"]
+    bc = np.array([0, 0, 1, 1, 0, 2], np.int32)
+    bm = np.array([100, 200, 100, 100, 100, 5], np.int32)          # (chr2, 100) and (chr1, 100) twice: the first occurrence wins
+    vals = np.array([1.5, -1.0, 0.7, 0.9, 2.0, 1.0])
+    want = {"chr1": {100: 1.5, 200: -1}, "chr2": {100: 0.7}, "chrX": {5: 1.0}}
+
+    def fresh():
+        return _BiasDic((names, bc, bm, vals), len(bc))
+    d = fresh()
+    assert bool(d) and dict.__len__(d) == 0
+    assert d == want and dict.__len__(d) == 3
+    assert isinstance(fresh()["chr1"][200], int) and fresh()["chr1"][200] == -1
+    assert len(fresh()) == 3 and list(fresh()) == list(want) and "chr2" in fresh() and "chr9" not in fresh()
+    assert fresh().get("chrX") == {5: 1.0} and fresh().get("nope", 7) == 7
+    assert sorted(fresh().keys()) == sorted(want) and dict(fresh().items()) == want and list(fresh().values()) == list(want.values())
+    assert fresh().copy() == want and repr(fresh()) == repr(want) and (fresh() != want) is False
+    e = fresh()
+    e.setdefault("chrY", {})[1] = 2.0
+    assert e["chrY"] == {1: 2.0} and e["chr1"][100] == 1.5
+    assert not _BiasDic((names, bc[:0], bm[:0], vals[:0]), 0) and not _BiasDic()
