@@ -133,13 +133,30 @@ def load_contacts(path, chroms, engine_of, threads=0):
             ctx.ingest_contacts_discard()
             raise
         return DeviceContacts(ctx, n)
-    eng = engine_of()
+    # a file without member sizes (plain gzip) is inflated by the host cores whatever follows: do that before waiting for the
+    # engine, whose start-up (HIP runtime, context) then hides behind it
+    text = None
+    tagged = False
+    try:
+        with open(path, "rb") as f:
+            head = f.read(16)
+        tagged = len(head) >= 14 and head[:3] == b"\x1f\x8b\x08" and bool(head[3] & 4) and head[12:14] in (b"FH", b"BC")
+    except OSError:
+        pass
+    if not tagged:
+        text = _capi.HostText(path, threads)
+        mark("read + inflate")
+    try:
+        eng = engine_of()
+    except BaseException:
+        if text is not None:
+            text.close()
+        raise
     mark("engine ready")
     ctx = getattr(eng, "ctx", None)
     on_device = ctx is not None and hasattr(ctx, "ingest_contacts_text") and not os.environ.get("FHX_HOST_READER")
-    text = None
     try:
-        if on_device and not os.environ.get("FHX_HOST_INFLATE"):
+        if text is None and on_device and not os.environ.get("FHX_HOST_INFLATE"):
             try:
                 n, names = ctx.ingest_contacts_file(path, threads)
                 mark("device inflate + parse")
@@ -150,8 +167,9 @@ def load_contacts(path, chroms, engine_of, threads=0):
                 mark("device refused")
                 if getattr(e, "refused", 1) == 2:
                     on_device = False
-        text = _capi.HostText(path, threads)
-        mark("read + inflate")
+        if text is None:
+            text = _capi.HostText(path, threads)
+            mark("read + inflate")
         if on_device:
             try:
                 n, names = ctx.ingest_contacts_text(text, threads)
