@@ -47,8 +47,9 @@ FIXED_CASES = ["f1_nobias", "f1_bias", "f2_all", "f2_inter", "f2_intra", "f2_all
                "f6_quirk_all", "f6_quirk_intra_nobounds", "f6_quirk_zero_flags", "f6_quirk_mapp2", "f7_pfal_all"]
 NONFIXED_CASES = ["f8_nonfixed_hESC", "f8_nonfixed_all", "f8_nonfixed_nobounds"]        # -r 0
 OFFGRID_CASES = ["f11_offgrid_all", "f11_offgrid_intra"]     # -r N on loci that are not on one grid (fixed-size possible pairs)
-ALL_CASES = FIXED_CASES + NONFIXED_CASES + OFFGRID_CASES
-SMALL_CASES = [c for c in ALL_CASES if not c.startswith("f1_")]
+MULTIPASS_CASES = ["f13_all_p3", "f13_quirk_p4", "f13_hESC_p3"]   # -p 3 / -p 4: one outlier list for the whole run (fithic.py:336-370)
+ALL_CASES = FIXED_CASES + NONFIXED_CASES + OFFGRID_CASES + MULTIPASS_CASES
+SMALL_CASES = [c for c in ALL_CASES if not c.startswith("f1_") and c != "f13_hESC_p3"]
 
 
 def bits_equal(a, b):

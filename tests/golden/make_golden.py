@@ -23,6 +23,7 @@ Fixture sets:
   F10 utils/CombineNearbyInteraction.py: merged loop lists (output files) in the modes its flags offer
 
 Usage:  python tests/golden/make_golden.py [f1] [f2] [f3] [f4] [f5] [f6]     (default: all)
+  F13 more than two passes on the F1 / F2 / F6 data (-p 3, -p 4): the outlier lists live for the whole run, duplicates included
 """
 import sys
 import os
@@ -732,9 +733,23 @@ def make_f11():
              ["-b", "8", "-p", "2", "-x", "intraOnly", "-L", "5000", "-U", "600000"])
 
 
+# ------------------------------------------------------------------------------------------------ F13
+def make_f13():
+    """More than two passes: the reference keeps ONE outliersline / outliersdist list for the whole run (fithic.py:336-370, 1216-1217),
+    so pass 3 skips the outlier lines of pass 1 and of pass 2, and a line that is an outlier twice is in the lists twice.
+    Run after f2 and f6 (it reuses their data files)."""
+    print("F13: -p 3 and -p 4 on the f2 / f6 / f1 data")
+    run_case("f13_all_p3", "synth_IMR90_w1Mb.contacts.gz", "IMR90_w1Mb.frags.gz", "IMR90_w1Mb.bias.gz", 1000000,
+             ["-b", "20", "-p", "3", "-x", "All"])
+    run_case("f13_quirk_p4", "quirk.contacts.gz", "quirk.frags.gz", "quirk.bias.gz", 10000,
+             ["-b", "12", "-p", "4", "-x", "All", "-L", "20000", "-U", "400000"])
+    run_case("f13_hESC_p3", "hESC_chr1_w40000.contacts.gz", "hESC_chr1_w40000.frags.gz", "hESC_chr1_w40000.bias.gz", 40000,
+             ["-L", "50000", "-U", "5000000", "-b", "50", "-p", "3", "-x", "intraOnly"], subsample=29)
+
+
 if __name__ == "__main__":
-    which = [a.lower() for a in sys.argv[1:]] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12"]
+    which = [a.lower() for a in sys.argv[1:]] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13"]
     jobs = dict(f1=make_f1, f2=make_f2, f3=make_f3, f4=make_f4, f5=make_f5, f6=make_f6, f7=make_f7, f8=make_f8, f9=make_f9,
-                f10=make_f10, f11=make_f11, f12=make_f12)
+                f10=make_f10, f11=make_f11, f12=make_f12, f13=make_f13)
     for w in which:
         jobs[w]()

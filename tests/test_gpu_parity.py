@@ -332,7 +332,8 @@ def test_three_passes_match_oracle(name):
     eng.close()
 
 
-@pytest.mark.parametrize("name", ["f1_nobias", "f1_bias", "f2_all", "f6_quirk_all", "f7_pfal_all", "f8_nonfixed_hESC", "f8_nonfixed_all"])
+@pytest.mark.parametrize("name", ["f1_nobias", "f1_bias", "f2_all", "f6_quirk_all", "f7_pfal_all", "f8_nonfixed_hESC", "f8_nonfixed_all",
+                                  "f13_all_p3", "f13_quirk_p4", "f13_hESC_p3"])
 def test_cli_writes_the_reference_files(name, tmp_path, capsys):
     """The drop-in command line: decompressed .significances.txt and .fithic_passN.txt equal the reference's byte for byte."""
     import gzip
@@ -360,7 +361,7 @@ def test_cli_writes_the_reference_files(name, tmp_path, capsys):
     assert mine == want
 
 
-@pytest.mark.parametrize("name,gpus", [("f1_bias", 2), ("f2_all", 3), ("f6_quirk_all", 2)])
+@pytest.mark.parametrize("name,gpus", [("f1_bias", 2), ("f2_all", 3), ("f6_quirk_all", 2), ("f13_all_p3", 2), ("f13_quirk_p4", 3)])
 def test_cli_gpus_n_writes_the_same_files(name, gpus, tmp_path, monkeypatch):
     """`fithic --gpus N`: rows sharded by chromosome over N ranks (worker processes), genome-wide steps through the library's
     communicator, rank 0 writes the ONE output set - byte-identical to the reference's.  On this one-GPU box the ranks share
