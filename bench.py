@@ -8,8 +8,13 @@ K3 Benjamini-Hochberg) on synthetic human contacts, with the inputs resident in 
 
 One JSON line on stdout (rank 0) with the driver's contract fields plus `roofline` (dominant kernel, HIP-event timed),
 `cpu_baseline` (the oracle timed on this box's host cores on a bounded sample of the same rows, N = 1 only) and
-`parity_check` (N = 1: the p-values of that sample recomputed by the oracle's Cephes from the ENGINE's own fit table, and
-q of EVERY row against the oracle's Benjamini-Hochberg of the engine's p - the run that is timed is the run that is checked).
+`parity_check` - the run that is timed is the run that is checked, at every N:
+  N = 1: the engine's K1 histogram and its fit (bins, possible pairs, x, y, s, knots, table, N) against what the REAL reference's
+         stage functions returned on this workload (fixtures tests/golden/f14_*), the p-values of the CPU sample recomputed by the
+         oracle's Cephes from that table, and q of EVERY row against the oracle's Benjamini-Hochberg of the engine's p;
+  N > 1: (and FHX_FORCE_DIST=1 on one GPU) after the timed steps rank 0 runs the whole genome alone on its GPU through the plain
+         single-GPU path - checked as above - and a 64-bit order-free hash of (row, p) and of (row, q) per chromosome, summed over
+         the ranks of the sharded run, must equal that run's: every p and q of the sharded pass is bit-identical to one GPU's.
 
 Workloads (`--config`, BASELINE.json configs):
   C3 (default, the configuration the metric is quoted on): 22 hg19 autosomes at 5 kb (576 216 loci), -L 20000 -U 2000000
@@ -46,10 +51,13 @@ CONFIGS = {
     "C5": dict(res=1000, lengths=None, L=2000, U=2000000, lo=2, hi=2000, amp_lo=2, keep=0.33, passes=1, mode="All",
                trans_per_locus=1.0e8 / 2881044),
 }
-# reference / restatement calibration (BASELINE.md sections 2 and 4.1), bundled hESC chr1 40 kb set, 778 363 rows, 1 core
-CALIBRATION = {"reference_rows_per_s": 25.9e3, "reference_fit_spline_only_rows_per_s": 47e3, "port_rows_per_s": 1.42e6,
-               "input": "bundled Dixon hESC chr1 40 kb, 778 363 rows, -L 50000 -U 5000000 -b 50, 1 pass",
-               "measured_in": "build container (reference = whole fithic.py CLI incl. text I/O; port = oracle on arrays in memory)"}
+
+
+def calibration():
+    """reference / restatement calibration on the bundled hESC chr1 40 kb set (778 363 rows, 1 core), measured in the build
+    container by tests/golden/make_golden.py calib (the real fithic.py next to the oracle on the same rows) -> dict."""
+    with open(os.path.join(ROOT, "tests", "golden", "calibration.json")) as f:
+        return json.load(f)
 
 
 def log(*a):
@@ -101,6 +109,60 @@ def build_rows(synth, torch, cfg, genome, mine, rank, world, device, overdispers
     return cols, n, n_cis, n_trans
 
 
+def row_keys(torch, synth, cols, n):
+    """64-bit identity of every row, independent of where the row sits: splitmix64 chained over (chr1, mid1, chr2, mid2, count)."""
+    k = cols[0][:n].to(torch.int64)
+    for c in cols[1:]:
+        k = synth._splitmix64(torch, (k * 0x100000001B3) ^ c[:n].to(torch.int64))
+    return k
+
+
+def result_hashes(torch, synth, eng, keys, chr1, n, n_chr):
+    """[2, n_chr] int64: per chromosome (of the row's first locus) the wrapping sum of splitmix64(key ^ splitmix64(bits)) over the
+    rows, for bits = the engine's p (row 0) and q (row 1), read from its device buffers.  A sum is order-free and additive over
+    shards, so the table of a sharded run is the sum of its ranks' tables."""
+    out = torch.zeros((2, n_chr), dtype=torch.int64, device=keys.device)
+    if n == 0:
+        return out
+    buf = torch.empty(n, dtype=torch.float64, device=keys.device)
+    idx = chr1[:n].to(torch.int64)
+    for which in (0, 1):
+        eng.ctx.memcpy_d2d(buf.data_ptr(), eng.ctx.device_ptr(which), 8 * n)
+        h = synth._splitmix64(torch, keys ^ synth._splitmix64(torch, buf.view(torch.int64)))
+        out[which].index_add_(0, idx, h)
+    return out
+
+
+class TorchComm:
+    """The handful of torch.distributed calls bench.py itself needs (the pass's own collectives run inside the library)."""
+
+    def __init__(self, td, torch, device):
+        self.td, self.torch, self.device = td, torch, device
+        self.rank, self.world = td.get_rank(), td.get_world_size()
+
+    def barrier(self):
+        self.td.barrier()
+
+    def gather_rows(self, t):
+        """all-gather of equally shaped tensors -> list, one per rank"""
+        t = t.to(self.device).contiguous()
+        out = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.td.all_gather(out, t)
+        return out
+
+    def max_float(self, v):
+        t = self.torch.tensor([float(v)], dtype=self.torch.float64, device=self.device)
+        return max(float(o.item()) for o in self.gather_rows(t))
+
+    def sum_int(self, v):
+        t = self.torch.tensor([int(v)], dtype=self.torch.int64, device=self.device)
+        return sum(int(o.item()) for o in self.gather_rows(t))
+
+    def gather_floats(self, vals):
+        t = self.torch.tensor([float(v) for v in vals], dtype=self.torch.float64, device=self.device)
+        return [o.cpu().tolist() for o in self.gather_rows(t)]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,11 +209,11 @@ def main():
 
     import numpy as np
     import torch
-    from fithic_amd import synth, dist
+    from fithic_amd import synth
     from fithic_amd.engine import Engine
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    world = world_all = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = rank_all = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -161,10 +223,12 @@ def main():
     comm = None
     rccl = None
     if world > 1 or os.environ.get("FHX_FORCE_DIST"):      # FHX_FORCE_DIST=1: run the RCCL path with a single rank
+        import datetime
         import torch.distributed as td
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        td.init_process_group("nccl", device_id=device)          # nccl == RCCL on ROCm
-        comm = dist.Comm(td, device)
+        # nccl == RCCL on ROCm; the long timeout covers rank 0's single-GPU verification run, during which the others wait
+        td.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(minutes=45))
+        comm = TorchComm(td, torch, device)
         try:
             ver = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:
@@ -173,6 +237,7 @@ def main():
                 "driver": "torch.distributed schedule (fithic_amd.dist)" if os.environ.get("FHX_DIST_PY") else
                           "library communicator: fhx_comm_init + fhx_run_pass_distributed (collectives on the engine's stream)"}
 
+    comm_all = comm
     cfg = dict(CONFIGS[args.config])
     if args.keep > 0:
         cfg["keep"] = args.keep
@@ -181,8 +246,12 @@ def main():
     if args.max_chroms:
         base_lengths = base_lengths[:args.max_chroms]
 
-    def measure(replicas, with_cpu_leg):
-        """Generate, load, warm up, time `steps` steps.  Returns the result pieces of this workload."""
+    def measure(replicas, with_cpu_leg, solo=False, want_hashes=False, steps=None, warmup=None):
+        """Generate, load, warm up, time `steps` steps.  Returns the result pieces of this workload.
+        solo: this process alone takes the whole genome through the plain single-GPU path (the verification run of rank 0)."""
+        world, rank, comm = (1, 0, None) if solo else (world_all, rank_all, comm_all)
+        steps = args.steps if steps is None else steps
+        warmup = args.warmup if warmup is None else warmup
         genome = synth.Genome(res, base_lengths, replicas=replicas)
         owner = synth.assign_chromosomes(genome, world)
         mine = [c for c in range(len(genome)) if owner[c] == rank]
@@ -224,12 +293,17 @@ def main():
             sample = {"rows": idx.cpu().numpy(), "cols": [cols[k][:n_local][idx].cpu().numpy() for k in range(5)],
                       "chroms": sorted(chosen), "cut_loci": cut_loci}
             del keep, idx, sel_chr
+        keys = chr1 = None
+        if want_hashes:                                          # row identities for the sharded-vs-single comparison
+            keys = row_keys(torch, synth, cols, n_local)
+            chr1 = cols[0][:n_local].clone()
         del cols
         torch.cuda.empty_cache()
 
         runner = None
         if comm and os.environ.get("FHX_DIST_PY"):               # the exchange schedule written over torch.distributed
-            runner = dist.DistributedPass(eng, comm)
+            from fithic_amd import dist
+            runner = dist.DistributedPass(eng, dist.Comm(comm.td, device))
         elif comm:                                               # the library's own RCCL communicator on the engine's stream
             import torch.distributed as td
             uid = [_capi_mod().comm_unique_id() if rank == 0 else None]
@@ -249,7 +323,8 @@ def main():
                 log("[rank %d] library communicator unavailable (%s): falling back to fithic_amd.dist" % (rank, why or "another rank failed"))
                 if ok:
                     eng.ctx.comm_destroy()
-                runner = dist.DistributedPass(eng, comm)
+                from fithic_amd import dist
+                runner = dist.DistributedPass(eng, dist.Comm(comm.td, device))
                 os.environ["FHX_DIST_PY"] = "fallback"
                 rccl["driver"] = "torch.distributed schedule (fithic_amd.dist); the library communicator did not start: %s" % (why or "on another rank")
         passes = cfg["passes"]
@@ -279,7 +354,7 @@ def main():
             if comm:
                 comm.barrier()
 
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             one_step()
         if runner:
             runner.timings.clear()
@@ -289,7 +364,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         info = None
-        for _ in range(args.steps):
+        for _ in range(steps):
             info = one_step(timed=True)
             kt += np.array(eng.kernel_seconds())          # HIP events on the engine's stream (syncs it); last pass of the step
             heavy += np.array(eng.ctx.k2_heavy_launch(), dtype=np.float64)
@@ -303,21 +378,43 @@ def main():
             n_total = n_local
         stage_ms = None
         if runner:
-            stage_ms = {k: 1e3 * v / max(args.steps * passes, 1) for k, v in runner.timings.items()}
+            stage_ms = {k: 1e3 * v / max(steps * passes, 1) for k, v in runner.timings.items()}
             if rank == 0:
                 log("[rank 0] host wall per pass of the distributed stages (ms): " + ", ".join("%s %.2f" % kv for kv in stage_ms.items()))
-        kt /= max(args.steps, 1)
-        heavy /= max(args.steps, 1)
+        kt /= max(steps, 1)
+        heavy /= max(steps, 1)
         mine_row = list(kt) + [float(n_local)] + list(heavy)
         k_all = comm.gather_floats(mine_row) if comm else [mine_row]
+        hashes = None
+        if want_hashes:
+            if passes > 1:                                       # the timed steps end with reset_passes(): hash an (untimed) pass 1
+                info = (runner.run().as_dict(), runner.stats.as_dict()) if runner else (lambda o: (o.info, o.stats))(eng.run_pass(collect=False))
+            eng.ctx.sync()
+            hashes = result_hashes(torch, synth, eng, keys, chr1, n_local, len(genome))
+            del keys, chr1
         return dict(genome=genome, eng=eng, sample=sample, elapsed=elapsed, n_total=n_total, n_local=n_local, k_all=k_all,
-                    stage_ms=stage_ms, pass_ms=pass_ms / max(args.steps, 1), info=info, n_trans=n_trans, replicas=replicas)
+                    stage_ms=stage_ms, pass_ms=pass_ms / max(steps, 1), info=info, n_trans=n_trans, replicas=replicas,
+                    hashes=hashes, hashed_pass1=want_hashes and passes > 1)
 
     weak_headline = args.weak and world > 1
     replicas = args.replicas if args.replicas > 0 else (world if weak_headline else 1)
-    M = measure(replicas, with_cpu_leg=(rank == 0 and world == 1 and not (args.no_cpu_baseline and args.no_parity_check)))
+    # the f14 fixture of this workload (the real reference's fit on it) applies when the run IS that workload
+    canonical = (args.keep == 0 and args.max_chroms == 0 and args.overdispersion == 0 and replicas == 1)
+    fixture_name = args.config if canonical and os.path.exists(os.path.join(ROOT, "tests", "golden", "f14_%s_fit.npz" % args.config)) else None
+    verify_sharded = comm is not None and not args.no_parity_check         # N > 1 (or FHX_FORCE_DIST): compare with one GPU
+    M = measure(replicas, with_cpu_leg=(rank == 0 and comm is None and not (args.no_cpu_baseline and args.no_parity_check)),
+                want_hashes=verify_sharded)
     eng, genome = M["eng"], M["genome"]
     passes = cfg["passes"]
+
+    def checked(eng_, genome_, sample_, info_, fixture):
+        """run_check on a finished pass; a failure of the checking leg is reported, never raised (the GPU line must not be lost)"""
+        try:
+            from oracle import run_check
+            return run_check.check_engine_run(eng_, genome_, sample_, cfg, info_, not args.no_bias, p_stride=4, fit_fixture_name=fixture)
+        except Exception as e:
+            log("parity_check failed: %r" % (e,))
+            return {"ok": False, "error": repr(e)}
 
     result = None
     if rank == 0:
@@ -379,27 +476,60 @@ def main():
                 rccl.update(world_in_library=w_, library_rccl_version_code=v_)
             result["rccl"] = rccl
             result["stage_ms"] = M["stage_ms"]
+        if args.no_parity_check:
+            result["parity_check"] = {"ok": None, "skipped": "--no-parity-check"}
         if M["sample"] is not None:
             if not args.no_parity_check:
-                try:
-                    if passes > 1:                          # the timed steps end with reset_passes(): check an (untimed) pass 1
-                        out1 = eng.run_pass(collect=False)
-                        M["info"] = (out1.info, out1.stats)
-                    from oracle import run_check
-                    result["parity_check"] = run_check.check_engine_run(eng, genome, M["sample"], cfg, M["info"], not args.no_bias,
-                                                                        p_stride=4)
-                except Exception as e:
-                    log("parity_check failed: %r" % (e,))
-                    result["parity_check"] = {"error": repr(e)}
+                if passes > 1:                              # the timed steps end with reset_passes(): check an (untimed) pass 1
+                    out1 = eng.run_pass(collect=False)
+                    M["info"] = (out1.info, out1.stats)
+                result["parity_check"] = checked(eng, genome, M["sample"], M["info"], fixture_name)
             if not args.no_cpu_baseline:
                 try:
                     result["cpu_baseline"] = cpu_baseline(genome, M["sample"], cfg, not args.no_bias)
                 except Exception as e:                           # the GPU line must not be lost to a problem of the CPU leg
                     log("cpu_baseline failed: %r" % (e,))
                     result["cpu_baseline"] = {"value": None, "unit": "contact-pairs/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+    sharded_hashes, sharded_info = M["hashes"], M["info"]
     eng.close()
     del M
     torch.cuda.empty_cache()
+    if verify_sharded:
+        # Every p and q of the sharded pass against ONE GPU: the ranks' hash tables are summed (a chromosome's cis rows live on
+        # one rank, the trans rows are spread: the sum is what one GPU holding everything computes); rank 0 then takes the whole
+        # genome through the plain single-GPU path (no communicator), which is checked against the fixtures and the oracle.
+        gathered = comm.gather_rows(sharded_hashes)
+        if rank == 0:
+            t_v = time.perf_counter()
+            try:
+                total = gathered[0].clone()
+                for g_ in gathered[1:]:
+                    total += g_.to(total.device)
+                V = measure(replicas, with_cpu_leg=True, solo=True, want_hashes=True, steps=1, warmup=0)
+                same = (V["hashes"] == total)
+                chk = checked(V["eng"], V["genome"], V["sample"], V["info"], fixture_name)
+                n_bad_p, n_bad_q = int((~same[0]).sum()), int((~same[1]).sum())
+                names = V["genome"].names
+                st_s, st_1 = sharded_info[1], V["info"][1]
+                stats_equal = all(int(st_s[k]) == int(st_1[k]) for k in ("inter_count", "inter_sum", "intra_all_sum", "in_range_sum", "max_count"))
+                fit_equal = all(sharded_info[0][k] == V["info"][0][k] for k in ("bh_total_tests", "spline_s", "spline_fp", "residual", "n_table", "inter_chr_prob"))
+                result["parity_check"] = dict(
+                    chk, ranks=world, rows=int(V["n_total"]), sharded_equals_single_gpu=bool(n_bad_p == 0 and n_bad_q == 0 and stats_equal and fit_equal),
+                    chromosomes_hashed=len(names), chromosomes_p_differ=[names[i] for i in torch.nonzero(~same[0]).flatten().tolist()],
+                    chromosomes_q_differ=[names[i] for i in torch.nonzero(~same[1]).flatten().tolist()],
+                    global_stats_equal=stats_equal, fit_scalars_equal=fit_equal,
+                    single_gpu_ms_per_pass=1e3 * V["elapsed"] / max(passes, 1), seconds_all=time.perf_counter() - t_v,
+                    sharded_how="64-bit order-free hash of (row identity, p bits) and (row identity, q bits) per chromosome: sum over the %d "
+                                "rank(s) of the timed sharded run == the same table of ONE GPU holding all rows (plain single-GPU path, no "
+                                "communicator); that single-GPU pass is the one checked against the reference fixtures and the oracle" % world)
+                result["parity_check"]["ok"] = bool(chk.get("ok") and result["parity_check"]["sharded_equals_single_gpu"])
+                V["eng"].close()
+                del V
+            except Exception as e:
+                log("sharded verification failed: %r" % (e,))
+                result["parity_check"] = {"ok": False, "error": repr(e)}
+            torch.cuda.empty_cache()
+        comm.barrier()
     if world > 1 and not weak_headline and not args.no_weak and args.replicas == 0:
         W = measure(world, with_cpu_leg=False)                  # the weak-scaling figure: genome replicated per GPU
         if rank == 0:
@@ -471,6 +601,7 @@ def cpu_baseline(genome, sample, cfg, with_bias):
     fo.run(pairs, frags, None, cfg["res"], n_bins=100, passes=cfg["passes"], mode=cfg["mode"], L=cfg["L"], U=cfg["U"],
            bias_dic=bias_dic)
     dt = time.perf_counter() - t0
+    cal = calibration()
     cpu_model = None
     try:
         for line in open("/proc/cpuinfo"):
@@ -484,10 +615,10 @@ def cpu_baseline(genome, sample, cfg, with_bias):
                       (len(pairs), ",".join(genome.names[c] for c in chr_ids),
                        "".join(" [first %d loci of %s]" % (v, genome.names[k]) for k, v in (sample.get("cut_loci") or {}).items()),
                        cfg["passes"], dt),
-            "cpu_model": cpu_model, "host_cores": os.cpu_count(),
-            "calibration": dict(CALIBRATION, reference_over_port=CALIBRATION["reference_rows_per_s"] / CALIBRATION["port_rows_per_s"],
+            "cpu_model": cpu_model, "host_cores": os.cpu_count(), "implementation": "oracle (numpy stage logic + C Cephes bdtrc, 1 thread)",
+            "calibration": dict(cal, reference_over_port=cal["reference_rows_per_s"] / cal["port_rows_per_s"],
                                 estimated_reference_pairs_per_s_here=len(pairs) * cfg["passes"] / dt *
-                                CALIBRATION["reference_rows_per_s"] / CALIBRATION["port_rows_per_s"])}
+                                cal["reference_rows_per_s"] / cal["port_rows_per_s"])}
 
 
 def cpu_baseline_kr(genome, cols, perc):

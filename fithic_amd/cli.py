@@ -201,7 +201,16 @@ def main(argv=None):
         print("Fit-Hi-C completed successfully")
         print("\n")
     finally:
+        stuck = F.session_stuck()
         F.reset_session()
+        if stuck:
+            # --gpus N lost a rank while this process's own rank sat in a collective: that thread can never return, and a normal
+            # interpreter exit (HIP / RCCL teardown) would wait for it.  Say what happened and leave.
+            import traceback
+            traceback.print_exc()
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(1)
 
 
 if __name__ == "__main__":

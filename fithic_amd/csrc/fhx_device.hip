@@ -1955,6 +1955,7 @@ struct fhx_ctx {
     std::vector<int64_t> fdr_counts;
     fhx::DistState* dist = nullptr;                 // communicator + exchange buffers of sharded runs (fhx_dist.inc)
     bool dist_ndist_agreed = false;                   // sharded runs: the histogram length was made equal on all ranks
+    bool dist_any_nonfixed = false;                   // ... and some rank holds off-grid / -r 0 rows (agreed in the same all-reduce)
 };
 
 namespace {
@@ -2427,6 +2428,7 @@ int alloc_row_arrays(fhx_ctx* ctx, int64_t n, int64_t n_dist) {
     ctx->tables_dirty = true;
     ctx->n_sorted = -1;
     ctx->dist_ndist_agreed = false;
+    ctx->dist_any_nonfixed = false;
     if (!ctx->nonfixed) ctx->h_dist_keys.clear();
     return FHX_OK;
 }

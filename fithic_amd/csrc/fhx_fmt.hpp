@@ -11,7 +11,7 @@
 #include <cstdint>
 #include <cstring>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)          // hipcc: usable in kernels; g++ (tests/native/fmt_check.cpp): plain inline functions
 #define FHX_HD __host__ __device__ __forceinline__
 #else
 #define FHX_HD inline

@@ -273,6 +273,7 @@ struct Chunk {
     std::vector<int32_t> ci[2], mi[2], iv;
     std::vector<double> dv;
     int64_t bad_line = -1;                        // chunk-relative
+    bool bad_is_range = false;                    // the bad line is well-formed for the reference; a number does not fit int32 here
     int64_t n_lines = 0;
     int32_t last_id[2] = {-1, -1};                // id of the previous line's name, per column
 };
@@ -294,8 +295,8 @@ struct fhx_table {
 namespace {
 
 // str.split() of a line read in text mode: ASCII whitespace as Python's str sees it (\x1c-\x1f are separators too; \n ends the
-// line).  Deviations, documented in INTEGRATION.md: non-ASCII whitespace (NBSP, U+2000...) is not a separator here, and a lone
-// \r is whitespace, not a line end (text mode's universal newlines); \r\n is handled (the \r is trailing whitespace).
+// line, and so does a lone \r: text mode's universal newlines turn \r and \r\n into \n before the reference sees the line).
+// Deviation, documented in INTEGRATION.md: non-ASCII whitespace (NBSP, U+2000...) is not a separator here.
 inline bool is_space(char c) { return c == ' ' || (c >= '\t' && c <= '\r') || (c >= '\x1c' && c <= '\x1f'); }
 
 // Python's int() / float() grammar on an ASCII token: underscores are allowed singly BETWEEN digits (PEP 515).  Copies the token
@@ -318,7 +319,8 @@ inline bool strip_underscores(const char* b, const char* e, char* dst, size_t ca
     return true;
 }
 
-inline bool parse_i32_plain(const char* b, const char* e, int32_t& out) {      // optional sign, ASCII digits
+// `range` is set when the token IS an integer for Python's int() (which has no upper limit) but does not fit the int32 columns
+inline bool parse_i32_plain(const char* b, const char* e, int32_t& out, bool& range) {      // optional sign, ASCII digits
     if (b == e) return false;
     bool neg = false;
     if (*b == '+' || *b == '-') {
@@ -327,24 +329,38 @@ inline bool parse_i32_plain(const char* b, const char* e, int32_t& out) {      /
     }
     if (b == e) return false;
     long long v = 0;
+    bool big = false;
     for (; b < e; ++b) {
         if (*b < '0' || *b > '9') return false;
-        v = v * 10 + (*b - '0');
-        if (v > 4000000000ll) return false;
+        if (!big) v = v * 10 + (*b - '0');
+        if (v > 4000000000ll) big = true;
     }
     if (neg) v = -v;
-    if (v < INT32_MIN || v > INT32_MAX) return false;
+    if (big || v < INT32_MIN || v > INT32_MAX) {
+        range = true;
+        return false;
+    }
     out = (int32_t)v;
     return true;
 }
 
-inline bool parse_i32(const char* b, const char* e, int32_t& out) {      // Python int(): optional sign, digits, single '_' between digits
-    if (parse_i32_plain(b, e, out)) return true;
-    if (std::memchr(b, '_', (size_t)(e - b)) == nullptr) return false;
+inline bool parse_i32(const char* b, const char* e, int32_t& out, bool& range) {      // Python int(): optional sign, digits, single '_' between digits
+    if (parse_i32_plain(b, e, out, range)) return true;
+    if (range || std::memchr(b, '_', (size_t)(e - b)) == nullptr) return false;
     char tmp[64];
     size_t n = 0;
-    if (!strip_underscores(b, e, tmp, sizeof(tmp), n)) return false;
-    return parse_i32_plain(tmp, tmp + n, out);
+    if (!strip_underscores(b, e, tmp, sizeof(tmp), n)) {
+        // longer than tmp and nothing but digits and well-placed underscores: an integer of more than 60 digits
+        if (e - b >= (long)sizeof(tmp)) {
+            bool digits = true;
+            for (const char* p = b; p < e && digits; ++p)
+                digits = (*p >= '0' && *p <= '9') || (*p == '_' && p > b && p + 1 < e && p[-1] != '_' && p[1] != '_') ||
+                         (p == b && (*p == '+' || *p == '-'));
+            range = digits;
+        }
+        return false;
+    }
+    return parse_i32_plain(tmp, tmp + n, out, range);
 }
 
 inline bool parse_f64(const char* b, const char* e, double& out) {       // Python float()
@@ -386,6 +402,15 @@ void parse_chunk(const char* b, const char* e, int kind, bool keep_float, Chunk&
     while (b < e) {
         const char* nl = (const char*)std::memchr(b, '\n', (size_t)(e - b));
         const char* le = nl ? nl : e;
+        // universal newlines (gzip.open(..., 'rt'), fithic.py:406): a \r that is not the first half of \r\n ends the line too
+        const char* next = nl ? nl + 1 : e;
+        if (const char* cr = (const char*)std::memchr(b, '\r', (size_t)(le - b))) {
+            if (cr + 1 < le || !nl) {
+                le = cr;
+                next = cr + 1;
+            }
+        }
+        bool range = false;
         int nf = 0, total = 0;
         const char* p = b;
         while (p < le) {
@@ -424,8 +449,12 @@ void parse_chunk(const char* b, const char* e, int kind, bool keep_float, Chunk&
         if (kind == 0) {                                   // ch1 mid1 ch2 mid2 count: exactly 5 fields (fithic.py:413)
             int32_t m1, m2;
             double raw;
-            ok = total == 5 && parse_i32(fld_b[1], fld_e[1], m1) && parse_i32(fld_b[3], fld_e[3], m2) &&
-                 parse_f64(fld_b[4], fld_e[4], raw);
+            // every field is checked even after one has failed: a line with an int32 overflow AND a malformed field is malformed
+            bool r1 = false, r2 = false;
+            const bool ok1 = total == 5 && parse_i32(fld_b[1], fld_e[1], m1, r1), ok2 = total == 5 && parse_i32(fld_b[3], fld_e[3], m2, r2);
+            const bool ok3 = total == 5 && parse_f64(fld_b[4], fld_e[4], raw);
+            ok = ok1 && ok2 && ok3;
+            range = total == 5 && ok3 && (ok1 || r1) && (ok2 || r2) && std::isfinite(raw);     // int(float) of nan / inf raises in Python
             if (ok) {
                 const double tr = std::trunc(raw);
                 ok = tr >= INT32_MIN && tr <= INT32_MAX;    // NaN fails both comparisons: int(float('nan')) raises in Python
@@ -440,7 +469,10 @@ void parse_chunk(const char* b, const char* e, int kind, bool keep_float, Chunk&
             }
         } else if (kind == 1) {                            // words[0], int(words[2]), int(words[3]) (fithic.py:583-586)
             int32_t mid, hits;
-            ok = total >= 4 && parse_i32(fld_b[2], fld_e[2], mid) && parse_i32(fld_b[3], fld_e[3], hits);
+            bool r1 = false, r2 = false;
+            const bool ok1 = total >= 4 && parse_i32(fld_b[2], fld_e[2], mid, r1), ok2 = total >= 4 && parse_i32(fld_b[3], fld_e[3], hits, r2);
+            ok = ok1 && ok2;
+            range = total >= 4 && (ok1 || r1) && (ok2 || r2);
             if (ok) {
                 c.ci[0].push_back(intern(fld_b[0], fld_e[0], 0));
                 c.mi[0].push_back(mid);
@@ -449,7 +481,10 @@ void parse_chunk(const char* b, const char* e, int kind, bool keep_float, Chunk&
         } else {                                           // words[0], int(words[1]), float(words[2]) (fithic.py:807-808)
             int32_t mid;
             double bias;
-            ok = total >= 3 && parse_i32(fld_b[1], fld_e[1], mid) && parse_f64(fld_b[2], fld_e[2], bias);
+            bool r1 = false;
+            const bool ok1 = total >= 3 && parse_i32(fld_b[1], fld_e[1], mid, r1), ok2 = total >= 3 && parse_f64(fld_b[2], fld_e[2], bias);
+            ok = ok1 && ok2;
+            range = total >= 3 && ok2 && (ok1 || r1);
             if (ok) {
                 c.ci[0].push_back(intern(fld_b[0], fld_e[0], 0));
                 c.mi[0].push_back(mid);
@@ -458,10 +493,11 @@ void parse_chunk(const char* b, const char* e, int kind, bool keep_float, Chunk&
         }
         if (!ok) {
             c.bad_line = c.n_lines;
+            c.bad_is_range = range;
             return;
         }
         ++c.n_lines;
-        b = nl ? nl + 1 : e;
+        b = next;
     }
 }
 
@@ -538,15 +574,25 @@ bool inflate_stream(const unsigned char* src, size_t n, std::string& text, std::
             rc = inflate(&zs, Z_NO_FLUSH);
             at += room - zs.avail_out;
             if (rc == Z_STREAM_END) {
+                // What Python's gzip module does after a member's trailer (gzip.py _GzipReader.read / _read_gzip_header; the
+                // reference reads through gzip.open(..., 'rt'), fithic.py:406): zero padding is skipped; nothing left = end of
+                // file; anything else must be the magic of another member, or it raises BadGzipFile("Not a gzipped file").
                 ended = true;
-                if (zs.avail_in > 0 && zs.next_in[0] == 0x1f) {        // the next member of a concatenation
-                    const size_t used = in_now - zs.avail_in;
-                    in_at += used;
-                    inflateReset(&zs);
-                    ended = false;
-                    goto next_input;
+                size_t at_in = in_at + (in_now - zs.avail_in);
+                while (at_in < n && src[at_in] == 0) ++at_in;
+                if (at_in == n) {
+                    in_at = n;
+                    goto finished;
                 }
-                break;
+                if (n - at_in < 2 || src[at_in] != 0x1f || src[at_in + 1] != 0x8b) {
+                    inflateEnd(&zs);
+                    err = "bytes that are neither zero padding nor another gzip member follow the last member";
+                    return false;
+                }
+                in_at = at_in;                                          // the next member of a concatenation
+                inflateReset(&zs);
+                ended = false;
+                goto next_input;
             }
             if (rc != Z_OK && rc != Z_BUF_ERROR) {
                 inflateEnd(&zs);
@@ -555,9 +601,9 @@ bool inflate_stream(const unsigned char* src, size_t n, std::string& text, std::
             }
         } while (zs.avail_in > 0 || zs.avail_out == 0);
         in_at += in_now - zs.avail_in;
-        if (ended) break;
     next_input:;
     }
+finished:
     inflateEnd(&zs);
     if (!ended) {
         err = "gzip stream ended before its end-of-stream marker";
@@ -780,6 +826,11 @@ static int parse_pieces(const std::vector<fhx::TextPiece>& pieces, const char* p
     int64_t line0 = 0;
     for (auto& c : chunks) {
         if (c.bad_line >= 0) {
+            if (c.bad_is_range) {               // the reference's int() takes it: a limit of this library, not an input error
+                t->error = "line " + std::to_string(line0 + c.bad_line + 1) + " in " + path +
+                           ": a coordinate or count outside the int32 range of this library's columns (the reference accepts it)";
+                return FHX_ERR_UNSUPPORTED;
+            }
             t->error = "malformed line " + std::to_string(line0 + c.bad_line + 1) + " in " + path +
                        " (the reference raises ValueError on it)";
             return FHX_ERR_REFERENCE_EXIT;

@@ -106,6 +106,11 @@ class _Session:
 _S = _Session()
 
 
+def session_stuck():
+    """True when a sharded engine was abandoned with this process's own rank still inside a collective (sharded._all)."""
+    return bool(getattr(_S.engine, "local_stuck", False))
+
+
 def reset_session():
     """Forget the loaded tables (a new run in the same interpreter)."""
     global _S

@@ -13,8 +13,11 @@ below, staged through host memory - for boxes where several ranks must share one
 tests).  No compute happens here: this module moves tables and commands.
 """
 import multiprocessing as mp
+from multiprocessing.connection import wait as mp_wait
 import os
 import sys
+import threading
+import time
 
 import numpy as np
 
@@ -255,28 +258,50 @@ class ShardedEngine:
         uid = _capi.comm_unique_id() if transport != "pipes" else None
         self.workers = []
         self.broken = None
-        for r in range(1, gpus):
-            parent, child = ctxmp.Pipe(duplex=True)
-            p = ctxmp.Process(target=_worker_main, args=(r, gpus, devices[r], transport, uid, mesh[r], child), daemon=True)
-            p.start()
-            self.workers.append((p, parent))
-        self.local = _Rank(0, gpus, devices[0], transport, uid, mesh[0])
-        for r, (p, conn) in enumerate(self.workers, start=1):
-            while not conn.poll(1.0):
-                if not p.is_alive():
-                    raise RuntimeError("rank %d died while starting (exit code %r)" % (r, p.exitcode))
-            status, msg = conn.recv()
-            if status != "ready":
-                raise RuntimeError("rank %d could not start: %s" % (r, msg))
+        self.local = None
+        self.local_stuck = False
+        try:
+            for r in range(1, gpus):
+                parent, child = ctxmp.Pipe(duplex=True)
+                p = ctxmp.Process(target=_worker_main, args=(r, gpus, devices[r], transport, uid, mesh[r], child), daemon=True)
+                p.start()
+                self.workers.append((p, parent))
+            self.local = _Rank(0, gpus, devices[0], transport, uid, mesh[0])
+            for r, (p, conn) in enumerate(self.workers, start=1):
+                while not conn.poll(1.0):
+                    if not p.is_alive():
+                        raise RuntimeError("rank %d died while starting (exit code %r)" % (r, p.exitcode))
+                status, msg = conn.recv()
+                if status != "ready":
+                    raise RuntimeError("rank %d could not start: %s" % (r, msg))
+        except BaseException:
+            # nobody will ever hold this object: stop the workers that did start (they keep a GPU and their pipes) and release
+            # rank 0's engine before the error travels on
+            for p, _ in self.workers:
+                if p.is_alive():
+                    p.terminate()
+            for p, _ in self.workers:
+                p.join(10)
+            if self.local is not None:
+                try:
+                    self.local.close()
+                except Exception:                              # noqa: BLE001
+                    pass
+            raise
         self.ctx = _CtxFacade(self)
         self.n_rows = 0
         self.rows_of = [np.zeros(0, np.int64) for _ in range(gpus)]
         self.resolution = None
 
+    GRACE_S = 30.0          # how long the other ranks may stay inside a command after one rank has failed in it
+
     def _all(self, name, *args, per_rank=None):
-        """Run one command on every rank (workers first: collectives need everybody inside the call) -> results by rank.
-        Every rank's answer is collected before anything is raised, so that a failure (the same refusal on every rank - a spline
-        the reference would exit on -, or one rank's own) leaves the command / answer protocol in step for the next call."""
+        """Run one command on every rank -> results by rank.  The workers get it first and rank 0's own part runs on a helper
+        thread, so that this thread can watch everybody: collectives need every rank inside the call, and a rank that fails
+        BEFORE a collective (its own HIP error, out of memory) leaves the others waiting in it for ever.  Every rank's answer is
+        collected before anything is raised, so that a failure all ranks share (a spline the reference would exit on, a refusal
+        agreed over the communicator) leaves the command / answer protocol in step for the next call; when some rank has failed
+        or died and another is still inside the command GRACE_S later, the engine is abandoned instead of waiting."""
         if self.broken:
             raise RuntimeError("the sharded engine lost a rank earlier (%s): create a new one" % self.broken)
         for r, (proc, conn) in enumerate(self.workers, start=1):
@@ -285,30 +310,77 @@ class ShardedEngine:
             except (BrokenPipeError, OSError) as e:
                 self._abandon("rank %d is gone (%r)" % (r, e))
                 raise RuntimeError("rank %d died before %s" % (r, name))
-        local_exc, out = None, [None]
-        try:
-            out[0] = getattr(self.local, name)(*(per_rank[0] if per_rank else args))
-        except Exception as e:                             # noqa: BLE001 - re-raised below, after the other ranks have answered
-            local_exc = e
+        box = {}
+        wake_r, wake_w = os.pipe()                         # rank 0's thread says "done" through it: one wait covers everybody
+
+        class _Wake:
+            def fileno(self):
+                return wake_r
+
+        def run_local():
+            try:
+                box["out"] = getattr(self.local, name)(*(per_rank[0] if per_rank else args))
+            except BaseException as e:                     # noqa: BLE001 - re-raised below, after the other ranks have answered
+                box["exc"] = e
+            finally:
+                try:
+                    os.write(wake_w, b"x")
+                except OSError:                            # abandoned meanwhile: nobody listens any more
+                    pass
+
+        th = threading.Thread(target=run_local, name="fhx-rank0-%s" % name, daemon=True)
+        th.start()
+        out = [None] * self.world
+        pending = set(range(1, self.world))
         failures = []
-        for r, (proc, conn) in enumerate(self.workers, start=1):
-            waited = 0.0
-            while not conn.poll(1.0):
-                waited += 1.0
-                if not proc.is_alive():
-                    self._abandon("rank %d died in %s (exit code %r)" % (r, name, proc.exitcode))
+        first_failure_at = None
+        local_done = False
+        wake = _Wake()
+        try:
+            while pending or not local_done:
+                ready = mp_wait([self.workers[r - 1][1] for r in sorted(pending)] + ([] if local_done else [wake]), timeout=1.0)
+                if wake in ready:
+                    th.join()
+                    local_done = True
+                for r in sorted(pending):
+                    proc, conn = self.workers[r - 1]
+                    if conn in ready:
+                        try:
+                            status, val = conn.recv()
+                        except (EOFError, OSError) as e:
+                            status, val = "error", "connection lost (%r)" % (e,)
+                            self.broken = "rank %d is gone in %s" % (r, name)
+                        pending.discard(r)
+                        if status != "ok":
+                            failures.append("rank %d failed in %s: %s" % (r, name, val))
+                        out[r] = val
+                    elif not proc.is_alive() and not conn.poll(0):
+                        pending.discard(r)
+                        failures.append("rank %d died in %s (exit code %r)" % (r, name, proc.exitcode))
+                        self.broken = failures[-1]
+                failed = bool(failures) or (local_done and "exc" in box)
+                if failed and first_failure_at is None:
+                    first_failure_at = time.monotonic()
+                if failed and (pending or not local_done) and time.monotonic() - first_failure_at >= self.GRACE_S:
+                    stuck = ([] if local_done else [0]) + sorted(pending)
+                    self.local_stuck = not local_done      # rank 0's thread sits in a collective nobody will complete
+                    why = "; ".join(failures) if failures else "rank 0 failed in %s: %r" % (name, box.get("exc"))
+                    self._abandon("%s - rank(s) %s were still inside the command %.0f s later" % (why, stuck, self.GRACE_S))
+                    if "exc" in box and not failures:
+                        raise box["exc"]
                     raise RuntimeError(self.broken)
-                if local_exc is not None and waited >= 30.0:   # rank 0 failed on its own: the others wait for it in a collective
-                    self._abandon("rank 0 failed in %s while rank %d was still inside it" % (name, r))
-                    raise local_exc
-            status, val = conn.recv()
-            if status != "ok":
-                failures.append("rank %d failed in %s: %s" % (r, name, val))
-            out.append(val)
-        if local_exc is not None:
-            raise local_exc
+        finally:
+            os.close(wake_r)
+            if local_done:
+                os.close(wake_w)                           # else the stuck thread still owns the write end
+        if self.broken:                                    # a worker died: nothing further can run
+            self._abandon(self.broken)
+            raise RuntimeError(self.broken)
+        if "exc" in box:
+            raise box["exc"]
         if failures:
             raise RuntimeError("; ".join(failures))
+        out[0] = box.get("out")
         return out
 
     def _abandon(self, why):
@@ -387,7 +459,7 @@ class ShardedEngine:
                 p.join(10)
                 if p.is_alive():
                     p.terminate()
-            if not closed_local:
+            if not closed_local and not self.local_stuck:  # a stuck rank-0 thread still uses the context: leave it to process exit
                 try:
                     self.local.close()
                 except Exception:                          # noqa: BLE001

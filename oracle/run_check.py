@@ -6,22 +6,103 @@ Checks a finished engine pass against the oracle without re-running the whole or
   (2) q of EVERY row against the oracle's Benjamini-Hochberg (myStats.py:24-48; pruned evaluation, proved and tested equal
       to the plain restatement) of the engine's p.
 """
+import os
 import time
 
 import numpy as np
 
 from . import fithic_oracle as fo
 
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
-def check_engine_run(eng, genome, sample, cfg, info, with_bias, p_stride=1):
+
+def fit_fixture(config):
+    """tests/golden/f14_<config>_fit.npz: what the REAL reference's makeBinsFromInteractions -> generate_FragPairs ->
+    calculateProbabilities -> fit_Spline returned on the full-size synth-v1 workload `config` (C3, C3w, C5) - made by
+    tests/golden/make_golden.py f14 - or None for a workload without one."""
+    path = os.path.join(GOLDEN, "f14_%s_fit.npz" % config)
+    return np.load(path) if os.path.exists(path) else None
+
+
+def _bits(a, b):
+    a, b = np.ascontiguousarray(a, np.float64), np.ascontiguousarray(b, np.float64)
+    return a.shape == b.shape and bool(np.array_equal(a.view(np.int64), b.view(np.int64)))
+
+
+def compare_histogram(hist_sumcc, hist_npairs, stats, g, res):
+    """The engine's K1 output against the fixture's histogram (computed with torch, without the engine).  -> list of names
+    that differ (empty = equal)."""
+    bad = []
+    idx = g["hist_dist_idx"]
+    want_cc = np.zeros(max(len(hist_sumcc), int(idx.max()) + 1), np.int64)
+    want_np = np.zeros_like(want_cc)
+    want_cc[idx] = g["hist_sumcc"]
+    want_np[idx] = g["hist_nrows"]
+    got_cc = np.zeros_like(want_cc)
+    got_np = np.zeros_like(want_cc)
+    got_cc[:len(hist_sumcc)] = hist_sumcc
+    got_np[:len(hist_npairs)] = hist_npairs
+    if not np.array_equal(got_cc, want_cc):
+        bad.append("hist_sumcc")
+    if not np.array_equal(got_np, want_np):
+        bad.append("hist_npairs")
+    inter_count, inter_sum, intra_all_sum, in_range_sum = [int(v) for v in g["sums"]]
+    for k, v in (("inter_count", inter_count), ("inter_sum", inter_sum), ("intra_all_sum", intra_all_sum), ("in_range_sum", in_range_sum)):
+        if int(stats[k]) != v:
+            bad.append(k)
+    return bad
+
+
+def compare_fit(get_array, info, g):
+    """The engine's host fit (fhx_fit) against the reference's stage outputs of fixture g, bit for bit: bins, possible pairs,
+    bin means, s, knots, coefficients, spline table before and after the isotonic regression, N.  get_array = Context.get_array,
+    info = the fhx_fit_info as a dict.  -> list of names that differ (empty = identical)."""
+    from fithic_amd import _capi as A
+    bad = []
+    for k, w in (("lb", A.A_BIN_LB), ("ub", A.A_BIN_UB), ("s1", A.A_BIN_POSS), ("s2", A.A_BIN_SUMCC), ("s7", A.A_BIN_POSS7)):
+        if not np.array_equal(get_array(w), g["bins1_" + k]):
+            bad.append("bins1_" + k)
+    if not np.array_equal(get_array(A.A_BIN_POSS0), g["bins0_s1"]):
+        bad.append("bins0_s1")
+    if not _bits(get_array(A.A_BIN_SUMDIST), g["bins1_s3"]):
+        bad.append("bins1_s3")
+    mine = np.array([info["n_frags"], info["max_possible_dist"], info["possible_intra_in_range"], info["possible_inter_all"],
+                     info["inter_chr_prob"], info["baseline_intra_prob"]], np.float64)
+    if not _bits(mine, g["frag_scalars"]):
+        bad.append("frag_scalars")
+    for k, w in (("x", A.A_X), ("y", A.A_Y), ("spl_t", A.A_KNOTS), ("spl_c", A.A_COEFFS), ("splineY", A.A_TABLE_Y0),
+                 ("newSplineY", A.A_TABLE_Y)):
+        if not _bits(get_array(w), g[k]):
+            bad.append(k)
+    if not np.array_equal(get_array(A.A_TABLE_X), g["splineX"]):
+        bad.append("splineX")
+    s, fp, ier = g["spl_s_fp_ier"]
+    if not (info["spline_s"] == s and info["spline_fp"] == fp and info["spline_ier"] == int(ier)):
+        bad.append("spl_s_fp_ier")
+    if info["residual"] != g["residual"][0]:
+        bad.append("residual")
+    if 1.0 / info["bh_total_tests"] != g["outlierThres"][0]:
+        bad.append("outlierThres")
+    return bad
+
+
+def check_engine_run(eng, genome, sample, cfg, info, with_bias, p_stride=1, fit_fixture_name=None):
     """sample = {"rows": row numbers, "cols": [chr1, mid1, chr2, mid2, count] of those rows, "chroms": chromosome ids they
     touch}; cfg = {"res", "L", "U", "mode"}; info = (fit-info dict, stats dict) of the pass.  Every p_stride-th sample row
-    is evaluated."""
+    is evaluated.  fit_fixture_name: the f14 fixture of this workload (the run must be the full-size synth-v1 workload of that
+    name): the engine's K1 histogram and its fit are then compared with the reference's before the table is used."""
     from fithic_amd import _capi
     fo.build()
     t0 = time.perf_counter()
     v = eng.fetch(p=True, q=True)
     info, st = info
+    fit_diff = hist_diff = None
+    if fit_fixture_name:
+        g = fit_fixture(fit_fixture_name)
+        if g is None:
+            raise FileNotFoundError("tests/golden/f14_%s_fit.npz" % fit_fixture_name)
+        hist_diff = compare_histogram(eng.ctx.get_array(_capi.A_HIST_SUMCC), eng.ctx.get_array(_capi.A_HIST_NPAIRS), st, g, cfg["res"])
+        fit_diff = compare_fit(eng.ctx.get_array, info, g)
     res = cfg["res"]
     c1, m1, c2, m2, cnt = [a[::p_stride] for a in sample["cols"]]
     rows = sample["rows"][::p_stride]
@@ -57,10 +138,20 @@ def check_engine_run(eng, genome, sample, cfg, info, with_bias, p_stride=1):
     qn = np.isnan(q_ref)
     dq = float(np.max(np.abs(np.where(qn, 0, v["q"]) - np.where(qn, 0, q_ref)))) if len(q_ref) else 0.0
     nan_equal = nan_equal and bool(np.array_equal(np.isnan(v["q"]), qn))
-    return {"max_dp": dp, "rows_p": int(len(rows)), "max_dq": dq, "rows_q": int(len(q_ref)), "nan_pattern_equal": nan_equal,
-            "tolerance": 1e-10, "ok": bool(dp <= 1e-10 and dq <= 1e-10 and nan_equal),
-            "p_bit_identical_frac": float(np.mean(got.view(np.int64) == want.view(np.int64))) if len(rows) else 1.0,
-            "how": "p: oracle Cephes bdtrc on the sampled rows with the engine's own fit table; q: oracle BH of the engine's p, all rows",
-            "seconds": time.perf_counter() - t0}
+    out = {"max_dp": dp, "rows_p": int(len(rows)), "max_dq": dq, "rows_q": int(len(q_ref)), "nan_pattern_equal": nan_equal,
+           "tolerance": 1e-10, "ok": bool(dp <= 1e-10 and dq <= 1e-10 and nan_equal),
+           "p_bit_identical_frac": float(np.mean(got.view(np.int64) == want.view(np.int64))) if len(rows) else 1.0}
+    if fit_fixture_name:
+        out["fit_vs_reference"] = {"fixture": "tests/golden/f14_%s_fit.npz" % fit_fixture_name, "k1_histogram_differs": hist_diff,
+                                   "fit_differs": fit_diff, "bit_identical": not hist_diff and not fit_diff}
+        out["ok"] = bool(out["ok"] and not hist_diff and not fit_diff)
+        out["how"] = ("K1 histogram and sums == the fixture's (torch bincount of the same rows); bins, possible pairs, x, y, s, knots, "
+                      "coefficients, spline table and N bit-identical to what the real reference's makeBinsFromInteractions / "
+                      "generate_FragPairs / calculateProbabilities / fit_Spline returned on that histogram (fixture f14); p: oracle Cephes "
+                      "bdtrc on the sampled rows with that table; q: oracle BH of the engine's p, all rows")
+    else:
+        out["how"] = "p: oracle Cephes bdtrc on the sampled rows with the engine's own fit table; q: oracle BH of the engine's p, all rows"
+    out["seconds"] = time.perf_counter() - t0
+    return out
 
 

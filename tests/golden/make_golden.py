@@ -71,11 +71,29 @@ def _bins_snapshot(binStats):
     return out
 
 
-def run_reference(argv, quiet=True):
-    """Run the reference's main() on argv; capture every stage's outputs through a profile hook."""
+def run_reference(argv, quiet=True, observed=None):
+    """Run the reference's main() on argv; capture every stage's outputs through a profile hook.
+    observed = (mainDic, interCount, interSum, intraAllSum, inRangeSum): what read_Interactions would return for a contacts file
+    too large to push through the reference's line loop (f14: 10^8..10^9 rows).  main() then runs unmodified on it - argument
+    handling, makeBinsFromInteractions, generate_FragPairs, calculateProbabilities, fit_Spline - with `-i` naming a few-line
+    contacts file for fit_Spline's own loop."""
     passes = []          # one dict per pass
     cur = {}
     ref_file = os.path.join(REF_PKG, "fithic.py")
+    real_read = F.read_Interactions
+
+    def given_observations(contactCountsFile, biasFile, outliers=None):
+        nonlocal cur
+        assert outliers is None, "one pass only"
+        mainDic, interCnt, interSum, intraAllSum, inRangeSum = observed
+        cur = {}
+        passes.append(cur)
+        keys = np.array(sorted(mainDic.keys()), np.int64)
+        cur["dist_keys"] = keys
+        cur["dist_sumcc"] = np.array([mainDic[int(k)][1] for k in keys], np.int64)
+        cur["sums"] = np.array([interCnt, interSum, intraAllSum, inRangeSum], np.int64)
+        open(F.logfile, "w").close()            # read_Interactions (re)creates the log the later stages append to
+        return ({int(k): [0, int(v[1])] for k, v in mainDic.items()}, interCnt, interSum, intraAllSum, inRangeSum)
 
     def hook(frame, event, arg):
         if event != "return":
@@ -136,12 +154,15 @@ def run_reference(argv, quiet=True):
     sink = io.StringIO()
     t0 = time.time()
     try:
+        if observed is not None:
+            F.read_Interactions = given_observations
         sys.setprofile(hook)
         with (contextlib.redirect_stdout(sink) if quiet else contextlib.nullcontext()):
             F.main()
     finally:
         sys.setprofile(None)
         sys.argv = old_argv
+        F.read_Interactions = real_read
     return passes, time.time() - t0
 
 
@@ -747,9 +768,127 @@ def make_f13():
              ["-L", "50000", "-U", "5000000", "-b", "50", "-p", "3", "-x", "intraOnly"], subsample=29)
 
 
+# ------------------------------------------------------------------------------------------------ F14
+def make_f14():
+    """The fit at the HEADLINE sizes (bench.py's C3, C3w, C5: 22 autosomes at 5 kb / 1 kb, 576 216 / 2 881 044 loci, 397 / 49 734 /
+    1 999 distance values): the reference's own main() - makeBinsFromInteractions, generate_FragPairs, calculateProbabilities and
+    the spline + isotonic table of fit_Spline (fithic.py:463-689, 843-918, 936-968) - on the fragments file of the synthetic genome
+    and on the distance histogram of the synth-v1 rows.  The 10^8..10^9 contact rows themselves cannot go through the reference's
+    Python line loop (25 k rows/s); their histogram is what read_Interactions would have returned, computed with plain torch
+    tensor arithmetic by tests/golden/dump_synth_hist.py on the GPU box (gpurun_out/r03/synth_hist/) and stored in the fixture,
+    so that the GPU tests and bench.py first check the engine's K1 output against it and then its fit against the reference's.
+    Stores every stage's outputs (bins, possible-pair counts, x, y, s, knots, coefficients, table) - no per-row arrays."""
+    print("F14: the reference's fit on the full-size synthetic workloads")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import bench
+    from fithic_amd import synth
+    src = os.environ.get("FHX_SYNTH_HIST", os.path.join(os.path.dirname(os.path.dirname(HERE)), "gpurun_out", "r03", "synth_hist"))
+    for name in ("C3", "C3w", "C5"):
+        cfg = bench.CONFIGS[name]
+        H = np.load(os.path.join(src, "synth_hist_%s.npz" % name))
+        res = cfg["res"]
+        genome = synth.Genome(res, cfg["lengths"])
+        tmp = tempfile.mkdtemp(prefix="golden_f14_")
+        frags = os.path.join(tmp, "frags.gz")
+        with gzip.open(frags, "wt", compresslevel=1) as f:
+            for c, n in enumerate(genome.n_loci):
+                nm = genome.names[c]
+                f.write("".join("%s\t0\t%d\t1\t0\n" % (nm, i * res + res // 2) for i in range(n)))
+        contacts = os.path.join(tmp, "few.gz")           # fit_Spline's own loop: three in-range rows, nothing is kept of them
+        lo = int(H["dist_idx"][0])
+        _write_gz(contacts, "".join("chr1\t%d\tchr1\t%d\t%d\n" % (res // 2, (lo + k) * res + res // 2, k + 1) for k in range(3)))
+        in_range_sum = int(H["sumcc"].sum())
+        main_dic = {int(i) * res: [0, int(v)] for i, v in zip(H["dist_idx"], H["sumcc"])}
+        inter_count, inter_sum = (int(v) for v in H["inter"])
+        argv = ["-i", contacts, "-f", frags, "-o", tmp, "-r", str(res), "-l", "G", "-b", "100", "-p", "1", "-x", cfg["mode"],
+                "-L", str(cfg["L"])]
+        if cfg["U"] != float("inf"):
+            argv += ["-U", str(cfg["U"])]
+        passes, dt = run_reference(argv, observed=(main_dic, inter_count, inter_sum, in_range_sum, in_range_sum))
+        P = passes[0]
+        keep = {k: v for k, v in P.items() if k not in ("p", "q", "expcc", "b1", "b2", "outliersline", "outliersdist", "fdr_y",
+                                                         "n_outlier_lines")}
+        keep["hist_dist_idx"] = H["dist_idx"].astype(np.int64)
+        keep["hist_sumcc"] = H["sumcc"].astype(np.int64)
+        keep["hist_nrows"] = H["nrows"].astype(np.int64)
+        keep["rows_per_chr"] = H["rows_per_chr"].astype(np.int64)
+        keep["inter"] = H["inter"].astype(np.int64)
+        np.savez_compressed(os.path.join(HERE, "f14_%s_fit.npz" % name), **keep)
+        meta = dict(name="f14_%s_fit" % name, config=name, argv=[a for a in argv[6:]], n_rows=int(H["nrows"].sum()) + inter_count,
+                    n_dist=len(H["dist_idx"]), in_range_sum=in_range_sum, inter_count=inter_count, inter_sum=inter_sum,
+                    n_loci=int(sum(genome.n_loci)), n_bins=int(len(P["x"])), n_knots=int(len(P["spl_t"])),
+                    n_table=int(len(P["splineX"])), possibleIntraInRangeCount=int(P["possibleIntraInRangeCount"][0]),
+                    outlierThres=float(P["outlierThres"][0]), reference_seconds_1core=round(dt, 1),
+                    histogram_from="tests/golden/dump_synth_hist.py on MI355X (torch %s)" % str(H["torch_version"][0]),
+                    fithic_pass1_txt=open(os.path.join(tmp, "G.fithic_pass1.res%d.txt" % res)).read(),
+                    log_txt=open(os.path.join(tmp, "G.fithic.log")).read() if name == "C3" else None)
+        with open(os.path.join(HERE, "f14_%s_fit.json" % name), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+        shutil.rmtree(tmp)
+        print("  f14_%s_fit: %d bins, %d knots, table of %d, N = %d, reference took %.1f s" %
+              (name, meta["n_bins"], meta["n_knots"], meta["n_table"], meta["possibleIntraInRangeCount"], dt))
+
+
+# ------------------------------------------------------------------------------------------------ calibration
+def make_calib():
+    """tests/golden/calibration.json: the REAL fithic.py (whole main(): text I/O included, and its fit_Spline alone) timed next to
+    the oracle (arrays in memory) on the bundled hESC chr1 40 kb set, one core, in this container.  bench.py scales its CPU leg
+    (the oracle timed on the GPU box) by reference/port to say what the reference itself would do there."""
+    print("calibration: the reference and the oracle on the bundled hESC set")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import fithic_oracle as fo
+    contacts, frags, bias = (os.path.join(DATA, "hESC_chr1_w40000.%s.gz" % k) for k in ("contacts", "frags", "bias"))
+    tmp = tempfile.mkdtemp(prefix="golden_calib_")
+    argv = ["-i", contacts, "-f", frags, "-t", bias, "-o", tmp, "-r", "40000", "-l", "G", "-L", "50000", "-U", "5000000", "-b", "50",
+            "-p", "1", "-x", "intraOnly"]
+    spent = {"fit_Spline": 0.0}
+    real_fit = F.fit_Spline
+
+    def timed_fit(*a, **k):
+        t = time.perf_counter()
+        try:
+            return real_fit(*a, **k)
+        finally:
+            spent["fit_Spline"] += time.perf_counter() - t
+    old_argv = sys.argv
+    sys.argv = ["fithic"] + argv
+    F.fit_Spline = timed_fit
+    try:
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):
+            F.main()
+        t_ref = time.perf_counter() - t0
+    finally:
+        F.fit_Spline = real_fit
+        sys.argv = old_argv
+    shutil.rmtree(tmp)
+    fo.build()
+    pairs = fo.read_contacts_file(contacts)                 # the oracle's own readers: arrays in memory before the clock starts
+    n = len(pairs)
+    frag_rows = fo.read_fragments_file(frags)
+    bias_dic = fo.read_biases(bias, 0.5, 2)
+    t0 = time.perf_counter()
+    fo.run(pairs, frag_rows, None, 40000, n_bins=50, passes=1, mode="intraOnly", L=50000, U=5000000, bias_dic=bias_dic)
+    t_port = time.perf_counter() - t0
+    cpu = None
+    for line in open("/proc/cpuinfo"):
+        if line.startswith("model name"):
+            cpu = line.split(":", 1)[1].strip()
+            break
+    out = {"reference_rows_per_s": n / t_ref, "reference_fit_spline_only_rows_per_s": n / spent["fit_Spline"], "port_rows_per_s": n / t_port,
+           "rows": n, "reference_seconds": round(t_ref, 2), "reference_fit_spline_seconds": round(spent["fit_Spline"], 2),
+           "port_seconds": round(t_port, 3),
+           "input": "bundled Dixon hESC chr1 40 kb, %d rows, -L 50000 -U 5000000 -b 50 -t bias, 1 pass, intraOnly" % n,
+           "measured_in": "build container, 1 core (%s): reference = whole fithic.py main() incl. text I/O; port = oracle on arrays in memory" % cpu,
+           "made_by": "tests/golden/make_golden.py calib"}
+    with open(os.path.join(HERE, "calibration.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("  reference %.1f s (fit_Spline %.1f s), oracle %.2f s on %d rows" % (t_ref, spent["fit_Spline"], t_port, n))
+
+
 if __name__ == "__main__":
     which = [a.lower() for a in sys.argv[1:]] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13"]
     jobs = dict(f1=make_f1, f2=make_f2, f3=make_f3, f4=make_f4, f5=make_f5, f6=make_f6, f7=make_f7, f8=make_f8, f9=make_f9,
-                f10=make_f10, f11=make_f11, f12=make_f12, f13=make_f13)
+                f10=make_f10, f11=make_f11, f12=make_f12, f13=make_f13, f14=make_f14, calib=make_calib)
     for w in which:
         jobs[w]()

@@ -304,9 +304,61 @@ def test_c3_at_full_size():
     assert out.stats["in_range_sum"] == total_cc and out.stats["n_rows"] == n
     hist_np, hist_cc = out.arrays["hist_npairs"], out.arrays["hist_sumcc"]
     assert np.array_equal(hist_np[:512], want_np[:512]) and np.array_equal(hist_cc[:512], want_cc[:512]) and hist_np[512:].sum() == 0
-    chk = run_check.check_engine_run(eng, genome, sample, cfg, (out.info, out.stats), True, p_stride=16)
+    # the fit at this size against the REAL reference (fixture f14_C3_fit: the reference's own stage functions on this histogram)
+    g = run_check.fit_fixture("C3")
+    assert run_check.compare_histogram(hist_cc, hist_np, out.stats, g, res) == []
+    assert run_check.compare_fit(eng.ctx.get_array, out.info, g) == []
+    chk = run_check.check_engine_run(eng, genome, sample, cfg, (out.info, out.stats), True, p_stride=16, fit_fixture_name="C3")
     assert chk["rows_q"] == n and chk["rows_p"] > 1_000_000
-    assert chk["nan_pattern_equal"] and chk["max_dp"] <= TOL and chk["max_dq"] == 0.0, chk
+    assert chk["nan_pattern_equal"] and chk["max_dp"] <= TOL and chk["max_dq"] == 0.0 and chk["fit_vs_reference"]["bit_identical"], chk
+    eng.close()
+
+
+@pytest.mark.parametrize("name,n_shards", [("C3w", 2), ("C5", 4)])
+def test_k1_and_fit_at_full_size_in_row_shards(name, n_shards):
+    """C3w (1.06e9 rows, 49 734 distance values: K1's wide LDS window) and C5 (1.9e9 cis + 1e8 trans rows, 1 kb loci) at their
+    FULL sizes: K1 over the rows in chromosome shards (its sums and histograms are additive - what the sharded run all-reduces),
+    the summed histogram against the fixture's (torch bincount of the same rows, computed without the engine), then fhx_fit on
+    it against what the real reference returned on that histogram (fixtures f14_C3w_fit / f14_C5_fit), bit for bit."""
+    import torch
+    import bench
+    from fithic_amd import _capi, synth
+    from oracle import run_check
+    g = run_check.fit_fixture(name)
+    cfg = dict(bench.CONFIGS[name])
+    dev = torch.device("cuda", 0)
+    genome = synth.Genome(cfg["res"], cfg["lengths"])
+    owner = synth.assign_chromosomes(genome, n_shards)
+    eng = _engine_for(genome, cfg["res"], cfg["L"], cfg["U"], 100, mode=cfg["mode"])
+    total = None
+    hist_cc = hist_np = None
+    n_all = 0
+    for r in range(n_shards):
+        mine = [c for c in range(len(genome)) if owner[c] == r]
+        cols, n, n_cis, n_trans = bench.build_rows(synth, torch, cfg, genome, mine, r, n_shards, dev)
+        eng.load_contacts_device([t.data_ptr() for t in cols], n)
+        del cols
+        torch.cuda.empty_cache()
+        st = eng.ctx.pass_stats().as_dict()
+        cc, npairs = eng.ctx.get_array(_capi.A_HIST_SUMCC), eng.ctx.get_array(_capi.A_HIST_NPAIRS)
+        if total is None:
+            total = dict(st)
+            hist_cc, hist_np = np.zeros(max(genome.n_loci) + 2, np.int64), np.zeros(max(genome.n_loci) + 2, np.int64)
+        else:
+            for k in ("inter_count", "inter_sum", "intra_all_count", "intra_all_sum", "in_range_count", "in_range_sum"):
+                total[k] += st[k]
+            total["max_count"] = max(total["max_count"], st["max_count"])
+        hist_cc[:len(cc)] += cc                         # a shard's histogram is as long as its longest chromosome
+        hist_np[:len(npairs)] += npairs
+        n_all += n
+    assert n_all == int(g["hist_nrows"].sum()) + int(g["inter"][0])
+    assert run_check.compare_histogram(hist_cc, hist_np, total, g, cfg["res"]) == []
+    stats = _capi.FhxStats()
+    for k, v in total.items():
+        setattr(stats, k, int(v))
+    eng.ctx.set_global_stats(stats, hist_cc, hist_np)
+    info = eng.ctx.fit().as_dict()
+    assert run_check.compare_fit(eng.ctx.get_array, info, g) == []
     eng.close()
 
 

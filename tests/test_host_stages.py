@@ -148,6 +148,39 @@ def test_host_fit_matches_reference(name):
         ctx.close()
 
 
+@pytest.mark.parametrize("name", ["C3", "C3w", "C5"])
+def test_host_fit_matches_reference_at_headline_sizes(name):
+    """The fit at the sizes the metric is quoted on - 22 autosomes at 5 kb / 1 kb (576 216 / 2 881 044 loci; 397, 49 734 and
+    1 999 distance values): fhx_fit fed with the histogram of the full synth-v1 workload reproduces what the REAL reference's
+    makeBinsFromInteractions -> generate_FragPairs -> calculateProbabilities -> fit_Spline returned on it (fixtures f14, made by
+    tests/golden/make_golden.py f14) bit for bit: bins, possible pairs, bin means (the 19999.999999999996-type values of SURVEY
+    fact 6 occur here), s = min(y)^2, knots, coefficients, the isotonic table, N."""
+    import bench
+    from fithic_amd import synth
+    from oracle import run_check
+    g = run_check.fit_fixture(name)
+    assert g is not None
+    cfg = bench.CONFIGS[name]
+    genome = synth.Genome(cfg["res"], cfg["lengths"])
+    ctx = _capi.Context(-1)
+    ctx.set_params(cfg["res"], cfg["L"], cfg["U"], 100, 1, MODES[cfg["mode"]])
+    ctx.load_fragments(*genome.fragments(), genome.sort_rank())
+    st = _capi.FhxStats()
+    st.inter_count, st.inter_sum, st.intra_all_sum, st.in_range_sum = [int(v) for v in g["sums"]]
+    n_dist = int(g["hist_dist_idx"].max()) + 1
+    hist_cc, hist_np = np.zeros(n_dist, np.int64), np.zeros(n_dist, np.int64)
+    hist_cc[g["hist_dist_idx"]] = g["hist_sumcc"]
+    hist_np[g["hist_dist_idx"]] = g["hist_nrows"]
+    assert np.array_equal(g["dist_keys"], g["hist_dist_idx"] * cfg["res"]) and np.array_equal(g["dist_sumcc"], g["hist_sumcc"])
+    ctx.set_global_stats(st, hist_cc, hist_np)
+    info = ctx.fit().as_dict()
+    assert run_check.compare_fit(ctx.get_array, info, g) == []
+    assert len(g["x"]) == 100 and len(g["splineX"]) > 300
+    x = g["x"]
+    assert np.any(x != np.round(x))            # bin means that are not whole numbers: the summation order matters here
+    ctx.close()
+
+
 def test_visual_plots_write_the_reference_figures(tmp_path):
     """-v: the four figure kinds of fithic.py:970-999,1256-1321 are produced from host arrays."""
     pytest.importorskip("matplotlib")

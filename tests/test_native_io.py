@@ -61,7 +61,8 @@ def test_reader_follows_python_number_and_split_grammar(tmp_path):
     ordinary and adversarial ASCII tokens (signs, underscores by PEP 515, exponents, nan / inf, hexadecimal forms that strtod
     takes and float() does not, values outside int32, wrong field counts, every ASCII separator str.split() knows) must be
     accepted or refused exactly as Python does, with the same values.  Non-ASCII digits and spaces (which Python would take)
-    are refused: a documented deviation."""
+    are refused: a documented deviation.  A number the reference takes but the int32 columns cannot hold is
+    FHX_ERR_UNSUPPORTED (a limit of the library), everything the reference itself raises on is FHX_ERR_REFERENCE_EXIT."""
     rng = np.random.default_rng(3)
     int_tok = ["5", "+5", "-5", "0", "007", "1_000", "1__0", "_1", "1_", "2147483647", "2147483648", "-2147483648", "-2147483649", "12a", "1.0",
                "1e3", "0x10", "+", "-", "+-3"]
@@ -70,19 +71,21 @@ def test_reader_follows_python_number_and_split_grammar(tmp_path):
                "9" * 20, "0" * 30 + "7", "1" + "0" * 70, "nan(1)", "1e+3", "1e+", "-.5e-2", "1_0e1_0", "_1.0", ".", "in", "infin"]
 
     def python_parse(line):
+        """-> (row, None), or (None, "range") when the reference takes the line but a number does not fit the int32 columns, or
+        (None, "malformed") when the reference itself raises"""
         f = line.split()
         if len(f) != 5:
-            return None
+            return None, "malformed"
         try:
             m1, m2, c = int(f[1]), int(f[3]), int(float(f[4]))
         except (ValueError, OverflowError):
-            return None
+            return None, "malformed"
         if not all(-2 ** 31 <= v < 2 ** 31 for v in (m1, m2, c)):
-            return None                                            # int32 columns: refusing is the documented behaviour
-        return (f[0], m1, f[2], m2, c)
+            return None, "range"                                   # int32 columns: refusing is the documented behaviour
+        return (f[0], m1, f[2], m2, c), None
 
     path = str(tmp_path / "c.gz")
-    checked = accepted = 0
+    checked = accepted = ranged = 0
     for trial in range(1500):
         t1 = "123" if rng.random() < 0.5 else str(rng.choice(int_tok))
         t2 = str(rng.choice(int_tok[:4]))
@@ -93,26 +96,79 @@ def test_reader_follows_python_number_and_split_grammar(tmp_path):
             fields = fields[:4]
         if rng.random() < 0.05:
             fields.append("x")
-        line = sep.join(fields) + str(rng.choice(["\n", "\r\n", " \n"]))
-        if sep == "\r":
-            continue                                               # a lone \r ends a line in text mode: documented deviation
-        with gzip.open(path, "wt") as f:
-            f.write("chr1\t5\tchr1\t9\t2\n" + line + "chr2\t1\tchr2\t2\t3\n")
-        want = python_parse(line)
+        line = sep.join(fields) + str(rng.choice(["\n", "\r\n", " \n", "\r", " \r"]))
+        with gzip.open(path, "wb") as f:
+            f.write(("chr1\t5\tchr1\t9\t2\n" + line + "chr2\t1\tchr2\t2\t3\n").encode())
+        # what the reference sees: the lines of text mode (universal newlines: \r and \r\n end a line too, fithic.py:406)
+        want_rows, why = [], None
+        for ln in gzip.open(path, "rt"):
+            row, bad = python_parse(ln)
+            if bad:
+                why = bad
+                break
+            want_rows.append(row)
         try:
             names, cols, _ = _capi.host_read_table(path, 0, 1)
-            got = (names[cols[0][1]], int(cols[1][1]), names[cols[2][1]], int(cols[3][1]), int(cols[4][1])) if len(cols[1]) == 3 else "rows"
-        except _capi.FhxError:
-            got = None
-        assert got == want, repr(line)
+            got = [(names[cols[0][i]], int(cols[1][i]), names[cols[2][i]], int(cols[3][i]), int(cols[4][i])) for i in range(len(cols[1]))]
+            assert why is None and got == want_rows, repr(line)
+        except _capi.FhxError as e:
+            assert why is not None, repr(line)
+            assert e.code == (_capi.FHX_ERR_UNSUPPORTED if why == "range" else _capi.FHX_ERR_REFERENCE_EXIT), (repr(line), why, str(e))
         checked += 1
-        accepted += want is not None
-    assert checked > 1000 and 300 < accepted < checked - 300
+        accepted += why is None
+        ranged += why == "range"
+    assert checked > 1000 and 300 < accepted < checked - 300 and ranged > 20
     for line in ("chrA\t\u0663\tchrB\t5\t4\n", "chrA\t3\tchrB\t5\t\u0661\u0662\n"):        # Arabic-Indic digits: Python reads 3 and 12
         with gzip.open(path, "wt", encoding="utf-8") as f:
             f.write(line)
         with pytest.raises(_capi.FhxError):
             _capi.host_read_table(path, 0, 1)
+
+
+def test_bytes_after_the_last_gzip_member_as_python_gzip_treats_them(tmp_path):
+    """gzip.open(..., 'rt') (fithic.py:406): zero padding after a member is skipped, another member is read, anything else raises
+    BadGzipFile once the reader gets there - the reference dies with a traceback; a truncated next member raises EOFError."""
+    text = b"chr1\t5\tchr1\t9\t2\nchr1\t5\tchr1\t19\t1\n"
+    member = gzip.compress(text)
+    path = str(tmp_path / "t.gz")
+    cases = [(member, True), (member + b"\0" * 7, True), (member + member, True), (member + b"\0\0\0" + member, True),
+             (member + b"garbage", False), (member + b"\0\0x", False), (member + b"\x1f", False), (member + b"\x1f\x8c" + b"\0" * 20, False),
+             (member + member[:12], False), (member + b"\x1f\x8b\x07" + b"\0" * 20, False)]
+    for data, fine in cases:
+        with open(path, "wb") as f:
+            f.write(data)
+        try:
+            with gzip.open(path, "rt") as f:
+                n_py = len(f.readlines())
+            py_ok = True
+        except (OSError, EOFError):
+            py_ok = False
+        assert py_ok == fine, data[len(member):]
+        if fine:
+            names, cols, _ = _capi.host_read_table(path, 0, 1)
+            assert len(cols[1]) == n_py
+        else:
+            with pytest.raises(_capi.FhxError) as e:
+                _capi.host_read_table(path, 0, 1)
+            assert e.value.code == _capi.FHX_ERR_REFERENCE_EXIT
+
+
+def test_lone_carriage_return_is_a_line_break(tmp_path):
+    """Text mode's universal newlines: \\r, \\n and \\r\\n all end a line, so the line NUMBERS the outlier lists carry follow."""
+    path = str(tmp_path / "cr.gz")
+    body = "chr1\t5\tchr1\t9\t2\rchr1\t5\tchr1\t19\t1\r\nchr2\t1\tchr2\t2\t3\nchr2\t1\tchr2\t7\t4\r"
+    with gzip.open(path, "wb") as f:
+        f.write(body.encode())
+    want = [ln.split() for ln in gzip.open(path, "rt")]
+    assert len(want) == 4
+    for threads in (1, 3):
+        names, cols, _ = _capi.host_read_table(path, 0, threads)
+        assert [int(v) for v in cols[3]] == [int(r[3]) for r in want] and [int(v) for v in cols[4]] == [int(r[4]) for r in want]
+    with gzip.open(path, "wb") as f:
+        f.write(b"chr1\t5\tchr1\t9\t2\r\rchr1\t5\tchr1\t19\t1\n")          # an empty line: split() gives [] -> ValueError
+    with pytest.raises(_capi.FhxError) as e:
+        _capi.host_read_table(path, 0, 1)
+    assert e.value.code == _capi.FHX_ERR_REFERENCE_EXIT and "line 2" in str(e.value)
 
 
 @pytest.mark.parametrize("name", ALL_CASES)

@@ -33,3 +33,102 @@ def test_pipe_exchange_with_large_messages(world):
         p.join(30)
     for me in range(world):
         assert res[me] == [((src * 16 + me) % 251, nbytes + me) for src in range(world)]
+
+
+def test_engine_that_cannot_start_leaves_no_worker_behind():
+    """No GPU here: rank 0's own engine (and every worker's) fails to start.  The constructor must stop and join the worker
+    processes it had already spawned before the error travels on - nobody will ever hold the object to close it."""
+    from fithic_amd import sharded
+    before = set(p.pid for p in mp.active_children())
+    with pytest.raises(Exception):
+        sharded.ShardedEngine(3, devices=[0, 1, 2], transport="pipes")
+    left = [p for p in mp.active_children() if p.pid not in before]
+    assert left == []
+
+
+def _scripted_worker(conn, script):
+    """a stand-in rank: answers every command as `script` says - ("ok", value), ("error", text), "hang" or "die" """
+    import os
+    import time
+    while True:
+        name, args = conn.recv()
+        what = script.get(name, ("ok", None))
+        if what == "hang":
+            time.sleep(3600)
+        if what == "die":
+            os._exit(7)
+        conn.send(what)
+        if name == "close":
+            return
+
+
+def _scripted_engine(scripts, local):
+    """A ShardedEngine around scripted ranks (no GPU, no library calls): scripts[r-1] drives worker r, `local` is rank 0."""
+    from fithic_amd import sharded
+    ctx = mp.get_context("fork")
+    eng = object.__new__(sharded.ShardedEngine)
+    eng.world, eng.transport, eng.broken, eng.local_stuck, eng.local = len(scripts) + 1, "pipes", None, False, local
+    eng.workers = []
+    for sc in scripts:
+        parent, child = ctx.Pipe(duplex=True)
+        p = ctx.Process(target=_scripted_worker, args=(child, sc), daemon=True)
+        p.start()
+        eng.workers.append((p, parent))
+    eng.GRACE_S = 1.5
+    return eng
+
+
+class _Local:
+    def __init__(self, **behaviour):
+        self.behaviour = behaviour
+
+    def __getattr__(self, name):
+        def call(*args):
+            what = self.behaviour.get(name, None)
+            if what == "hang":
+                import time
+                time.sleep(3600)
+            if isinstance(what, Exception):
+                raise what
+            return what
+        return call
+
+
+def test_a_rank_that_fails_before_a_collective_does_not_hang_the_others():
+    """one rank returns an error before the first collective of a command while the others (rank 0 among
+    them, whose part runs in this process) sit in it.  The engine must give up after the grace period - not wait for ever -
+    name the failed rank, and say that this process's own rank is stuck (the CLI then leaves through os._exit)."""
+    import time
+    eng = _scripted_engine([{"pass_stats": ("error", "FhxError(-3, 'out of memory')")}, {"pass_stats": "hang"}], _Local(pass_stats="hang"))
+    t0 = time.monotonic()
+    with pytest.raises(RuntimeError) as e:
+        eng._all("pass_stats")
+    assert time.monotonic() - t0 < 20
+    assert "rank 1 failed in pass_stats" in str(e.value) and "[0, 2]" in str(e.value)
+    assert eng.local_stuck and eng.broken
+    for p, _ in eng.workers:
+        p.join(10)
+        assert not p.is_alive()
+    with pytest.raises(RuntimeError):                      # and it stays unusable
+        eng._all("fit")
+    eng.close()                                            # never raises
+
+
+def test_a_failure_on_every_rank_keeps_the_protocol_in_step():
+    """A refusal all ranks share (agreed over the communicator, or the same host-side error everywhere) is an ordinary
+    exception: every answer is collected first, and the next command runs."""
+    err = ("error", "FhxError(-4, 'a rank of this run holds loci that are not on one grid')")
+    eng = _scripted_engine([{"pass_stats": err, "fit": ("ok", {"a": 1})}], _Local(pass_stats=ValueError("same refusal on rank 0"), fit={"a": 0}))
+    with pytest.raises(ValueError):
+        eng._all("pass_stats")
+    assert not eng.broken and not eng.local_stuck
+    assert eng._all("fit") == [{"a": 0}, {"a": 1}]
+    eng.close()
+
+
+def test_a_rank_that_dies_is_reported():
+    eng = _scripted_engine([{"pvalues": "die"}], _Local(pvalues=None))
+    with pytest.raises(RuntimeError) as e:
+        eng._all("pvalues")
+    assert "rank 1" in str(e.value) and eng.broken
+    eng.close()
