@@ -2592,7 +2592,10 @@ int fhx_load_pairs_device(fhx_ctx* ctx, const void* c1, const void* m1, const vo
     if (!ctx || n < 0 || (n > 0 && (!c1 || !m1 || !c2 || !m2 || !cnt))) return FHX_ERR_ARG;
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
     FHX_HIP(hipSetDevice(ctx->device));
-    if (stream) FHX_HIP(hipStreamSynchronize((hipStream_t)stream));
+    // the producer's stream; nullptr = the legacy default stream, which is where PyTorch computes unless told otherwise.  The
+    // context's own stream is non-blocking (no implicit ordering with the default stream), so this wait is what makes rows that
+    // were just written by the caller's kernels safe to read here.
+    FHX_HIP(hipStreamSynchronize((hipStream_t)stream));
     ctx->offgrid = false;
     ctx->nonfixed = ctx->have_params && ctx->prm.resolution == 0;
     if (ctx->have_params && ctx->nonfixed)

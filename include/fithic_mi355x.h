@@ -140,7 +140,8 @@ int fhx_load_bias(fhx_ctx* ctx, const int32_t* chr, const int32_t* mid, const do
 int fhx_load_pairs(fhx_ctx* ctx, const int32_t* chr1, const int32_t* mid1, const int32_t* chr2,
                    const int32_t* mid2, const int32_t* count, int64_t n);
 /* Same, but the five arrays already live in this GPU's memory (e.g. written by a generator kernel or
- * received over xGMI); `stream` is a hipStream_t or NULL. */
+ * received over xGMI).  `stream` = the hipStream_t the arrays were produced on, NULL = the legacy default stream
+ * (PyTorch's, unless the caller chose another): the call waits for it before reading the arrays. */
 int fhx_load_pairs_device(fhx_ctx* ctx, const void* d_chr1, const void* d_mid1, const void* d_chr2,
                           const void* d_mid2, const void* d_count, int64_t n, void* stream);
 

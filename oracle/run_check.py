@@ -42,10 +42,10 @@ def compare_histogram(hist_sumcc, hist_npairs, stats, g, res):
     got_np = np.zeros_like(want_cc)
     got_cc[:len(hist_sumcc)] = hist_sumcc
     got_np[:len(hist_npairs)] = hist_npairs
-    if not np.array_equal(got_cc, want_cc):
-        bad.append("hist_sumcc")
-    if not np.array_equal(got_np, want_np):
-        bad.append("hist_npairs")
+    for name, got, want in (("hist_sumcc", got_cc, want_cc), ("hist_npairs", got_np, want_np)):
+        if not np.array_equal(got, want):
+            at = np.flatnonzero(got != want)
+            bad.append("%s (%d entries, first at distance index %d: %d, fixture %d)" % (name, len(at), at[0], got[at[0]], want[at[0]]))
     inter_count, inter_sum, intra_all_sum, in_range_sum = [int(v) for v in g["sums"]]
     for k, v in (("inter_count", inter_count), ("inter_sum", inter_sum), ("intra_all_sum", intra_all_sum), ("in_range_sum", in_range_sum)):
         if int(stats[k]) != v:

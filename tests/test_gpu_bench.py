@@ -1,0 +1,47 @@
+"""bench.py itself on the GPU: every configuration that prints a `value` carries a parity verdict.  Small workloads (the first
+chromosomes of C3) so that the two runs take seconds; the full-size checks live in tests/test_gpu_scale.py."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra_env, *flags):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1"] + list(flags),
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]               # exactly one JSON line on stdout
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_is_checked_against_the_oracle():
+    out = _run({}, "--max-chroms", "2", "--no-cpu-baseline")
+    pc = out["parity_check"]
+    assert pc["ok"] and pc["max_dp"] <= 1e-10 and pc["max_dq"] == 0.0 and pc["rows_q"] == out["config"]["pairs"]
+    assert "fit_vs_reference" not in pc                     # two chromosomes are not the workload the f14 fixture was made on
+    assert out["n_gpus"] == 1 and out["roofline"]["frac"] > 0 and out["value"] > 1e8
+
+
+def test_sharded_schedule_over_rccl_is_verified_against_one_gpu():
+    """FHX_FORCE_DIST=1: the library's communicator (real RCCL, one rank) and fhx_run_pass_distributed carry the timed pass; the
+    same code then verifies it as an N > 1 run is verified - per-chromosome hashes of (row, p) and (row, q) of the sharded run
+    against a plain single-GPU pass over all rows, which in turn is checked against the oracle."""
+    out = _run({"FHX_FORCE_DIST": "1"}, "--max-chroms", "3", "--no-weak")
+    pc = out["parity_check"]
+    assert pc["ok"] and pc["sharded_equals_single_gpu"] and pc["ranks"] == 1 and pc["chromosomes_hashed"] == 3
+    assert pc["chromosomes_p_differ"] == [] and pc["chromosomes_q_differ"] == [] and pc["global_stats_equal"] and pc["fit_scalars_equal"]
+    assert pc["rows"] == out["config"]["pairs"] and pc["max_dp"] <= 1e-10 and pc["max_dq"] == 0.0
+    assert out["rccl"]["world_in_library"] == 1 and "library communicator" in out["rccl"]["driver"]
