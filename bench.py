@@ -402,8 +402,9 @@ def main():
     canonical = (args.keep == 0 and args.max_chroms == 0 and args.overdispersion == 0 and replicas == 1)
     fixture_name = args.config if canonical and os.path.exists(os.path.join(ROOT, "tests", "golden", "f14_%s_fit.npz" % args.config)) else None
     verify_sharded = comm is not None and not args.no_parity_check         # N > 1 (or FHX_FORCE_DIST): compare with one GPU
+    want_digest = bool(os.environ.get("FHX_BENCH_HASH"))          # A/B of kernel variants: a digest of every p and q in the result line
     M = measure(replicas, with_cpu_leg=(rank == 0 and comm is None and not (args.no_cpu_baseline and args.no_parity_check)),
-                want_hashes=verify_sharded)
+                want_hashes=verify_sharded or want_digest)
     eng, genome = M["eng"], M["genome"]
     passes = cfg["passes"]
 
@@ -478,6 +479,9 @@ def main():
             result["stage_ms"] = M["stage_ms"]
         if args.no_parity_check:
             result["parity_check"] = {"ok": None, "skipped": "--no-parity-check"}
+        if want_digest and M["hashes"] is not None:
+            import hashlib
+            result["result_digest"] = hashlib.sha256(M["hashes"].cpu().numpy().tobytes()).hexdigest()[:16]
         if M["sample"] is not None:
             if not args.no_parity_check:
                 if passes > 1:                              # the timed steps end with reset_passes(): check an (untimed) pass 1

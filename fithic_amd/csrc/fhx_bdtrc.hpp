@@ -327,7 +327,11 @@ __device__ __forceinline__ double contfrac_lazy(double a, double b, double x) {
 //     the same bits as Cephes' data-dependent one.  Here every lane renormalises at the same iterations (every 8th, by
 //     the exponent of the largest of its four values): no per-lane exec masking in the loop.
 //     Range proof: x < 1, b <= a  =>  |xk| <= 2 in the first half step and <= 1 in the second, so the largest value grows
-//     by at most 4x per iteration: from <= 2 after a renormalisation to <= 2^17 before the next, products <= 2^34.
+//     by at most 4x per iteration: from < 1 after a renormalisation to <= 2^16 before the next, products <= 2^32.
+//     The renormalisation cannot be made rarer: on Hi-C rows (x = 1 - prior ~ 1 - 1e-8, a ~ 1e9) every step cancels
+//     pk = pkm1 - ~pkm2 and the values SHRINK by 2^-24..2^-30 per iteration (Cephes multiplies by 2^52 every ~2.4 iterations);
+//     eight iterations stay inside the 2^-300 window of the exact statements, sixteen do not (tried: every row came back
+//     irregular and went through the per-lane loop - correct results, twice the time).
 //     Smallness is checked where it matters (below).
 //   * the lazy convergence test of contfrac_lazy_impl (cross-multiplication instead of two divisions) needs Cephes'
 //     previous r = ans.  In the common case that is the pair (pkm1, qkm1) the iteration started with - still live for
@@ -338,6 +342,7 @@ struct CfRow {          // one iteration's constants, 64 bytes = one scalar-cach
     double k1, k2, k5, k6, d0, y0, d1, y1;
 };
 constexpr int kCfIters = 300;
+constexpr double kCfLazyT = 2e-15;          // cf_swapped_step: |d| > kCfLazyT |c2| proves Cephes' t >= 3 MACHEP (derivation there)
 
 typedef const CfRow __attribute__((address_space(4))) * CfRowConstPtr;      // constant address space: s_load
 
@@ -384,80 +389,159 @@ __device__ __forceinline__ bool cf_swapped_regular(double a, double b, double x)
     return x > 1e-150 && x < 1.0 && a >= 1.0 && a < 4.5e15 && b >= 1.0 && b <= a;
 }
 
-// incbcf(a, b, x) for the rows of one wave that share (a, b); `rows` must be wave-uniform.  Returns Cephes' value for the
-// lanes it leaves regular; lanes that come back irregular must be recomputed.
+// incbcf(a, b, x) for R rows per lane of one wave, all rows of the wave sharing (a, b); `rows` must be wave-uniform.
+// R > 1: the R recurrences of a lane are independent instruction streams (plus the two divisions each): a dependent fp64
+// instruction issues ~32 cycles behind its producer on this chip and eight waves per SIMD of single-row lanes do not hide
+// that (profiles/fp64_rate.hip: one chain per lane tops out at 41 % of the issue rate whatever the occupancy, eight chains
+// reach 85-93 % from two waves per SIMD up) - more rows per lane, not more waves, is what fills the fp64 pipe.  The scalar
+// loads, the loop control and the wave-uniform exactness branch are shared by the R rows.
+// Returns Cephes' value for the rows it leaves regular; rows that come back irregular must be recomputed.
+template <int R>
 struct CfState {
-    double pm, qm, p0, q0;        // pkm2, qkm2, pkm1, qkm1
-    double result;
+    double pm[R], qm[R], p0[R], q0[R];        // pkm2, qkm2, pkm1, qkm1
+    double result[R];
     // lane masks, wave-uniform (SGPR pairs): which lanes are finished (converged or given up - they keep iterating and are
     // ignored) and which must be recomputed by the caller
-    unsigned long long done, irregular;
+    unsigned long long done[R], irregular[R];
 };
 
 __device__ __forceinline__ bool cf_lane_bit(unsigned long long m) {
     return (m >> (threadIdx.x & 63)) & 1ull;
 }
 
-__device__ __forceinline__ void cf_swapped_step(CfState& S, const CfRow c, double arg) {
-    // xk = -(x*k1*k2)/(k3*k4): lean_div with the tabulated reciprocal
-    double n = arg * c.k1 * c.k2;
-    double t0 = n * c.y0;
-    double r0 = __builtin_fma(-c.d0, t0, n);
-    double xk = __builtin_fma(r0, c.y0, t0);
-    const double p1 = S.p0 - S.pm * xk;
-    const double q1 = S.q0 - S.qm * xk;
-    // xk = (x*k5*k6)/(k7*k8)
-    n = arg * c.k5 * c.k6;
-    t0 = n * c.y1;
-    r0 = __builtin_fma(-c.d1, t0, n);
-    xk = __builtin_fma(r0, c.y1, t0);
-    const double p2 = p1 + S.p0 * xk;
-    const double q2 = q1 + S.q0 * xk;
+template <int R>
+__device__ __forceinline__ void cf_swapped_step(CfState<R>& S, const CfRow c, const double (&arg)[R]) {
+    // Written stage by stage ACROSS the rows (and across the two divisions of a row, which do not depend on each other): the
+    // compiler keeps this order, so every instruction sits 2R (the divisions) or R (the recurrence, the test) instructions
+    // behind its producer instead of right behind it.
+    double p1[R], q1[R], p2[R], q2[R];
+    double na[R], nb[R], ta[R], tb[R];
+    unsigned long long exact[R], any_exact = 0ull;
+    // xk_a = -(x*k1*k2)/(k3*k4), xk_b = (x*k5*k6)/(k7*k8): lean_div with the tabulated reciprocals
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        na[r] = arg[r] * c.k1;
+        nb[r] = arg[r] * c.k5;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        na[r] = na[r] * c.k2;
+        nb[r] = nb[r] * c.k6;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        ta[r] = na[r] * c.y0;
+        tb[r] = nb[r] * c.y1;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        na[r] = __builtin_fma(-c.d0, ta[r], na[r]);
+        nb[r] = __builtin_fma(-c.d1, tb[r], nb[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        ta[r] = __builtin_fma(na[r], c.y0, ta[r]);          // xk_a (sign folded into the subtraction below)
+        tb[r] = __builtin_fma(nb[r], c.y1, tb[r]);          // xk_b
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        na[r] = S.pm[r] * ta[r];
+        nb[r] = S.qm[r] * ta[r];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        p1[r] = S.p0[r] - na[r];
+        q1[r] = S.q0[r] - nb[r];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        na[r] = S.p0[r] * tb[r];
+        nb[r] = S.q0[r] * tb[r];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        p2[r] = p1[r] + na[r];
+        q2[r] = q1[r] + nb[r];
+    }
     // Lazy convergence test.  Cephes' ans is the r of the previous iteration, fl(pk/qk) of the pair this iteration started
     // with (1.0 = 1/1 before the first) - for every lane that is still regular, because those never met pk == 0 or qk == 0.
-    // With C = p2*q0 and E = p0*q2 - C:  c2 = C(1 + e1), d = fl(p0*q2 - c2) = (E - C e1)(1 + e2) (one fused rounding), so
-    // |d| > 1e-13 |c2| gives |E/C| > 1e-13 - 2.3e-16, and Cephes' t = |fl(fl(ans - r)/r)| with ans = fl(p0/q0), r = fl(p2/q2)
-    // is within 3.4e-16 of |E/C|: certainly t > 3 MACHEP, Cephes goes on.  c2 must not have lost bits to underflow and p2,
-    // q0 must not be zero: |c2| > 2^-600 (values are <= 2^17).  q2 == 0 shows up as q0 == 0 one iteration later - or in
-    // the caller's final check - and sends the row to the per-lane loop like every other unusual state.
-    const double c2 = p2 * S.q0;
-    const double d = __builtin_fma(S.p0, q2, -c2);
-    const unsigned long long differ = __builtin_amdgcn_ballot_w64(fabs(d) > 1e-13 * fabs(c2)) &
-                                      __builtin_amdgcn_ballot_w64(fabs(c2) > 0x1p-600);
-    const unsigned long long exact = ~(differ | S.done);
-    if (__builtin_expect(exact != 0ull, 0)) {                           // wave-uniform branch; Cephes' statements, literally
-        const bool mine = cf_lane_bit(exact);
-        const bool window = fabs(S.p0) > 0x1p-300 && fabs(S.q0) > 0x1p-300 && fabs(p2) > 0x1p-300 && fabs(q2) > 0x1p-300;
-        const bool go = mine && window;
-        const double ans = go ? S.p0 / S.q0 : 1.0;                      // the pending quotient
-        const double r = go ? p2 / q2 : 1.0;                            // != 0 inside the window
-        const double t = fabs((ans - r) / r);
-        const unsigned long long fin = __builtin_amdgcn_ballot_w64(go && t < 3.0 * kMachEp);
-        const unsigned long long bad = __builtin_amdgcn_ballot_w64(mine && !window);
-        if (cf_lane_bit(fin)) S.result = r;
-        S.done |= fin | bad;
-        S.irregular |= bad;
+    // With u = 2^-53, C = p2*q0 and E = p0*q2 - C (exact values):  c2 = C(1 + e1), d = fl(p0*q2 - c2) = (E - C e1)(1 + e2)
+    // (one fused rounding), so |d| > T |c2| gives |E/C| > T(1 - 2u) - u.  Cephes forms ans = fl(p0/q0) = (p0/q0)(1 + a1),
+    // r = fl(p2/q2) = (p2/q2)(1 + a2), the difference ans - r exactly (Sterbenz: the two are within a factor 1 + 1e-10 of
+    // each other here) and t = |fl((ans - r)/r)| = |ans/r - 1|(1 + a3) with ans/r - 1 = E/C + (a1 - a2)(1 + E/C) + O(u^2):
+    // t > (|E/C| - 2u(1 + |E/C|))(1 - u) > T - 3.4e-16.  Cephes goes on iff t >= 3 MACHEP = 3.33e-16, so any T >= 6.8e-16 proves
+    // it; T = kCfLazyT = 2e-15 leaves 1.3e-15 of margin.  (Round 2 used 1e-13: a hundred times more rows than necessary fell
+    // through to the exact statements - a wave-uniform branch of two IEEE divisions that a single lane of the wave triggers.)
+    // c2 must not have lost bits to underflow and p2, q0 must not be zero: |c2| > 2^-600 (values are <= 2^17).  q2 == 0
+    // shows up as q0 == 0 one iteration later - or in the caller's final check - and sends the row to the per-lane loop like
+    // every other unusual state.
+#pragma unroll
+    for (int r = 0; r < R; ++r) na[r] = p2[r] * S.q0[r];                                  // c2
+#pragma unroll
+    for (int r = 0; r < R; ++r) nb[r] = __builtin_fma(S.p0[r], q2[r], -na[r]);            // d
+#pragma unroll
+    for (int r = 0; r < R; ++r) ta[r] = kCfLazyT * fabs(na[r]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned long long differ = __builtin_amdgcn_ballot_w64(fabs(nb[r]) > ta[r]) & __builtin_amdgcn_ballot_w64(fabs(na[r]) > 0x1p-600);
+        exact[r] = ~(differ | S.done[r]);
+        any_exact |= exact[r];
     }
-    S.pm = p1; S.qm = q1; S.p0 = p2; S.q0 = q2;
+    if (__builtin_expect(any_exact != 0ull, 0)) {                       // wave-uniform branch; Cephes' statements, literally
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (exact[r] == 0ull) continue;                             // wave-uniform
+            const bool mine = cf_lane_bit(exact[r]);
+            const bool window = fabs(S.p0[r]) > 0x1p-300 && fabs(S.q0[r]) > 0x1p-300 && fabs(p2[r]) > 0x1p-300 && fabs(q2[r]) > 0x1p-300;
+            const bool go = mine && window;
+            const double ans = go ? S.p0[r] / S.q0[r] : 1.0;            // the pending quotient
+            const double rr = go ? p2[r] / q2[r] : 1.0;                 // != 0 inside the window
+            const double t = fabs((ans - rr) / rr);
+            const unsigned long long fin = __builtin_amdgcn_ballot_w64(go && t < 3.0 * kMachEp);
+            const unsigned long long bad = __builtin_amdgcn_ballot_w64(mine && !window);
+            if (cf_lane_bit(fin)) S.result[r] = rr;
+            S.done[r] |= fin | bad;
+            S.irregular[r] |= bad;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        S.pm[r] = p1[r];
+        S.qm[r] = q1[r];
+        S.p0[r] = p2[r];
+        S.q0[r] = q2[r];
+    }
 }
 
-__device__ __forceinline__ void cf_swapped_renorm(CfState& S) {      // same iterations for every lane: no exec masking
-    const double big = fmax(fmax(fabs(S.pm), fabs(S.p0)), fmax(fabs(S.qm), fabs(S.q0)));
-    const int e = -__builtin_amdgcn_frexp_exp(big);
-    S.pm = __builtin_amdgcn_ldexp(S.pm, e);
-    S.p0 = __builtin_amdgcn_ldexp(S.p0, e);
-    S.qm = __builtin_amdgcn_ldexp(S.qm, e);
-    S.q0 = __builtin_amdgcn_ldexp(S.q0, e);
+template <int R>
+__device__ __forceinline__ void cf_swapped_renorm(CfState<R>& S) {      // same iterations for every lane: no exec masking
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const double big = fmax(fmax(fabs(S.pm[r]), fabs(S.p0[r])), fmax(fabs(S.qm[r]), fabs(S.q0[r])));
+        const int e = -__builtin_amdgcn_frexp_exp(big);
+        S.pm[r] = __builtin_amdgcn_ldexp(S.pm[r], e);
+        S.p0[r] = __builtin_amdgcn_ldexp(S.p0[r], e);
+        S.qm[r] = __builtin_amdgcn_ldexp(S.qm[r], e);
+        S.q0[r] = __builtin_amdgcn_ldexp(S.q0[r], e);
+    }
 }
 
-// incbcf(a, b, x) for the rows of one wave that share (a, b); `rows` must be wave-uniform.  Returns Cephes' value for the
-// lanes it leaves regular; lanes that come back irregular must be recomputed.
-__device__ __forceinline__ double cf_swapped_uniform(CfRowConstPtr rows, double arg, bool& irregular) {
-    CfState S;
-    S.pm = 0.0; S.qm = 1.0; S.p0 = 1.0; S.q0 = 1.0;
-    S.result = 1.0;
-    S.irregular = __builtin_amdgcn_ballot_w64(irregular);
-    S.done = S.irregular;
+// arg[r] = x of row r; irregular[r]: in = rows this lane does not really have (or that are outside cf_swapped_regular), out =
+// rows that must be recomputed by the per-lane loop; result[r] = Cephes' incbcf value for the other rows
+template <int R>
+__device__ __forceinline__ void cf_swapped_uniform(CfRowConstPtr rows, const double (&arg)[R], bool (&irregular)[R], double (&result)[R]) {
+    CfState<R> S;
+    unsigned long long all_done = ~0ull;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        S.pm[r] = 0.0;
+        S.qm[r] = 1.0;
+        S.p0[r] = 1.0;
+        S.q0[r] = 1.0;
+        S.result[r] = 1.0;
+        S.irregular[r] = __builtin_amdgcn_ballot_w64(irregular[r]);
+        S.done[r] = S.irregular[r];
+    }
     static_assert(kCfIters % 8 == 4, "blocks of 8 iterations, then one of 4");
     int i = 0;
     // Scalar loads return out of order, so the only wait is "all of them": each iteration first waits for its own row (the
@@ -465,7 +549,7 @@ __device__ __forceinline__ double cf_swapped_uniform(CfRowConstPtr rows, double 
 #define FHX_CF_NEXT(cur, nxt, idx)            \
     asm volatile("" ::"s"(cur.k1));           \
     const CfRow nxt = cf_load_row(rows + (idx)); \
-    cf_swapped_step(S, cur, arg);
+    cf_swapped_step<R>(S, cur, arg);
 #pragma unroll 1
     for (; i + 8 <= kCfIters; i += 8) {
         const CfRow c0 = cf_load_row(rows + i);
@@ -476,25 +560,31 @@ __device__ __forceinline__ double cf_swapped_uniform(CfRowConstPtr rows, double 
         FHX_CF_NEXT(c4, c5, i + 5)
         FHX_CF_NEXT(c5, c6, i + 6)
         FHX_CF_NEXT(c6, c7, i + 7)
-        cf_swapped_step(S, c7, arg);
-        cf_swapped_renorm(S);
-        if (S.done == ~0ull) break;
+        cf_swapped_step<R>(S, c7, arg);
+        cf_swapped_renorm<R>(S);
+        all_done = ~0ull;
+#pragma unroll
+        for (int r = 0; r < R; ++r) all_done &= S.done[r];
+        if (all_done == ~0ull) break;
     }
     if (i + 8 > kCfIters) {
         const CfRow c0 = cf_load_row(rows + i);
         FHX_CF_NEXT(c0, c1, i + 1)
         FHX_CF_NEXT(c1, c2, i + 2)
         FHX_CF_NEXT(c2, c3, i + 3)
-        cf_swapped_step(S, c3, arg);
+        cf_swapped_step<R>(S, c3, arg);
     }
 #undef FHX_CF_NEXT
-    irregular = cf_lane_bit(S.irregular);
-    // the loop ran to the cap: Cephes returns the last r = pk/qk
-    if (!cf_lane_bit(S.done)) {
-        if (!(fabs(S.p0) > 0x1p-300 && fabs(S.q0) > 0x1p-300)) irregular = true;     // a zero in the last iteration
-        S.result = S.p0 / S.q0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        irregular[r] = cf_lane_bit(S.irregular[r]);
+        // the loop ran to the cap: Cephes returns the last r = pk/qk
+        if (!cf_lane_bit(S.done[r])) {
+            if (!(fabs(S.p0[r]) > 0x1p-300 && fabs(S.q0[r]) > 0x1p-300)) irregular[r] = true;     // a zero in the last iteration
+            S.result[r] = S.p0[r] / S.q0[r];
+        }
+        result[r] = S.result[r];
     }
-    return S.result;
 }
 
 // branch classes of one incbet evaluation (used to run branch-homogeneous waves)

@@ -771,10 +771,13 @@ __global__ __launch_bounds__(K2H_THREADS) void k2h_count(QSpan q, unsigned int* 
     for (int d = threadIdx.x; d < K2H_BUCKETS; d += K2H_THREADS) block_hist[(size_t)d * K2H_BLOCKS + blockIdx.x] = h[d];
 }
 
-// bucket starts, each rounded up to a multiple of 64 entries: off[b] for b = 0..K2H_BUCKETS (the last one = padded total)
-__global__ __launch_bounds__(1024) void k2h_offsets(const unsigned int* __restrict__ digit_total, unsigned int* __restrict__ off) {
+// bucket starts, each rounded up to a multiple of `granule` entries (64 x the rows a lane of k2h_heavy takes): off[b] for
+// b = 0..K2H_BUCKETS (the last one = padded total)
+__global__ __launch_bounds__(1024) void k2h_offsets(const unsigned int* __restrict__ digit_total, unsigned int* __restrict__ off,
+                                                    unsigned int granule) {
     __shared__ unsigned int part[1024];
-    const unsigned int a = (digit_total[2 * threadIdx.x] + 63u) & ~63u, b = (digit_total[2 * threadIdx.x + 1] + 63u) & ~63u;
+    const unsigned int g1 = granule - 1u;
+    const unsigned int a = (digit_total[2 * threadIdx.x] + g1) / granule * granule, b = (digit_total[2 * threadIdx.x + 1] + g1) / granule * granule;
     part[threadIdx.x] = a + b;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -825,19 +828,25 @@ struct K2HeavyParams {            // the few fields of K2Params this kernel read
     unsigned long long* top_hist;
 };
 
-__global__ __launch_bounds__(K2H_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k2h_heavy(
+// R rows per lane (a task = 64 R consecutive entries of one bucket: every bucket starts at a multiple of that), WPE waves per
+// SIMD: see cf_swapped_uniform for why more rows per lane beat more waves.
+constexpr int K2H_MAX_ROWS = 4;
+template <int R, int WPE>
+__global__ __launch_bounds__(K2H_THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k2h_heavy(
     K2HeavyParams P, const QEntry* __restrict__ sorted, const unsigned int* __restrict__ off,
     const unsigned int* __restrict__ digit_total, const dev::CfRow* __restrict__ tab, QEntry* __restrict__ redo,
     unsigned long long* __restrict__ n_redo) {
+    static_assert(R >= 1 && R <= K2H_MAX_ROWS, "the sorted queue is padded for at most K2H_MAX_ROWS rows per lane");
     __shared__ unsigned int hist_lds[K2_HIST_BINS];
     FusedHist H;
     H.init(hist_lds, P.top_hist);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    const unsigned int n_tasks = off[K2H_GENERIC] >> 6;          // 64-entry tasks in front of the generic bucket
+    constexpr unsigned int TASK = 64u * R;
+    const unsigned int n_tasks = off[K2H_GENERIC] / TASK;        // tasks in front of the generic bucket
     const unsigned int stride = gridDim.x * (K2H_THREADS / 64);
     for (unsigned int task = blockIdx.x * (K2H_THREADS / 64) + wave; task < n_tasks; task += stride) {
-        const unsigned int first = task << 6;
+        const unsigned int first = task * TASK;
         // bucket of this task: the last b with off[b] <= first (empty buckets share their successor's start: skip them)
         int lo = 0, hi = K2H_GENERIC;                             // invariant: off[lo] <= first < off[hi]
         while (hi - lo > 1) {
@@ -849,33 +858,42 @@ __global__ __launch_bounds__(K2H_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
         }
         const int b = __builtin_amdgcn_readfirstlane(lo);
         const unsigned int live = off[b] + digit_total[b];        // entries of the bucket end here, padding follows
-        const bool have = first + lane < live;
-        QEntry e;
-        e.row = 0u;
-        e.count = b >= K2H_KCAP ? -(b - K2H_KCAP) : b;
-        e.prior = 0.5;
-        if (have) e = sorted[first + lane];
         const bool is_inter = b >= K2H_KCAP;
         const int c = is_inter ? b - K2H_KCAP : b;
         const dev::BinomTables& T = is_inter ? P.inter : P.intra;
         // bdtrc_count_class<BC_CF_SWAPPED>: incbet_finish(bb, aa, 1 - xx, xx, incbcf(bb, aa, 1 - xx), flag = 1, ...)
         const double fk = (double)c - 1.0;
-        const double aa = fk + 1.0, bb = T.n - fk, xx = e.prior;
-        const double w1 = 1.0 - xx;
-        bool irregular = !have || !dev::cf_swapped_regular(bb, aa, w1);
-        const dev::CfRowConstPtr rows = (dev::CfRowConstPtr)(uintptr_t)(tab + (size_t)b * dev::kCfIters);
-        const double cf = dev::cf_swapped_uniform(rows, w1, irregular);      // every lane of the wave takes part
-        double pv = 0.0;
-        const bool mine = have && !irregular;
-        if (have) {
-            if (__builtin_expect(irregular, 0))
-                redo[atomicAdd(n_redo, 1ull)] = e;
-            else {
-                pv = dev::incbet_finish(bb, aa, w1, xx, cf, 1, T.lbeta[c], T.small_n ? T.inv_beta[c] : 0.0);
-                store_p<true>(P.p + e.row, pv);
-            }
+        const double aa = fk + 1.0, bb = T.n - fk;
+        QEntry e[R];
+        bool have[R], irregular[R];
+        double w1[R], cf[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const unsigned int j = first + (unsigned int)r * 64u + (unsigned int)lane;
+            have[r] = j < live;
+            e[r].row = 0u;
+            e[r].count = is_inter ? -c : c;
+            e[r].prior = 0.5;
+            if (have[r]) e[r] = sorted[j];
+            w1[r] = 1.0 - e[r].prior;
+            irregular[r] = !have[r] || !dev::cf_swapped_regular(bb, aa, w1[r]);
         }
-        H.add_wave_min(pv, mine);
+        const dev::CfRowConstPtr rows = (dev::CfRowConstPtr)(uintptr_t)(tab + (size_t)b * dev::kCfIters);
+        dev::cf_swapped_uniform<R>(rows, w1, irregular, cf);                  // every lane of the wave takes part
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            double pv = 0.0;
+            const bool mine = have[r] && !irregular[r];
+            if (have[r]) {
+                if (__builtin_expect(irregular[r], 0))
+                    redo[atomicAdd(n_redo, 1ull)] = e[r];
+                else {
+                    pv = dev::incbet_finish(bb, aa, w1[r], e[r].prior, cf[r], 1, T.lbeta[c], T.small_n ? T.inv_beta[c] : 0.0);
+                    store_p<true>(P.p + e[r].row, pv);
+                }
+            }
+            H.add_wave_min(pv, mine);
+        }
     }
     H.flush(P.top_hist);
 }
@@ -2399,7 +2417,7 @@ int alloc_row_arrays(fhx_ctx* ctx, int64_t n, int64_t n_dist) {
     // (-r 0 sorts distances in K1 and lists outlier distances after K3 through the K3 view.)
     dev_free(ctx->d_work);
     const size_t qcap = std::max<size_t>(cap, (size_t)K2_SHARDS * (size_t)k2_shard_capacity((int64_t)cap));   // sharded queues: k2_classify
-    const size_t work_bytes = qcap * 32 + std::max(qcap, cap + (size_t)K2H_BUCKETS * 64) * sizeof(QEntry);   // queue 0 | queue 1 | sorted heavy queue / closed-form queue
+    const size_t work_bytes = qcap * 32 + std::max(qcap, cap + (size_t)K2H_BUCKETS * 64 * K2H_MAX_ROWS) * sizeof(QEntry);   // queue 0 | queue 1 | sorted heavy queue / closed-form queue
     FHX_HIP(hipMalloc(&ctx->d_work, work_bytes));
     ctx->queue_cap = (int64_t)qcap;
     ctx->d_queue[0] = reinterpret_cast<QEntry*>(ctx->d_work);
@@ -3039,7 +3057,16 @@ int fhx_pvalues(fhx_ctx* ctx) {
         FHX_HIP(hipMemsetAsync(n_redo, 0, sizeof(unsigned long long), ctx->stream));
         hipLaunchKernelGGL(k2h_count, dim3(K2H_BLOCKS), dim3(K2H_THREADS), 0, ctx->stream, hs, ctx->d_block_hist);
         hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3(SORT_BLOCKS), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total, (int)SORT_BLOCKS);
-        hipLaunchKernelGGL(k2h_offsets, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned int*)ctx->d_digit_total, ctx->d_k2h_off);
+        // rows per lane: 4 at 4 waves/SIMD (7.43 -> 6.66 ms per 2.7e7 rows against one row per lane at 8 waves/SIMD; 2 x 8, 2 x 6,
+        // 3 x 5, 4 x 3 are within 3 % of each other, profiles/r03_c_heavy_variants.txt); FHX_K2H_ROWS / FHX_K2H_WAVES: measurements
+        // rows per lane: 4 at 4 waves/SIMD - C3 (2.7e7 rows in the class) 7.43 -> 6.66 ms, a 1/18 shard (1.5e6 rows) 0.87 -> 0.78 ms of
+        // K2 against one row per lane at 8 waves/SIMD; 2 x 8, 3 x 5 and 4 x 3 are within 3 % (profiles/r03_c_*heavy_variants.txt).
+        // FHX_K2H_ROWS / FHX_K2H_WAVES select the other instantiations for measurements.
+        static const int heavy_rows = std::getenv("FHX_K2H_ROWS") ? std::atoi(std::getenv("FHX_K2H_ROWS")) : 4;
+        static const int heavy_wpe = std::getenv("FHX_K2H_WAVES") ? std::atoi(std::getenv("FHX_K2H_WAVES")) : 0;
+        const int hr = (heavy_rows >= 1 && heavy_rows <= K2H_MAX_ROWS) ? heavy_rows : 4;
+        hipLaunchKernelGGL(k2h_offsets, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned int*)ctx->d_digit_total, ctx->d_k2h_off,
+                           64u * (unsigned int)hr);
         hipLaunchKernelGGL(k2h_tables, dim3(K2H_GENERIC), dim3(K2H_TABLE_THREADS), 0, ctx->stream, (const unsigned int*)ctx->d_digit_total,
                            P.intra.n, P.inter.n, ctx->d_cf_tab);
         hipLaunchKernelGGL(k2h_scatter, dim3(K2H_BLOCKS), dim3(K2H_THREADS), 0, ctx->stream, hs,
@@ -3047,9 +3074,20 @@ int fhx_pvalues(fhx_ctx* ctx) {
         FHX_LAUNCH_QUEUE(dev::BC_PSERIES);               // before the redo list reuses the buffer it shares with the heavy queue
         FHX_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
         const K2HeavyParams HP{P.intra, P.inter, P.p, P.top_hist};
-        hipLaunchKernelGGL(k2h_heavy, dim3(256 * 8), dim3(K2H_THREADS), 0, ctx->stream, HP, (const QEntry*)ctx->d_queue_sorted,
-                           (const unsigned int*)ctx->d_k2h_off, (const unsigned int*)ctx->d_digit_total, (const dev::CfRow*)ctx->d_cf_tab,
-                           hq, n_redo);
+#define FHX_HEAVY(R, W)                                                                                                            \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k2h_heavy<R, W>), dim3(256 * W), dim3(K2H_THREADS), 0, ctx->stream, HP,                        \
+                       (const QEntry*)ctx->d_queue_sorted, (const unsigned int*)ctx->d_k2h_off, (const unsigned int*)ctx->d_digit_total, \
+                       (const dev::CfRow*)ctx->d_cf_tab, hq, n_redo)
+        if (hr == 1) FHX_HEAVY(1, 8);
+        else if (hr == 2 && heavy_wpe == 8) FHX_HEAVY(2, 8);
+        else if (hr == 2 && heavy_wpe == 4) FHX_HEAVY(2, 4);
+        else if (hr == 2) FHX_HEAVY(2, 6);
+        else if (hr == 3 && heavy_wpe == 4) FHX_HEAVY(3, 4);
+        else if (hr == 3) FHX_HEAVY(3, 5);
+        else if (heavy_wpe == 3) FHX_HEAVY(4, 3);
+        else if (heavy_wpe == 2) FHX_HEAVY(4, 2);
+        else FHX_HEAVY(4, 4);
+#undef FHX_HEAVY
         FHX_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
         hipLaunchKernelGGL(k2h_generic, dim3(256 * 4), dim3(K2_THREADS), 0, ctx->stream, P, (const QEntry*)ctx->d_queue_sorted,
                            (const unsigned int*)ctx->d_k2h_off, (const unsigned int*)ctx->d_digit_total, (const QEntry*)hq,
@@ -3747,6 +3785,11 @@ int fhx_k2_heavy_launch(fhx_ctx* ctx, double* seconds, int64_t* rows) {
     if (!ctx->d_k2_counts) return fail(ctx, FHX_ERR_ARG, "fhx_pvalues has not run");
     FHX_HIP(hipMemcpy(part, ctx->d_k2_counts + (size_t)(dev::BC_CF_SWAPPED - 1) * K2_SHARDS * K2_COUNT_STRIDE, sizeof(part), hipMemcpyDeviceToHost));
     for (int sh = 0; sh < K2_SHARDS; ++sh) n += part[sh * K2_COUNT_STRIDE];
+    if (std::getenv("FHX_DEBUG_HEAVY")) {                  // how many rows the uniform kernel handed back to the per-lane loop
+        unsigned long long redo = 0;
+        FHX_HIP(hipMemcpy(&redo, ctx->d_misc + 11, sizeof(redo), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "k2h_heavy: %.3f ms, %llu rows in the class, %llu handed back\n", ms, n, redo);
+    }
     if (seconds) *seconds = ms * 1e-3;
     if (rows) *rows = (int64_t)n;
     return FHX_OK;
