@@ -150,9 +150,7 @@ def main(argv=None):
         if args.gpus < 1:
             print("Invalid Option. --gpus must be at least 1")
             sys.exit(2)
-        if args.gpus > 1 and resolution == 0:
-            print("--gpus N needs fixed-size data (-r > 0); running on one GPU")
-        F.gpus = args.gpus if resolution > 0 else 1
+        F.gpus = args.gpus
         F.logfile = os.path.join(outputPath, libName + ".fithic.log")
 
         (mainDic, observedInterAllCount, observedInterAllSum, observedIntraAllSum, observedIntraInRangeSum) = \

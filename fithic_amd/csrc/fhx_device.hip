@@ -1964,6 +1964,8 @@ struct fhx_ctx {
     std::vector<unsigned long long> h_slot_keys;      // sorted distinct (chr << 32 | mid) of every locus the rows touch
     std::vector<int64_t> h_dist_keys;                 // distinct in-range distances of the current pass, ascending
     std::vector<int64_t> h_outlier_dists;             // outlier distances of all earlier passes, ascending (a multiset)
+    std::vector<int64_t> h_outlier_dists_global;      // sharded runs with explicit distances: the multiset over all ranks
+    bool outlier_dists_are_global = false;
     double *d_table_x = nullptr, *d_table_y = nullptr;
     unsigned int* d_seg_ids = nullptr;                // run ids / tile counts scratch
     unsigned int* d_seg_tiles = nullptr;
@@ -2298,6 +2300,8 @@ int ingest_device_rows_nonfixed(fhx_ctx* ctx, const int32_t* c1, const int32_t* 
         FHX_HIP(hipGetLastError());
         FHX_HIP(hipStreamSynchronize(ctx->stream));
         ctx->h_outlier_dists.clear();
+    ctx->h_outlier_dists_global.clear();
+    ctx->outlier_dists_are_global = false;
         ctx->h_dist_keys.clear();
     }
     return rc;
@@ -2447,6 +2451,8 @@ int alloc_row_arrays(fhx_ctx* ctx, int64_t n, int64_t n_dist) {
     ctx->n_sorted = -1;
     ctx->dist_ndist_agreed = false;
     ctx->dist_any_nonfixed = false;
+    ctx->h_outlier_dists_global.clear();
+    ctx->outlier_dists_are_global = false;
     if (!ctx->nonfixed) ctx->h_dist_keys.clear();
     return FHX_OK;
 }
@@ -2841,10 +2847,11 @@ static void fill_pass_inputs(fhx_ctx* ctx, PassInputs& in) {
     in.inter_sum = ctx->stats.inter_sum;
     if (ctx->nonfixed) {
         in.dist_keys = ctx->h_dist_keys.data();
-        in.outlier_dists = ctx->pass_no > 0 ? ctx->h_outlier_dists.data() : nullptr;
-        in.n_outlier_dists = (int64_t)ctx->h_outlier_dists.size();
+        const std::vector<int64_t>& od = ctx->outlier_dists_are_global ? ctx->h_outlier_dists_global : ctx->h_outlier_dists;
+        in.outlier_dists = ctx->pass_no > 0 ? od.data() : nullptr;
+        in.n_outlier_dists = (int64_t)od.size();
         static const int64_t none = 0;
-        if (ctx->pass_no > 0 && ctx->h_outlier_dists.empty()) in.outlier_dists = &none;      // an empty multiset, not "pass 1"
+        if (ctx->pass_no > 0 && od.empty()) in.outlier_dists = &none;      // an empty multiset, not "pass 1"
         in.outlier_dist_hist = nullptr;
         return;
     }
@@ -3600,6 +3607,8 @@ int fhx_reset_passes(fhx_ctx* ctx) {
     ctx->outlier_hist_nonempty = false;
     ctx->h_out_hist.assign((size_t)ctx->n_dist, 0);
     ctx->h_outlier_dists.clear();
+    ctx->h_outlier_dists_global.clear();
+    ctx->outlier_dists_are_global = false;
     ctx->n_sorted = -1;
     return FHX_OK;
 }
@@ -3705,7 +3714,10 @@ int fhx_get_array(fhx_ctx* ctx, int which, void* dst, int64_t cap, int64_t* n_ou
         case FHX_A_HIST_NPAIRS: return put(ctx->h_hist_np.data(), ctx->h_hist_np.size(), sizeof(int64_t));
         case FHX_A_OUTLIER_DIST_HIST: return put(ctx->h_out_hist.data(), ctx->h_out_hist.size(), sizeof(int64_t));
         case FHX_A_DIST_KEYS: return put(ctx->h_dist_keys.data(), ctx->h_dist_keys.size(), sizeof(int64_t));
-        case FHX_A_OUTLIER_DISTS: return put(ctx->h_outlier_dists.data(), ctx->h_outlier_dists.size(), sizeof(int64_t));
+        case FHX_A_OUTLIER_DISTS: {
+            const std::vector<int64_t>& od = ctx->outlier_dists_are_global ? ctx->h_outlier_dists_global : ctx->h_outlier_dists;
+            return put(od.data(), od.size(), sizeof(int64_t));
+        }
         default: break;
     }
     if (which == FHX_A_FDR_COUNTS) {

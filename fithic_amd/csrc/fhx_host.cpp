@@ -3,9 +3,14 @@
 #include "fhx_host.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <thread>
+#include <vector>
+
+#include "fhx_cpus.hpp"
 
 #include "../../include/fithic_mi355x.h"
 
@@ -815,47 +820,121 @@ int run_host_pass(const PassInputs& in, const FragTable& frags, PassFit& out, st
         // restarted for every x, npairs = n - (#in-range y seen so far for this x) weights slots [7] and [3], slot [1]
         // counts pairs; slot [3] is a sequential double sum in visiting order.  Chromosomes without mappable fragments are
         // skipped here (no error in this branch).
+        //
+        // The reference visits all pairs from one thread (O(n * window) Python iterations: hours on a restriction-fragment
+        // genome).  What it computes per bin separates cleanly:
+        //   * slot [1], slot [7] and the counters are integers: for one x the y of a bin are a contiguous run (the mids are
+        //     sorted, distances ascend in y, the cursor only moves forward), so a run contributes its length and an arithmetic
+        //     series of npairs - no pair is touched;
+        //   * slot [3] is a double accumulated pair by pair: every bin's sum is its own sequential chain over the bin's pairs in
+        //     (chromosome, x, y) order.  The chains of different bins are independent, so they run on different host threads
+        //     (largest distances first: those bins hold the most possible pairs), each with the reference's rounding sequence.
+        // The bin of a distance does not depend on the cursor's history: bins are contiguous from 0 and distances ascend, so it
+        // is the first bin whose upper end is >= the distance, or the last bin (the cursor sticks there, fithic.py:723-735).
         int64_t n_frags = 0;
         for (const auto& m : frags.mids) n_frags += (int64_t)m.size();
         int64_t poss_in_range = 0, poss_inter2 = 0, poss_intra_all = 0;
         double max_possible = 0.0;
-        const double lo = static_cast<double>(in.dist_low);
+        const int64_t lo_i = in.dist_low;
         const bool bounded = in.dist_up != INT64_MAX;
-        const double hi = static_cast<double>(in.dist_up);
-        for (const auto& m : frags.mids) {                       // already in sorted(name) order
+        const int64_t hi_i = in.dist_up;
+        const int64_t nb = (int64_t)out.bins.size();
+        // integer mids: |float(a) - float(b)| is the exact integer distance for |mid| < 2^53, and its comparisons with the
+        // integer thresholds / bin ends are exact too
+        for (const auto& m : frags.mids) {                       // already in sorted(name) order, each sorted ascending
             const int64_t n = (int64_t)m.size();
             if (n == 0) continue;
             poss_inter2 += (n_frags - n) * n;
-            int64_t per_chr = 0;
+            int64_t y0 = 0, yend = 0;                            // first y with dist >= lo; first y with dist > hi
             for (int64_t x = 0; x < n; ++x) {
-                size_t cur = 0;
-                int64_t k = 0;
-                const double fx = static_cast<double>(m[x]);
-                for (int64_t y = x + 1; y < n; ++y) {
-                    const double dist = std::fabs(fx - static_cast<double>(m[y]));
-                    if (bounded && dist > hi) break;             // ascending in y: nothing further is in range
-                    if (dist < lo) continue;
-                    ++per_chr;
-                    max_possible = std::max(max_possible, dist);
-                    const int64_t npairs = n - k;
-                    ++k;
-                    if (!out.bins.empty()) {
-                        while (!(static_cast<double>(out.bins[cur].lb) <= dist && dist <= static_cast<double>(out.bins[cur].ub))) {
-                            ++cur;
-                            if (cur >= out.bins.size()) {
-                                --cur;
-                                break;
-                            }
-                        }
-                        Bin& b = out.bins[cur];
-                        b.poss7 += npairs;
-                        b.poss += 1;
-                        b.sumdist += (dist / 1000000.0) * static_cast<double>(npairs);
-                        poss_intra_all += 1;
-                    }
+                const int64_t mx = m[x];
+                if (y0 < x + 1) y0 = x + 1;
+                while (y0 < n && (int64_t)m[y0] - mx < lo_i) ++y0;
+                if (yend < y0) yend = y0;
+                if (bounded)
+                    while (yend < n && (int64_t)m[yend] - mx <= hi_i) ++yend;
+                else
+                    yend = n;
+                if (yend > y0) {
+                    poss_in_range += yend - y0;
+                    max_possible = std::max(max_possible, static_cast<double>((int64_t)m[yend - 1] - mx));
                 }
             }
-            poss_in_range += per_chr;
+        }
+        if (nb > 0) {
+            struct BinSums {
+                int64_t poss7 = 0, poss = 0;
+                double sumdist = 0.0;
+            };
+            std::vector<BinSums> acc((size_t)nb);
+            std::atomic<int64_t> next{nb - 1};
+            constexpr int64_t TERM_BLOCK = 256;
+            auto work = [&]() {
+                for (;;) {
+                    const int64_t b = next.fetch_sub(1);
+                    if (b < 0) return;
+                    const bool last = b == nb - 1;
+                    const int64_t below = b == 0 ? -1 : out.bins[(size_t)b - 1].ub;      // the bin takes below < dist <= ub
+                    const int64_t ub = out.bins[(size_t)b].ub;
+                    BinSums A;
+                    A.sumdist = out.bins[(size_t)b].sumdist;                               // 0.0: the chain starts here
+                    for (const auto& m : frags.mids) {
+                        const int64_t n = (int64_t)m.size();
+                        int64_t y0 = 0, yend = 0, ya = 0, yb = 0;
+                        for (int64_t x = 0; x < n; ++x) {
+                            const int64_t mx = m[x];
+                            if (y0 < x + 1) y0 = x + 1;
+                            while (y0 < n && (int64_t)m[y0] - mx < lo_i) ++y0;
+                            if (yend < y0) yend = y0;
+                            if (bounded)
+                                while (yend < n && (int64_t)m[yend] - mx <= hi_i) ++yend;
+                            else
+                                yend = n;
+                            if (ya < y0) ya = y0;
+                            while (ya < yend && (int64_t)m[ya] - mx <= below) ++ya;
+                            if (ya > yend) ya = yend;
+                            if (last) {
+                                yb = yend;
+                            } else {
+                                if (yb < ya) yb = ya;
+                                while (yb < yend && (int64_t)m[yb] - mx <= ub) ++yb;
+                                if (yb > yend) yb = yend;
+                            }
+                            const int64_t cnt = yb - ya;
+                            if (cnt <= 0) continue;
+                            // npairs of pair (x, y) = n - (y - y0): the k-th in-range y of this x weighs n - k (fithic.py:714-715)
+                            const int64_t k0 = ya - y0, k1 = yb - 1 - y0;
+                            A.poss += cnt;
+                            A.poss7 += cnt * n - (k0 + k1) * cnt / 2;
+                            // terms (dist / 1e6) * npairs of a block first - independent of each other: the divisions
+                            // pipeline (and vectorise) - then the block is added in visiting order, one rounded add at a time
+                            const int32_t* my = m.data();
+                            for (int64_t y = ya; y < yb; y += TERM_BLOCK) {
+                                const int64_t len = std::min<int64_t>(TERM_BLOCK, yb - y);
+                                double term[TERM_BLOCK];
+                                for (int64_t j = 0; j < len; ++j)
+                                    term[j] = (static_cast<double>((int64_t)my[y + j] - mx) / 1000000.0) *
+                                              static_cast<double>(n - (y + j - y0));
+                                double acc_s = A.sumdist;
+                                for (int64_t j = 0; j < len; ++j) acc_s += term[j];
+                                A.sumdist = acc_s;
+                            }
+                        }
+                    }
+                    acc[(size_t)b] = A;
+                }
+            };
+            const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(nb, (int64_t)fhx::usable_cpus()));
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+            work();
+            for (auto& th : pool) th.join();
+            for (int64_t b = 0; b < nb; ++b) {
+                out.bins[(size_t)b].poss7 += acc[(size_t)b].poss7;
+                out.bins[(size_t)b].poss += acc[(size_t)b].poss;
+                out.bins[(size_t)b].sumdist = acc[(size_t)b].sumdist;
+                poss_intra_all += acc[(size_t)b].poss;
+            }
         }
         out.n_frags = n_frags;
         out.max_possible_dist = max_possible;

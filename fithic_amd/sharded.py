@@ -395,8 +395,6 @@ class ShardedEngine:
                   bias_low=0.5, bias_up=2.0):
         if mode not in MODES:
             raise ValueError("Invalid Option. Only options are 'All', 'interOnly', or 'intraOnly'")
-        if int(resolution) == 0:
-            raise NotImplementedError("--gpus N needs fixed-size loci (-r > 0); -r 0 runs on one GPU")
         self.resolution = int(resolution)
         self._all("configure", resolution, dist_low, dist_up, n_bins, mapp_thres, mode, bias_low, bias_up)
 

@@ -145,9 +145,31 @@ def _run_world(world, case, passes, split, tmp_path):
 
 @pytest.mark.parametrize("world,case,passes,split", [
     (2, "f2_all", 2, "by_chr"), (2, "f1_bias", 2, "blocks"), (2, "f6_quirk_all", 3, "by_chr"),
-    (3, "f2_all", 2, "empty_last"), (3, "f2_intra", 2, "blocks")])
+    (3, "f2_all", 2, "empty_last"), (3, "f2_intra", 2, "blocks"),
+    # explicit distances (-r 0, and -r N on loci that are not on one grid): mainDic travels as (distance, sum, rows) triples
+    (2, "f8_nonfixed_all", 3, "by_chr"), (3, "f8_nonfixed_hESC", 1, "blocks"), (3, "f8_nonfixed_nobounds", 2, "random:5"),
+    (2, "f11_offgrid_all", 2, "by_chr"), (3, "f11_offgrid_intra", 2, "empty_last")])
 def test_native_sharded_pass_equals_single_gpu(world, case, passes, split, tmp_path):
     _run_world(world, case, passes, split, tmp_path)
+
+
+def test_ranks_on_a_grid_follow_the_ranks_that_are_not(tmp_path):
+    """-r 10000 on a genome where only SOME chromosomes have irregular midpoints, sharded by chromosome: the ranks whose rows sit
+    on a grid learn (in the all-reduce that equalises the histogram lengths) that another rank's do not, re-slot their rows the
+    same way, and the pass runs on explicit distances everywhere - the same bits as one GPU holding all rows, 2 passes."""
+    import gzip
+    import json
+    data = os.path.join(ROOT, "tests", "golden", "data")
+    paths = {}
+    for kind in ("contacts", "frags", "bias"):
+        text = b"".join(gzip.open(os.path.join(data, "%s.%s.gz" % (name, kind)), "rb").read() for name in ("quirk", "irregular"))
+        paths[kind] = os.path.join(str(tmp_path), "mixed.%s.gz" % kind)
+        with gzip.open(paths[kind], "wb") as f:
+            f.write(text)
+    kw = dict(contacts=paths["contacts"], frags=paths["frags"], bias_path=paths["bias"], resolution=10000, n_bins=12, passes=2,
+              mode="All", L=10000, U=900000, mapp_thres=1, tL=0.5, tU=2)
+    for world, split in ((2, "by_chr"), (3, "by_chr")):
+        _run_world(world, json.dumps(kw), 2, split, tmp_path)
 
 
 # FHX_FUZZ_SEEDS="lo:hi": random cases of tests/test_gpu_fuzz.py's generator, rows dealt to 2 or 3 ranks at random (one rank may
@@ -208,7 +230,7 @@ def _rccl_single_rank(case, passes, result_path):
         f.write("OK" if not msgs else "FAIL: " + "; ".join(msgs))
 
 
-@pytest.mark.parametrize("case,passes", [("f2_all", 2), ("f1_bias", 1)])
+@pytest.mark.parametrize("case,passes", [("f2_all", 2), ("f1_bias", 1), ("f8_nonfixed_all", 2)])
 def test_rccl_transport_with_one_rank(case, passes, tmp_path):
     """Real RCCL, world size 1, in a fresh process without torch (the library loads the system's librccl itself)."""
     out = os.path.join(str(tmp_path), "rccl.txt")

@@ -361,7 +361,8 @@ def test_cli_writes_the_reference_files(name, tmp_path, capsys):
     assert mine == want
 
 
-@pytest.mark.parametrize("name,gpus", [("f1_bias", 2), ("f2_all", 3), ("f6_quirk_all", 2), ("f13_all_p3", 2), ("f13_quirk_p4", 3)])
+@pytest.mark.parametrize("name,gpus", [("f1_bias", 2), ("f2_all", 3), ("f6_quirk_all", 2), ("f13_all_p3", 2), ("f13_quirk_p4", 3),
+                                       ("f8_nonfixed_all", 2), ("f8_nonfixed_hESC", 3), ("f11_offgrid_all", 3)])
 def test_cli_gpus_n_writes_the_same_files(name, gpus, tmp_path, monkeypatch):
     """`fithic --gpus N`: rows sharded by chromosome over N ranks (worker processes), genome-wide steps through the library's
     communicator, rank 0 writes the ONE output set - byte-identical to the reference's.  On this one-GPU box the ranks share
@@ -377,12 +378,12 @@ def test_cli_gpus_n_writes_the_same_files(name, gpus, tmp_path, monkeypatch):
     if kw["bias_path"]:
         argv += ["-t", kw["bias_path"]]
     cli.main(argv)
-    res = kw["resolution"]
+    tag = ".res%d" % kw["resolution"] if kw["resolution"] else ""          # -r 0: no resolution in the file names
     for pi in range(1, meta["n_passes"] + 1):
-        with gzip.open(os.path.join(str(tmp_path), "G.spline_pass%d.res%d.significances.txt.gz" % (pi, res)), "rb") as f:
+        with gzip.open(os.path.join(str(tmp_path), "G.spline_pass%d%s.significances.txt.gz" % (pi, tag)), "rb") as f:
             text = f.read()
         assert hashlib.md5(text).hexdigest() == meta["sig_md5_pass%d" % pi]
-        with open(os.path.join(str(tmp_path), "G.fithic_pass%d.res%d.txt" % (pi, res))) as f:
+        with open(os.path.join(str(tmp_path), "G.fithic_pass%d%s.txt" % (pi, tag))) as f:
             assert f.read() == meta["fithic_pass%d_txt" % pi]
     with open(os.path.join(str(tmp_path), "G.fithic.log")) as f:
         mine = [ln for ln in f.read().splitlines() if not ln.startswith("Means and error written")]

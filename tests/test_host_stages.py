@@ -181,6 +181,67 @@ def test_host_fit_matches_reference_at_headline_sizes(name):
     ctx.close()
 
 
+def test_nonfixed_possible_pairs_in_parallel_equal_the_sequential_walk(monkeypatch):
+    compared = sum(_nonfixed_case(seed, monkeypatch) for seed in range(16))
+    assert compared >= 16            # 16 seeds x 2 thread counts, minus the cases the reference's spline stage exits on
+
+
+def _nonfixed_case(seed, monkeypatch):
+    """-r 0 (fithic.py:691-778): the library counts slots [1] / [7] per run of y in closed form and sums slot [3] as one
+    sequential chain per bin, the bins spread over host threads.  Against the oracle's literal pair walk on random
+    irregular fragments (duplicate midpoints, unmappable ones, chromosomes without fragments in range, bounds on and
+    off): integer slots equal, slot [3] bit for bit, for 1 and 5 threads."""
+    from oracle import fithic_oracle as fo
+    rng = np.random.default_rng(100 + seed)
+    n_chr = int(rng.integers(1, 5))
+    frag_rows, f_chr, f_mid, f_hit = [], [], [], []
+    for c in range(n_chr):
+        n = int(rng.integers(0, 400))
+        mids = np.sort(rng.integers(0, 3_000_000, n))
+        if n > 10:
+            mids[rng.integers(0, n, 5)] = mids[rng.integers(0, n, 5)]          # duplicates: distance 0
+        hits = (rng.random(n) > 0.1).astype(np.int64)
+        for m, h in zip(rng.permutation(n), hits):                             # file order is not sorted
+            frag_rows.append(("c%d" % c, int(mids[m]), int(h)))
+            f_chr.append(c)
+            f_mid.append(int(mids[m]))
+            f_hit.append(int(h))
+    L = int(rng.choice([0, 0, 20000, 150000]))
+    U = float(rng.choice([np.inf, 400000, 1500000]))
+    # observed distances -> bins (any ascending keys with counts will do: the enumeration only needs the bin ends)
+    keys = np.unique(rng.integers(max(L, 1), int(min(U, 2_500_000)), 300)).astype(np.int64)
+    sumcc = rng.integers(1, 50, len(keys)).astype(np.int64)
+    n_bins = int(rng.choice([1, 3, 12, 40]))
+    bins = fo.make_bins(keys, sumcc, n_bins, int(sumcc.sum()))
+    want = fo.generate_frag_pairs_nonfixed(frag_rows, bins, L, U, 1, 7)
+    compared = 0
+    for threads in ("1", "5"):
+        monkeypatch.setenv("FHX_THREADS", threads)
+        ctx = _capi.Context(-1)
+        ctx.set_params(0, L, U, n_bins, 1, MODES["intraOnly"])
+        rank = np.argsort(np.argsort(["c%d" % c for c in range(n_chr)])).astype(np.int32)
+        ctx.load_fragments(np.array(f_chr, np.int32), np.array(f_mid, np.int32), np.array(f_hit, np.int32), rank)
+        st = _capi.FhxStats()
+        st.in_range_sum, st.inter_count = int(sumcc.sum()), 7
+        ctx.set_dist_keys(keys)
+        ctx.set_global_stats(st, sumcc, np.ones(len(keys), np.int64))
+        try:
+            info = ctx.fit()
+        except _capi.FhxError as e:                                            # bin means the reference's spline stage exits on
+            assert e.code == _capi.FHX_ERR_REFERENCE_EXIT, str(e)
+            info = None
+        if info is not None:
+            compared += 1
+            assert np.array_equal(ctx.get_array(_capi.A_BIN_POSS), [b["s1"] for b in bins])
+            assert np.array_equal(ctx.get_array(_capi.A_BIN_POSS7), [b["s7"] for b in bins])
+            assert bits_equal(ctx.get_array(_capi.A_BIN_SUMDIST), np.array([b["s3"] for b in bins], np.float64))
+        if info is not None:
+            assert info.possible_intra_in_range == want["poss_in_range"] and info.max_possible_dist == want["max_possible_dist"]
+            assert info.possible_inter_all == want["poss_inter"] and info.n_frags == want["n_frags"]
+        ctx.close()
+    return compared
+
+
 def test_visual_plots_write_the_reference_figures(tmp_path):
     """-v: the four figure kinds of fithic.py:970-999,1256-1321 are produced from host arrays."""
     pytest.importorskip("matplotlib")
