@@ -117,19 +117,25 @@ def row_keys(torch, synth, cols, n):
     return k
 
 
+def hash_table(torch, synth, keys, chr1, values, n_chr):
+    """[n_chr] int64: per chromosome (of the row's first locus) the wrapping sum of splitmix64(key ^ splitmix64(bits of value))
+    over the rows.  A sum is order-free and additive over shards: the table of a sharded run is the sum of its ranks' tables."""
+    out = torch.zeros(n_chr, dtype=torch.int64, device=keys.device)
+    if keys.numel():
+        h = synth._splitmix64(torch, keys ^ synth._splitmix64(torch, values.view(torch.int64)))
+        out.index_add_(0, chr1.to(torch.int64), h)
+    return out
+
+
 def result_hashes(torch, synth, eng, keys, chr1, n, n_chr):
-    """[2, n_chr] int64: per chromosome (of the row's first locus) the wrapping sum of splitmix64(key ^ splitmix64(bits)) over the
-    rows, for bits = the engine's p (row 0) and q (row 1), read from its device buffers.  A sum is order-free and additive over
-    shards, so the table of a sharded run is the sum of its ranks' tables."""
+    """[2, n_chr] int64: hash_table of the engine's p (row 0) and q (row 1), read from its device buffers."""
     out = torch.zeros((2, n_chr), dtype=torch.int64, device=keys.device)
     if n == 0:
         return out
     buf = torch.empty(n, dtype=torch.float64, device=keys.device)
-    idx = chr1[:n].to(torch.int64)
     for which in (0, 1):
         eng.ctx.memcpy_d2d(buf.data_ptr(), eng.ctx.device_ptr(which), 8 * n)
-        h = synth._splitmix64(torch, keys ^ synth._splitmix64(torch, buf.view(torch.int64)))
-        out[which].index_add_(0, idx, h)
+        out[which] = hash_table(torch, synth, keys, chr1[:n], buf, n_chr)
     return out
 
 
@@ -234,8 +240,7 @@ def main():
         except Exception:
             ver = None
         rccl = {"world": td.get_world_size(), "backend": td.get_backend(), "torch_rccl_version": ver,
-                "driver": "torch.distributed schedule (fithic_amd.dist)" if os.environ.get("FHX_DIST_PY") else
-                          "library communicator: fhx_comm_init + fhx_run_pass_distributed (collectives on the engine's stream)"}
+                "driver": "library communicator: fhx_comm_init + fhx_run_pass_distributed (collectives on the engine's stream)"}
 
     comm_all = comm
     cfg = dict(CONFIGS[args.config])
@@ -301,32 +306,12 @@ def main():
         torch.cuda.empty_cache()
 
         runner = None
-        if comm and os.environ.get("FHX_DIST_PY"):               # the exchange schedule written over torch.distributed
-            from fithic_amd import dist
-            runner = dist.DistributedPass(eng, dist.Comm(comm.td, device))
-        elif comm:                                               # the library's own RCCL communicator on the engine's stream
+        if comm:                                                 # the library's own RCCL communicator on the engine's stream
             import torch.distributed as td
             uid = [_capi_mod().comm_unique_id() if rank == 0 else None]
             td.broadcast_object_list(uid, src=0)                 # torch.distributed only carries the 128-byte id
-            ok, why = 1, ""
-            try:
-                if os.environ.get("FHX_BENCH_NO_LIBRARY_COMM"):      # exercise the fallback below
-                    raise RuntimeError("FHX_BENCH_NO_LIBRARY_COMM is set")
-                eng.ctx.comm_init(uid[0], rank, world)
-            except Exception as e:                               # e.g. librccl cannot be loaded a second time on this system
-                ok, why = 0, repr(e)
-            flag = torch.tensor([ok], device=device, dtype=torch.int32)
-            td.all_reduce(flag, op=td.ReduceOp.MIN)              # every rank takes the same path
-            if int(flag.item()) == 1:
-                runner = NativeRunner(eng)
-            else:                                                # say so in the result line and run the torch-driven schedule
-                log("[rank %d] library communicator unavailable (%s): falling back to fithic_amd.dist" % (rank, why or "another rank failed"))
-                if ok:
-                    eng.ctx.comm_destroy()
-                from fithic_amd import dist
-                runner = dist.DistributedPass(eng, dist.Comm(comm.td, device))
-                os.environ["FHX_DIST_PY"] = "fallback"
-                rccl["driver"] = "torch.distributed schedule (fithic_amd.dist); the library communicator did not start: %s" % (why or "on another rank")
+            eng.ctx.comm_init(uid[0], rank, world)               # fails loudly: there is no second implementation to fall back to
+            runner = NativeRunner(eng)
         passes = cfg["passes"]
         pass_ms = np.zeros(passes)
 
@@ -472,9 +457,8 @@ def main():
         if passes > 1:
             result["ms_per_pass"] = [float(v) for v in M["pass_ms"]]
         if rccl:
-            if not os.environ.get("FHX_DIST_PY"):
-                r_, w_, v_ = eng.ctx.comm_info()
-                rccl.update(world_in_library=w_, library_rccl_version_code=v_)
+            r_, w_, v_ = eng.ctx.comm_info()
+            rccl.update(world_in_library=w_, library_rccl_version_code=v_)
             result["rccl"] = rccl
             result["stage_ms"] = M["stage_ms"]
         if args.no_parity_check:

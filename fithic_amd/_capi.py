@@ -113,6 +113,7 @@ SYMBOLS = {
     "fhx_debug_format": (ctypes.c_int, [_P, _F64P, ctypes.c_int64, ctypes.c_int32, ctypes.c_char_p, _I32P]),
     "fhx_debug_contfrac": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _F64P, _F64P, _F64P, ctypes.c_int64, _F64P]),
     "fhx_debug_lean_div": (ctypes.c_int, [_P, _F64P, _F64P, ctypes.c_int64, _F64P]),
+    "fhx_debug_classify": (ctypes.c_int, [_P, ctypes.c_double, _I32P, _F64P, ctypes.c_int64, _I32P, _I32P, _F64P]),
     "fhx_bh_array": (ctypes.c_int, [_P, _F64P, ctypes.c_int64, ctypes.c_double, _F64P]),
     "fhx_bh_top_hist": (ctypes.c_int, [_P, _I64P, ctypes.c_int64]),
     "fhx_bh_set_cutoff": (ctypes.c_int, [_P, _I64P, ctypes.c_int64, ctypes.c_double]),
@@ -541,6 +542,17 @@ class Context:
         self._check(self._L.fhx_bdtrc_array(self._h, float(n_total), _ptr(c, ctypes.c_int32), _ptr(pr, ctypes.c_double), len(c),
                                             _ptr(out, ctypes.c_double)))
         return out
+
+    def debug_classify(self, n_total, count, prior, thresholds=False):
+        """(class by the threshold table, class by incbet's predicates[, thresholds n x 5]) for integer counts and priors"""
+        c = _i32(count)
+        pr = np.ascontiguousarray(prior, np.float64)
+        t, a = np.empty(len(c), np.int32), np.empty(len(c), np.int32)
+        thr = np.empty((len(c), 5), np.float64) if thresholds else None
+        self._check(self._L.fhx_debug_classify(self._h, float(n_total), _ptr(c, ctypes.c_int32), _ptr(pr, ctypes.c_double), len(c),
+                                               _ptr(t, ctypes.c_int32), _ptr(a, ctypes.c_int32),
+                                               _ptr(thr, ctypes.c_double) if thresholds else None))
+        return (t, a, thr) if thresholds else (t, a)
 
     def debug_contfrac(self, kind, lazy, a, b, x):
         a, b, x = (np.ascontiguousarray(v, np.float64) for v in (a, b, x))

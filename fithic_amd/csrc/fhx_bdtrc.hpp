@@ -720,6 +720,83 @@ __device__ __forceinline__ int bdtrc_class(int count, double n_total, double p) 
     return BC_CF_BD;
 }
 
+// bdtrc_class as a table: for one (n_total, count) every predicate of the classification is a monotone function of the prior
+// (IEEE multiplication by a positive constant, 1 - x and the subtraction of a constant are monotone; a rounded difference has the
+// sign of the exact one), so each is ONE threshold on the prior - found by bisection over the bit patterns of the doubles in
+// [0, 1) with the very statements of bdtrc_class, on the device, once per pass and count:
+//   tA  largest  x with  bb*x <= 1 && x <= 0.95                                  (power series, direct orientation)
+//   tB  = aa / (aa + bb): x > tB is the swapped orientation
+//   tC  smallest x with  aa*(1-x) <= 1 && (1-x) <= 0.95                          (power series, swapped)
+//   tD  smallest x with  (1-x)*(bb+aa-2) - (bb-1) < 0                            (swapped: incbcf, else incbd)
+//   tE  largest  x with  x*(aa+bb-2) - (aa-1) < 0                                (direct: incbcf, else incbd)
+// "none" is -1 for the "largest" kind and 2 for the "smallest" kind.  The classify kernel then needs one 64-byte row and
+// four comparisons per contact instead of a division and five multiplications (tests: fhx_debug_classify against bdtrc_class
+// on random priors and on the neighbours of every threshold).
+struct ClsRow {
+    double tA, tB, tC, tD, tE, pad0, pad1, pad2;
+};
+
+__device__ __forceinline__ bool cls_pred(int which, double aa, double bb, double xx) {
+    const double w = 1.0 - xx;
+    switch (which) {
+        case 0: return bb * xx <= 1.0 && xx <= 0.95;
+        case 2: return aa * w <= 1.0 && w <= 0.95;
+        case 3: return w * (bb + aa - 2.0) - (bb - 1.0) < 0.0;
+        default: return xx * (aa + bb - 2.0) - (aa - 1.0) < 0.0;
+    }
+}
+
+__device__ __forceinline__ ClsRow cls_row(double n_total, int count) {
+    const double fk = (double)count - 1.0;
+    const double aa = fk + 1.0, bb = n_total - fk;
+    ClsRow r;
+    r.pad0 = r.pad1 = r.pad2 = 0.0;
+    r.tB = aa / (aa + bb);
+    const long long one = 0x3FF0000000000000ll;                 // bits of 1.0: the candidates are the patterns below it
+    auto largest_true = [&](int which) -> double {              // predicate true on an initial segment of [0, 1)
+        if (!cls_pred(which, aa, bb, 0.0)) return -1.0;
+        long long lo = 0, hi = one;                             // P(lo) true, P(hi) treated as false
+        while (hi - lo > 1) {
+            const long long mid = lo + ((hi - lo) >> 1);
+            if (cls_pred(which, aa, bb, __longlong_as_double(mid)))
+                lo = mid;
+            else
+                hi = mid;
+        }
+        return __longlong_as_double(lo);
+    };
+    auto smallest_true = [&](int which) -> double {             // predicate true on a final segment of [0, 1)
+        if (!cls_pred(which, aa, bb, __longlong_as_double(one - 1))) return 2.0;
+        long long lo = -1, hi = one - 1;                        // P(hi) true, P(lo) treated as false
+        while (hi - lo > 1) {
+            const long long mid = lo + ((hi - lo) >> 1);
+            if (cls_pred(which, aa, bb, __longlong_as_double(mid)))
+                hi = mid;
+            else
+                lo = mid;
+        }
+        return __longlong_as_double(hi);
+    };
+    r.tA = largest_true(0);
+    r.tC = smallest_true(2);
+    r.tD = smallest_true(3);
+    r.tE = largest_true(4);
+    return r;
+}
+
+// bdtrc_class(count, n_total, p) for a proper probability 0 < p < 1 and 2 <= count <= n_total (everything else is BC_TRIVIAL)
+__device__ __forceinline__ int cls_lookup(const ClsRow& r, double xx) {
+    if (xx <= r.tA) return BC_PSERIES;
+    if (xx > r.tB) {
+        if (xx >= r.tC) return BC_PSERIES;
+        return xx >= r.tD ? BC_CF_SWAPPED : BC_CF_BD;
+    }
+    return xx <= r.tE ? BC_CF_BCF : BC_CF_BD;
+}
+__device__ __forceinline__ bool cls_is_trivial(int count, double n_total, double p) {
+    return !(p > 0.0 && p < 1.0) || count < 2 || (double)count - 1.0 >= n_total;
+}
+
 // Multiply the continued fraction / series value by x^a (1-x)^b / (a B(a,b)) and undo the swap (incbet.c tail).
 __device__ __forceinline__ double incbet_finish(double a, double b, double x, double xc, double w, int flag,
                                                 double lbeta_ab, double inv_beta_ab) {

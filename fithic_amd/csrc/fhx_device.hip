@@ -300,6 +300,8 @@ struct K2Params {
     bool no_bias;                 // no bias table was loaded: slot_bias is all 1.0 and need not be read
     const double* prior_lut;      // newSplineY by distance index (clamp + bisect_left folded in)
     dev::BinomTables intra, inter;
+    const dev::ClsRow* cls_intra; // bdtrc_class as five thresholds on the prior per count (k2_class_tables)
+    const dev::ClsRow* cls_inter;
     double inter_chr_prob;
     double outlier_thres;         // 1/N
     int lo_idx, hi_idx;
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE,
                 cls = 0;
                 if (row_prior<NF>(P, l1, l2, prior, is_inter)) {
                     const dev::BinomTables& T = is_inter ? P.inter : P.intra;
-                    cls = dev::bdtrc_class(c, T.n, prior);
+                    cls = dev::cls_is_trivial(c, T.n, prior) ? (int)dev::BC_TRIVIAL : dev::cls_lookup((is_inter ? P.cls_inter : P.cls_intra)[c], prior);
                     if (cls == dev::BC_TRIVIAL) {
                         if (dev::bdtrc_is_closed_form(c, T.n, prior))
                             cls = prior < 0.01 ? K2_CLOSED_LOCAL : K2_CLOSED;
@@ -920,6 +922,33 @@ __global__ __launch_bounds__(K2_THREADS) void k2h_generic(K2Params P, const QEnt
         H.add(pv);
     }
     H.flush(P.top_hist);
+}
+
+// the class thresholds of every count 0..max_count for the two binomials of a pass (dev::cls_row): one thread per (binomial, count)
+__global__ void k2_class_tables(double n_intra, double n_inter, int max_count, dev::ClsRow* __restrict__ intra,
+                                dev::ClsRow* __restrict__ inter) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > 2 * max_count + 1) return;
+    const bool e = i > max_count;
+    const int c = e ? i - (max_count + 1) : i;
+    (e ? inter : intra)[c] = dev::cls_row(e ? n_inter : n_intra, c);
+}
+
+// test hook: class of (count, prior) by the table and by bdtrc_class's arithmetic, and the five thresholds of the count
+__global__ void k_debug_classify(double n_total, const int32_t* __restrict__ count, const double* __restrict__ prior, int64_t n,
+                                 int32_t* __restrict__ by_table, int32_t* __restrict__ by_arith, double* __restrict__ thr5) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const dev::ClsRow r = dev::cls_row(n_total, count[i]);
+    by_table[i] = dev::cls_is_trivial(count[i], n_total, prior[i]) ? (int)dev::BC_TRIVIAL : dev::cls_lookup(r, prior[i]);
+    by_arith[i] = dev::bdtrc_class(count[i], n_total, prior[i]);
+    if (thr5) {
+        thr5[5 * i] = r.tA;
+        thr5[5 * i + 1] = r.tB;
+        thr5[5 * i + 2] = r.tC;
+        thr5[5 * i + 3] = r.tD;
+        thr5[5 * i + 4] = r.tE;
+    }
 }
 
 // outlier flags (p < 1/N, fithic.py:1215) are derived from p when somebody asks: K2 never writes per-row bytes
@@ -1952,6 +1981,9 @@ struct fhx_ctx {
     unsigned long long* d_k2_counts = nullptr;        // (K2_QUEUES + 1) x K2_SHARDS queue counters
     QEntry* d_queue_sorted = nullptr;                 // the 300-iteration class, bucketed by (binomial, count), 64-aligned buckets
     dev::CfRow* d_cf_tab = nullptr;                   // K2H_GENERIC x 300 rows of iteration constants
+    dev::ClsRow* d_cls_tab = nullptr;                 // class thresholds: (max_count + 1) rows for the intra binomial, then the inter one
+    int64_t cls_tab_counts = 0;                       // rows per binomial it was built for, with these totals:
+    double cls_tab_n[2] = {-1.0, -1.0};
     unsigned int* d_k2h_off = nullptr;                // K2H_BUCKETS + 1 bucket starts
     unsigned char* d_memo = nullptr;                  // no-bias table path: virtual rows, table, overflow list (kept across passes)
     size_t memo_bytes = 0;
@@ -2966,6 +2998,25 @@ int fhx_pvalues(fhx_ctx* ctx) {
     }
     K2Params P = make_k2_params(ctx);
     FHX_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    {   // class thresholds per count for this pass's two binomials (kept while the totals and the largest count stay the same)
+        const int64_t mc = std::max<int64_t>(ctx->stats.max_count, 1);
+        if (mc >= INT32_MAX / 2) return fail(ctx, FHX_ERR_UNSUPPORTED, "contact counts beyond 2^30");
+        if (!ctx->d_cls_tab || ctx->cls_tab_counts != mc + 1 || ctx->cls_tab_n[0] != P.intra.n || ctx->cls_tab_n[1] != P.inter.n) {
+            if (ctx->cls_tab_counts < mc + 1 || !ctx->d_cls_tab) {
+                FHX_HIP(hipStreamSynchronize(ctx->stream));
+                dev_free(ctx->d_cls_tab);
+                FHX_HIP(hipMalloc(&ctx->d_cls_tab, (size_t)(2 * (mc + 1)) * sizeof(dev::ClsRow)));
+            }
+            ctx->cls_tab_counts = mc + 1;
+            ctx->cls_tab_n[0] = P.intra.n;
+            ctx->cls_tab_n[1] = P.inter.n;
+            hipLaunchKernelGGL(k2_class_tables, dim3(grid_for(2 * (mc + 1), 128)), dim3(128), 0, ctx->stream, P.intra.n, P.inter.n, (int)mc,
+                               ctx->d_cls_tab, ctx->d_cls_tab + (mc + 1));
+            FHX_HIP(hipGetLastError());
+        }
+        P.cls_intra = ctx->d_cls_tab;
+        P.cls_inter = ctx->d_cls_tab + (mc + 1);
+    }
     // no bias table, fixed-size loci: evaluate a (distance, count) table instead of every row (see k2_memo_rows)
     int32_t *v_loc1 = nullptr, *v_loc2 = nullptr, *v_count = nullptr;
     double* v_table = nullptr;
@@ -3338,6 +3389,32 @@ int fhx_debug_contfrac(fhx_ctx* ctx, int kind, int lazy, const double* a, const 
     FHX_HIP(hipMemcpyAsync(out, d[3], bytes, hipMemcpyDeviceToHost, ctx->stream));
     FHX_HIP(hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < 4; ++k) dev_free(d[k]);
+    return FHX_OK;
+}
+
+int fhx_debug_classify(fhx_ctx* ctx, double n_total, const int32_t* count, const double* prior, int64_t n, int32_t* by_table,
+                       int32_t* by_arith, double* thr5) {
+    if (!ctx || n < 0 || (n > 0 && (!count || !prior || !by_table || !by_arith))) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (n == 0) return FHX_OK;
+    FHX_HIP(hipSetDevice(ctx->device));
+    DeviceScratch G;
+    int32_t *d_c = nullptr, *d_t = nullptr, *d_a = nullptr;
+    double *d_p = nullptr, *d_thr = nullptr;
+    FHX_HIP(G.get(&d_c, (size_t)n * 4));
+    FHX_HIP(G.get(&d_t, (size_t)n * 4));
+    FHX_HIP(G.get(&d_a, (size_t)n * 4));
+    FHX_HIP(G.get(&d_p, (size_t)n * 8));
+    if (thr5) FHX_HIP(G.get(&d_thr, (size_t)n * 40));
+    FHX_HIP(hipMemcpyAsync(d_c, count, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    FHX_HIP(hipMemcpyAsync(d_p, prior, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_debug_classify, dim3(grid_for(n, 128)), dim3(128), 0, ctx->stream, n_total, (const int32_t*)d_c, (const double*)d_p, n,
+                       d_t, d_a, d_thr);
+    FHX_HIP(hipGetLastError());
+    FHX_HIP(hipMemcpyAsync(by_table, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    FHX_HIP(hipMemcpyAsync(by_arith, d_a, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (thr5) FHX_HIP(hipMemcpyAsync(thr5, d_thr, (size_t)n * 40, hipMemcpyDeviceToHost, ctx->stream));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
     return FHX_OK;
 }
 

@@ -244,6 +244,11 @@ int fhx_bdtrc_array(fhx_ctx* ctx, double n_total, const int32_t* count, const do
 int fhx_debug_contfrac(fhx_ctx* ctx, int kind, int lazy, const double* a, const double* b, const double* x, int64_t n,
                        double* out);
 
+/* Test hook: the branch class K2 assigns to (count, prior) under the binomial total n_total - by the per-count threshold table
+ * the classify kernel reads (by_table) and by the predicates of Cephes' incbet evaluated directly (by_arith); the two must agree
+ * for every double.  thr5 (optional, n x 5): the thresholds tA, tB, tC, tD, tE of each count. */
+int fhx_debug_classify(fhx_ctx* ctx, double n_total, const int32_t* count, const double* prior, int64_t n, int32_t* by_table,
+                       int32_t* by_arith, double* thr5);
 /* Test hook: out[i] = K2's lean division of n[i] / d[i] (must equal IEEE n/d inside the operand window it is used in). */
 int fhx_debug_lean_div(fhx_ctx* ctx, const double* n, const double* d, int64_t len, double* out);
 /* Test hook: the device writer's number formatting on arbitrary doubles - kind 0 "%e", 1 "%f"; text32 receives 32 bytes per value

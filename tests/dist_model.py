@@ -1,4 +1,12 @@
-"""Multi-GPU pass: one process per GPU, contacts sharded by chromosome, torch.distributed for the exchanges
+"""TEST INFRASTRUCTURE - a model of the library's sharded schedule (fithic_amd/csrc/fhx_dist.inc) written over torch.distributed.
+
+The product runs the sharded pass inside libfithic_mi355x.so (fhx_run_pass_distributed; RCCL or a caller-provided transport).
+This file restates that schedule in Python so that it can be exercised WITHOUT a GPU: tests/test_dist_gloo.py runs it at world
+size 2 over gloo with the oracle standing in for the kernels (the exchange logic - what is reduced, gathered, cut and sent
+where - is then checked against a one-process run), and tests/test_gpu_dist.py runs it over the C ABI's building blocks
+(fhx_bh_top_hist, fhx_bh_local_sort, fhx_bh_apply_sorted ...) with two ranks sharing GPU 0.  Nothing under fithic_amd/ imports it.
+
+Multi-GPU pass: one process per GPU, contacts sharded by chromosome, torch.distributed for the exchanges
 (backend "nccl" = RCCL over xGMI on the GPU box; "gloo" on CPU tensors in the tests).
 
 The reference is single-process; what has to be global is exactly what its data structures
@@ -130,7 +138,7 @@ class LocalOps:
         self.eng, self.ctx, self.torch, self.device = engine, engine.ctx, torch, device
 
     def local_stats(self):
-        from . import _capi
+        from fithic_amd import _capi
         st = self.ctx.pass_stats()
         return st, self.ctx.get_array(_capi.A_HIST_SUMCC), self.ctx.get_array(_capi.A_HIST_NPAIRS)
 
@@ -152,7 +160,7 @@ class LocalOps:
 
     def local_dist_keys(self):
         """-r 0: the distinct in-range distances of this rank's rows (its histograms are aligned to them)."""
-        from . import _capi
+        from fithic_amd import _capi
         return self.ctx.get_array(_capi.A_DIST_KEYS)
 
     def set_dist_keys(self, keys):
@@ -202,7 +210,7 @@ class LocalOps:
         self.ctx.bh_scatter(q_sorted_local.data_ptr() if q_sorted_local.numel() else 0)
 
     def next_pass_local(self):
-        from . import _capi
+        from fithic_amd import _capi
         n = self.ctx.next_pass()
         if self.nonfixed:
             # the context's list = what was set last (the genome-wide list of the previous pass) + this rank's fresh ones

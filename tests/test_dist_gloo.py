@@ -1,4 +1,4 @@
-"""world_size-2 test of the multi-GPU exchange logic (fithic_amd/dist.py) on CPU tensors over gloo.
+"""world_size-2 test of the multi-GPU exchange logic (tests/dist_model.py, the model of the library's schedule in csrc/fhx_dist.inc) on CPU tensors over gloo.
 
 The per-GPU compute of a distributed pass goes through `LocalOps`; here it is replaced by a checker-backed
 implementation (oracle + numpy) so that what is exercised is exactly the product's exchange code: the packed
@@ -32,7 +32,8 @@ def _worker(rank, world, port, case, passes, result_dir):
     import torch
     import torch.distributed as td
     from conftest import load_case, case_args
-    from fithic_amd import dist, _capi, tables
+    import dist_model as dist
+    from fithic_amd import _capi, tables
     from fithic_amd.engine import MODES
     from oracle import fithic_oracle as fo
 
@@ -232,7 +233,8 @@ def test_distributed_pass_world2_gloo(case, passes, tmp_path):
 
 def test_splitters_and_chromosome_assignment():
     torch = pytest.importorskip("torch")
-    from fithic_amd import dist, synth
+    import dist_model as dist
+    from fithic_amd import synth
     s = torch.arange(0, 1000, dtype=torch.int64)
     sp = dist.choose_splitters(torch, s, 4)
     assert sp.tolist() == [250, 500, 750]
@@ -241,3 +243,68 @@ def test_splitters_and_chromosome_assignment():
     owner = synth.assign_chromosomes(g, 8)
     load = [sum(g.n_loci[c] for c in range(len(g)) if owner[c] == r) for r in range(8)]
     assert len(set(owner)) == 8 and max(load) / (sum(load) / 8) < 1.15          # greedy balance within 15 %
+
+
+def _bench_hash_worker(rank, world, port, result_dir):
+    """bench.py's N > 1 verification plumbing on CPU tensors over gloo: per-chromosome hash tables of (row identity, value) are
+    additive over ranks whatever the sharding - cis rows by chromosome, trans rows dealt in blocks - and TorchComm's helpers
+    return the same numbers on every rank."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as td
+    import bench
+    from fithic_amd import synth
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    comm = bench.TorchComm(td, torch, torch.device("cpu"))
+    cfg = dict(bench.CONFIGS["C5"], keep=0.2)
+    genome = synth.Genome(cfg["res"], [300_000, 250_000, 200_000])
+    dev = torch.device("cpu")
+
+    def rows_of(r, w):
+        owner = synth.assign_chromosomes(genome, w)
+        mine = [c for c in range(len(genome)) if owner[c] == r]
+        cols, n, n_cis, n_trans = bench.build_rows(synth, torch, cfg, genome, mine, r, w, dev)
+        return [c[:n] for c in cols], n, n_trans
+
+    def table(cols, n):
+        keys = bench.row_keys(torch, synth, cols, n)
+        value = (cols[4].to(torch.float64) + 0.25) / (1.0 + cols[1].to(torch.float64))      # any function of the row
+        return bench.hash_table(torch, synth, keys, cols[0], value, len(genome))
+
+    mine, n_mine, n_trans = rows_of(rank, world)
+    parts = comm.gather_rows(table(mine, n_mine))
+    total = parts[0].clone()
+    for t in parts[1:]:
+        total += t
+    whole, n_whole, _ = rows_of(0, 1)
+    msgs = []
+    if not torch.equal(total, table(whole, n_whole)):
+        msgs.append("summed hash tables differ from the one-process table")
+    if comm.sum_int(n_mine) != n_whole or n_trans < 100:
+        msgs.append("row counts")
+    if comm.max_float(1.5 + rank) != 1.5 + (world - 1) or comm.gather_floats([float(rank), 2.0]) != [[float(r), 2.0] for r in range(world)]:
+        msgs.append("TorchComm helpers")
+    # a single flipped bit in one rank's values must show in exactly that row's chromosome
+    if rank == 0:
+        keys = bench.row_keys(torch, synth, whole, n_whole)
+        v = (whole[4].to(torch.float64) + 0.25) / (1.0 + whole[1].to(torch.float64))
+        good = bench.hash_table(torch, synth, keys, whole[0], v, len(genome))
+        v2 = v.clone()
+        v2.view(torch.int64)[n_whole // 2] ^= 1
+        bad = bench.hash_table(torch, synth, keys, whole[0], v2, len(genome))
+        if int((good != bad).sum()) != 1:
+            msgs.append("a one-ulp change is not seen (or seen in the wrong chromosome)")
+    with open(os.path.join(result_dir, "rank%d.txt" % rank), "w") as f:
+        f.write("OK" if not msgs else "FAIL: " + "; ".join(msgs))
+    td.destroy_process_group()
+
+
+def test_bench_sharded_verification_hashes_over_gloo(tmp_path):
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    mp.spawn(_bench_hash_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        with open(os.path.join(str(tmp_path), "rank%d.txt" % r)) as f:
+            assert f.read() == "OK"

@@ -28,7 +28,8 @@ def _worker(rank, world, port, case, passes, result_dir):
     import torch
     import torch.distributed as td
     from conftest import load_case, case_args
-    from fithic_amd import dist, tables
+    import dist_model as dist
+    from fithic_amd import tables
     from fithic_amd.engine import Engine
 
     td.init_process_group("gloo", rank=rank, world_size=world)

@@ -110,6 +110,39 @@ def test_continued_fraction_bit_exact_large_n(ctx, kind):
         assert same.all() and np.isnan(ref).sum() < 20
 
 
+def test_class_threshold_table_equals_incbet_predicates(ctx):
+    """k2_classify reads bdtrc_class as five thresholds on the prior per count (dev::cls_row, bisected on the device with the
+    predicates of Cephes' incbet).  Table and arithmetic must agree on EVERY double: random priors over twelve decades, the
+    domain edges, and - where a wrong threshold would show - each threshold itself with its 3 neighbours on both sides, for
+    Hi-C-sized and small binomials (the small ones exercise the direct orientation and both power-series tests)."""
+    rng = np.random.default_rng(21)
+    for n_total in (645040870.0, 7150761687.0, 1.0e6, 5000.0, 170.0, 3.0):
+        counts = np.unique(np.concatenate([np.arange(0, 40), rng.integers(1, 5000, 300), [int(min(n_total, 2e9)) - 1, int(min(n_total, 2e9)),
+                                                                                           int(min(n_total, 2e9)) + 1]])).astype(np.int32)
+        counts = counts[counts >= 0]
+        _, _, thr = ctx.debug_classify(n_total, counts, np.full(len(counts), 0.5), thresholds=True)
+        cs, ps = [], []
+        for c, row in zip(counts, thr):
+            pri = [0.0, 1.0, -0.1, 1.5, np.nan, 5e-324, 1.0 - 2.0 ** -53, 0.95, np.nextafter(0.95, 1), 0.05, np.nextafter(0.05, 0)]
+            for t in row:
+                if 0.0 <= t <= 1.0:
+                    v = t
+                    for _ in range(4):
+                        pri.append(v)
+                        v = np.nextafter(v, 2.0)
+                    v = t
+                    for _ in range(3):
+                        v = np.nextafter(v, -1.0)
+                        pri.append(v)
+            pri += list(10.0 ** rng.uniform(-12, 0, 24)) + list(1.0 - 10.0 ** rng.uniform(-12, 0, 12))
+            cs += [c] * len(pri)
+            ps += pri
+        by_table, by_arith = ctx.debug_classify(n_total, np.array(cs, np.int32), np.array(ps, np.float64))
+        bad = np.flatnonzero(by_table != by_arith)
+        assert len(bad) == 0, (n_total, cs[bad[0]], ps[bad[0]], int(by_table[bad[0]]), int(by_arith[bad[0]]), len(bad))
+        assert len(np.unique(by_arith)) >= (4 if n_total > 1000 else 2)         # the classes really occur
+
+
 def test_lean_division_matches_ieee(ctx):
     """K2 divides with the core of hipcc's own f64 division expansion (no scaling scaffolding): must equal IEEE n/d
     bit for bit on the operand window it is used in - numerators 0 or arg*k*k', denominators (a+2n)(a+2n+1)."""
