@@ -797,6 +797,21 @@ __device__ __forceinline__ bool cls_is_trivial(int count, double n_total, double
     return !(p > 0.0 && p < 1.0) || count < 2 || (double)count - 1.0 >= n_total;
 }
 
+// bdtrc_class with the one division of the classification - the orientation threshold aa / (aa + bb) - read from the count's
+// table row (ClsRow::tB holds exactly that quotient) instead of being computed per contact
+__device__ __forceinline__ int bdtrc_class_tb(int count, double n_total, double p, double tB) {
+    if (cls_is_trivial(count, n_total, p)) return BC_TRIVIAL;
+    const double fk = (double)count - 1.0;
+    const double aa = fk + 1.0, bb = n_total - fk, xx = p;
+    if (bb * xx <= 1.0 && xx <= 0.95) return BC_PSERIES;
+    const double w = 1.0 - xx;
+    if (xx > tB) {
+        if (aa * w <= 1.0 && w <= 0.95) return BC_PSERIES;
+        return w * (bb + aa - 2.0) - (bb - 1.0) < 0.0 ? BC_CF_SWAPPED : BC_CF_BD;
+    }
+    return xx * (aa + bb - 2.0) - (aa - 1.0) < 0.0 ? BC_CF_BCF : BC_CF_BD;
+}
+
 // Multiply the continued fraction / series value by x^a (1-x)^b / (a B(a,b)) and undo the swap (incbet.c tail).
 __device__ __forceinline__ double incbet_finish(double a, double b, double x, double xc, double w, int flag,
                                                 double lbeta_ab, double inv_beta_ab) {

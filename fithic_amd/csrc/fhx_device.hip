@@ -453,106 +453,99 @@ struct QEntry {
     double prior;
 };
 
-// Queues are SHARDED: a tile's slots come from one returning atomic per class, and all workgroups adding to ONE address
-// retire at ~88 M atomics/s (MI355X_MICROARCH.md "dequeue") - 144 500 tiles of C3 on one counter per class were 1.64 ms, the
-// whole of k2_classify (r02_s_classify_variants.txt: 2 / 4 / 8 rows per thread = 289 k / 145 k / 72 k tiles = 3.6 / 1.9 /
-// 1.7 ms whatever the occupancy).  So every class has K2_SHARDS counters and K2_SHARDS sub-buffers; workgroup b uses shard
-// b % 8 (the XCD it runs on, for speed only).  A shard's tiles are known in advance (tile t belongs to workgroup t % grid), so
-// a sub-buffer of ceil(grid / 8) * ceil(tiles / grid) tiles can never overflow.  Consumers see one logical queue: entry j of
-// the concatenation of the shards (qspan_at).
-constexpr int K2_SHARDS = 8;
-constexpr int K2_COUNT_STRIDE = 16;                      // counters 128 B apart: one L2 line each
+// Queues are SHARDED BY WORKGROUP: workgroup b of k2_classify appends only to shard b of every class queue, so its slot counters
+// are its own (LDS, kept across its tiles and written to HBM once at the end) and nothing in its tile loop waits for another
+// workgroup - or for another wave: a wave reserves its slots with one LDS atomic per class and goes on.  (Round 2 took one
+// returning GLOBAL atomic per class and tile, eight counters per class: all workgroups adding to one address retire at ~88 M
+// atomics/s on this chip, and the two block barriers around that round trip left the kernel at 29 % of HBM and 49 % VALU busy -
+// bound by neither, profiles/r02_z_pmc.txt.)  A shard's tiles are known in advance (tile t belongs to workgroup t % grid), so a
+// region of ceil(tiles / grid) tiles per shard can never overflow; two classes share a buffer, growing towards each other
+// inside every shard's region.  Consumers walk the queue shard by shard (a consumer workgroup takes whole shards: no index
+// arithmetic over shard boundaries).
+constexpr int K2_MAX_SHARDS = 2048;                      // the largest k2_classify grid: 256 CUs x 8
 
 struct QSpan {
-    QEntry* base;                      // slot 0 of shard 0 (queues that grow downwards: the LAST entry of shard 0's sub-buffer)
-    long long cap_s;                   // entries per shard sub-buffer
-    int dir;                           // +1 / -1: two queues share one buffer, growing towards each other inside every shard
-    const unsigned long long* count;   // K2_SHARDS counters, K2_COUNT_STRIDE apart
+    QEntry* base;                      // slot 0 of shard 0 (queues that grow downwards: the LAST entry of shard 0's region)
+    long long cap_s;                   // entries per shard region
+    int dir;                           // +1 / -1
+    int n_shards;
+    const unsigned long long* count;   // n_shards counters
 };
-struct QIndex {
-    long long start[K2_SHARDS + 1];    // exclusive prefix of the shard counts; start[K2_SHARDS] = entries in the queue
-};
-__device__ __forceinline__ QIndex qindex_of(const unsigned long long* __restrict__ count) {
-    QIndex ix;
-    long long a = 0;
-#pragma unroll
-    for (int s = 0; s < K2_SHARDS; ++s) {
-        ix.start[s] = a;
-        a += (long long)count[s * K2_COUNT_STRIDE];
-    }
-    ix.start[K2_SHARDS] = a;
-    return ix;
-}
-// offset (in elements, from the queue's base) of logical entry j
-__device__ __forceinline__ long long qslot(const QIndex& ix, long long cap_s, int dir, long long j) {
-    int s = 0;
-    long long st = 0;
-#pragma unroll
-    for (int k = 1; k < K2_SHARDS; ++k)
-        if (j >= ix.start[k]) {
-            s = k;
-            st = ix.start[k];
-        }
-    return (long long)s * cap_s + dir * (j - st);
+__device__ __forceinline__ QEntry* qentry(const QSpan& q, int shard, long long j) {
+    return q.base + (long long)shard * q.cap_s + (long long)q.dir * j;
 }
 
 struct K2Queues {
-    QSpan q[K2_QUEUES + 1];            // classes 1..4, then the closed-form class (count == 1)
-    unsigned long long* count;         // (K2_QUEUES + 1) x K2_SHARDS counters: [(class * K2_SHARDS + shard) * K2_COUNT_STRIDE]
+    QSpan q[K2_QUEUES + 1];            // classes 1..4, then the closed-form class (count == 1, prior >= 0.01)
+    unsigned long long* count;         // (K2_QUEUES + 1) x K2_MAX_SHARDS counters: [class * K2_MAX_SHARDS + shard]
 };
 
 constexpr int K2_CL_ITEMS = 4;
-constexpr int K2_CL_TILE = K2_THREADS * K2_CL_ITEMS;     // 1024 rows per workgroup step (8 items/thread costs 189 VGPRs -> 2 waves/SIMD and is slower)
+constexpr int K2_CL_TILE = K2_THREADS * K2_CL_ITEMS;     // 1024 rows per workgroup step: four waves of 256 consecutive rows
 
 constexpr int K2_CLOSED = K2_QUEUES + 1;                 // count == 1 rows with prior >= 0.01 (Cephes takes pow there): queued, k2_closed
-constexpr int K2_CLOSED_LOCAL = K2_QUEUES + 2;           // count == 1 rows with prior < 0.01: tile-local, evaluated densely from LDS
+constexpr int K2_CLOSED_LOCAL = K2_QUEUES + 2;           // count == 1 rows with prior < 0.01: wave-local, evaluated densely from LDS
 constexpr int K2_CLASSES = K2_QUEUES + 2;
 
-template <int NF, int ITEMS, int WPE>
+// TABLE: 0 = incbet's predicates evaluated per row (bdtrc_class), 1 = the per-count threshold rows (dev::cls_lookup), 2 = the
+// predicates with the orientation threshold (their one division) read from the count's row
+template <int NF, int WPE, int TABLE>
 __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k2_classify(K2Params P, K2Queues Q) {
-    constexpr int TILE = K2_THREADS * ITEMS;
-    // Per tile: every wave reserves slots per class with ballots + ONE LDS atomic per (wave, class, item), then each
-    // class takes ONE global atomic per tile (a same-address global atomic per wave would cap the kernel at ~88 M
-    // atomics/s - MI355X_MICROARCH.md "dequeue" - i.e. slower than the arithmetic it feeds), then the lanes write
-    // their own 16-byte entries at base + slot (lanes of one class hold consecutive slots).
-    // The closed-form rows (count == 1: a third of a Hi-C run) are not evaluated where they are met - with a third of the lanes
-    // active that costs every wave the full price four times per tile - but compacted into LDS and evaluated with all lanes busy
-    // at the end of the tile: -expm1(n * log1p(-prior)), ~150 fp64 instructions and few registers.  Cephes' other branch
-    // (prior >= 0.01: 1 - pow(1 - prior, n); practically never on Hi-C data) would bring pow's ~90 VGPRs into this kernel, which
-    // needs its 8 waves/SIMD (a tile is a chain of dependent round trips): those rows are queued for k2_closed instead.
-    __shared__ unsigned int cnt[K2_CLASSES];
-    __shared__ unsigned long long gbase[K2_QUEUES + 1];
-    __shared__ double cf_prior[TILE];
-    __shared__ unsigned short cf_idx[TILE];          // tile-local row | 0x8000 for the inter-chromosomal binomial
+    constexpr int ITEMS = K2_CL_ITEMS, WAVES = K2_THREADS / 64, WAVE_ROWS = 64 * ITEMS;
+    // Per wave and step: 256 consecutive rows, four per lane (16-byte loads of the three columns).  Every looping row becomes a
+    // 16-byte entry of its class queue, in this workgroup's shard: the wave counts its rows per class with ballots, reserves the
+    // slots with ONE LDS atomic instruction (lane k adds class k's total to the workgroup's running counter) and writes - no
+    // barrier, no global atomic.  The closed-form rows (count == 1: a third of a Hi-C run) are not evaluated where they are met -
+    // with a third of the lanes active that costs the wave the full price four times per step - but compacted into the wave's
+    // own LDS strip and evaluated with all lanes busy: -expm1(n * log1p(-prior)), ~150 fp64 instructions and few registers.
+    // Cephes' other branch (prior >= 0.01: 1 - pow(1 - prior, n); practically never on Hi-C data) would bring pow's ~90 VGPRs
+    // into this kernel: those rows are queued for k2_closed instead.
+    __shared__ unsigned int cnt[K2_QUEUES + 1];                 // entries of this shard per queued class, so far
+    __shared__ double cf_prior[WAVES][WAVE_ROWS];
+    __shared__ unsigned short cf_idx[WAVES][WAVE_ROWS];         // row within the wave's 256 | 0x8000 for the inter-chromosomal binomial
     __shared__ unsigned int hist_lds[K2_HIST_BINS];
+    if (threadIdx.x <= K2_QUEUES) cnt[threadIdx.x] = 0;
     FusedHist H;
     H.init(hist_lds, P.top_hist);
+    __syncthreads();
     const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
-    const int shard = (int)(blockIdx.x % K2_SHARDS);
-    const int64_t tiles = (P.n + TILE - 1) / TILE;
+    const int shard = (int)blockIdx.x;
+    const int64_t tiles = (P.n + K2_CL_TILE - 1) / K2_CL_TILE;
+    const int4* a4 = reinterpret_cast<const int4*>(P.loc1);
+    const int4* b4 = reinterpret_cast<const int4*>(P.loc2);
+    const int4* c4 = reinterpret_cast<const int4*>(P.count);
     for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
-        if (threadIdx.x < K2_CLASSES) cnt[threadIdx.x] = 0;
-        __syncthreads();
+        const int64_t wave_row0 = t * K2_CL_TILE + (int64_t)wave * WAVE_ROWS;
+        const int64_t row0 = wave_row0 + lane * ITEMS;
+        int l1_of[ITEMS] = {0, 0, 0, 0}, l2_of[ITEMS] = {0, 0, 0, 0}, count_of[ITEMS] = {0, 0, 0, 0};
+        if (row0 < P.n) {                                       // the columns are padded to a multiple of four rows
+            const int4 a = a4[row0 >> 2], b = b4[row0 >> 2], c = c4[row0 >> 2];
+            l1_of[0] = a.x; l1_of[1] = a.y; l1_of[2] = a.z; l1_of[3] = a.w;
+            l2_of[0] = b.x; l2_of[1] = b.y; l2_of[2] = b.z; l2_of[3] = b.w;
+            count_of[0] = c.x; count_of[1] = c.y; count_of[2] = c.z; count_of[3] = c.w;
+        }
         int cls_of[ITEMS];
-        unsigned int slot_of[ITEMS];
-        int count_of[ITEMS];
         double prior_of[ITEMS];
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
-            const int64_t i = t * TILE + r * K2_THREADS + threadIdx.x;
-            int cls = -1;                                              // -1: no row, 0: done here, 1..4: queued, 5: closed form
+            const int64_t i = row0 + r;
+            int cls = -1;                                              // -1: no row, 0: done here, 1..4: queued, 5 / 6: closed form
             double prior = 1.0;
-            int c = 0;
+            int c = count_of[r];
             if (i < P.n) {
-                const int l1 = P.loc1[i], l2 = P.loc2[i];
-                c = P.count[i];
                 double pv = 1.0;
                 bool is_inter = false;
                 cls = 0;
-                if (row_prior<NF>(P, l1, l2, prior, is_inter)) {
+                if (row_prior<NF>(P, l1_of[r], l2_of[r], prior, is_inter)) {
                     const dev::BinomTables& T = is_inter ? P.inter : P.intra;
-                    cls = dev::cls_is_trivial(c, T.n, prior) ? (int)dev::BC_TRIVIAL : dev::cls_lookup((is_inter ? P.cls_inter : P.cls_intra)[c], prior);
+                    if (TABLE == 1)
+                        cls = dev::cls_is_trivial(c, T.n, prior) ? (int)dev::BC_TRIVIAL : dev::cls_lookup((is_inter ? P.cls_inter : P.cls_intra)[c], prior);
+                    else if (TABLE == 2)
+                        cls = dev::bdtrc_class_tb(c, T.n, prior, (c >= 0 && (double)c - 1.0 < T.n) ? (is_inter ? P.cls_inter : P.cls_intra)[c].tB : 0.0);
+                    else
+                        cls = dev::bdtrc_class(c, T.n, prior);
                     if (cls == dev::BC_TRIVIAL) {
                         if (dev::bdtrc_is_closed_form(c, T.n, prior))
                             cls = prior < 0.01 ? K2_CLOSED_LOCAL : K2_CLOSED;
@@ -570,9 +563,8 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE,
             count_of[r] = c;
             prior_of[r] = prior;
         }
-        // slot reservation for the whole wave at once: 20 ballots (4 items x 5 classes), then ONE LDS atomic instruction
-        // (lane k reserves class k's total) and five broadcasts.  One atomic + shuffle per (item, class) made 16 dependent
-        // LDS round trips per wave and tile, which the 3 waves/SIMD of this kernel cannot hide.
+        // slot reservation for the whole wave at once: 24 ballots (4 items x 6 classes), then ONE LDS atomic instruction
+        // (lane k reserves class k's total in the workgroup's running counter) and the broadcasts
         unsigned int before_cls[ITEMS];          // rank of this lane's item r among the wave's items of its class
         unsigned int tot[K2_CLASSES] = {0u, 0u, 0u, 0u, 0u, 0u};
 #pragma unroll
@@ -585,54 +577,47 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE,
                 tot[k - 1] += (unsigned int)__popcll(m);
             }
         }
-        static_assert(K2_CLASSES == 6, "lane k reserves class k");
-        const unsigned int my_tot =
-            lane == 0 ? tot[0] : (lane == 1 ? tot[1] : (lane == 2 ? tot[2] : (lane == 3 ? tot[3] : (lane == 4 ? tot[4] : tot[5]))));
+        static_assert(K2_CLASSES == 6 && K2_QUEUES == 4, "lane k reserves class k; the sixth class is wave-local");
+        const unsigned int my_tot = lane == 0 ? tot[0] : (lane == 1 ? tot[1] : (lane == 2 ? tot[2] : (lane == 3 ? tot[3] : tot[4])));
         unsigned int my_base = 0;
-        if (lane < K2_CLASSES && my_tot) my_base = atomicAdd(&cnt[lane], my_tot);
-        unsigned int wave_base[K2_CLASSES];
+        if (lane <= K2_QUEUES && my_tot) my_base = atomicAdd(&cnt[lane], my_tot);
+        unsigned int wave_base[K2_QUEUES + 1];
 #pragma unroll
-        for (int k = 0; k < K2_CLASSES; ++k) wave_base[k] = __shfl(my_base, k, 64);
-#pragma unroll
-        for (int r = 0; r < ITEMS; ++r) {
-            const int k = cls_of[r] - 1;
-            const unsigned int wb =
-                k == 0 ? wave_base[0] : (k == 1 ? wave_base[1] : (k == 2 ? wave_base[2] : (k == 3 ? wave_base[3] : (k == 4 ? wave_base[4] : wave_base[5]))));
-            slot_of[r] = k >= 0 ? wb + before_cls[r] : 0u;
-            if (cls_of[r] == K2_CLOSED_LOCAL) {
-                cf_prior[slot_of[r]] = prior_of[r];
-                cf_idx[slot_of[r]] = (unsigned short)((r * K2_THREADS + threadIdx.x) | (count_of[r] < 0 ? 0x8000 : 0));
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x <= K2_QUEUES)
-            gbase[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&Q.count[(threadIdx.x * K2_SHARDS + shard) * K2_COUNT_STRIDE],
-                                                              (unsigned long long)cnt[threadIdx.x]) : 0ull;
-        __syncthreads();
+        for (int k = 0; k <= K2_QUEUES; ++k) wave_base[k] = __shfl(my_base, k, 64);
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
             const int k = cls_of[r] - 1;
             if (k >= 0 && k <= K2_QUEUES) {
+                const unsigned int wb = k == 0 ? wave_base[0] : (k == 1 ? wave_base[1] : (k == 2 ? wave_base[2] : (k == 3 ? wave_base[3] : wave_base[4])));
                 QEntry e;
-                e.row = (unsigned int)(t * TILE + r * K2_THREADS + threadIdx.x);
+                e.row = (unsigned int)(row0 + r);
                 e.count = count_of[r];
                 e.prior = prior_of[r];
-                const long long pos = (long long)(gbase[k] + slot_of[r]);
-                Q.q[k].base[shard * Q.q[k].cap_s + Q.q[k].dir * pos] = e;
+                *qentry(Q.q[k], shard, (long long)(wb + before_cls[r])) = e;
+            } else if (cls_of[r] == K2_CLOSED_LOCAL) {
+                cf_prior[wave][before_cls[r]] = prior_of[r];
+                cf_idx[wave][before_cls[r]] = (unsigned short)((lane * ITEMS + r) | (count_of[r] < 0 ? 0x8000 : 0));
             }
         }
-        // the small-prior closed-form rows of the tile, all lanes busy; after the entries, so that the per-row state above is dead
-        // while log1p / expm1 need their registers
-        const unsigned int n_local = cnt[K2_CLASSES - 1];
-        for (unsigned int j = threadIdx.x; j < n_local; j += K2_THREADS) {
-            const unsigned int ix = cf_idx[j];
+        // the small-prior closed-form rows of this wave, all lanes busy.  The strip is the wave's own: LDS operations of one
+        // wave complete in order, so its reads below see its writes above without a barrier (the fence keeps the compiler from
+        // moving them)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const unsigned int n_local = tot[K2_CLASSES - 1];
+        for (unsigned int j = lane; j < n_local; j += 64) {
+            const unsigned int ix = cf_idx[wave][j];
             const double n_total = (ix & 0x8000u) ? P.inter.n : P.intra.n;
-            const double pv = -dev::cephes_expm1(n_total * dev::cephes_log1p(-cf_prior[j]));        // bdtrc_closed_form, prior < 0.01
-            P.p[t * TILE + (ix & 0x7FFFu)] = pv;
+            const double pv = -dev::cephes_expm1(n_total * dev::cephes_log1p(-cf_prior[wave][j]));        // bdtrc_closed_form, prior < 0.01
+            P.p[wave_row0 + (ix & 0x7FFFu)] = pv;
             H.add(pv);
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the strip is rewritten in the next step
+        __builtin_amdgcn_wave_barrier();
     }
+    __syncthreads();
+    if (threadIdx.x <= K2_QUEUES) Q.count[(size_t)threadIdx.x * K2_MAX_SHARDS + shard] = cnt[threadIdx.x];
     H.flush(P.top_hist);
 }
 
@@ -641,14 +626,14 @@ __global__ __launch_bounds__(K2_THREADS) void k2_closed(K2Params P, QSpan q) {
     __shared__ unsigned int hist_lds[K2_HIST_BINS];
     FusedHist H;
     H.init(hist_lds, P.top_hist);
-    const QIndex ix = qindex_of(q.count);
-    const int64_t n = ix.start[K2_SHARDS];
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
-        const QEntry e = q.base[qslot(ix, q.cap_s, q.dir, j)];
-        const double pv = dev::bdtrc_closed_form(e.count < 0 ? P.inter.n : P.intra.n, e.prior);
-        store_p<false>(P.p + e.row, pv);
-        H.add(pv);
+    for (int sh = blockIdx.x; sh < q.n_shards; sh += gridDim.x) {
+        const long long n = (long long)q.count[sh];
+        for (long long j = threadIdx.x; j < n; j += blockDim.x) {
+            const QEntry e = *qentry(q, sh, j);
+            const double pv = dev::bdtrc_closed_form(e.count < 0 ? P.inter.n : P.intra.n, e.prior);
+            store_p<false>(P.p + e.row, pv);
+            H.add(pv);
+        }
     }
     H.flush(P.top_hist);
 }
@@ -658,16 +643,16 @@ __global__ __launch_bounds__(K2_THREADS) void k2_queue(K2Params P, QSpan q) {
     __shared__ unsigned int hist_lds[K2_HIST_BINS];
     FusedHist H;
     H.init(hist_lds, P.top_hist);
-    const QIndex ix = qindex_of(q.count);
-    const int64_t n = ix.start[K2_SHARDS];
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
-        const QEntry e = q.base[qslot(ix, q.cap_s, q.dir, j)];
-        const bool is_inter = e.count < 0;
-        const int c = is_inter ? -e.count : e.count;
-        const double pv = dev::bdtrc_count_class<CLS>(c, is_inter ? P.inter : P.intra, e.prior);
-        store_p<false>(P.p + e.row, pv);
-        H.add(pv);
+    for (int sh = blockIdx.x; sh < q.n_shards; sh += gridDim.x) {
+        const long long n = (long long)q.count[sh];
+        for (long long j = threadIdx.x; j < n; j += blockDim.x) {
+            const QEntry e = *qentry(q, sh, j);
+            const bool is_inter = e.count < 0;
+            const int c = is_inter ? -e.count : e.count;
+            const double pv = dev::bdtrc_count_class<CLS>(c, is_inter ? P.inter : P.intra, e.prior);
+            store_p<false>(P.p + e.row, pv);
+            H.add(pv);
+        }
     }
     H.flush(P.top_hist);
 }
@@ -686,10 +671,10 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
     __shared__ unsigned int hist_lds[K2_HIST_BINS];
     FusedHist H;
     H.init(hist_lds, P.top_hist);
-    const QIndex ix = qindex_of(q.count);
-    const int64_t n = ix.start[K2_SHARDS];
-    const int64_t tiles = (n + K2_SORT_TILE - 1) / K2_SORT_TILE;
-    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    for (int sh = blockIdx.x; sh < q.n_shards; sh += gridDim.x) {
+      const int64_t n = (int64_t)q.count[sh];
+      const int64_t tiles = (n + K2_SORT_TILE - 1) / K2_SORT_TILE;
+      for (int64_t t = 0; t < tiles; ++t) {
         if (threadIdx.x < K2_SORT_BUCKETS) bucket_cnt[threadIdx.x] = 0;
         __syncthreads();
         QEntry e[4];
@@ -700,7 +685,7 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
             const int64_t j = t * K2_SORT_TILE + r * K2_THREADS + threadIdx.x;
             bucket[r] = -1;
             if (j < n) {
-                e[r] = q.base[qslot(ix, q.cap_s, q.dir, j)];
+                e[r] = *qentry(q, sh, j);
                 const int c = e[r].count < 0 ? -e[r].count : e[r].count;
                 bucket[r] = c < K2_SORT_BUCKETS - 1 ? c : K2_SORT_BUCKETS - 1;
                 slot[r] = atomicAdd(&bucket_cnt[bucket[r]], 1u);
@@ -731,6 +716,7 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
             }
         }
         __syncthreads();
+      }
     }
     H.flush(P.top_hist);
 }
@@ -753,22 +739,16 @@ __device__ __forceinline__ int k2h_bucket(int signed_count) {
     return c < K2H_KCAP ? (inter ? K2H_KCAP + c : c) : K2H_GENERIC;
 }
 
-__device__ __forceinline__ void k2h_chunk(int64_t n, int64_t& beg, int64_t& end) {
-    const int64_t chunk = ((n + K2H_BLOCKS - 1) / K2H_BLOCKS + 1023) / 1024 * 1024;
-    beg = (int64_t)blockIdx.x * chunk;
-    end = min(n, beg + chunk);
-}
-
-// per-workgroup bucket counts of its contiguous chunk of the queue (digit-major matrix, as rs_count writes it)
+// per-workgroup bucket counts of its shards of the queue (digit-major matrix, as rs_count writes it): workgroup b takes the
+// shards b, b + K2H_BLOCKS, ...
 __global__ __launch_bounds__(K2H_THREADS) void k2h_count(QSpan q, unsigned int* __restrict__ block_hist) {
     __shared__ unsigned int h[K2H_BUCKETS];
     for (int d = threadIdx.x; d < K2H_BUCKETS; d += K2H_THREADS) h[d] = 0;
     __syncthreads();
-    const QIndex ix = qindex_of(q.count);
-    int64_t beg, end;
-    k2h_chunk(ix.start[K2_SHARDS], beg, end);
-    for (int64_t i = beg + threadIdx.x; i < end; i += K2H_THREADS)
-        atomicAdd(&h[k2h_bucket(q.base[qslot(ix, q.cap_s, q.dir, i)].count)], 1u);
+    for (int sh = blockIdx.x; sh < q.n_shards; sh += K2H_BLOCKS) {
+        const long long n = (long long)q.count[sh];
+        for (long long i = threadIdx.x; i < n; i += K2H_THREADS) atomicAdd(&h[k2h_bucket(qentry(q, sh, i)->count)], 1u);
+    }
     __syncthreads();
     for (int d = threadIdx.x; d < K2H_BUCKETS; d += K2H_THREADS) block_hist[(size_t)d * K2H_BLOCKS + blockIdx.x] = h[d];
 }
@@ -801,12 +781,12 @@ __global__ __launch_bounds__(K2H_THREADS) void k2h_scatter(QSpan q, const unsign
     __shared__ unsigned int cursor[K2H_BUCKETS];
     for (int d = threadIdx.x; d < K2H_BUCKETS; d += K2H_THREADS) cursor[d] = off[d] + block_hist[(size_t)d * K2H_BLOCKS + blockIdx.x];
     __syncthreads();
-    const QIndex ix = qindex_of(q.count);
-    int64_t beg, end;
-    k2h_chunk(ix.start[K2_SHARDS], beg, end);
-    for (int64_t i = beg + threadIdx.x; i < end; i += K2H_THREADS) {
-        const QEntry e = q.base[qslot(ix, q.cap_s, q.dir, i)];
-        out[atomicAdd(&cursor[k2h_bucket(e.count)], 1u)] = e;       // order inside a bucket is free: results go to p[row]
+    for (int sh = blockIdx.x; sh < q.n_shards; sh += K2H_BLOCKS) {
+        const long long n = (long long)q.count[sh];
+        for (long long i = threadIdx.x; i < n; i += K2H_THREADS) {
+            const QEntry e = *qentry(q, sh, i);
+            out[atomicAdd(&cursor[k2h_bucket(e.count)], 1u)] = e;       // order inside a bucket is free: results go to p[row]
+        }
     }
 }
 
@@ -1978,9 +1958,10 @@ struct fhx_ctx {
     unsigned char* d_work = nullptr;                  // the K2 queues and the K3 sort buffers are views into this block
     QEntry* d_queue[2] = {nullptr, nullptr};          // K2's per-class row queues (sharded, see QSpan)
     int64_t queue_cap = 0;                            // entries per queue buffer
-    unsigned long long* d_k2_counts = nullptr;        // (K2_QUEUES + 1) x K2_SHARDS queue counters
+    unsigned long long* d_k2_counts = nullptr;        // (K2_QUEUES + 1) x K2_MAX_SHARDS queue counters
     QEntry* d_queue_sorted = nullptr;                 // the 300-iteration class, bucketed by (binomial, count), 64-aligned buckets
     dev::CfRow* d_cf_tab = nullptr;                   // K2H_GENERIC x 300 rows of iteration constants
+    int k2_shards = 0;                                // shards (= k2_classify workgroups) of the last fhx_pvalues
     dev::ClsRow* d_cls_tab = nullptr;                 // class thresholds: (max_count + 1) rows for the intra binomial, then the inter one
     int64_t cls_tab_counts = 0;                       // rows per binomial it was built for, with these totals:
     double cls_tab_n[2] = {-1.0, -1.0};
@@ -2092,12 +2073,12 @@ int grid_for(int64_t n, int threads, int max_blocks = 256 * 8) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(b, max_blocks));
 }
 
-// k2_classify over n rows: workgroup b of `grid` takes tiles b, b + grid, ... and queues into shard b % K2_SHARDS, so a shard
-// receives at most ceil(grid / K2_SHARDS) * ceil(tiles / grid) tiles of rows, whatever their classes
-int k2_classify_grid(int64_t n) { return grid_for(n, K2_CL_TILE, 256 * 8); }
-long long k2_shard_capacity(int64_t n) {
+// k2_classify over n rows: workgroup b of `grid` takes tiles b, b + grid, ... and queues into shard b, so a shard receives at
+// most ceil(tiles / grid) tiles of rows, whatever their classes
+int k2_classify_grid(int64_t n) { return grid_for(n, K2_CL_TILE, K2_MAX_SHARDS); }
+long long k2_shard_capacity(int64_t n) {              // entries per shard region: the rows one workgroup of k2_classify can meet
     const long long tiles = std::max<long long>(1, (n + K2_CL_TILE - 1) / K2_CL_TILE), grid = k2_classify_grid(n);
-    return ((grid + K2_SHARDS - 1) / K2_SHARDS) * ((tiles + grid - 1) / grid) * (long long)K2_CL_TILE;
+    return ((tiles + grid - 1) / grid) * (long long)K2_CL_TILE;
 }
 
 K2Params make_k2_params(fhx_ctx* c) {
@@ -2452,7 +2433,7 @@ int alloc_row_arrays(fhx_ctx* ctx, int64_t n, int64_t n_dist) {
     //   K3: keys[0], keys[1] (8 B/row each)            | vals[0], vals[1] (4 B/row each)
     // (-r 0 sorts distances in K1 and lists outlier distances after K3 through the K3 view.)
     dev_free(ctx->d_work);
-    const size_t qcap = std::max<size_t>(cap, (size_t)K2_SHARDS * (size_t)k2_shard_capacity((int64_t)cap));   // sharded queues: k2_classify
+    const size_t qcap = std::max<size_t>(cap, (size_t)k2_classify_grid((int64_t)cap) * (size_t)k2_shard_capacity((int64_t)cap));   // sharded queues: k2_classify
     const size_t work_bytes = qcap * 32 + std::max(qcap, cap + (size_t)K2H_BUCKETS * 64 * K2H_MAX_ROWS) * sizeof(QEntry);   // queue 0 | queue 1 | sorted heavy queue / closed-form queue
     FHX_HIP(hipMalloc(&ctx->d_work, work_bytes));
     ctx->queue_cap = (int64_t)qcap;
@@ -3046,18 +3027,19 @@ int fhx_pvalues(fhx_ctx* ctx) {
     if (memo_cap >= 0) {
         k2_n = (int64_t)memo_nd * (memo_cap + 1) + (memo_inter ? (memo_cap + 1) : 0);
         over_cap = (unsigned long long)std::max<int64_t>(ctx->n_rows / 16, 1024);
-        const size_t need = (size_t)k2_n * (4 + 4 + 4 + 8) + (size_t)over_cap * 4 + 64;
+        const size_t col = ((size_t)k2_n + 3) / 4 * 4;                               // the three columns are read 16 bytes at a time
+        const size_t need = col * (4 + 4 + 4 + 8) + (size_t)over_cap * 4 + 64;
         if (need > ctx->memo_bytes) {
             dev_free(ctx->d_memo);
             ctx->memo_bytes = 0;
             FHX_HIP(hipMalloc(&ctx->d_memo, need));
             ctx->memo_bytes = need;
         }
-        v_table = reinterpret_cast<double*>(ctx->d_memo);                             // 8-byte items first
-        v_loc1 = reinterpret_cast<int32_t*>(ctx->d_memo + (size_t)k2_n * 8);
-        v_loc2 = v_loc1 + k2_n;
-        v_count = v_loc2 + k2_n;
-        over_rows = reinterpret_cast<unsigned int*>(v_count + k2_n);
+        v_loc1 = reinterpret_cast<int32_t*>(ctx->d_memo);
+        v_loc2 = v_loc1 + col;
+        v_count = v_loc2 + col;
+        v_table = reinterpret_cast<double*>(v_count + col);
+        over_rows = reinterpret_cast<unsigned int*>(v_table + col);
         hipLaunchKernelGGL(k2_memo_rows, dim3(grid_for(k2_n, 256)), dim3(256), 0, ctx->stream, memo_nd, P.lo_idx, memo_cap, (int)memo_inter,
                            v_loc1, v_loc2, v_count, k2_n);
         P.loc1 = v_loc1;
@@ -3070,33 +3052,43 @@ int fhx_pvalues(fhx_ctx* ctx) {
     // two entry buffers of n_rows each: [swapped CF up | power series down] and [incbcf up | incbd down]
     K2Queues Q;
     const long long cap_s = k2_shard_capacity(k2_n);
-    if ((int64_t)K2_SHARDS * cap_s > ctx->queue_cap) return fail(ctx, FHX_ERR_HIP, "internal: queue workspace smaller than the shard layout");
-    if (!ctx->d_k2_counts) FHX_HIP(hipMalloc(&ctx->d_k2_counts, (size_t)(K2_QUEUES + 1) * K2_SHARDS * K2_COUNT_STRIDE * sizeof(unsigned long long)));
+    const int n_shards = k2_classify_grid(k2_n);
+    if ((int64_t)n_shards * cap_s > ctx->queue_cap) return fail(ctx, FHX_ERR_HIP, "internal: queue workspace smaller than the shard layout");
+    if (!ctx->d_k2_counts) FHX_HIP(hipMalloc(&ctx->d_k2_counts, (size_t)(K2_QUEUES + 1) * K2_MAX_SHARDS * sizeof(unsigned long long)));
     Q.count = ctx->d_k2_counts;
+    ctx->k2_shards = n_shards;
     auto span = [&](int cls, QEntry* buf, int dir) {
         QSpan& q = Q.q[cls - 1];
         q.base = dir > 0 ? buf : buf + cap_s - 1;
         q.cap_s = cap_s;
         q.dir = dir;
-        q.count = Q.count + (size_t)(cls - 1) * K2_SHARDS * K2_COUNT_STRIDE;
+        q.n_shards = n_shards;
+        q.count = Q.count + (size_t)(cls - 1) * K2_MAX_SHARDS;
     };
     span(dev::BC_CF_SWAPPED, ctx->d_queue[0], 1);
     span(dev::BC_PSERIES, ctx->d_queue[0], -1);
     span(dev::BC_CF_BCF, ctx->d_queue[1], 1);
     span(dev::BC_CF_BD, ctx->d_queue[1], -1);
     span(K2_CLOSED, ctx->d_queue_sorted, 1);             // the sorted heavy queue is written after k2_closed has run
-    FHX_HIP(hipMemsetAsync(Q.count, 0, (size_t)(K2_QUEUES + 1) * K2_SHARDS * K2_COUNT_STRIDE * sizeof(unsigned long long), ctx->stream));
+    // (no reset of the counters: every workgroup of k2_classify writes its own shard's counts)
     {
         const dim3 cgrid(k2_classify_grid(k2_n)), cblock(K2_THREADS);
+        static const int wpe = std::getenv("FHX_CL_WAVES") ? std::atoi(std::getenv("FHX_CL_WAVES")) : 0;        // measurements only
+        static const int table = std::getenv("FHX_CL_TABLE") ? std::atoi(std::getenv("FHX_CL_TABLE")) : 0;
         if (P.nonfixed)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<1, K2_CL_ITEMS, 4>), cgrid, cblock, 0, ctx->stream, P, Q);
-        else {
-            static const int wpe = std::getenv("FHX_CL_WAVES") ? std::atoi(std::getenv("FHX_CL_WAVES")) : 0;    // measurements only
-            if (wpe == 4)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, K2_CL_ITEMS, 4>), cgrid, cblock, 0, ctx->stream, P, Q);
-            else        // 6 waves/SIMD: 80 VGPRs + 20 B of scratch; measured 1.92 ms against 2.01 at 4 (102 VGPRs), r02_v_classify.txt
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, K2_CL_ITEMS, 6>), cgrid, cblock, 0, ctx->stream, P, Q);
-        }
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<1, 4, 0>), cgrid, cblock, 0, ctx->stream, P, Q);
+        else if (table == 1 && wpe == 6)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, 6, 1>), cgrid, cblock, 0, ctx->stream, P, Q);
+        else if (table == 1)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, 4, 1>), cgrid, cblock, 0, ctx->stream, P, Q);
+        else if (table == 2 && wpe == 6)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, 6, 2>), cgrid, cblock, 0, ctx->stream, P, Q);
+        else if (table == 2)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, 4, 2>), cgrid, cblock, 0, ctx->stream, P, Q);
+        else if (wpe == 6)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, 6, 0>), cgrid, cblock, 0, ctx->stream, P, Q);
+        else        // 4 waves/SIMD (98 VGPRs, no scratch): 1.85 ms against 1.95 at 6 (80 VGPRs + 44 B of scratch), profiles/r03_e_*
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, 4, 0>), cgrid, cblock, 0, ctx->stream, P, Q);
     }
     const dim3 qgrid(256 * 8), qblock(K2_THREADS);
     hipLaunchKernelGGL(k2_closed, qgrid, qblock, 0, ctx->stream, P, Q.q[K2_CLOSED - 1]);
@@ -3870,10 +3862,12 @@ int fhx_k2_heavy_launch(fhx_ctx* ctx, double* seconds, int64_t* rows) {
     FHX_HIP(hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
     FHX_HIP(hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]));
-    unsigned long long n = 0, part[K2_SHARDS * K2_COUNT_STRIDE];
-    if (!ctx->d_k2_counts) return fail(ctx, FHX_ERR_ARG, "fhx_pvalues has not run");
-    FHX_HIP(hipMemcpy(part, ctx->d_k2_counts + (size_t)(dev::BC_CF_SWAPPED - 1) * K2_SHARDS * K2_COUNT_STRIDE, sizeof(part), hipMemcpyDeviceToHost));
-    for (int sh = 0; sh < K2_SHARDS; ++sh) n += part[sh * K2_COUNT_STRIDE];
+    unsigned long long n = 0;
+    if (!ctx->d_k2_counts || ctx->k2_shards <= 0) return fail(ctx, FHX_ERR_ARG, "fhx_pvalues has not run");
+    std::vector<unsigned long long> part((size_t)ctx->k2_shards);
+    FHX_HIP(hipMemcpy(part.data(), ctx->d_k2_counts + (size_t)(dev::BC_CF_SWAPPED - 1) * K2_MAX_SHARDS, part.size() * sizeof(unsigned long long),
+                      hipMemcpyDeviceToHost));
+    for (unsigned long long v : part) n += v;
     if (std::getenv("FHX_DEBUG_HEAVY")) {                  // how many rows the uniform kernel handed back to the per-lane loop
         unsigned long long redo = 0;
         FHX_HIP(hipMemcpy(&redo, ctx->d_misc + 11, sizeof(redo), hipMemcpyDeviceToHost));
