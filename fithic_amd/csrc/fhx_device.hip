@@ -289,6 +289,26 @@ __global__ __launch_bounds__(THREADS) void k1_classify_hist(
     }
 }
 
+// [7 sums | max_count | sumCC[a .. a + w) | rows[a .. a + w)] in one block: what the host fit needs of K1's output leaves the
+// device in ONE small copy (the histograms are as long as the longest chromosome - 400 KB each at 5 kb - but only the distance
+// window of the run can be non-zero: 397 entries of each on C3)
+__global__ void k1_pack_window(const K1Sums* __restrict__ sums, const unsigned long long* __restrict__ hist_cc,
+                               const unsigned long long* __restrict__ hist_np, int a, int w, long long* __restrict__ pack) {
+    const int total = 8 + 2 * w;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        long long v;
+        if (i < 7)
+            v = reinterpret_cast<const long long*>(sums)[i];
+        else if (i == 7)
+            v = (long long)sums->max_count;
+        else if (i < 8 + w)
+            v = (long long)hist_cc[a + (i - 8)];
+        else
+            v = (long long)hist_np[a + (i - 8 - w)];
+        pack[i] = v;
+    }
+}
+
 // ===================================================================================================
 // K2: per-pair prior + binomial survival p-value
 // ===================================================================================================
@@ -1961,6 +1981,8 @@ struct fhx_ctx {
     unsigned long long* d_k2_counts = nullptr;        // (K2_QUEUES + 1) x K2_MAX_SHARDS queue counters
     QEntry* d_queue_sorted = nullptr;                 // the 300-iteration class, bucketed by (binomial, count), 64-aligned buckets
     dev::CfRow* d_cf_tab = nullptr;                   // K2H_GENERIC x 300 rows of iteration constants
+    long long *d_stats_stage = nullptr, *h_stats_stage = nullptr;   // K1's sums + histogram window: device block, pinned host copy
+    size_t stats_stage_cap = 0;
     int k2_shards = 0;                                // shards (= k2_classify workgroups) of the last fhx_pvalues
     dev::ClsRow* d_cls_tab = nullptr;                 // class thresholds: (max_count + 1) rows for the intra binomial, then the inter one
     int64_t cls_tab_counts = 0;                       // rows per binomial it was built for, with these totals:
@@ -2543,6 +2565,9 @@ void fhx_destroy(fhx_ctx* ctx) {
         dev_free(ctx->d_top_hist);
         dev_free(ctx->d_k2_hist);
         dev_free(ctx->d_cf_tab);
+        dev_free(ctx->d_cls_tab);
+        dev_free(ctx->d_stats_stage);
+        if (ctx->h_stats_stage) (void)hipHostFree(ctx->h_stats_stage);
         dev_free(ctx->d_k2h_off);
         dev_free(ctx->d_k2_counts);
         dev_free(ctx->d_memo);
@@ -2769,26 +2794,46 @@ int fhx_pass_stats(fhx_ctx* ctx, fhx_stats* out) {
         const int rc = launch_k1(ctx);
         if (rc != FHX_OK) return rc;
     }
-    K1Sums s{};
-    ctx->h_hist_cc.assign((size_t)ctx->n_dist, 0);
-    ctx->h_hist_np.assign((size_t)ctx->n_dist, 0);
-    FHX_HIP(hipMemcpyAsync(&s, ctx->d_sums, sizeof(K1Sums), hipMemcpyDeviceToHost, ctx->stream));
-    FHX_HIP(hipMemcpyAsync(ctx->h_hist_cc.data(), ctx->d_hist_cc, ctx->n_dist * sizeof(int64_t), hipMemcpyDeviceToHost,
-                           ctx->stream));
-    FHX_HIP(hipMemcpyAsync(ctx->h_hist_np.data(), ctx->d_hist_np, ctx->n_dist * sizeof(int64_t), hipMemcpyDeviceToHost,
-                           ctx->stream));
+    // the sums and the in-range window of the two histograms (K1 touches no bin outside it) packed on the device and copied
+    // in one piece into pinned memory: three pageable copies of 64 B + 2 x n_dist x 8 B were ~100 us of a small shard's pass
+    const int64_t res = ctx->prm.resolution;
+    const int64_t nd = ctx->n_dist;
+    const int64_t a = std::min<int64_t>(std::max<int64_t>(0, (ctx->prm.dist_low + res - 1) / res), nd);
+    const int64_t b = (ctx->prm.dist_up == INT64_MAX) ? nd : std::max(a, std::min<int64_t>(nd, ctx->prm.dist_up / res + 1));
+    const int w = (int)(b - a);
+    const size_t pack_len = 8 + 2 * (size_t)w;
+    if (pack_len > ctx->stats_stage_cap) {
+        if (ctx->d_stats_stage) (void)hipFree(ctx->d_stats_stage);
+        if (ctx->h_stats_stage) (void)hipHostFree(ctx->h_stats_stage);
+        ctx->d_stats_stage = ctx->h_stats_stage = nullptr;
+        ctx->stats_stage_cap = 0;
+        FHX_HIP(hipMalloc(&ctx->d_stats_stage, (pack_len + 1024) * sizeof(long long)));
+        FHX_HIP(hipHostMalloc((void**)&ctx->h_stats_stage, (pack_len + 1024) * sizeof(long long), hipHostMallocDefault));
+        ctx->stats_stage_cap = pack_len + 1024;
+    }
+    hipLaunchKernelGGL(k1_pack_window, dim3(grid_for((int64_t)pack_len, 256, 64)), dim3(256), 0, ctx->stream, (const K1Sums*)ctx->d_sums,
+                       (const unsigned long long*)ctx->d_hist_cc, (const unsigned long long*)ctx->d_hist_np, (int)a, w, ctx->d_stats_stage);
+    FHX_HIP(hipGetLastError());
+    FHX_HIP(hipMemcpyAsync(ctx->h_stats_stage, ctx->d_stats_stage, pack_len * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
     FHX_HIP(hipStreamSynchronize(ctx->stream));
+    const long long* pk = ctx->h_stats_stage;
+    ctx->h_hist_cc.assign((size_t)nd, 0);
+    ctx->h_hist_np.assign((size_t)nd, 0);
+    for (int i = 0; i < w; ++i) {
+        ctx->h_hist_cc[(size_t)a + i] = pk[8 + i];
+        ctx->h_hist_np[(size_t)a + i] = pk[8 + w + i];
+    }
     fhx_stats& st = ctx->stats;
     st.n_rows = ctx->n_rows;
-    st.inter_count = s.inter_count;
-    st.inter_sum = s.inter_sum;
-    st.intra_all_count = s.intra_all_count;
-    st.intra_all_sum = s.intra_all_sum;
-    st.in_range_count = s.in_range_count;
-    st.in_range_sum = s.in_range_sum;
-    st.max_count = s.max_count;
+    st.inter_count = pk[0];
+    st.inter_sum = pk[1];
+    st.intra_all_count = pk[2];
+    st.intra_all_sum = pk[3];
+    st.in_range_count = pk[4];
+    st.in_range_sum = pk[5];
+    st.max_count = pk[7];
     st.n_dist = ctx->n_dist;
-    st.n_skipped = s.n_skipped;
+    st.n_skipped = pk[6];
     ctx->have_stats = true;
     ctx->have_fit = ctx->have_bins = ctx->have_p = ctx->have_q = false;
     if (out) *out = st;
