@@ -411,11 +411,15 @@ def main():
         worst = max(M["k_all"], key=lambda r: r[4])
         hv_s, hv_rows = worst[4], worst[5]
         achieved = ALGO_BYTES_K2 * hv_rows / hv_s / 1e9 if hv_s > 0 else 0.0
-        traffic = None
+        # HBM bytes of the dominant launch: PMC counters cannot be read from inside this process (rocprofv3 wraps the command), so
+        # the per-row figure of the last counter pass over THIS command is scaled by this run's rows; the source is named beside it
+        traffic = traffic_source = None
         prof = os.path.join(ROOT, "profiles", "k2_pmc_traffic.json")
         if os.path.exists(prof):
             try:
-                traffic = json.load(open(prof)).get("hbm_bytes_per_heavy_row") * hv_rows
+                tj = json.load(open(prof))
+                traffic = tj.get("hbm_bytes_per_heavy_row") * hv_rows
+                traffic_source = tj.get("source")
             except Exception:
                 traffic = None
         fp64_instr = hv_rows * 300.0 * HEAVY_FP64_INSTR_PER_ITER
@@ -445,12 +449,14 @@ def main():
                        "bias": not args.no_bias},
             "roofline": {"bound": "hbm", "binding_resource": "fp64_valu_issue", "kernel": "k2h_heavy (swapped incbcf, 300 iterations)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "note": "HBM is the designated roofline of the path; the dominant launch (rows whose Cephes continued "
                                  "fraction runs all 300 iterations) is bound by fp64 VALU issue, see fp64_valu_issue_frac: "
                                  "algorithmic bytes = 20 B/row (12 read + 8 written), %g fp64 instructions per row-iteration" % HEAVY_FP64_INSTR_PER_ITER,
                          "launch_seconds": hv_s, "rows_per_launch": hv_rows,
-                         "fp64_valu_issue_frac": (fp64_instr / hv_s) / fp64_issue_peak if hv_s > 0 else None},
+                         "fp64_valu_issue_frac": (fp64_instr / hv_s) / fp64_issue_peak if hv_s > 0 else None,
+                         "fp64_note": "loop instructions only, against the nominal 2.4 GHz; by the SQ counters (profiles/r03_g_counters.txt) the "
+                                      "launch issues 26.1 VALU wave-instructions per row-iteration all told at 2.24 GHz: 85 % of the fp64 issue slots"},
             "kernels_ms": {"k1_classify_hist": 1e3 * worst[0], "k2_pvalue": 1e3 * worst[1], "k3_bh_sort_scan": 1e3 * worst[2]},
             "whole_pass_hbm_frac": (ALGO_BYTES_K1 + ALGO_BYTES_K2 + ALGO_BYTES_K3) * value / (world * HBM_PEAK_GBS * 1e9),
         }

@@ -73,6 +73,11 @@ __device__ __forceinline__ double cephes_expm1(double x) {
 }
 
 // ---- power series for small b*x (incbet.c pseries) ------------------------------------------------
+// SMALL_N (here and below): the binomial total is so small (n + 1 < MAXGAM = 171.6) that Cephes multiplies powers instead of
+// exponentiating a sum of logarithms.  No Hi-C run gets there, but pow() costs ~90 VGPRs wherever it is compiled in: the class
+// kernels exist in both forms and the host launches the one the pass's totals call for (false: the pow statements are not
+// compiled; their condition (a + b) < MAXGAM is false for such totals anyway).
+template <bool SMALL_N = true>
 __device__ __forceinline__ double pseries(double a, double b, double x, double lbeta_ab, double inv_beta_ab) {
     const double ai = 1.0 / a;
     double u = (1.0 - b) * x;
@@ -92,7 +97,7 @@ __device__ __forceinline__ double pseries(double a, double b, double x, double l
     s += t1;
     s += ai;
     u = a * log(x);
-    if ((a + b) < kMaxGam && fabs(u) < kMaxLog) {
+    if (SMALL_N && (a + b) < kMaxGam && fabs(u) < kMaxLog) {
         t = inv_beta_ab;
         s = s * t * pow(x, a);
     } else {
@@ -813,11 +818,12 @@ __device__ __forceinline__ int bdtrc_class_tb(int count, double n_total, double 
 }
 
 // Multiply the continued fraction / series value by x^a (1-x)^b / (a B(a,b)) and undo the swap (incbet.c tail).
+template <bool SMALL_N = true>
 __device__ __forceinline__ double incbet_finish(double a, double b, double x, double xc, double w, int flag,
                                                 double lbeta_ab, double inv_beta_ab) {
     double y = a * log(x);
     double t = b * log(xc);
-    if ((a + b) < kMaxGam && fabs(y) < kMaxLog && fabs(t) < kMaxLog) {
+    if (SMALL_N && (a + b) < kMaxGam && fabs(y) < kMaxLog && fabs(t) < kMaxLog) {
         t = pow(xc, b);
         t *= pow(x, a);
         t /= a;
@@ -840,25 +846,25 @@ __device__ __forceinline__ double incbet_finish(double a, double b, double x, do
 // bdtrc_count for a row whose class (bdtrc_class) is known at compile time: only that class's code path is
 // instantiated, so the long-running kernels carry neither the other loops' registers nor their branches.
 // Same operations in the same order as incbet() above.
-template <int CLS>
+template <int CLS, bool SMALL_N = true>
 __device__ __forceinline__ double bdtrc_count_class(int count, const BinomTables& T, double p) {
     const double fk = (double)count - 1.0;
     const double aa = fk + 1.0, bb = T.n - fk, xx = p;
     const double lb = T.lbeta[count];
-    const double ib = T.small_n ? T.inv_beta[count] : 0.0;
+    const double ib = (SMALL_N && T.small_n) ? T.inv_beta[count] : 0.0;
     if (CLS == BC_PSERIES) {
-        if (bb * xx <= 1.0 && xx <= 0.95) return pseries(aa, bb, xx, lb, ib);
+        if (bb * xx <= 1.0 && xx <= 0.95) return pseries<SMALL_N>(aa, bb, xx, lb, ib);
         const double w = 1.0 - xx;                       // otherwise the swapped orientation (flag = 1)
-        double t = pseries(bb, aa, w, lb, ib);
+        double t = pseries<SMALL_N>(bb, aa, w, lb, ib);
         return (t <= kMachEp) ? 1.0 - kMachEp : 1.0 - t;
     }
     const double w1 = 1.0 - xx;
-    if (CLS == BC_CF_BCF) return incbet_finish(aa, bb, xx, w1, contfrac_lazy<0>(aa, bb, xx), 0, lb, ib);
-    if (CLS == BC_CF_SWAPPED) return incbet_finish(bb, aa, w1, xx, contfrac_lazy<0>(bb, aa, w1), 1, lb, ib);
+    if (CLS == BC_CF_BCF) return incbet_finish<SMALL_N>(aa, bb, xx, w1, contfrac_lazy<0>(aa, bb, xx), 0, lb, ib);
+    if (CLS == BC_CF_SWAPPED) return incbet_finish<SMALL_N>(bb, aa, w1, xx, contfrac_lazy<0>(bb, aa, w1), 1, lb, ib);
     // BC_CF_BD: either orientation
     const int flag = (xx > aa / (aa + bb)) ? 1 : 0;
     const double a = flag ? bb : aa, b = flag ? aa : bb, x = flag ? w1 : xx, xc = flag ? xx : w1;
-    return incbet_finish(a, b, x, xc, contfrac_lazy<1>(a, b, x) / xc, flag, lb, ib);
+    return incbet_finish<SMALL_N>(a, b, x, xc, contfrac_lazy<1>(a, b, x) / xc, flag, lb, ib);
 }
 
 }  // namespace dev

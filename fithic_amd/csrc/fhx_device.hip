@@ -658,7 +658,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_closed(K2Params P, QSpan q) {
     H.flush(P.top_hist);
 }
 
-template <int CLS>
+template <int CLS, bool SMALL_N>
 __global__ __launch_bounds__(K2_THREADS) void k2_queue(K2Params P, QSpan q) {
     __shared__ unsigned int hist_lds[K2_HIST_BINS];
     FusedHist H;
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_queue(K2Params P, QSpan q) {
             const QEntry e = *qentry(q, sh, j);
             const bool is_inter = e.count < 0;
             const int c = is_inter ? -e.count : e.count;
-            const double pv = dev::bdtrc_count_class<CLS>(c, is_inter ? P.inter : P.intra, e.prior);
+            const double pv = dev::bdtrc_count_class<CLS, SMALL_N>(c, is_inter ? P.inter : P.intra, e.prior);
             store_p<false>(P.p + e.row, pv);
             H.add(pv);
         }
@@ -683,8 +683,8 @@ __global__ __launch_bounds__(K2_THREADS) void k2_queue(K2Params P, QSpan q) {
 // every wave 64 neighbours of that order (per-wave maximum 11.4).  Results go to P.p[row], so the order is free.
 constexpr int K2_SORT_TILE = 1024;
 constexpr int K2_SORT_BUCKETS = 32;
-template <int CLS>
-__global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void k2_queue_by_count(K2Params P, QSpan q) {
+template <int CLS, bool SMALL_N, int WPE>
+__global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE))) void k2_queue_by_count(K2Params P, QSpan q) {
     static_assert(K2_SORT_TILE == 4 * K2_THREADS, "four entries per thread");
     __shared__ QEntry tile[K2_SORT_TILE];
     __shared__ unsigned int bucket_cnt[K2_SORT_BUCKETS], bucket_off[K2_SORT_BUCKETS];
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
                 const QEntry x = tile[idx];
                 const bool is_inter = x.count < 0;
                 const int c = is_inter ? -x.count : x.count;
-                const double pv = dev::bdtrc_count_class<CLS>(c, is_inter ? P.inter : P.intra, x.prior);
+                const double pv = dev::bdtrc_count_class<CLS, SMALL_N>(c, is_inter ? P.inter : P.intra, x.prior);
                 store_p<false>(P.p + x.row, pv);
                 H.add(pv);
             }
@@ -833,7 +833,7 @@ struct K2HeavyParams {            // the few fields of K2Params this kernel read
 // R rows per lane (a task = 64 R consecutive entries of one bucket: every bucket starts at a multiple of that), WPE waves per
 // SIMD: see cf_swapped_uniform for why more rows per lane beat more waves.
 constexpr int K2H_MAX_ROWS = 4;
-template <int R, int WPE>
+template <int R, int WPE, bool SMALL_N>
 __global__ __launch_bounds__(K2H_THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k2h_heavy(
     K2HeavyParams P, const QEntry* __restrict__ sorted, const unsigned int* __restrict__ off,
     const unsigned int* __restrict__ digit_total, const dev::CfRow* __restrict__ tab, QEntry* __restrict__ redo,
@@ -890,7 +890,7 @@ __global__ __launch_bounds__(K2H_THREADS) __attribute__((amdgpu_waves_per_eu(WPE
                 if (__builtin_expect(irregular[r], 0))
                     redo[atomicAdd(n_redo, 1ull)] = e[r];
                 else {
-                    pv = dev::incbet_finish(bb, aa, w1[r], e[r].prior, cf[r], 1, T.lbeta[c], T.small_n ? T.inv_beta[c] : 0.0);
+                    pv = dev::incbet_finish<SMALL_N>(bb, aa, w1[r], e[r].prior, cf[r], 1, T.lbeta[c], (SMALL_N && T.small_n) ? T.inv_beta[c] : 0.0);
                     store_p<true>(P.p + e[r].row, pv);
                 }
             }
@@ -3137,7 +3137,16 @@ int fhx_pvalues(fhx_ctx* ctx) {
     }
     const dim3 qgrid(256 * 8), qblock(K2_THREADS);
     hipLaunchKernelGGL(k2_closed, qgrid, qblock, 0, ctx->stream, P, Q.q[K2_CLOSED - 1]);
-#define FHX_LAUNCH_QUEUE(CLS) hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue<CLS>), qgrid, qblock, 0, ctx->stream, P, Q.q[(CLS) - 1])
+    // totals below 171: the kernels that carry Cephes' pow branch (a binomial without a single contact - no inter-chromosomal
+    // rows - classifies every row as trivial and reaches no class kernel: it does not count)
+    const bool small_n = (P.intra.small_n && P.intra.n >= 1.0) || (P.inter.small_n && P.inter.n >= 1.0);
+#define FHX_LAUNCH_QUEUE(CLS)                                                                                         \
+    do {                                                                                                              \
+        if (small_n)                                                                                                  \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue<CLS, true>), qgrid, qblock, 0, ctx->stream, P, Q.q[(CLS) - 1]);  \
+        else                                                                                                          \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue<CLS, false>), qgrid, qblock, 0, ctx->stream, P, Q.q[(CLS) - 1]); \
+    } while (0)
     const bool legacy_heavy = getenv("FHX_K2_LEGACY") != nullptr;      // A/B and tests: the per-lane kernel of round 1
     if (legacy_heavy) {
         FHX_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
@@ -3156,7 +3165,7 @@ int fhx_pvalues(fhx_ctx* ctx) {
         // 3 x 5, 4 x 3 are within 3 % of each other, profiles/r03_c_heavy_variants.txt); FHX_K2H_ROWS / FHX_K2H_WAVES: measurements
         // rows per lane: 4 at 4 waves/SIMD - C3 (2.7e7 rows in the class) 7.43 -> 6.66 ms, a 1/18 shard (1.5e6 rows) 0.87 -> 0.78 ms of
         // K2 against one row per lane at 8 waves/SIMD; 2 x 8, 3 x 5 and 4 x 3 are within 3 % (profiles/r03_c_*heavy_variants.txt).
-        // FHX_K2H_ROWS / FHX_K2H_WAVES select the other instantiations for measurements.
+        // FHX_K2H_ROWS (1, 2) / FHX_K2H_WAVES (3) select the instantiations kept for measurements.
         static const int heavy_rows = std::getenv("FHX_K2H_ROWS") ? std::atoi(std::getenv("FHX_K2H_ROWS")) : 4;
         static const int heavy_wpe = std::getenv("FHX_K2H_WAVES") ? std::atoi(std::getenv("FHX_K2H_WAVES")) : 0;
         const int hr = (heavy_rows >= 1 && heavy_rows <= K2H_MAX_ROWS) ? heavy_rows : 4;
@@ -3169,27 +3178,38 @@ int fhx_pvalues(fhx_ctx* ctx) {
         FHX_LAUNCH_QUEUE(dev::BC_PSERIES);               // before the redo list reuses the buffer it shares with the heavy queue
         FHX_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
         const K2HeavyParams HP{P.intra, P.inter, P.p, P.top_hist};
-#define FHX_HEAVY(R, W)                                                                                                            \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k2h_heavy<R, W>), dim3(256 * W), dim3(K2H_THREADS), 0, ctx->stream, HP,                        \
+#define FHX_HEAVY_N(R, W, S)                                                                                                        \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k2h_heavy<R, W, S>), dim3(256 * W), dim3(K2H_THREADS), 0, ctx->stream, HP,                     \
                        (const QEntry*)ctx->d_queue_sorted, (const unsigned int*)ctx->d_k2h_off, (const unsigned int*)ctx->d_digit_total, \
                        (const dev::CfRow*)ctx->d_cf_tab, hq, n_redo)
+#define FHX_HEAVY(R, W)           \
+    do {                          \
+        if (small_n)              \
+            FHX_HEAVY_N(R, W, true);  \
+        else                      \
+            FHX_HEAVY_N(R, W, false); \
+    } while (0)
         if (hr == 1) FHX_HEAVY(1, 8);
-        else if (hr == 2 && heavy_wpe == 8) FHX_HEAVY(2, 8);
-        else if (hr == 2 && heavy_wpe == 4) FHX_HEAVY(2, 4);
-        else if (hr == 2) FHX_HEAVY(2, 6);
-        else if (hr == 3 && heavy_wpe == 4) FHX_HEAVY(3, 4);
-        else if (hr == 3) FHX_HEAVY(3, 5);
+        else if (hr == 2) FHX_HEAVY(2, 8);
         else if (heavy_wpe == 3) FHX_HEAVY(4, 3);
-        else if (heavy_wpe == 2) FHX_HEAVY(4, 2);
         else FHX_HEAVY(4, 4);
 #undef FHX_HEAVY
+#undef FHX_HEAVY_N
         FHX_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
         hipLaunchKernelGGL(k2h_generic, dim3(256 * 4), dim3(K2_THREADS), 0, ctx->stream, P, (const QEntry*)ctx->d_queue_sorted,
                            (const unsigned int*)ctx->d_k2h_off, (const unsigned int*)ctx->d_digit_total, (const QEntry*)hq,
                            (const unsigned long long*)n_redo);
     }
-#define FHX_LAUNCH_QUEUE_BY_COUNT(CLS) \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue_by_count<CLS>), qgrid, qblock, 0, ctx->stream, P, Q.q[(CLS) - 1])
+    static const int cf_wpe = std::getenv("FHX_CF_WAVES") ? std::atoi(std::getenv("FHX_CF_WAVES")) : 0;              // measurements
+#define FHX_LAUNCH_QUEUE_BY_COUNT(CLS)                                                                                                \
+    do {                                                                                                                              \
+        if (small_n)                                                                                                                  \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue_by_count<CLS, true, 4>), qgrid, qblock, 0, ctx->stream, P, Q.q[(CLS) - 1]);      \
+        else if (cf_wpe == 4)                                                                                                         \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue_by_count<CLS, false, 4>), qgrid, qblock, 0, ctx->stream, P, Q.q[(CLS) - 1]);     \
+        else                                                                                                                          \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue_by_count<CLS, false, 5>), qgrid, qblock, 0, ctx->stream, P, Q.q[(CLS) - 1]);     \
+    } while (0)
     FHX_LAUNCH_QUEUE_BY_COUNT(dev::BC_CF_BD);
     FHX_LAUNCH_QUEUE_BY_COUNT(dev::BC_CF_BCF);
     if (legacy_heavy) FHX_LAUNCH_QUEUE(dev::BC_PSERIES);
