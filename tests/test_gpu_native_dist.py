@@ -173,8 +173,8 @@ def test_ranks_on_a_grid_follow_the_ranks_that_are_not(tmp_path):
 
 
 # FHX_FUZZ_SEEDS="lo:hi": random cases of tests/test_gpu_fuzz.py's generator, rows dealt to 2 or 3 ranks at random (one rank may
-# get nothing): every rank's p and q must equal the single-GPU run's bits.  Default: four seeds.
-_LO, _HI = (int(v) for v in os.environ.get("FHX_FUZZ_SEEDS", "0:4").split(":"))
+# get nothing): every rank's p and q must equal the single-GPU run's bits.  Default: six seeds (two of each kind of loci).
+_LO, _HI = (int(v) for v in os.environ.get("FHX_FUZZ_SEEDS", "0:6").split(":"))
 
 
 @pytest.mark.parametrize("seed", range(_LO, _HI))
@@ -183,7 +183,8 @@ def test_native_sharded_pass_on_random_cases(seed, tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import test_gpu_fuzz as tf
     rng = np.random.default_rng(77000 + seed)
-    paths, kw, n_rows, _ = tf._make_case(rng, str(tmp_path), False)
+    # every third case with irregular midpoints under -r 0, every third with irregular midpoints under -r N (explicit distances)
+    paths, kw, n_rows, _ = tf._make_case(rng, str(tmp_path), seed % 3 == 1, offgrid=seed % 3 == 2)
     if kw["mode"] == "interOnly" or n_rows < 8:
         pytest.skip("no spline pass / too few rows")
     from oracle import fithic_oracle as fo
