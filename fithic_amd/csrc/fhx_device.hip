@@ -1237,26 +1237,45 @@ __global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restr
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     const int64_t tiles = (n + SORT_TILE - 1) / SORT_TILE;
     const unsigned long long cutoff = *cutoff_key;
+    const double2* p2 = reinterpret_cast<const double2*>(p);
+    double2* q2 = reinterpret_cast<double2*>(q);
     for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
         const int64_t wave_base = t * SORT_TILE + (int64_t)wave * (64 * SORT_ITEMS);
+        // two consecutive rows per lane and step: 16-byte loads of p and (for the rows that are not ranked: nearly all) 16-byte
+        // stores of q
         double v[SORT_ITEMS];
         unsigned int before[SORT_ITEMS];
         unsigned long long keepmask = 0;          // bit r: this lane keeps item r
         unsigned int run = 0;
 #pragma unroll
-        for (int r = 0; r < SORT_ITEMS; ++r) {
-            const int64_t i = wave_base + r * 64 + lane;
-            bool keep = false;
-            v[r] = 1.0;
-            if (i < n) {
-                v[r] = p[i];
-                keep = (v[r] == v[r]) && (pvalue_key(v[r]) < cutoff);        // false for NaN; p >= 1 stays when nothing saturates
-                if (!keep) q[i] = (v[r] == v[r]) ? 1.0 : v[r];
+        for (int h = 0; h < SORT_ITEMS / 2; ++h) {
+            const int64_t i = wave_base + (int64_t)(h * 64 + lane) * 2;
+            bool keep0 = false, keep1 = false;
+            v[2 * h] = v[2 * h + 1] = 1.0;
+            if (i + 1 < n) {
+                const double2 w = p2[i >> 1];
+                v[2 * h] = w.x;
+                v[2 * h + 1] = w.y;
+                keep0 = (w.x == w.x) && (pvalue_key(w.x) < cutoff);        // false for NaN; p >= 1 stays when nothing saturates
+                keep1 = (w.y == w.y) && (pvalue_key(w.y) < cutoff);
+                if (!keep0 && !keep1) {
+                    q2[i >> 1] = make_double2((w.x == w.x) ? 1.0 : w.x, (w.y == w.y) ? 1.0 : w.y);
+                } else {
+                    if (!keep0) q[i] = (w.x == w.x) ? 1.0 : w.x;
+                    if (!keep1) q[i + 1] = (w.y == w.y) ? 1.0 : w.y;
+                }
+            } else if (i < n) {                                            // the last row of an odd count
+                v[2 * h] = p[i];
+                keep0 = (v[2 * h] == v[2 * h]) && (pvalue_key(v[2 * h]) < cutoff);
+                if (!keep0) q[i] = (v[2 * h] == v[2 * h]) ? 1.0 : v[2 * h];
             }
-            const unsigned long long m = __ballot(keep);
-            before[r] = run + __popcll(m & lane_lt);
-            run += __popcll(m);
-            if (keep) keepmask |= (1ull << r);
+            const unsigned long long m0 = __ballot(keep0), m1 = __ballot(keep1);
+            before[2 * h] = run + __popcll(m0 & lane_lt);
+            run += __popcll(m0);
+            before[2 * h + 1] = run + __popcll(m1 & lane_lt);
+            run += __popcll(m1);
+            if (keep0) keepmask |= (1ull << (2 * h));
+            if (keep1) keepmask |= (1ull << (2 * h + 1));
         }
         if (lane == 0) wave_cnt[wave] = run;
         __syncthreads();
@@ -1275,7 +1294,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restr
         for (int r = 0; r < SORT_ITEMS; ++r) {
             if ((keepmask >> r) & 1ull) {
                 keys[base + before[r]] = pvalue_key(v[r]);
-                vals[base + before[r]] = (unsigned int)(wave_base + r * 64 + lane);
+                vals[base + before[r]] = (unsigned int)(wave_base + (int64_t)((r >> 1) * 64 + lane) * 2 + (r & 1));
             }
         }
         __syncthreads();
