@@ -783,7 +783,7 @@ def make_f14():
     import bench
     from fithic_amd import synth
     src = os.environ.get("FHX_SYNTH_HIST", os.path.join(os.path.dirname(os.path.dirname(HERE)), "gpurun_out", "r03", "synth_hist"))
-    for name in ("C3", "C3w", "C5"):
+    for name in ("C2", "C3", "C3w", "C5"):                 # C2: pass 1 of its two passes (the second depends on the first's outliers)
         cfg = bench.CONFIGS[name]
         H = np.load(os.path.join(src, "synth_hist_%s.npz" % name))
         res = cfg["res"]
@@ -800,8 +800,9 @@ def make_f14():
         in_range_sum = int(H["sumcc"].sum())
         main_dic = {int(i) * res: [0, int(v)] for i, v in zip(H["dist_idx"], H["sumcc"])}
         inter_count, inter_sum = (int(v) for v in H["inter"])
-        argv = ["-i", contacts, "-f", frags, "-o", tmp, "-r", str(res), "-l", "G", "-b", "100", "-p", "1", "-x", cfg["mode"],
-                "-L", str(cfg["L"])]
+        argv = ["-i", contacts, "-f", frags, "-o", tmp, "-r", str(res), "-l", "G", "-b", "100", "-p", "1", "-x", cfg["mode"]]
+        if cfg["L"]:
+            argv += ["-L", str(cfg["L"])]
         if cfg["U"] != float("inf"):
             argv += ["-U", str(cfg["U"])]
         passes, dt = run_reference(argv, observed=(main_dic, inter_count, inter_sum, in_range_sum, in_range_sum))

@@ -148,7 +148,7 @@ def test_host_fit_matches_reference(name):
         ctx.close()
 
 
-@pytest.mark.parametrize("name", ["C3", "C3w", "C5"])
+@pytest.mark.parametrize("name", ["C2", "C3", "C3w", "C5"])
 def test_host_fit_matches_reference_at_headline_sizes(name):
     """The fit at the sizes the metric is quoted on - 22 autosomes at 5 kb / 1 kb (576 216 / 2 881 044 loci; 397, 49 734 and
     1 999 distance values): fhx_fit fed with the histogram of the full synth-v1 workload reproduces what the REAL reference's
