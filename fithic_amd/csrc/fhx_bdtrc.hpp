@@ -347,7 +347,7 @@ struct CfRow {          // one iteration's constants, 64 bytes = one scalar-cach
     double k1, k2, k5, k6, d0, y0, d1, y1;
 };
 constexpr int kCfIters = 300;
-constexpr double kCfLazyT = 2e-15;          // cf_swapped_step: |d| > kCfLazyT |c2| proves Cephes' t >= 3 MACHEP (derivation there)
+constexpr double kCfLazyT = 1e-15;          // cf_swapped_step: |d| > kCfLazyT |c2| proves Cephes' t >= 3 MACHEP (derivation there)
 
 typedef const CfRow __attribute__((address_space(4))) * CfRowConstPtr;      // constant address space: s_load
 
@@ -475,8 +475,10 @@ __device__ __forceinline__ void cf_swapped_step(CfState<R>& S, const CfRow c, co
     // r = fl(p2/q2) = (p2/q2)(1 + a2), the difference ans - r exactly (Sterbenz: the two are within a factor 1 + 1e-10 of
     // each other here) and t = |fl((ans - r)/r)| = |ans/r - 1|(1 + a3) with ans/r - 1 = E/C + (a1 - a2)(1 + E/C) + O(u^2):
     // t > (|E/C| - 2u(1 + |E/C|))(1 - u) > T - 3.4e-16.  Cephes goes on iff t >= 3 MACHEP = 3.33e-16, so any T >= 6.8e-16 proves
-    // it; T = kCfLazyT = 2e-15 leaves 1.3e-15 of margin.  (Round 2 used 1e-13: a hundred times more rows than necessary fell
-    // through to the exact statements - a wave-uniform branch of two IEEE divisions that a single lane of the wave triggers.)
+    // it; T = kCfLazyT = 1e-15 leaves 3.2e-16 (one more 3u) of margin.  (Round 2 used 1e-13: a hundred times more rows than
+    // necessary fell through to the exact statements - a wave-uniform branch of three IEEE divisions, 55 instructions, that a
+    // single lane of the wave triggers; at 2e-15 that branch was still taken in 2 % of the wave-row-iterations = 1.2 of the
+    // 26.1 VALU instructions per row-iteration.)
     // c2 must not have lost bits to underflow and p2, q0 must not be zero: |c2| > 2^-600 (values are <= 2^17).  q2 == 0
     // shows up as q0 == 0 one iteration later - or in the caller's final check - and sends the row to the per-lane loop like
     // every other unusual state.
@@ -499,9 +501,10 @@ __device__ __forceinline__ void cf_swapped_step(CfState<R>& S, const CfRow c, co
             const bool mine = cf_lane_bit(exact[r]);
             const bool window = fabs(S.p0[r]) > 0x1p-300 && fabs(S.q0[r]) > 0x1p-300 && fabs(p2[r]) > 0x1p-300 && fabs(q2[r]) > 0x1p-300;
             const bool go = mine && window;
-            const double ans = go ? S.p0[r] / S.q0[r] : 1.0;            // the pending quotient
-            const double rr = go ? p2[r] / q2[r] : 1.0;                 // != 0 inside the window
-            const double t = fabs((ans - rr) / rr);
+            // inside the window every operand is in lean_div's (2^-300 < |p|, |q| <= 2^17; ans - rr is 0 or >= 2^-370)
+            const double ans = go ? lean_div(S.p0[r], S.q0[r]) : 1.0;   // the pending quotient
+            const double rr = go ? lean_div(p2[r], q2[r]) : 1.0;        // != 0 inside the window
+            const double t = fabs(lean_div(ans - rr, rr));
             const unsigned long long fin = __builtin_amdgcn_ballot_w64(go && t < 3.0 * kMachEp);
             const unsigned long long bad = __builtin_amdgcn_ballot_w64(mine && !window);
             if (cf_lane_bit(fin)) S.result[r] = rr;
@@ -522,8 +525,15 @@ template <int R>
 __device__ __forceinline__ void cf_swapped_renorm(CfState<R>& S) {      // same iterations for every lane: no exec masking
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const double big = fmax(fmax(fabs(S.pm[r]), fabs(S.p0[r])), fmax(fabs(S.qm[r]), fabs(S.q0[r])));
-        const int e = -__builtin_amdgcn_frexp_exp(big);
+        // exponent of the largest of the four magnitudes from the HIGH WORDS alone: for finite doubles below 2^1017 a high word
+        // without its sign, read as binary32, is an ordinary number and orders like the double (ties differ in the low word
+        // only: same exponent), so two f32 maxima with |.| operand modifiers replace seven v_max_f64 (hipcc canonicalises
+        // every fabs() operand of fmax with a v_max_f64 x, x of its own).  Any power of two is a correct scale (above).
+        unsigned int top;
+        asm("v_max3_f32 %0, |%1|, |%2|, |%3|\n\tv_max_f32 %0, %0, |%4|"
+            : "=&v"(top)
+            : "v"(__double2hiint(S.pm[r])), "v"(__double2hiint(S.p0[r])), "v"(__double2hiint(S.qm[r])), "v"(__double2hiint(S.q0[r])));
+        const int e = 1022 - (int)((top >> 20) & 0x7ffu);            // -frexp_exp(largest) for normal numbers
         S.pm[r] = __builtin_amdgcn_ldexp(S.pm[r], e);
         S.p0[r] = __builtin_amdgcn_ldexp(S.p0[r], e);
         S.qm[r] = __builtin_amdgcn_ldexp(S.qm[r], e);
