@@ -455,8 +455,8 @@ def main():
                                  "algorithmic bytes = 20 B/row (12 read + 8 written), %g fp64 instructions per row-iteration" % HEAVY_FP64_INSTR_PER_ITER,
                          "launch_seconds": hv_s, "rows_per_launch": hv_rows,
                          "fp64_valu_issue_frac": (fp64_instr / hv_s) / fp64_issue_peak if hv_s > 0 else None,
-                         "fp64_note": "loop instructions only, against the nominal 2.4 GHz; by the SQ counters (profiles/r03_g_counters.txt) the "
-                                      "launch issues 26.1 VALU wave-instructions per row-iteration all told at 2.24 GHz: 85 % of the fp64 issue slots"},
+                         "fp64_note": "loop instructions only, against the nominal 2.4 GHz; by the SQ counters (profiles/r03_s_counters.txt) the "
+                                      "launch issues 25.4 VALU wave-instructions per row-iteration all told at 2.2 GHz: 86 % of the fp64 issue slots"},
             "kernels_ms": {"k1_classify_hist": 1e3 * worst[0], "k2_pvalue": 1e3 * worst[1], "k3_bh_sort_scan": 1e3 * worst[2]},
             "whole_pass_hbm_frac": (ALGO_BYTES_K1 + ALGO_BYTES_K2 + ALGO_BYTES_K3) * value / (world * HBM_PEAK_GBS * 1e9),
         }
