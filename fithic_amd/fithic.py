@@ -64,6 +64,8 @@ class _Session:
         self.arrays = {}
         self.values = None
         self.pass_started = 0
+        self.main_dic = None          # the dict read_Interactions handed out, and what it held then (_main_dic_sig)
+        self.main_dic_sig = None
 
     def mode(self):
         return "All" if allReg else ("interOnly" if interOnly else "intraOnly")
@@ -165,6 +167,7 @@ def read_Interactions(contactCountsFile, biasFile, outliers=None):
     S.pass_started += 1
     keys, hist_cc = _dist_keys(S)
     mainDic = {int(k): [0, int(c)] for k, c in zip(keys, hist_cc)}
+    S.main_dic, S.main_dic_sig = mainDic, _main_dic_sig(mainDic)
     print("Interactions file read. Time took %s" % (time.time() - t0))
     lo = int(keys[0]) if len(keys) else float("inf")
     hi = int(keys[-1]) if len(keys) else 0
@@ -176,6 +179,54 @@ def read_Interactions(contactCountsFile, biasFile, outliers=None):
          "Range of observed genomic distances [%s %s]\n\n"
          % (st.in_range_count, st.in_range_sum, st.intra_all_count, st.intra_all_sum, st.inter_count, st.inter_sum, lo, hi), "w")
     return (mainDic, st.inter_count, st.inter_sum, st.intra_all_sum, st.in_range_sum)
+
+
+def _main_dic_sig(mainDic):
+    """what identifies the contents of a mainDic for the stages below: number of distances, their sum, the summed counts"""
+    return (len(mainDic), sum(mainDic), sum(v[1] for v in mainDic.values()))
+
+
+def _adopt_main_dic(S, mainDic, observedIntraInRangeSum):
+    """The reference bins whatever mainDic it is handed (fithic/fithic.py:463-553).  The engine bins the histogram K1 left on
+    the host; when the caller passes the dict read_Interactions returned, untouched, that IS this histogram and nothing is
+    done.  A dict the caller built or edited (distances removed, counts changed) replaces the engine's histogram through
+    fhx_set_global_stats, so the bins, the fit and the p-values follow the argument like the reference's do."""
+    if mainDic is S.main_dic and _main_dic_sig(mainDic) == S.main_dic_sig and observedIntraInRangeSum == S.stats["in_range_sum"]:
+        return
+    if S.engine is None or S.stats is None:
+        raise ValueError("fithic_amd: makeBinsFromInteractions needs read_Interactions first (the contact rows live on the GPU)")
+    ctx = S.engine.ctx
+    if not hasattr(ctx, "set_global_stats"):
+        raise ValueError("fithic_amd: a mainDic other than the one read_Interactions returned is not supported with gpus > 1")
+    keys = np.array(sorted(mainDic), np.int64)
+    sums = np.array([mainDic[int(k)][1] for k in keys], np.int64)
+    st = _capi.FhxStats()
+    for name, _ in st._fields_:
+        setattr(st, name, S.stats[name])
+    st.in_range_sum = int(observedIntraInRangeSum)
+    if resolution == 0 or len(ctx.get_array(_capi.A_DIST_KEYS)):           # explicit distances: -r 0 / loci off the grid
+        ctx.set_dist_keys(keys)
+        ctx.set_global_stats(st, sums, np.ones(len(keys), np.int64))
+    else:
+        if len(keys) and (keys % resolution).any():
+            raise ValueError("fithic_amd: mainDic holds distances that are not multiples of the resolution %d" % resolution)
+        idx = keys // resolution
+        n = max(int(S.stats["n_dist"]), int(idx.max()) + 1 if len(idx) else 1)
+        hist_cc, hist_np = np.zeros(n, np.int64), np.zeros(n, np.int64)
+        hist_cc[idx] = sums
+        hist_np[idx] = 1
+        ctx.set_global_stats(st, hist_cc, hist_np)
+    S.stats = dict(S.stats, in_range_sum=int(observedIntraInRangeSum))
+    S.main_dic, S.main_dic_sig = mainDic, _main_dic_sig(mainDic)
+    S.fit_done = False
+
+
+def _check_session_values(what, given, own):
+    """calculateProbabilities / fit_Spline take x, y and binStats as arguments in the reference; here they are views of the
+    engine's fit.  Values the caller changed in between would be ignored silently - refuse instead."""
+    if len(given) != len(own) or any(float(a) != float(b) for a, b in zip(given, own)):
+        raise ValueError("fithic_amd: %s differs from what the engine computed in the previous stage; the engine fits its own "
+                         "bins (edit mainDic before makeBinsFromInteractions instead)" % what)
 
 
 def _dist_keys(S):
@@ -212,6 +263,7 @@ def makeBinsFromInteractions(mainDic, noOfBins, observedIntraInRangeSum, outlier
          % (observedIntraInRangeSum, noPerBin, noOfBins))
     S.fit_done = False
     S.configure()
+    _adopt_main_dic(S, mainDic, observedIntraInRangeSum)
     S.engine.ctx.make_bins()
     A = _capi
     for k, w in dict(bin_lb=A.A_BIN_LB, bin_ub=A.A_BIN_UB, bin_poss0=A.A_BIN_POSS0, bin_sumcc=A.A_BIN_SUMCC).items():
@@ -379,6 +431,9 @@ def calculateProbabilities(mainDic, binStats, resolution, outfilename, observedI
     _log("\nCalculating probability means and standard deviations of contact counts\n"
          "------------------------------------------------------------------------------------\n")
     S.ensure_fit()
+    _check_session_values("binStats (bin bounds / summed counts)",
+                          [v for b in sorted(binStats) for v in (binStats[b][0][0], binStats[b][0][1], binStats[b][2])],
+                          [v for b in range(len(S.arrays["bin_lb"])) for v in (S.arrays["bin_lb"][b], S.arrays["bin_ub"][b], S.arrays["bin_sumcc"][b])])
     x = [float(v) for v in S.arrays["x"]]
     y = [float(v) for v in S.arrays["y"]]
     yerr = [0] * len(x)
@@ -404,6 +459,8 @@ def fit_Spline(mainDic, x, y, yerr, infilename, outfilename, biasDic, outliersli
     _log("\nFitting a univariate spline to the probability means\n"
          "------------------------------------------------------------------------------------\n")
     info = S.ensure_fit()
+    _check_session_values("x (avgGenomicDist)", x, S.arrays["x"])
+    _check_session_values("y (contactProbability)", y, S.arrays["y"])
     splineX = newSplineY = residual = None
     if not interOnly:
         splineX = [int(v) for v in S.arrays["table_x"]]

@@ -499,3 +499,77 @@ def test_mirror_read_biases_returns_the_reference_dictionary_lazily():
     assert d[chrom][mid] == want[chrom][mid] and d.get("no such chromosome") is None
     assert {k: len(v) for k, v in d.items()} == {k: len(v) for k, v in want.items()}
     F.reset_session()
+
+
+def _mirror_globals(F, kw):
+    F.reset_session()
+    F.resolution = kw["resolution"]
+    F.biasLowerBound, F.biasUpperBound = kw["tL"], kw["tU"]
+    F.distLowThres, F.distUpThres = kw["L"], kw["U"]
+    F.mappThres = kw["mapp_thres"]
+    F.interOnly, F.allReg = kw["mode"] == "interOnly", kw["mode"] == "All"
+    F.logfile, F.visual, F.gpus = None, False, 1
+
+
+@pytest.mark.parametrize("name", ["f1_bias", "f6_quirk_all"])
+def test_mirror_stages_follow_the_mainDic_they_are_handed(name, tmp_path):
+    """The reference's stage functions work on their ARGUMENTS (fithic.py:463, 843, 925): a caller may edit mainDic between
+    read_Interactions and makeBinsFromInteractions.  The mirrors must then bin / fit / score that dict - checked against the
+    oracle's stages run on the same edited histogram - and must refuse x, y or binStats that were changed behind the engine's
+    back instead of ignoring them."""
+    from fithic_amd import fithic as F
+    from oracle import fithic_oracle as fo
+    meta, _ = load_case(name)
+    kw = case_args(meta)
+    _mirror_globals(F, kw)
+    try:
+        biasDic = F.read_biases(kw["bias_path"]) if kw["bias_path"] else 0
+        mainDic, icnt, isum, intra_all, rng_sum = F.read_Interactions(kw["contacts"], kw["bias_path"])
+        # the caller's edit: every third distance loses half its contacts, two distances disappear
+        keys = sorted(mainDic)
+        edited = {k: [0, mainDic[k][1] - (mainDic[k][1] // 2 if i % 3 == 0 else 0)] for i, k in enumerate(keys)}
+        for k in (keys[1], keys[len(keys) // 2]):
+            del edited[k]
+        new_sum = sum(v[1] for v in edited.values())
+        assert new_sum != rng_sum
+        binStats = F.makeBinsFromInteractions(edited, kw["n_bins"], new_sum)
+        out = F.generate_FragPairs(icnt, isum, binStats, kw["frags"], kw["resolution"])
+        binStats = out[0]
+        x, y, yerr = F.calculateProbabilities(edited, binStats, kw["resolution"], str(tmp_path / "pass1"), new_sum)
+        # the oracle on the same histogram
+        pairs = fo.read_contacts_file(kw["contacts"])
+        frag_rows = fo.read_fragments_file(kw["frags"])
+        okeys = np.array(sorted(edited), np.int64)
+        osum = np.array([edited[int(k)][1] for k in okeys], np.int64)
+        bins = fo.make_bins(okeys, osum, kw["n_bins"], new_sum)
+        frag = fo.generate_frag_pairs(frag_rows, bins, kw["resolution"], kw["L"], kw["U"], kw["mapp_thres"], icnt)
+        ox, oy, _ = fo.calculate_probabilities(bins, new_sum)
+        assert [b["lb"] for b in bins] == [binStats[i][0][0] for i in sorted(binStats)]
+        assert [b["ub"] for b in bins] == [binStats[i][0][1] for i in sorted(binStats)]
+        assert bits_equal(np.array(x), np.array(ox, float)) and bits_equal(np.array(y), np.array(oy, float))
+        bias_dic = fo.read_biases(kw["bias_path"], kw["tL"], kw["tU"]) if kw["bias_path"] else 0
+        b1, b2 = fo.gather_bias(pairs, bias_dic)
+        R = fo.fit_spline(pairs, okeys, ox, oy, b1, b2, kw["mode"], kw["L"], kw["U"], kw["tL"], kw["tU"],
+                          (icnt, isum, intra_all, new_sum), frag)
+        # changed x: refused, not ignored
+        with pytest.raises(ValueError, match="differs from what the engine computed"):
+            F.fit_Spline(edited, [v * 2 for v in x], y, yerr, kw["contacts"], str(tmp_path / "o"), biasDic, [], [], new_sum,
+                         out[3], out[4], icnt, intra_all, isum, kw["tL"], kw["tU"], kw["resolution"], 1)
+        res = F.fit_Spline(edited, x, y, yerr, kw["contacts"], str(tmp_path / "o"), biasDic, [], [], new_sum,
+                           out[3], out[4], icnt, intra_all, isum, kw["tL"], kw["tU"], kw["resolution"], 1)
+        if R.newSplineY is not None:
+            assert bits_equal(np.asarray(res[1]), np.asarray(R.newSplineY, float))
+        v = F._S.engine.fetch(p=True, q=True)
+        assert max_abs_diff(v["p"], R.p) <= TOL and max_abs_diff(v["q"], R.q) <= TOL
+        assert sorted(res[3]) == sorted(R.outlier_lines.tolist())
+        # untouched dict: nothing is replaced (the object and its contents are what read_Interactions handed out)
+        mainDic2, *_rest = F.read_Interactions(kw["contacts"], kw["bias_path"])
+        F.makeBinsFromInteractions(mainDic2, kw["n_bins"], _rest[-1])
+        assert F._S.main_dic is mainDic2
+        binStats2 = F.generate_FragPairs(icnt, isum, {}, kw["frags"], kw["resolution"])[0]
+        bad = dict(binStats2)
+        bad[0] = [(binStats2[0][0][0], binStats2[0][0][1] + kw["resolution"])] + list(binStats2[0][1:])
+        with pytest.raises(ValueError, match="binStats"):
+            F.calculateProbabilities(mainDic2, bad, kw["resolution"], str(tmp_path / "pass1b"), _rest[-1])
+    finally:
+        F.reset_session()
