@@ -3298,7 +3298,11 @@ static int sort_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned lon
                         double* d_q, unsigned long long* counter, const unsigned long long* d_cutoff, int* sorted_buf,
                         int64_t* n_sorted_out = nullptr) {
     FHX_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL(k3_compact, dim3(grid_for(n, SORT_TILE, 256 * 8)), dim3(SORT_THREADS), 0, ctx->stream, d_p, n,
+    // one workgroup per tile, not a resident grid walking the column: 0.507 -> 0.451 ms on C3 (profiles/r03_x_k3_grid.txt); the
+    // plain copy kernel of profiles/hbm_rate.hip shows the same (4.9 TB/s with 2048 grid-striding workgroups, 5.6 with one per
+    // chunk).  FHX_K3_GRID caps the grid for measurements.
+    static const int k3_cap = std::getenv("FHX_K3_GRID") ? std::atoi(std::getenv("FHX_K3_GRID")) : (1 << 30);
+    hipLaunchKernelGGL(k3_compact, dim3(grid_for(n, SORT_TILE, k3_cap)), dim3(SORT_THREADS), 0, ctx->stream, d_p, n,
                        keys[0], vals[0], d_q, counter, d_cutoff);
     // how many keys survived decides the shape of the sort (one 8-byte read back: ~20 us against ~190 us of fixed cost saved)
     unsigned long long n_kept = 0;
