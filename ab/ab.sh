@@ -1,0 +1,17 @@
+#!/bin/bash
+# same-box A/B: FHX_LIB=ab/libbase.so (HEAD) against the tree's library; digest from bench, per-kernel times from rocprofv3
+ROOT=$PWD
+mkdir -p gpurun_out/r03
+cd /tmp && export TMPDIR=/tmp
+for rep in 1 2; do
+for v in base new; do
+  if [ $v = base ]; then export FHX_LIB=$ROOT/ab/libbase.so; else unset FHX_LIB; fi
+  rm -rf /tmp/prof_ab
+  FHX_BENCH_HASH=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_ab -o run -- python $ROOT/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-parity-check 2>/dev/null | grep '^{' | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('$v: pass %.3f ms  %s digest %s' % (d['ms_per_step'], {k: round(v,3) for k,v in d['kernels_ms'].items()}, d.get('result_digest')))"
+  DB=$(find /tmp/prof_ab -name '*.db' | head -1)
+  python $ROOT/profiles/summarize_rocprof.py $DB | sed -n 3,10p
+done
+done

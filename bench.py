@@ -377,7 +377,13 @@ def main():
             eng.ctx.sync()
             hashes = result_hashes(torch, synth, eng, keys, chr1, n_local, len(genome))
             del keys, chr1
-        return dict(genome=genome, eng=eng, sample=sample, elapsed=elapsed, n_total=n_total, n_local=n_local, k_all=k_all,
+        try:
+            bh_sorted = int(eng.ctx.n_sorted())                  # rows below the exact BH cutoff = what K3 had to sort (last pass)
+            if bh_sorted < 0:                                    # multi-pass steps end with reset_passes()
+                bh_sorted = None
+        except Exception:                                        # noqa: BLE001 - informational only
+            bh_sorted = None
+        return dict(genome=genome, eng=eng, sample=sample, elapsed=elapsed, n_total=n_total, n_local=n_local, k_all=k_all, bh_sorted=bh_sorted,
                     stage_ms=stage_ms, pass_ms=pass_ms / max(steps, 1), info=info, n_trans=n_trans, replicas=replicas,
                     hashes=hashes, hashed_pass1=want_hashes and passes > 1)
 
@@ -458,6 +464,7 @@ def main():
                          "fp64_note": "loop instructions only, against the nominal 2.4 GHz; by the SQ counters (profiles/r03_s_counters.txt) the "
                                       "launch issues 25.4 VALU wave-instructions per row-iteration all told at 2.2 GHz: 86 % of the fp64 issue slots"},
             "kernels_ms": {"k1_classify_hist": 1e3 * worst[0], "k2_pvalue": 1e3 * worst[1], "k3_bh_sort_scan": 1e3 * worst[2]},
+            "bh_rows_sorted_rank0": M.get("bh_sorted"),
             "whole_pass_hbm_frac": (ALGO_BYTES_K1 + ALGO_BYTES_K2 + ALGO_BYTES_K3) * value / (world * HBM_PEAK_GBS * 1e9),
         }
         if passes > 1:
