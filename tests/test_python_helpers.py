@@ -49,3 +49,33 @@ def test_bias_dictionary_fills_itself_on_first_use():
     e.setdefault("chrY", {})[1] = 2.0
     assert e["chrY"] == {1: 2.0} and e["chr1"][100] == 1.5
     assert not _BiasDic((names, bc[:0], bm[:0], vals[:0]), 0) and not _BiasDic()
+
+
+def test_myUtils_names_follow_the_reference_predicates():
+    """fithic/myUtils.py:85-147: -1 = no bound, both ends inclusive; 'intraShort' only with a lower bound, 'intraLong' only with
+    an upper one; the oracle's vectorised in_range is the same predicate with 0 / inf as 'no bound'."""
+    from fithic_amd import myUtils
+    from oracle import fithic_oracle as fo
+    import numpy as np
+    cases = [(d, lo, up) for d in (0, 1, 5000, 20000, 20001, 2000000, 2000001) for lo in (-1, 0, 20000) for up in (-1, 20000, 2000000)]
+    for d, lo, up in cases:
+        want = (lo == -1 or d >= lo) and (up == -1 or d <= up)
+        assert myUtils.in_range_check(d, lo, up) is want, (d, lo, up)
+        assert bool(fo.in_range(np.array([d]), max(lo, 0), float("inf") if up == -1 else up)[0]) is want
+        it = myUtils.Interaction(["chr1", 100000, "chr1", 100000 + d])
+        assert it.type == "intra" and it.getDistance() == d
+        t = it.getType(lo, up)
+        assert t == ("intraInRange" if want else ("intraShort" if (lo > -1 and d <= lo) else "intraLong"))
+    inter = myUtils.Interaction(["chr1", "5", "chr2", 7])
+    assert inter.getType(0, 10) == "inter" and inter.distance == -1 and (inter.mid1, inter.mid2) == (5, 7)
+    inter.setCount("3")
+    assert inter.getCount() == 3
+    assert myUtils.scale_a_list([1, 2], 0.5) == [0.5, 1.0]
+
+
+def test_myStats_mean_and_variance():
+    """fithic/myStats.py:53-63: E(x^2) - (Ex)^2; the module imports without a GPU (the BH name binds to the engine lazily)"""
+    from fithic_amd import myStats
+    m, v = myStats.meanAndVariance([1, 2, 3, 4])
+    assert m == 2.5 and v == 30 / 4.0 - 2.5 * 2.5
+    assert callable(myStats.benjamini_hochberg_correction)
