@@ -66,6 +66,7 @@ class _Session:
         self.pass_started = 0
         self.main_dic = None          # the dict read_Interactions handed out, and what it held then (_main_dic_sig)
         self.main_dic_sig = None
+        self.outlier_refs = None      # (outliersline, len, outliersdist, len) as fit_Spline left them: the engine's own lists
 
     def mode(self):
         return "All" if allReg else ("interOnly" if interOnly else "intraOnly")
@@ -159,6 +160,9 @@ def read_Interactions(contactCountsFile, biasFile, outliers=None):
                   % (len(S.contacts), time.time() - t0, "device" if isinstance(S.contacts, tables.DeviceContacts) else "host"))
         S.pass_started = 0
     elif outliers is not None and S.pass_started >= 1 and S.values is not None:
+        if S.outlier_refs is not None and not (outliers is S.outlier_refs[0] and len(outliers) == S.outlier_refs[1]):
+            raise ValueError("fithic_amd: read_Interactions skips the lines the ENGINE flagged in the previous fit_Spline; an outlier "
+                             "list that was edited or built elsewhere cannot be honoured (pass the list fit_Spline returned)")
         S.engine.next_pass()                 # fold the previous pass's outliers into the skip mask (K1 skips them)
     S.configure()
     st = S.engine.pass_stats()
@@ -221,6 +225,28 @@ def _adopt_main_dic(S, mainDic, observedIntraInRangeSum):
     S.fit_done = False
 
 
+def _adopt_outlier_dists(S, outliersdist):
+    """makeBinsFromInteractions subtracts one possible pair per outlier distance of the earlier passes (fithic/fithic.py:533-551).
+    The engine keeps that multiset itself; the list fit_Spline extended and returned, passed back untouched, is that multiset.
+    Any other list replaces it for this call (fhx_set_outlier_dists / fhx_set_outlier_dist_hist), like the argument does in
+    the reference."""
+    refs = S.outlier_refs
+    if outliersdist is None or (refs is not None and outliersdist is refs[2] and len(outliersdist) == refs[3]):
+        return
+    ctx = S.engine.ctx
+    if not hasattr(ctx, "set_outlier_dist_hist"):
+        raise ValueError("fithic_amd: an outliersdist list other than the one fit_Spline returned is not supported with gpus > 1")
+    dists = np.sort(np.asarray(list(outliersdist), np.int64))
+    if resolution == 0 or len(ctx.get_array(_capi.A_DIST_KEYS)):
+        ctx.set_outlier_dists(dists)
+        return
+    if len(dists) and ((dists % resolution).any() or dists.min() < 0):
+        raise ValueError("fithic_amd: outliersdist holds distances that are not multiples of the resolution %d" % resolution)
+    n = int(S.stats["n_dist"])
+    # distances beyond the histogram fall behind the last bin, where the reference's cursor stops (fithic.py:541-547): slot n - 1
+    ctx.set_outlier_dist_hist(np.bincount(np.minimum(dists // resolution, n - 1), minlength=n).astype(np.int64))
+
+
 def _check_session_values(what, given, own):
     """calculateProbabilities / fit_Spline take x, y and binStats as arguments in the reference; here they are views of the
     engine's fit.  Values the caller changed in between would be ignored silently - refuse instead."""
@@ -264,6 +290,7 @@ def makeBinsFromInteractions(mainDic, noOfBins, observedIntraInRangeSum, outlier
     S.fit_done = False
     S.configure()
     _adopt_main_dic(S, mainDic, observedIntraInRangeSum)
+    _adopt_outlier_dists(S, outliersdist)
     S.engine.ctx.make_bins()
     A = _capi
     for k, w in dict(bin_lb=A.A_BIN_LB, bin_ub=A.A_BIN_UB, bin_poss0=A.A_BIN_POSS0, bin_sumcc=A.A_BIN_SUMCC).items():
@@ -519,6 +546,7 @@ def fit_Spline(mainDic, x, y, yerr, infilename, outfilename, biasDic, outliersli
         outliersdist.sort()
     if os.environ.get("FHX_TIMING"):
         print("stage: %d outlier lines collected in %.3f s" % (len(rows), time.time() - t_stage))
+    S.outlier_refs = (outliersline, len(outliersline), outliersdist, len(outliersdist))
     FDRx = np.arange(0.0, 0.05 + 0.001, 0.001)
     FDRy = [int(c) for c in eng.fdr_counts()]                # plot_qvalues' counts (fithic.py:1235-1254), device histogram
     if visual:

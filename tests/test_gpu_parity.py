@@ -573,3 +573,42 @@ def test_mirror_stages_follow_the_mainDic_they_are_handed(name, tmp_path):
             F.calculateProbabilities(mainDic2, bad, kw["resolution"], str(tmp_path / "pass1b"), _rest[-1])
     finally:
         F.reset_session()
+
+
+@pytest.mark.parametrize("name", ["f6_quirk_all", "f13_hESC_p3"])
+def test_mirror_makeBins_follows_the_outlier_distances_it_is_handed(name, tmp_path):
+    """Pass 2 of the reference subtracts one possible pair per entry of the `outliersdist` ARGUMENT (fithic.py:533-551).  The
+    list fit_Spline returned is the engine's own multiset; an edited copy must replace it for that call (checked against the
+    oracle's make_bins on the same list), and read_Interactions must refuse an outlier-line list it cannot honour."""
+    from fithic_amd import fithic as F
+    from oracle import fithic_oracle as fo
+    meta, _ = load_case(name)
+    kw = case_args(meta)
+    _mirror_globals(F, kw)
+    try:
+        biasDic = F.read_biases(kw["bias_path"]) if kw["bias_path"] else 0
+        mainDic, icnt, isum, intra_all, rng_sum = F.read_Interactions(kw["contacts"], kw["bias_path"])
+        binStats = F.makeBinsFromInteractions(mainDic, kw["n_bins"], rng_sum)
+        out = F.generate_FragPairs(icnt, isum, binStats, kw["frags"], kw["resolution"])
+        x, y, yerr = F.calculateProbabilities(mainDic, out[0], kw["resolution"], str(tmp_path / "pass1"), rng_sum)
+        res = F.fit_Spline(mainDic, x, y, yerr, kw["contacts"], str(tmp_path / "o1"), biasDic, [], [], rng_sum, out[3], out[4], icnt,
+                           intra_all, isum, kw["tL"], kw["tU"], kw["resolution"], 1)
+        outliersline, outliersdist = res[3], res[4]
+        assert len(outliersline) > 4 and len(outliersdist) == len(outliersline)
+        with pytest.raises(ValueError, match="cannot be honoured"):
+            F.read_Interactions(kw["contacts"], kw["bias_path"], list(outliersline)[:-1])
+        mainDic2, icnt2, isum2, intra_all2, rng_sum2 = F.read_Interactions(kw["contacts"], kw["bias_path"], outliersline)
+        keys = np.array(sorted(mainDic2), np.int64)
+        sums = np.array([mainDic2[int(k)][1] for k in keys], np.int64)
+        # the engine's own list, passed back untouched
+        own = F.makeBinsFromInteractions(mainDic2, kw["n_bins"], rng_sum2, outliersdist)
+        want = fo.make_bins(keys, sums, kw["n_bins"], rng_sum2, outliersdist)
+        assert [own[b][1] for b in sorted(own)] == [b["s1"] for b in want]
+        # an edited copy: every other distance dropped, one far beyond the last bin added
+        edited = sorted(list(outliersdist)[::2] + [int(keys[-1]) + 50 * max(kw["resolution"], 1)])
+        got = F.makeBinsFromInteractions(mainDic2, kw["n_bins"], rng_sum2, edited)
+        want = fo.make_bins(keys, sums, kw["n_bins"], rng_sum2, edited)
+        assert [got[b][1] for b in sorted(got)] == [b["s1"] for b in want]
+        assert [got[b][1] for b in sorted(got)] != [own[b][1] for b in sorted(own)]
+    finally:
+        F.reset_session()
