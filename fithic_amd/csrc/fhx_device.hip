@@ -498,7 +498,16 @@ __device__ __forceinline__ QEntry* qentry(const QSpan& q, int shard, long long j
 struct K2Queues {
     QSpan q[K2_QUEUES + 1];            // classes 1..4, then the closed-form class (count == 1, prior >= 0.01)
     unsigned long long* count;         // (K2_QUEUES + 1) x K2_MAX_SHARDS counters: [class * K2_MAX_SHARDS + shard]
+    unsigned int* heavy_hist;          // K2H_BUCKETS x K2H_BLOCKS bucket counts of the swapped-fraction queue (zeroed before the
+                                       // launch; column = shard % K2H_BLOCKS, the workgroup of k2h_scatter that will move the shard);
+                                       // nullptr = not collected
 };
+
+// bucket of a swapped-continued-fraction row in the count sort that feeds k2h_heavy (defined with that sort, below); k2_classify
+// counts its shard's rows per bucket while it queues them, so that the sort needs no counting pass of its own
+constexpr int K2H_BUCKETS = 2048;                       // == RADIX: the radix sort's count matrix and scan are reused
+constexpr int K2H_BLOCKS = 1024;                        // == SORT_BLOCKS
+__device__ __forceinline__ int k2h_bucket(int signed_count);
 
 constexpr int K2_CL_ITEMS = 4;
 constexpr int K2_CL_TILE = K2_THREADS * K2_CL_ITEMS;     // 1024 rows per workgroup step: four waves of 256 consecutive rows
@@ -524,7 +533,11 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE,
     __shared__ double cf_prior[WAVES][WAVE_ROWS];
     __shared__ unsigned short cf_idx[WAVES][WAVE_ROWS];         // row within the wave's 256 | 0x8000 for the inter-chromosomal binomial
     __shared__ unsigned int hist_lds[K2_HIST_BINS];
+    __shared__ unsigned int heavy_lds[K2H_BUCKETS];             // this shard's swapped-fraction rows per bucket of the count sort
     if (threadIdx.x <= K2_QUEUES) cnt[threadIdx.x] = 0;
+    const bool count_heavy = Q.heavy_hist != nullptr;
+    if (count_heavy)
+        for (int d = threadIdx.x; d < K2H_BUCKETS; d += K2_THREADS) heavy_lds[d] = 0;
     FusedHist H;
     H.init(hist_lds, P.top_hist);
     __syncthreads();
@@ -614,6 +627,7 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE,
                 e.count = count_of[r];
                 e.prior = prior_of[r];
                 *qentry(Q.q[k], shard, (long long)(wb + before_cls[r])) = e;
+                if (k == dev::BC_CF_SWAPPED - 1 && count_heavy) atomicAdd(&heavy_lds[k2h_bucket(e.count)], 1u);
             } else if (cls_of[r] == K2_CLOSED_LOCAL) {
                 cf_prior[wave][before_cls[r]] = prior_of[r];
                 cf_idx[wave][before_cls[r]] = (unsigned short)((lane * ITEMS + r) | (count_of[r] < 0 ? 0x8000 : 0));
@@ -638,6 +652,9 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE,
     }
     __syncthreads();
     if (threadIdx.x <= K2_QUEUES) Q.count[(size_t)threadIdx.x * K2_MAX_SHARDS + shard] = cnt[threadIdx.x];
+    if (count_heavy)                    // a handful of counts are met in a shard: only those words of the matrix are touched
+        for (int d = threadIdx.x; d < K2H_BUCKETS; d += K2_THREADS)
+            if (heavy_lds[d]) atomicAdd(&Q.heavy_hist[(size_t)d * K2H_BLOCKS + (shard & (K2H_BLOCKS - 1))], heavy_lds[d]);
     H.flush(P.top_hist);
 }
 
@@ -749,8 +766,6 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE)
 // kernel).  Every bucket starts at a multiple of 64 entries in the sorted queue, so a wave never straddles two counts.
 constexpr int K2H_KCAP = 1023;
 constexpr int K2H_GENERIC = 2 * K2H_KCAP;               // 2046
-constexpr int K2H_BUCKETS = 2048;                       // == RADIX: the radix sort's count matrix and scan are reused
-constexpr int K2H_BLOCKS = 1024;                        // == SORT_BLOCKS
 constexpr int K2H_THREADS = 256;
 
 __device__ __forceinline__ int k2h_bucket(int signed_count) {
@@ -3120,6 +3135,14 @@ int fhx_pvalues(fhx_ctx* ctx) {
     if ((int64_t)n_shards * cap_s > ctx->queue_cap) return fail(ctx, FHX_ERR_HIP, "internal: queue workspace smaller than the shard layout");
     if (!ctx->d_k2_counts) FHX_HIP(hipMalloc(&ctx->d_k2_counts, (size_t)(K2_QUEUES + 1) * K2_MAX_SHARDS * sizeof(unsigned long long)));
     Q.count = ctx->d_k2_counts;
+    static const bool own_count_pass = std::getenv("FHX_K2H_COUNT") != nullptr;          // measurements: the separate k2h_count launch
+    const bool heavy_sorted = getenv("FHX_K2_LEGACY") == nullptr;
+    Q.heavy_hist = nullptr;
+    if (heavy_sorted && !own_count_pass) {
+        static_assert((K2H_BLOCKS & (K2H_BLOCKS - 1)) == 0, "shard -> column by masking");
+        FHX_HIP(hipMemsetAsync(ctx->d_block_hist, 0, (size_t)K2H_BUCKETS * K2H_BLOCKS * sizeof(unsigned int), ctx->stream));
+        Q.heavy_hist = ctx->d_block_hist;
+    }
     ctx->k2_shards = n_shards;
     auto span = [&](int cls, QEntry* buf, int dir) {
         QSpan& q = Q.q[cls - 1];
@@ -3178,7 +3201,8 @@ int fhx_pvalues(fhx_ctx* ctx) {
                                                          // power-series class (its other tenant) has run
         unsigned long long* n_redo = ctx->d_misc + 11;
         FHX_HIP(hipMemsetAsync(n_redo, 0, sizeof(unsigned long long), ctx->stream));
-        hipLaunchKernelGGL(k2h_count, dim3(K2H_BLOCKS), dim3(K2H_THREADS), 0, ctx->stream, hs, ctx->d_block_hist);
+        if (!Q.heavy_hist)              // otherwise k2_classify has counted while it queued
+            hipLaunchKernelGGL(k2h_count, dim3(K2H_BLOCKS), dim3(K2H_THREADS), 0, ctx->stream, hs, ctx->d_block_hist);
         hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3(SORT_BLOCKS), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total, (int)SORT_BLOCKS);
         // rows per lane: 4 at 4 waves/SIMD (7.43 -> 6.66 ms per 2.7e7 rows against one row per lane at 8 waves/SIMD; 2 x 8, 2 x 6,
         // 3 x 5, 4 x 3 are within 3 % of each other, profiles/r03_c_heavy_variants.txt); FHX_K2H_ROWS / FHX_K2H_WAVES: measurements
