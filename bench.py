@@ -109,6 +109,49 @@ def build_rows(synth, torch, cfg, genome, mine, rank, world, device, overdispers
     return cols, n, n_cis, n_trans
 
 
+def build_sample(torch, cols, n_local, n_cis_local, genome, mine, cfg, res, device, budget=3.0e7, chunk=1 << 27):
+    """Bounded sample for the CPU legs: whole chromosomes, smallest first, up to ~3e7 cis rows (10-15 s of one core), plus every
+    trans row between two sampled chromosomes; a chromosome that alone exceeds the budget (1 kb loci) is cut to its first loci -
+    rows with both ends below the cut - so that the sample is a complete small genome.  The columns are walked in chunks of
+    2^27 rows: at C5 (2e9 rows next to the engine's 158 GB) whole-column temporaries would not fit."""
+    import numpy as np
+    n_chr = len(genome)
+    counts = torch.zeros(n_chr, dtype=torch.int64, device=device)
+    for lo in range(0, n_cis_local, chunk):
+        hi = min(n_cis_local, lo + chunk)
+        counts += torch.bincount(cols[0][lo:hi].to(torch.int64), minlength=n_chr)
+    counts = counts.cpu().numpy()
+    order = sorted(mine, key=lambda c: counts[c])
+    chosen, rows, cut_loci = [], 0, {}
+    for c in order:
+        if chosen and rows + counts[c] > budget:
+            break
+        chosen.append(c)
+        rows += int(counts[c])
+    sel_chr = torch.zeros(n_chr, dtype=torch.bool, device=device)
+    sel_chr[torch.tensor(sorted(chosen), device=device)] = True
+    cut = None
+    if rows > 1.3 * budget:                           # one oversized chromosome: keep its first loci only
+        c = chosen[0]
+        cut = max(int(genome.n_loci[c] * budget / rows), min(genome.n_loci[c], (cfg["hi"] or 0) + 64))
+        cut_loci[c] = cut
+    idx_parts, col_parts = [], [[] for _ in range(5)]
+    for lo in range(0, n_local, chunk):
+        hi = min(n_local, lo + chunk)
+        keep = sel_chr[cols[0][lo:hi].to(torch.int64)] & sel_chr[cols[2][lo:hi].to(torch.int64)]
+        if cut is not None:
+            keep &= (cols[1][lo:hi] < cut * res) & (cols[3][lo:hi] < cut * res)
+        idx = torch.nonzero(keep).squeeze(1)
+        if idx.numel():
+            idx_parts.append((idx + lo).cpu().numpy())
+            for k in range(5):
+                col_parts[k].append(cols[k][lo:hi][idx].cpu().numpy())
+        del keep, idx
+    cat = lambda parts, dt: np.concatenate(parts) if parts else np.empty(0, dt)
+    return {"rows": cat(idx_parts, np.int64), "cols": [cat(col_parts[k], np.int32) for k in range(5)], "chroms": sorted(chosen),
+            "cut_loci": cut_loci}
+
+
 def row_keys(torch, synth, cols, n):
     """64-bit identity of every row, independent of where the row sits: splitmix64 chained over (chr1, mid1, chr2, mid2, count)."""
     k = cols[0][:n].to(torch.int64)
@@ -191,6 +234,11 @@ def main():
     ap.add_argument("--replicas", type=int, default=0, help="debug: replicate the genome R times per run regardless of --gpus (size test)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` outside a launcher: this process starts the N ranks itself (torch.distributed.run on 127.0.0.1)
+    # and passes their one JSON line through; with fewer than N visible GPUs the one line is a diagnostic instead
+    if "RANK" not in os.environ and args.path == "fithic" and (args.gpus > 1 or os.environ.get("FHX_FORCE_DIST")):
+        raise SystemExit(self_launch(args))
+
     # stdout carries exactly ONE line (the JSON): libraries that print banners there (RCCL prints its version block to
     # stdout when the first communicator is created) are diverted to stderr for the whole run
     sys.stdout.flush()
@@ -221,9 +269,11 @@ def main():
     world = world_all = int(os.environ.get("WORLD_SIZE", "1"))
     rank = rank_all = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if world != args.gpus and rank == 0:                     # the launcher's world is what runs; the line reports it as n_gpus
+        log("[bench] --gpus %d but the launcher started %d rank(s): running with %d" % (args.gpus, world, world))
+    if torch.cuda.device_count() <= local_rank:
+        diagnostic(json_fd, args, "rank %d finds %d visible GPU(s)" % (rank, torch.cuda.device_count()), visible_devices=torch.cuda.device_count())
+        raise SystemExit(2)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     comm = None
@@ -276,28 +326,7 @@ def main():
             # bounded sample for the CPU legs: whole chromosomes, smallest first, up to ~3e7 cis rows (10-15 s of one core),
             # plus every trans row between two sampled chromosomes; a chromosome that alone exceeds the budget (1 kb loci)
             # is cut to its first loci - rows with both ends below the cut - so that the sample is a complete small genome
-            c1 = cols[0][:n_local]
-            counts = torch.bincount(c1[:n_cis_local].to(torch.int64), minlength=len(genome)).cpu().numpy()
-            order = sorted(mine, key=lambda c: counts[c])
-            budget = 3.0e7
-            chosen, rows, cut_loci = [], 0, {}
-            for c in order:
-                if chosen and rows + counts[c] > budget:
-                    break
-                chosen.append(c)
-                rows += int(counts[c])
-            sel_chr = torch.zeros(len(genome), dtype=torch.bool, device=device)
-            sel_chr[torch.tensor(sorted(chosen), device=device)] = True
-            keep = sel_chr[cols[0][:n_local].to(torch.int64)] & sel_chr[cols[2][:n_local].to(torch.int64)]
-            if rows > 1.3 * budget:                       # one oversized chromosome: keep its first loci only
-                c = chosen[0]
-                cut = max(int(genome.n_loci[c] * budget / rows), min(genome.n_loci[c], (cfg["hi"] or 0) + 64))
-                cut_loci[c] = cut
-                keep &= (cols[1][:n_local] < cut * res) & (cols[3][:n_local] < cut * res)
-            idx = torch.nonzero(keep).squeeze(1)
-            sample = {"rows": idx.cpu().numpy(), "cols": [cols[k][:n_local][idx].cpu().numpy() for k in range(5)],
-                      "chroms": sorted(chosen), "cut_loci": cut_loci}
-            del keep, idx, sel_chr
+            sample = build_sample(torch, cols, n_local, n_cis_local, genome, mine, cfg, res, device)
         keys = chr1 = None
         if want_hashes:                                          # row identities for the sharded-vs-single comparison
             keys = row_keys(torch, synth, cols, n_local)
@@ -383,7 +412,7 @@ def main():
                 bh_sorted = None
         except Exception:                                        # noqa: BLE001 - informational only
             bh_sorted = None
-        return dict(genome=genome, eng=eng, sample=sample, elapsed=elapsed, n_total=n_total, n_local=n_local, k_all=k_all, bh_sorted=bh_sorted,
+        return dict(steps=steps, genome=genome, eng=eng, sample=sample, elapsed=elapsed, n_total=n_total, n_local=n_local, k_all=k_all, bh_sorted=bh_sorted,
                     stage_ms=stage_ms, pass_ms=pass_ms / max(steps, 1), info=info, n_trans=n_trans, replicas=replicas,
                     hashes=hashes, hashed_pass1=want_hashes and passes > 1)
 
@@ -403,7 +432,8 @@ def main():
         """run_check on a finished pass; a failure of the checking leg is reported, never raised (the GPU line must not be lost)"""
         try:
             from oracle import run_check
-            return run_check.check_engine_run(eng_, genome_, sample_, cfg, info_, not args.no_bias, p_stride=4, fit_fixture_name=fixture)
+            return run_check.check_engine_run(eng_, genome_, sample_, cfg, info_, not args.no_bias, p_stride=4, fit_fixture_name=fixture,
+                                              torch=torch)            # p and q streamed in 1.3e8-row chunks: C5's 2e9 rows as well
         except Exception as e:
             log("parity_check failed: %r" % (e,))
             return {"ok": False, "error": repr(e)}
@@ -445,9 +475,11 @@ def main():
         else:
             workload = desc["C5"] % (replicas, n_chr, res, L, U, n_total - M["n_trans"], M["n_trans"])
         result = {
-            "metric": "contact-pairs/sec through spline+p-value+BH pass (5 kb cis, whole node)",
+            "metric": METRIC,
             "value": value, "unit": "contact-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak" if (weak_headline or world == 1) else "strong",
+            "ms_per_step": ms, "higher_is_better": True,
+            # the headline shards ONE genome over the ranks: total work is fixed as N grows (at N = 1 it is the whole genome)
+            "scaling": "weak" if weak_headline else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "name": args.config, "pairs": n_total, "resolution": res,
                        "generator": "synth-v1" if args.overdispersion == 0 else "synth-v1 + lognormal rate noise s=%g" % args.overdispersion,
@@ -474,6 +506,11 @@ def main():
             rccl.update(world_in_library=w_, library_rccl_version_code=v_)
             result["rccl"] = rccl
             result["stage_ms"] = M["stage_ms"]
+            # what every rank held and how long its three kernel groups ran (HIP events on its own stream, mean per step)
+            result["per_rank"] = [{"rank": i, "rows": int(r[3]), "k1_ms": 1e3 * r[0], "k2_ms": 1e3 * r[1], "k3_ms": 1e3 * r[2],
+                                   "heavy_ms": 1e3 * r[4], "heavy_rows": int(r[5])} for i, r in enumerate(M["k_all"])]
+            if not weak_headline:
+                result["predicted_ms"] = predicted_pass_ms(world, max(int(r[3]) for r in M["k_all"]), args.config)
         if args.no_parity_check:
             result["parity_check"] = {"ok": None, "skipped": "--no-parity-check"}
         if want_digest and M["hashes"] is not None:
@@ -506,7 +543,7 @@ def main():
                 total = gathered[0].clone()
                 for g_ in gathered[1:]:
                     total += g_.to(total.device)
-                V = measure(replicas, with_cpu_leg=True, solo=True, want_hashes=True, steps=1, warmup=0)
+                V = measure(replicas, with_cpu_leg=True, solo=True, want_hashes=True, steps=max(2, min(args.steps, 5)), warmup=1)
                 same = (V["hashes"] == total)
                 chk = checked(V["eng"], V["genome"], V["sample"], V["info"], fixture_name)
                 n_bad_p, n_bad_q = int((~same[0]).sum()), int((~same[1]).sum())
@@ -519,11 +556,17 @@ def main():
                     chromosomes_hashed=len(names), chromosomes_p_differ=[names[i] for i in torch.nonzero(~same[0]).flatten().tolist()],
                     chromosomes_q_differ=[names[i] for i in torch.nonzero(~same[1]).flatten().tolist()],
                     global_stats_equal=stats_equal, fit_scalars_equal=fit_equal,
-                    single_gpu_ms_per_pass=1e3 * V["elapsed"] / max(passes, 1), seconds_all=time.perf_counter() - t_v,
+                    single_gpu_ms_per_pass=1e3 * V["elapsed"] / max(passes * V["steps"], 1), seconds_all=time.perf_counter() - t_v,
                     sharded_how="64-bit order-free hash of (row identity, p bits) and (row identity, q bits) per chromosome: sum over the %d "
                                 "rank(s) of the timed sharded run == the same table of ONE GPU holding all rows (plain single-GPU path, no "
                                 "communicator); that single-GPU pass is the one checked against the reference fixtures and the oracle" % world)
                 result["parity_check"]["ok"] = bool(chk.get("ok") and result["parity_check"]["sharded_equals_single_gpu"])
+                if not weak_headline:
+                    # strong scaling against ONE GPU timed in this very run: rank 0's verification pass over the whole genome
+                    one_ms = result["parity_check"]["single_gpu_ms_per_pass"] * passes
+                    result["single_gpu_ms_per_step"] = one_ms
+                    result["strong_speedup"] = one_ms / result["ms_per_step"]
+                    result["strong_efficiency"] = one_ms / (world * result["ms_per_step"])
                 V["eng"].close()
                 del V
             except Exception as e:
@@ -545,6 +588,67 @@ def main():
     if comm:
         import torch.distributed as td
         td.destroy_process_group()
+
+
+METRIC = "contact-pairs/sec through spline+p-value+BH pass (5 kb cis, whole node)"
+
+
+def diagnostic(fd, args, message, **extra):
+    """The one JSON line of a run that cannot produce a value: same head as a result line, `value` null, the reason in `error`."""
+    line = dict({"metric": METRIC, "value": None, "unit": "contact-pairs/s", "n_gpus": args.gpus, "steps": args.steps,
+                 "warmup": args.warmup, "higher_is_better": True, "error": message}, **extra)
+    os.write(fd, (json.dumps(line) + "\n").encode())
+
+
+def visible_gpus():
+    """GPUs this process could use, without creating a HIP context here (the ranks are separate processes)."""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:                                            # noqa: BLE001 - no torch / no driver: nothing visible
+        return 0
+
+
+def self_launch(args):
+    """Start `--gpus N` ranks of this script (one per GPU, RCCL rendezvous on 127.0.0.1) and hand their single JSON line on.
+    Returns the exit code.  Whatever happens, stdout carries exactly one JSON line: the ranks' result, or a diagnostic."""
+    import socket
+    import subprocess
+    n_vis = visible_gpus()
+    if n_vis < args.gpus:
+        diagnostic(1, args, "--gpus %d asked for, %d GPU(s) visible on this node: nothing was run" % (args.gpus, n_vis), visible_devices=n_vis)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), FHX_BENCH_SELF_LAUNCHED="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("[bench] no launcher environment: starting %d rank(s) myself: %s" % (args.gpus, " ".join(cmd[1:8])))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.strip().startswith("{")]
+    if lines:
+        os.write(1, (lines[-1] + "\n").encode())
+        return r.returncode
+    diagnostic(1, args, "the %d rank(s) started by bench.py ended with exit code %d without a result line (see stderr)" % (args.gpus, r.returncode),
+               visible_devices=n_vis)
+    return r.returncode or 1
+
+
+def predicted_pass_ms(world, rows_largest_rank, config):
+    """Pass time the one-GPU measurements predict for this sharding (profiles/scaling_model.json, made by profiles/stage_times.py:
+    fixed per-pass cost + per-row cost of the largest rank + the BH exchange over xGMI); None when no model is committed for the
+    workload.  Printed next to the measured ms_per_step so that the driver's scaling curve can be held against it."""
+    path = os.path.join(ROOT, "profiles", "scaling_model.json")
+    try:
+        m = json.load(open(path)).get(config)
+        if not m:
+            return None
+        ms = m["fixed_ms"] + m["dist_fixed_ms"] * (world > 1) + m["ns_per_row"] * 1e-6 * rows_largest_rank
+        return {"ms": ms, "model": m, "rows_largest_rank": rows_largest_rank, "source": "profiles/scaling_model.json"}
+    except Exception:                                            # noqa: BLE001 - informational
+        return None
 
 
 def _capi_mod():

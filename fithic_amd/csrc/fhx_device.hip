@@ -2044,6 +2044,7 @@ struct fhx_ctx {
     std::vector<int64_t> fdr_counts;
     fhx::DistState* dist = nullptr;                 // communicator + exchange buffers of sharded runs (fhx_dist.inc)
     bool dist_ndist_agreed = false;                   // sharded runs: the histogram length was made equal on all ranks
+    long long dist_ndist_global = -1;                 // ... the all-reduced answer (max length | non-fixed bit), -1 = not asked yet
     bool dist_any_nonfixed = false;                   // ... and some rank holds off-grid / -r 0 rows (agreed in the same all-reduce)
 };
 
@@ -2519,6 +2520,7 @@ int alloc_row_arrays(fhx_ctx* ctx, int64_t n, int64_t n_dist) {
     ctx->tables_dirty = true;
     ctx->n_sorted = -1;
     ctx->dist_ndist_agreed = false;
+    ctx->dist_ndist_global = -1;
     ctx->dist_any_nonfixed = false;
     ctx->h_outlier_dists_global.clear();
     ctx->outlier_dists_are_global = false;
@@ -3058,9 +3060,12 @@ int fhx_pvalues(fhx_ctx* ctx) {
     }
     K2Params P = make_k2_params(ctx);
     FHX_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
-    {   // class thresholds per count for this pass's two binomials (kept while the totals and the largest count stay the same)
+    static const int cl_table = std::getenv("FHX_CL_TABLE") ? std::atoi(std::getenv("FHX_CL_TABLE")) : 0;     // measurements only
+    if (cl_table == 1 || cl_table == 2) {
+        // class thresholds per count for this pass's two binomials (kept while the totals and the largest count stay the same): only
+        // the table variants of k2_classify read them - the default kernel evaluates incbet's predicates per row and needs no table
         const int64_t mc = std::max<int64_t>(ctx->stats.max_count, 1);
-        if (mc >= INT32_MAX / 2) return fail(ctx, FHX_ERR_UNSUPPORTED, "contact counts beyond 2^30");
+        if (mc >= INT32_MAX / 2) return fail(ctx, FHX_ERR_UNSUPPORTED, "FHX_CL_TABLE: contact counts beyond 2^30");
         if (!ctx->d_cls_tab || ctx->cls_tab_counts != mc + 1 || ctx->cls_tab_n[0] != P.intra.n || ctx->cls_tab_n[1] != P.inter.n) {
             if (ctx->cls_tab_counts < mc + 1 || !ctx->d_cls_tab) {
                 FHX_HIP(hipStreamSynchronize(ctx->stream));
@@ -3161,7 +3166,7 @@ int fhx_pvalues(fhx_ctx* ctx) {
     {
         const dim3 cgrid(k2_classify_grid(k2_n)), cblock(K2_THREADS);
         static const int wpe = std::getenv("FHX_CL_WAVES") ? std::atoi(std::getenv("FHX_CL_WAVES")) : 0;        // measurements only
-        static const int table = std::getenv("FHX_CL_TABLE") ? std::atoi(std::getenv("FHX_CL_TABLE")) : 0;
+        const int table = cl_table;
         if (P.nonfixed)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<1, 4, 0>), cgrid, cblock, 0, ctx->stream, P, Q);
         else if (table == 1 && wpe == 6)
@@ -3211,7 +3216,8 @@ int fhx_pvalues(fhx_ctx* ctx) {
         // FHX_K2H_ROWS (1, 2) / FHX_K2H_WAVES (3) select the instantiations kept for measurements.
         static const int heavy_rows = std::getenv("FHX_K2H_ROWS") ? std::atoi(std::getenv("FHX_K2H_ROWS")) : 4;
         static const int heavy_wpe = std::getenv("FHX_K2H_WAVES") ? std::atoi(std::getenv("FHX_K2H_WAVES")) : 0;
-        const int hr = (heavy_rows >= 1 && heavy_rows <= K2H_MAX_ROWS) ? heavy_rows : 4;
+        const int hr = (heavy_rows == 1 || heavy_rows == 2) ? heavy_rows : 4;     // the instantiations below: 1, 2 or 4 rows per lane - the
+                                                                                   // bucket granule must be the launched kernel's task size
         hipLaunchKernelGGL(k2h_offsets, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned int*)ctx->d_digit_total, ctx->d_k2h_off,
                            64u * (unsigned int)hr);
         hipLaunchKernelGGL(k2h_tables, dim3(K2H_GENERIC), dim3(K2H_TABLE_THREADS), 0, ctx->stream, (const unsigned int*)ctx->d_digit_total,

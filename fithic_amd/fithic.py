@@ -250,7 +250,10 @@ def _adopt_outlier_dists(S, outliersdist):
 def _check_session_values(what, given, own):
     """calculateProbabilities / fit_Spline take x, y and binStats as arguments in the reference; here they are views of the
     engine's fit.  Values the caller changed in between would be ignored silently - refuse instead."""
-    if len(given) != len(own) or any(float(a) != float(b) for a, b in zip(given, own)):
+    def same(a, b):                            # NaN is how the host fit marks a value Python would have raised on: untouched, it is equal
+        a, b = float(a), float(b)
+        return a == b or (a != a and b != b)
+    if len(given) != len(own) or not all(same(a, b) for a, b in zip(given, own)):
         raise ValueError("fithic_amd: %s differs from what the engine computed in the previous stage; the engine fits its own "
                          "bins (edit mainDic before makeBinsFromInteractions instead)" % what)
 

@@ -492,6 +492,44 @@ def _running_python_max(v):
     return np.where(m == 0.0, np.where(neg_zero, -0.0, 0.0), m)
 
 
+def bh_prune_threshold(n_valid, n_tests, count_below):
+    """tau such that every value >= tau has q = 1 exactly (see benjamini_hochberg_pruned for the proof); count_below(t) must
+    return the exact number of values < t (NaN never counts).  n_valid = number of values that are not NaN; n_tests > 0."""
+    N = float(n_tests)
+    c = int(n_valid)
+    tau = np.inf
+    while c > 0:
+        tau2 = c / N
+        while not (tau2 * N / c >= 1.0):              # fl(fl(tau2*N)/c) >= 1, as the reference associates it
+            tau2 = np.nextafter(tau2, np.inf)
+        if tau2 >= tau:
+            break
+        kept = int(count_below(tau2))
+        tau = tau2
+        if kept == c:
+            break
+        c = kept
+    return tau
+
+
+def bh_of_survivors(vals, n_tests):
+    """q of the values below the pruning threshold (they occupy ranks 1..len(vals) of the whole array), in input order:
+    myStats.py:31-46 on the stable ascending order."""
+    vals = np.asarray(vals, np.float64)
+    N = float(n_tests)
+    out = np.empty(len(vals), np.float64)
+    c = len(vals)
+    if c:
+        order = np.argsort(vals, kind="stable")
+        sp = vals[order]
+        rank = np.arange(1, c + 1, dtype=np.float64)
+        with np.errstate(over="ignore"):
+            bh = sp * N / rank
+        bh = np.where(sp == 1.0, 1.0, np.where(bh > 1.0, 1.0, bh))
+        out[order] = _running_python_max(bh)
+    return out
+
+
 def benjamini_hochberg_pruned(p, n_tests):
     """The same function as benjamini_hochberg(), evaluated without sorting the rows whose q is provably 1 - for checking
     q of 10^8-row runs in seconds instead of a minute of argsort.
@@ -502,7 +540,8 @@ def benjamini_hochberg_pruned(p, n_tests):
     p >= tau2 has fl(fl(p*N)/rank) >= fl(fl(tau2*N)/c) (IEEE rounding is monotone); if that bound is >= 1 it is saturated
     as well, and so is everything after it.  Iterating tau <- tau2 with exact counts shrinks the survivor set to the
     enriched tail; only that tail is sorted.  NaN rows sort last in the reference and stay NaN without touching the others.
-    Pinned against benjamini_hochberg() by tests/test_oracle_golden.py."""
+    Pinned against benjamini_hochberg() by tests/test_oracle_golden.py.  (bh_prune_threshold / bh_of_survivors are the two
+    halves: run_check.py streams 10^9-row columns through them chunk by chunk.)"""
     p = np.asarray(p, np.float64)
     N = float(n_tests)
     if not N > 0.0:                                    # no value ever saturates: nothing to prune
@@ -510,32 +549,15 @@ def benjamini_hochberg_pruned(p, n_tests):
     q = np.ones(len(p), np.float64)
     nan = np.isnan(p)
     q[nan] = np.nan
-    c = int(len(p) - nan.sum())
-    tau = np.inf
-    while c > 0:
-        tau2 = c / N
-        while not (tau2 * N / c >= 1.0):              # fl(fl(tau2*N)/c) >= 1, as the reference associates it
-            tau2 = np.nextafter(tau2, np.inf)
-        if tau2 >= tau:
-            break
+
+    def count_below(t):
         with np.errstate(invalid="ignore"):
-            kept = int(np.count_nonzero(p < tau2))
-        tau = tau2
-        if kept == c:
-            break
-        c = kept
+            return np.count_nonzero(p < t)
+
+    tau = bh_prune_threshold(len(p) - nan.sum(), N, count_below)
     with np.errstate(invalid="ignore"):
         cand = np.flatnonzero(p < tau)
-    vals = p[cand]
-    c = len(vals)
-    if c:
-        order = np.argsort(vals, kind="stable")
-        sp = vals[order]
-        rank = np.arange(1, c + 1, dtype=np.float64)
-        with np.errstate(over="ignore"):
-            bh = sp * N / rank
-        bh = np.where(sp == 1.0, 1.0, np.where(bh > 1.0, 1.0, bh))
-        q[cand[order]] = _running_python_max(bh)
+    q[cand] = bh_of_survivors(p[cand], N)
     return q
 
 

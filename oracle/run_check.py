@@ -86,16 +86,92 @@ def compare_fit(get_array, info, g):
     return bad
 
 
-def check_engine_run(eng, genome, sample, cfg, info, with_bias, p_stride=1, fit_fixture_name=None):
+class _StreamedColumns:
+    """The engine's p and q columns read in chunks of `chunk` rows through torch tensors on the device (copied out of the
+    engine's buffers chunk by chunk): what lets a 2e9-row run be checked without 32 GB of host arrays.  The device only
+    counts, compares with constants and compacts here - torch operators, none of the engine's kernels; every BH value
+    that is compared is computed by the oracle on the host."""
+
+    def __init__(self, eng, torch, n, chunk):
+        self.eng, self.torch, self.n, self.chunk = eng, torch, int(n), int(chunk)
+        dev = torch.device("cuda", eng.ctx.device)
+        self.buf = [torch.empty(min(self.n, self.chunk), dtype=torch.float64, device=dev) for _ in range(2)]
+
+    def chunks(self, which=(0, 1)):
+        """-> (lo, hi, [tensor of column w for w in which]); the tensors are reused by the next step"""
+        eng = self.eng
+        for lo in range(0, self.n, self.chunk):
+            hi = min(self.n, lo + self.chunk)
+            out = []
+            for w in which:
+                eng.ctx.memcpy_d2d(self.buf[w].data_ptr(), eng.ctx.device_ptr(w) + 8 * lo, 8 * (hi - lo))
+                out.append(self.buf[w][:hi - lo])
+            yield lo, hi, out
+
+
+def _p_and_q_streamed(eng, torch, n, n_tests, sample_rows, chunk):
+    """-> (p of the sample rows, dict with the q verdict of EVERY row).  Three sweeps over the columns: NaN count, the oracle's
+    pruning threshold (fo.bh_prune_threshold with the counts taken on the device), then per chunk the sampled p, the rows at
+    or above the threshold (q must be exactly 1, NaN rows NaN) and the survivors, which go to the host for the oracle's BH."""
+    cols = _StreamedColumns(eng, torch, n, chunk)
+    N = float(n_tests)
+    if not N > 0.0:
+        raise ValueError("streamed check needs N > 0 (nothing can be pruned otherwise)")
+    n_nan = 0
+    for lo, hi, (p_t,) in cols.chunks((0,)):
+        n_nan += int(torch.isnan(p_t).sum())
+    sweeps = [0]
+
+    def count_below(t):
+        sweeps[0] += 1
+        c = 0
+        for lo, hi, (p_t,) in cols.chunks((0,)):
+            c += int((p_t < t).sum())
+        return c
+
+    tau = fo.bh_prune_threshold(n - n_nan, N, count_below)
+    rows_t = torch.as_tensor(np.ascontiguousarray(sample_rows, np.int64), device=cols.buf[0].device)
+    got = np.empty(len(sample_rows), np.float64)
+    order = np.argsort(sample_rows, kind="stable")
+    sorted_rows = np.asarray(sample_rows)[order]
+    bad_pruned = 0
+    nan_equal = True
+    surv_rows, surv_p, surv_q = [], [], []
+    for lo, hi, (p_t, q_t) in cols.chunks((0, 1)):
+        a, b = np.searchsorted(sorted_rows, lo), np.searchsorted(sorted_rows, hi)
+        if b > a:
+            got[order[a:b]] = p_t[rows_t[order[a:b]] - lo].cpu().numpy()
+        nan = torch.isnan(p_t)
+        nan_equal = nan_equal and bool(torch.equal(nan, torch.isnan(q_t)))
+        keep = p_t < tau
+        bad_pruned += int(((q_t != 1.0) & ~keep & ~nan).sum())
+        idx = torch.nonzero(keep).squeeze(1)
+        if idx.numel():
+            surv_rows.append((idx + lo).cpu().numpy())
+            surv_p.append(p_t[idx].cpu().numpy())
+            surv_q.append(q_t[idx].cpu().numpy())
+    sp = np.concatenate(surv_p) if surv_p else np.empty(0)
+    sq = np.concatenate(surv_q) if surv_q else np.empty(0)
+    q_ref = fo.bh_of_survivors(sp, N)                  # chunks come in row order: the stable order of equal values is the reference's
+    dq = float(np.max(np.abs(sq - q_ref))) if len(sp) else 0.0
+    if bad_pruned:
+        dq = max(dq, 1.0)
+    return got, {"max_dq": dq, "rows_q": int(n), "nan_pattern_equal": bool(nan_equal), "q_rows_ranked_by_oracle": int(len(sp)),
+                 "q_rows_pruned_not_one": int(bad_pruned), "streamed": {"chunk_rows": int(chunk), "threshold_sweeps": sweeps[0], "tau": float(tau)}}
+
+
+def check_engine_run(eng, genome, sample, cfg, info, with_bias, p_stride=1, fit_fixture_name=None, torch=None, chunk_rows=1 << 27):
     """sample = {"rows": row numbers, "cols": [chr1, mid1, chr2, mid2, count] of those rows, "chroms": chromosome ids they
     touch}; cfg = {"res", "L", "U", "mode"}; info = (fit-info dict, stats dict) of the pass.  Every p_stride-th sample row
     is evaluated.  fit_fixture_name: the f14 fixture of this workload (the run must be the full-size synth-v1 workload of that
-    name): the engine's K1 histogram and its fit are then compared with the reference's before the table is used."""
+    name): the engine's K1 histogram and its fit are then compared with the reference's before the table is used.
+    torch: given, p and q are read in chunks of chunk_rows rows through device tensors (_p_and_q_streamed: any size); without
+    it both columns are fetched whole (16 B/row of host memory)."""
     from fithic_amd import _capi
     fo.build()
     t0 = time.perf_counter()
-    v = eng.fetch(p=True, q=True)
     info, st = info
+    v = eng.fetch(p=True, q=True) if torch is None else None
     fit_diff = hist_diff = None
     if fit_fixture_name:
         g = fit_fixture(fit_fixture_name)
@@ -131,16 +207,23 @@ def check_engine_run(eng, genome, sample, cfg, info, with_bias, p_stride=1, fit_
     if mode in ("All", "interOnly"):
         sel = np.flatnonzero(~discard & (inter if mode == "All" else np.ones(len(rows), bool)))
         want[sel] = fo.bdtrc(cnt[sel].astype(np.float64) - 1, float(st["inter_sum"]), info["inter_chr_prob"] * (b1[sel] * b2[sel]))
-    got = v["p"][rows]
-    nan_equal = bool(np.array_equal(np.isnan(got), np.isnan(want)))
+    extra = {}
+    if torch is not None:
+        got, qv = _p_and_q_streamed(eng, torch, int(eng.n_rows), info["bh_total_tests"], rows, chunk_rows)
+        dq, n_q, q_nan_equal = qv.pop("max_dq"), qv.pop("rows_q"), qv.pop("nan_pattern_equal")
+        extra = qv
+    else:
+        got = v["p"][rows]
+        q_ref = fo.benjamini_hochberg_pruned(v["p"], info["bh_total_tests"])
+        qn = np.isnan(q_ref)
+        dq = float(np.max(np.abs(np.where(qn, 0, v["q"]) - np.where(qn, 0, q_ref)))) if len(q_ref) else 0.0
+        n_q, q_nan_equal = int(len(q_ref)), bool(np.array_equal(np.isnan(v["q"]), qn))
+    nan_equal = bool(np.array_equal(np.isnan(got), np.isnan(want))) and q_nan_equal
     dp = float(np.nanmax(np.abs(np.where(np.isnan(got), 0, got) - np.where(np.isnan(want), 0, want)))) if len(rows) else 0.0
-    q_ref = fo.benjamini_hochberg_pruned(v["p"], info["bh_total_tests"])
-    qn = np.isnan(q_ref)
-    dq = float(np.max(np.abs(np.where(qn, 0, v["q"]) - np.where(qn, 0, q_ref)))) if len(q_ref) else 0.0
-    nan_equal = nan_equal and bool(np.array_equal(np.isnan(v["q"]), qn))
-    out = {"max_dp": dp, "rows_p": int(len(rows)), "max_dq": dq, "rows_q": int(len(q_ref)), "nan_pattern_equal": nan_equal,
+    out = {"max_dp": dp, "rows_p": int(len(rows)), "max_dq": dq, "rows_q": n_q, "nan_pattern_equal": nan_equal,
            "tolerance": 1e-10, "ok": bool(dp <= 1e-10 and dq <= 1e-10 and nan_equal),
            "p_bit_identical_frac": float(np.mean(got.view(np.int64) == want.view(np.int64))) if len(rows) else 1.0}
+    out.update(extra)
     if fit_fixture_name:
         out["fit_vs_reference"] = {"fixture": "tests/golden/f14_%s_fit.npz" % fit_fixture_name, "k1_histogram_differs": hist_diff,
                                    "fit_differs": fit_diff, "bit_identical": not hist_diff and not fit_diff}

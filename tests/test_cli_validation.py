@@ -48,3 +48,20 @@ def test_banner_reports_the_zero_means_unset_rule(tmp_path, capsys):
     code, out = _run(["-i", CON, "-f", FRG, "-o", str(tmp_path / "new_dir"), "-r", "-1", "-p", "0", "-b", "0"], capsys)
     assert code == 2 and "Output path created" in out and os.path.isdir(str(tmp_path / "new_dir"))
     assert out.index("Reading fragments file from") < out.index("Reading interactions file from") < out.index("INVALID RESOLUTION")
+
+
+def test_console_script_is_declared_like_the_reference():
+    """ay-lab/fithic installs `fithic = fithic.fithic:main` (setup.py:14-16); pyproject.toml declares the same command."""
+    import importlib
+    import os
+    import subprocess
+    import sys
+    import tomli
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "pyproject.toml"), "rb") as f:
+        meta = tomli.load(f)
+    mod, fn = meta["project"]["scripts"]["fithic"].split(":")
+    assert callable(getattr(importlib.import_module(mod), fn))
+    out = subprocess.run([sys.executable, "-c", "import sys; sys.argv = ['fithic', '-V']; from %s import %s as m; m()" % (mod, fn)],
+                         capture_output=True, text=True, cwd=root, timeout=120)
+    assert out.returncode == 0 and "Fit-Hi-C" in out.stdout

@@ -45,3 +45,40 @@ def test_sharded_schedule_over_rccl_is_verified_against_one_gpu():
     assert pc["chromosomes_p_differ"] == [] and pc["chromosomes_q_differ"] == [] and pc["global_stats_equal"] and pc["fit_scalars_equal"]
     assert pc["rows"] == out["config"]["pairs"] and pc["max_dp"] <= 1e-10 and pc["max_dq"] == 0.0
     assert out["rccl"]["world_in_library"] == 1 and "library communicator" in out["rccl"]["driver"]
+
+
+def _plain(extra_env, *flags, expect_rc=0):
+    """bench.py as the driver starts it for one GPU: no launcher environment at all"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1"] + list(flags),
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == expect_rc, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_plain_invocation_starts_its_own_ranks():
+    """`python bench.py --gpus N` without torch.distributed.run: the script launches the ranks itself (here N = 1 with the
+    sharded schedule forced) and the one line carries everything an N > 1 line must carry."""
+    out = _plain({"FHX_FORCE_DIST": "1"}, "--gpus", "1", "--max-chroms", "3", "--no-weak")
+    assert out["value"] > 1e8 and out["scaling"] == "strong" and out["n_gpus"] == 1
+    assert out["rccl"]["world_in_library"] == 1
+    assert len(out["per_rank"]) == 1 and out["per_rank"][0]["rows"] == out["config"]["pairs"]
+    assert all(out["per_rank"][0][k] > 0 for k in ("k1_ms", "k2_ms", "k3_ms"))
+    assert len(out["stage_ms"]) == 5
+    assert out["parity_check"]["ok"] and out["parity_check"]["sharded_equals_single_gpu"]
+    assert 0.3 < out["strong_efficiency"] < 1.5 and out["single_gpu_ms_per_step"] > 0
+
+
+def test_more_gpus_than_the_node_has_yields_one_diagnostic_line():
+    import torch
+    n = torch.cuda.device_count()
+    out = _plain({}, "--gpus", str(n + 1), expect_rc=2)
+    assert out["value"] is None and out["visible_devices"] == n and out["n_gpus"] == n + 1 and "visible" in out["error"]
+
+
+def test_single_gpu_line_says_strong_scaling():
+    out = _plain({}, "--max-chroms", "2", "--no-cpu-baseline", "--no-parity-check")
+    assert out["scaling"] == "strong" and out["n_gpus"] == 1 and out["value"] > 1e8

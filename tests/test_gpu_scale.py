@@ -311,6 +311,42 @@ def test_c3_at_full_size():
     chk = run_check.check_engine_run(eng, genome, sample, cfg, (out.info, out.stats), True, p_stride=16, fit_fixture_name="C3")
     assert chk["rows_q"] == n and chk["rows_p"] > 1_000_000
     assert chk["nan_pattern_equal"] and chk["max_dp"] <= TOL and chk["max_dq"] == 0.0 and chk["fit_vs_reference"]["bit_identical"], chk
+    # the streamed form of the same check (what bench.py and the C5 test below use: p and q read in chunks through device
+    # tensors, survivors of the oracle's pruning threshold ranked by the oracle on the host) must give the same verdict
+    st = run_check.check_engine_run(eng, genome, sample, cfg, (out.info, out.stats), True, p_stride=16, fit_fixture_name="C3",
+                                    torch=torch, chunk_rows=40_000_000)
+    assert st["streamed"]["chunk_rows"] == 40_000_000 and st["rows_q"] == n and st["q_rows_pruned_not_one"] == 0
+    for k in ("max_dp", "max_dq", "rows_p", "nan_pattern_equal", "p_bit_identical_frac", "ok"):
+        assert st[k] == chk[k], (k, st[k], chk[k])
+    assert 0 < st["q_rows_ranked_by_oracle"] < n // 10
+    eng.close()
+
+
+def test_c5_at_full_size():
+    """BASELINE configs[4] at its full size on one GPU - 22 autosomes at 1 kb, 1.9e9 cis + 1e8 trans rows, -x All, exactly what
+    `bench.py --config C5` times: K1 + fit against the real reference's (fixture f14_C5_fit), p of a 1-in-8 sample of the
+    smallest chromosome's ~3e7 rows (and the trans rows inside it) against the oracle's Cephes with that table, and q of ALL
+    2.0e9 rows: rows at or above the oracle's pruning threshold must be exactly 1, the rest is ranked by the oracle."""
+    import torch
+    import bench
+    from fithic_amd import synth
+    from oracle import run_check
+    cfg = dict(bench.CONFIGS["C5"])
+    dev = torch.device("cuda", 0)
+    genome = synth.Genome(cfg["res"], synth.HG19_AUTOSOMES)
+    mine = list(range(len(genome)))
+    cols, n, n_cis, n_trans = bench.build_rows(synth, torch, cfg, genome, mine, 0, 1, dev)
+    assert 1.9e9 < n < 2.1e9 and n_trans > 9e7
+    eng = _engine_for(genome, cfg["res"], cfg["L"], cfg["U"], 100, mode="All")
+    eng.load_contacts_device([t.data_ptr() for t in cols], n)
+    sample = bench.build_sample(torch, cols, n, n_cis, genome, mine, cfg, cfg["res"], dev)
+    del cols
+    torch.cuda.empty_cache()
+    out = eng.run_pass(collect=False)
+    chk = run_check.check_engine_run(eng, genome, sample, cfg, (out.info, out.stats), True, p_stride=8, fit_fixture_name="C5", torch=torch)
+    assert chk["rows_q"] == n and chk["rows_p"] > 2_000_000 and chk["q_rows_pruned_not_one"] == 0
+    assert chk["nan_pattern_equal"] and chk["max_dp"] <= TOL and chk["max_dq"] == 0.0 and chk["fit_vs_reference"]["bit_identical"], chk
+    assert chk["ok"]
     eng.close()
 
 

@@ -79,3 +79,16 @@ def test_myStats_mean_and_variance():
     m, v = myStats.meanAndVariance([1, 2, 3, 4])
     assert m == 2.5 and v == 30 / 4.0 - 2.5 * 2.5
     assert callable(myStats.benjamini_hochberg_correction)
+
+
+def test_session_value_check_treats_untouched_nan_as_equal():
+    """x / y handed back untouched must pass even where the host fit left NaN or inf (a 0-pair bin, where the reference's Python
+    would have raised): NaN != NaN must not read as "the caller edited it"."""
+    import pytest
+    from fithic_amd.fithic import _check_session_values
+    own = [1.0, float("nan"), float("inf"), 0.0]
+    _check_session_values("x", list(own), own)
+    _check_session_values("x", np.array(own), own)
+    for edited in ([1.0, 2.0, float("inf"), 0.0], [1.0, float("nan"), float("inf")], [float("nan")] * 4):
+        with pytest.raises(ValueError):
+            _check_session_values("x", edited, own)
