@@ -319,6 +319,7 @@ struct K2Params {
     const double* slot_bias;      // -1 = discarded / missing; all 1.0 without a bias file
     bool no_bias;                 // no bias table was loaded: slot_bias is all 1.0 and need not be read
     const double* prior_lut;      // newSplineY by distance index (clamp + bisect_left folded in)
+    int lut_len;                  // entries of prior_lut (= length of the distance histogram)
     dev::BinomTables intra, inter;
     const dev::ClsRow* cls_intra; // bdtrc_class as five thresholds on the prior per count (k2_class_tables)
     const dev::ClsRow* cls_inter;
@@ -386,6 +387,38 @@ __device__ __forceinline__ bool row_prior(const K2Params& P, int l1, int l2, dou
     prior = P.inter_chr_prob * (b1 * b2);                                 // fithic.py:1100 (also intra rows when interOnly)
     is_inter = true;
     return true;
+}
+
+// row_prior<0> for the four rows a lane of k2_classify holds, with every gather issued up front: the three table reads of a row
+// (two biases, the prior by distance index) do not depend on the row's fate, so all twelve go out back to back - unconditionally,
+// on clamped indices - and the branch table of fithic.py:1057-1116 is applied to the values afterwards.  (Evaluated row by row,
+// each row's gathers sat behind the previous row's classification: four exposed round trips per step at four waves per SIMD.)
+// Same values, same order of the two multiplications: prior = table * (b1 * b2).
+template <int ITEMS>
+__device__ __forceinline__ void rows_prior_fixed(const K2Params& P, const int (&l1)[ITEMS], const int (&l2)[ITEMS], double (&prior)[ITEMS],
+                                                 bool (&is_inter)[ITEMS], bool (&live)[ITEMS]) {
+    double b1[ITEMS], b2[ITEMS], tab[ITEMS];
+    int dist[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const bool inter = l2[r] < 0;
+        const int s2 = inter ? ~l2[r] : l2[r];
+        dist[r] = abs(l1[r] - s2);
+        b1[r] = P.no_bias ? 1.0 : P.slot_bias[l1[r]];
+        b2[r] = P.no_bias ? 1.0 : P.slot_bias[s2];
+        tab[r] = P.prior_lut[min(dist[r], P.lut_len - 1)];             // inter rows: any entry, unused
+    }
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const bool inter = l2[r] < 0;
+        const double bb = b1[r] * b2[r];
+        const bool as_intra = !inter && P.mode != FHX_MODE_INTER_ONLY;
+        const bool discarded = (b1[r] < 0 || b2[r] < 0) && !inter;                      // fithic.py:1057-1064
+        const bool in_range = dist[r] >= P.lo_idx && dist[r] <= P.hi_idx;
+        live[r] = !discarded && (as_intra ? in_range : P.mode != FHX_MODE_INTRA_ONLY);
+        is_inter[r] = !as_intra;
+        prior[r] = live[r] ? (as_intra ? tab[r] : P.inter_chr_prob) * bb : 1.0;        // fithic.py:1069 / :1100
+    }
 }
 
 // The top-bits histogram of K3's early cutoff (k3_top_hist) gathered by the kernels that store p: bdtrc values are NaN or in
@@ -518,8 +551,9 @@ constexpr int K2_CLASSES = K2_QUEUES + 2;
 
 // TABLE: 0 = incbet's predicates evaluated per row (bdtrc_class), 1 = the per-count threshold rows (dev::cls_lookup), 2 = the
 // predicates with the orientation threshold (their one division) read from the count's row
-template <int NF, int WPE, int TABLE>
+template <int NF, int WPE, int TABLE, bool HOIST = false>
 __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k2_classify(K2Params P, K2Queues Q) {
+    static_assert(!HOIST || NF == 0, "the hoisted gathers are the fixed-size path's");
     constexpr int ITEMS = K2_CL_ITEMS, WAVES = K2_THREADS / 64, WAVE_ROWS = 64 * ITEMS;
     // Per wave and step: 256 consecutive rows, four per lane (16-byte loads of the three columns).  Every looping row becomes a
     // 16-byte entry of its class queue, in this workgroup's shard: the wave counts its rows per class with ballots, reserves the
@@ -561,6 +595,8 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE,
         }
         int cls_of[ITEMS];
         double prior_of[ITEMS];
+        bool inter_of[ITEMS], live_of[ITEMS];
+        if (HOIST) rows_prior_fixed<ITEMS>(P, l1_of, l2_of, prior_of, inter_of, live_of);
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
             const int64_t i = row0 + r;
@@ -571,7 +607,15 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE,
                 double pv = 1.0;
                 bool is_inter = false;
                 cls = 0;
-                if (row_prior<NF>(P, l1_of[r], l2_of[r], prior, is_inter)) {
+                bool live;
+                if (HOIST) {
+                    live = live_of[r];
+                    prior = prior_of[r];
+                    is_inter = inter_of[r];
+                } else {
+                    live = row_prior<NF>(P, l1_of[r], l2_of[r], prior, is_inter);
+                }
+                if (live) {
                     const dev::BinomTables& T = is_inter ? P.inter : P.intra;
                     if (TABLE == 1)
                         cls = dev::cls_is_trivial(c, T.n, prior) ? (int)dev::BC_TRIVIAL : dev::cls_lookup((is_inter ? P.cls_inter : P.cls_intra)[c], prior);
@@ -2146,6 +2190,7 @@ K2Params make_k2_params(fhx_ctx* c) {
     P.slot_bias = c->d_slot_bias;
     P.no_bias = !c->have_bias;
     P.prior_lut = c->d_lut;
+    P.lut_len = (int)std::min<size_t>(std::max<size_t>(c->fit.prior_lut.size(), 1), (size_t)INT32_MAX);
     const double n_intra = (double)c->stats.in_range_sum, n_inter = (double)c->stats.inter_sum;
     P.intra = dev::BinomTables{c->d_lbeta_intra, c->d_invb_intra, n_intra, (n_intra + 1.0) < dev::kMaxGam};
     P.inter = dev::BinomTables{c->d_lbeta_inter, c->d_invb_inter, n_inter, (n_inter + 1.0) < dev::kMaxGam};
@@ -3167,6 +3212,7 @@ int fhx_pvalues(fhx_ctx* ctx) {
         const dim3 cgrid(k2_classify_grid(k2_n)), cblock(K2_THREADS);
         static const int wpe = std::getenv("FHX_CL_WAVES") ? std::atoi(std::getenv("FHX_CL_WAVES")) : 0;        // measurements only
         const int table = cl_table;
+        static const int cl_hoist = std::getenv("FHX_CL_HOIST") ? std::atoi(std::getenv("FHX_CL_HOIST")) : 1;    // 0: measurements (row-by-row gathers)
         if (P.nonfixed)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<1, 4, 0>), cgrid, cblock, 0, ctx->stream, P, Q);
         else if (table == 1 && wpe == 6)
@@ -3179,8 +3225,10 @@ int fhx_pvalues(fhx_ctx* ctx) {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, 4, 2>), cgrid, cblock, 0, ctx->stream, P, Q);
         else if (wpe == 6)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, 6, 0>), cgrid, cblock, 0, ctx->stream, P, Q);
-        else        // 4 waves/SIMD (98 VGPRs, no scratch): 1.85 ms against 1.95 at 6 (80 VGPRs + 44 B of scratch), profiles/r03_e_*
+        else if (cl_hoist == 0)   // 4 waves/SIMD (98 VGPRs, no scratch): 1.85 ms against 1.95 at 6 (80 VGPRs + 44 B of scratch), profiles/r03_e_*
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, 4, 0>), cgrid, cblock, 0, ctx->stream, P, Q);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, 4, 0, true>), cgrid, cblock, 0, ctx->stream, P, Q);
     }
     const dim3 qgrid(256 * 8), qblock(K2_THREADS);
     hipLaunchKernelGGL(k2_closed, qgrid, qblock, 0, ctx->stream, P, Q.q[K2_CLOSED - 1]);

@@ -3,14 +3,16 @@
 # One rocprofv3 --pmc pass per counter (kernel-trace only), summed per kernel: total and per launch.
 set -e
 TAG=$1; shift
+T=${TAG//\//_}            # the tag may name a sub-directory of gpurun_out/; /tmp paths use a flat name
+mkdir -p "$(dirname "$(pwd)/gpurun_out/${TAG}_x")"
 ROOT=$(pwd)
 mkdir -p "$ROOT/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 : > "$ROOT/gpurun_out/${TAG}_counters.txt"
 for C in "$@"; do
-  rm -rf /tmp/pmcc_${TAG}_$C
-  rocprofv3 --kernel-trace --pmc $C -d /tmp/pmcc_${TAG}_$C -o run -- python "$ROOT/bench.py" --no-cpu-baseline --steps 3 > /tmp/pmcc_${TAG}_$C.log 2>&1 || { echo "$C: failed"; tail -3 /tmp/pmcc_${TAG}_$C.log; continue; }
-  DB=$(find /tmp/pmcc_${TAG}_$C -name '*.db' | head -1)
+  rm -rf /tmp/pmcc_${T}_$C
+  rocprofv3 --kernel-trace --pmc $C -d /tmp/pmcc_${T}_$C -o run -- python "$ROOT/bench.py" --no-cpu-baseline --steps 3 > /tmp/pmcc_${T}_$C.log 2>&1 || { echo "$C: failed"; tail -3 /tmp/pmcc_${T}_$C.log; continue; }
+  DB=$(find /tmp/pmcc_${T}_$C -name '*.db' | head -1)
   python - "$DB" "$C" >> "$ROOT/gpurun_out/${TAG}_counters.txt" <<'PY'
 import sqlite3, sys, re
 con = sqlite3.connect(sys.argv[1])
