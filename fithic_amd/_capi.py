@@ -109,6 +109,7 @@ SYMBOLS = {
     "fhx_n_sorted": (ctypes.c_int64, [_P]),
     "fhx_kernel_seconds": (ctypes.c_int, [_P, _F64P, _F64P, _F64P]),
     "fhx_k2_heavy_launch": (ctypes.c_int, [_P, _F64P, _I64P]),
+    "fhx_k2_class_rows": (ctypes.c_int, [_P, _I64P]),
     "fhx_bdtrc_array": (ctypes.c_int, [_P, ctypes.c_double, _I32P, _F64P, ctypes.c_int64, _F64P]),
     "fhx_debug_format": (ctypes.c_int, [_P, _F64P, ctypes.c_int64, ctypes.c_int32, ctypes.c_char_p, _I32P]),
     "fhx_debug_contfrac": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _F64P, _F64P, _F64P, ctypes.c_int64, _F64P]),
@@ -134,6 +135,7 @@ SYMBOLS = {
     "fhx_pass_stats_distributed": (ctypes.c_int, [_P, ctypes.POINTER(FhxStats)]),
     "fhx_bh_distributed": (ctypes.c_int, [_P, ctypes.c_double]),
     "fhx_dist_stage_seconds": (ctypes.c_int, [_P, _F64P]),
+    "fhx_dist_trace": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int64, _I64P, ctypes.c_int]),
     "fhx_copy": (ctypes.c_int, [_P, _P, _P, ctypes.c_int64, ctypes.c_int]),
     "fhx_host_read_table": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_P)]),
     "fhx_table_rows": (ctypes.c_int64, [_P]),
@@ -462,6 +464,19 @@ class Context:
         self._check(self._L.fhx_dist_stage_seconds(self._h, _ptr(out, ctypes.c_double)))
         return dict(zip(STAGE_NAMES, out.tolist()))
 
+    def dist_trace(self, clear=True):
+        """[(step, kind, size)] of the collectives issued so far (FHX_DIST_TRACE=1 at comm_init time), in the vocabulary of
+        csrc/fhx_dist_schedule.def"""
+        n = ctypes.c_int64(0)
+        self._check(self._L.fhx_dist_trace(self._h, None, 0, ctypes.byref(n), 0))
+        buf = ctypes.create_string_buffer(max(int(n.value), 1))
+        self._check(self._L.fhx_dist_trace(self._h, buf, int(n.value), ctypes.byref(n), 1 if clear else 0))
+        rows = []
+        for line in buf.raw[:n.value].decode().splitlines():
+            step, kind, size = line.split()
+            rows.append((step, kind, int(size)))
+        return rows
+
     def copy(self, dst, src, nbytes, kind):
         """kind 0 = host to device, 1 = device to host, 2 = device to device (addresses as ints)."""
         self._check(self._L.fhx_copy(self._h, _P(int(dst)), _P(int(src)), int(nbytes), int(kind)))
@@ -531,6 +546,12 @@ class Context:
         sec, rows = ctypes.c_double(0), ctypes.c_int64(0)
         self._check(self._L.fhx_k2_heavy_launch(self._h, ctypes.byref(sec), ctypes.byref(rows)))
         return sec.value, rows.value
+
+    def k2_class_rows(self):
+        """rows the last pvalues() queued per class: power series, incbcf, incbd, swapped incbcf (300 iterations), closed form >= 0.01"""
+        out = (ctypes.c_int64 * 5)()
+        self._check(self._L.fhx_k2_class_rows(self._h, out))
+        return dict(zip(("pseries", "cf_bcf", "cf_bd", "cf_swapped", "closed_pow"), [int(v) for v in out]))
 
     def device_ptr(self, which):
         return self._L.fhx_device_ptr(self._h, which)

@@ -52,6 +52,18 @@ __device__ __forceinline__ int wave_max_i32(int v) {
     return v;
 }
 
+// inclusive add-scan over the 64 lanes of a wave in six DPP adds (row shifts inside each row of 16 lanes, then the last lane of
+// rows 0 / 2 broadcast into rows 1 / 3 and lane 31 into the upper half); lanes a shift leaves without a source add 0
+__device__ __forceinline__ unsigned int wave_incl_sum_u32(unsigned int v) {
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);     // row_shr:1
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);     // row_shr:2
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);     // row_shr:4
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);     // row_shr:8
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // ===================================================================================================
 // K0: ingest.  Slot of a locus = chr_base[chr] + mid / res; a chromosome's loci must share mid % res
 // (that is what "fixed-size" data looks like: createFitHiCFragments-fixedsize.py writes mid = i*res + res/2).
@@ -321,8 +333,6 @@ struct K2Params {
     const double* prior_lut;      // newSplineY by distance index (clamp + bisect_left folded in)
     int lut_len;                  // entries of prior_lut (= length of the distance histogram)
     dev::BinomTables intra, inter;
-    const dev::ClsRow* cls_intra; // bdtrc_class as five thresholds on the prior per count (k2_class_tables)
-    const dev::ClsRow* cls_inter;
     double inter_chr_prob;
     double outlier_thres;         // 1/N
     int lo_idx, hi_idx;
@@ -549,11 +559,17 @@ constexpr int K2_CLOSED = K2_QUEUES + 1;                 // count == 1 rows with
 constexpr int K2_CLOSED_LOCAL = K2_QUEUES + 2;           // count == 1 rows with prior < 0.01: wave-local, evaluated densely from LDS
 constexpr int K2_CLASSES = K2_QUEUES + 2;
 
-// TABLE: 0 = incbet's predicates evaluated per row (bdtrc_class), 1 = the per-count threshold rows (dev::cls_lookup), 2 = the
-// predicates with the orientation threshold (their one division) read from the count's row
-template <int NF, int WPE, int TABLE, bool HOIST = false>
+// TABLE: 0 = incbet's predicates evaluated per row (bdtrc_class); 3 = the same predicates with their one division - the orientation
+// threshold aa / (aa + bb), a function of the count alone - read from an LDS table the workgroup fills for counts < K2_TB_COUNTS
+// (larger counts divide, as before).  Rounds 2-3 measured a per-count row of all five thresholds in HBM (slower: the dependent
+// 64-byte gather cost more than the arithmetic) and the orientation threshold alone from that table (no change): DESIGN.md 4.
+// HOIST: all gathers of the four rows up front (rows_prior_fixed).  PACK: slots reserved with two packed DPP prefix sums
+// instead of 24 ballots.
+constexpr int K2_TB_COUNTS = 128;
+template <int NF, int WPE, int TABLE, bool HOIST = false, bool PACK = false>
 __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k2_classify(K2Params P, K2Queues Q) {
     static_assert(!HOIST || NF == 0, "the hoisted gathers are the fixed-size path's");
+    static_assert(TABLE == 0 || TABLE == 3, "table variants 1 and 2 were measured and dropped");
     constexpr int ITEMS = K2_CL_ITEMS, WAVES = K2_THREADS / 64, WAVE_ROWS = 64 * ITEMS;
     // Per wave and step: 256 consecutive rows, four per lane (16-byte loads of the three columns).  Every looping row becomes a
     // 16-byte entry of its class queue, in this workgroup's shard: the wave counts its rows per class with ballots, reserves the
@@ -568,6 +584,17 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE,
     __shared__ unsigned short cf_idx[WAVES][WAVE_ROWS];         // row within the wave's 256 | 0x8000 for the inter-chromosomal binomial
     __shared__ unsigned int hist_lds[K2_HIST_BINS];
     __shared__ unsigned int heavy_lds[K2H_BUCKETS];             // this shard's swapped-fraction rows per bucket of the count sort
+    __shared__ double tb_lds[TABLE == 3 ? 2 * K2_TB_COUNTS : 1];   // aa / (aa + bb) of counts 0..127: intra binomial, then inter
+    if (TABLE == 3) {
+        static_assert(2 * K2_TB_COUNTS <= K2_THREADS, "one thread per table entry");
+        if (threadIdx.x < 2 * K2_TB_COUNTS) {
+            const int c = threadIdx.x & (K2_TB_COUNTS - 1);
+            const double n_total = threadIdx.x < K2_TB_COUNTS ? P.intra.n : P.inter.n;
+            const double fk = (double)c - 1.0;                   // bdtrc_class's own statements
+            const double aa = fk + 1.0, bb = n_total - fk;
+            tb_lds[threadIdx.x] = aa / (aa + bb);
+        }
+    }
     if (threadIdx.x <= K2_QUEUES) cnt[threadIdx.x] = 0;
     const bool count_heavy = Q.heavy_hist != nullptr;
     if (count_heavy)
@@ -592,6 +619,11 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE,
             l1_of[0] = a.x; l1_of[1] = a.y; l1_of[2] = a.z; l1_of[3] = a.w;
             l2_of[0] = b.x; l2_of[1] = b.y; l2_of[2] = b.z; l2_of[3] = b.w;
             count_of[0] = c.x; count_of[1] = c.y; count_of[2] = c.z; count_of[3] = c.w;
+            if (HOIST && row0 + ITEMS > P.n) {                  // the padding rows of the last group hold whatever the allocation held:
+#pragma unroll
+                for (int r = 1; r < ITEMS; ++r)                 // their (unconditional) gathers must stay inside the tables
+                    if (row0 + r >= P.n) l1_of[r] = l2_of[r] = 0;
+            }
         }
         int cls_of[ITEMS];
         double prior_of[ITEMS];
@@ -617,12 +649,19 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE,
                 }
                 if (live) {
                     const dev::BinomTables& T = is_inter ? P.inter : P.intra;
-                    if (TABLE == 1)
-                        cls = dev::cls_is_trivial(c, T.n, prior) ? (int)dev::BC_TRIVIAL : dev::cls_lookup((is_inter ? P.cls_inter : P.cls_intra)[c], prior);
-                    else if (TABLE == 2)
-                        cls = dev::bdtrc_class_tb(c, T.n, prior, (c >= 0 && (double)c - 1.0 < T.n) ? (is_inter ? P.cls_inter : P.cls_intra)[c].tB : 0.0);
-                    else
+                    if (TABLE == 3) {
+                        double tB;
+                        if (c >= 0 && c < K2_TB_COUNTS) {
+                            tB = tb_lds[(is_inter ? K2_TB_COUNTS : 0) + c];
+                        } else {                                 // a wave without such a count skips the division
+                            const double fk = (double)c - 1.0;
+                            const double aa = fk + 1.0, bb = T.n - fk;
+                            tB = aa / (aa + bb);
+                        }
+                        cls = dev::bdtrc_class_tb(c, T.n, prior, tB);
+                    } else {
                         cls = dev::bdtrc_class(c, T.n, prior);
+                    }
                     if (cls == dev::BC_TRIVIAL) {
                         if (dev::bdtrc_is_closed_form(c, T.n, prior))
                             cls = prior < 0.01 ? K2_CLOSED_LOCAL : K2_CLOSED;
@@ -644,17 +683,48 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE,
         // (lane k reserves class k's total in the workgroup's running counter) and the broadcasts
         unsigned int before_cls[ITEMS];          // rank of this lane's item r among the wave's items of its class
         unsigned int tot[K2_CLASSES] = {0u, 0u, 0u, 0u, 0u, 0u};
+        static_assert(K2_CLASSES == 6 && K2_QUEUES == 4, "lane k reserves class k; the sixth class is wave-local");
+        if (PACK) {
+            // Six counters of 10 bits (a wave holds 256 rows) in two words - classes 1..3 and 4..6 - summed over the lanes by
+            // two DPP prefix scans; an item's rank is the field of its class in the lanes' exclusive prefix plus the lane's own
+            // earlier items of that class.  Order inside a class is (lane, item) instead of (item, lane): queue order is free.
+            unsigned int mine[2] = {0u, 0u};
+            unsigned int shift_of[ITEMS];
 #pragma unroll
-        for (int r = 0; r < ITEMS; ++r) {
-            before_cls[r] = 0;
+            for (int r = 0; r < ITEMS; ++r) {
+                const int k = cls_of[r] - 1;                      // 0..5 counted; -2, -1: no rank
+                const int f = k >= 3 ? k - 3 : k;
+                shift_of[r] = 10u * (unsigned int)(f < 0 ? 0 : f);
+                const unsigned int one = k >= 0 ? (1u << shift_of[r]) : 0u;
+                mine[0] += k < 3 ? one : 0u;
+                mine[1] += k >= 3 ? one : 0u;
+            }
+            const unsigned int incl0 = wave_incl_sum_u32(mine[0]), incl1 = wave_incl_sum_u32(mine[1]);
+            const unsigned int all0 = (unsigned int)__builtin_amdgcn_readlane((int)incl0, 63), all1 = (unsigned int)__builtin_amdgcn_readlane((int)incl1, 63);
+            tot[0] = all0 & 1023u; tot[1] = (all0 >> 10) & 1023u; tot[2] = (all0 >> 20) & 1023u;
+            tot[3] = all1 & 1023u; tot[4] = (all1 >> 10) & 1023u; tot[5] = (all1 >> 20) & 1023u;
+            unsigned int run[2] = {incl0 - mine[0], incl1 - mine[1]};
 #pragma unroll
-            for (int k = 1; k <= K2_CLASSES; ++k) {
-                const unsigned long long m = __ballot(cls_of[r] == k);
-                if (cls_of[r] == k) before_cls[r] = tot[k - 1] + (unsigned int)__popcll(m & lane_lt);
-                tot[k - 1] += (unsigned int)__popcll(m);
+            for (int r = 0; r < ITEMS; ++r) {
+                const int k = cls_of[r] - 1;
+                const unsigned int word = k >= 3 ? run[1] : run[0];
+                before_cls[r] = (word >> shift_of[r]) & 1023u;
+                const unsigned int one = k >= 0 ? (1u << shift_of[r]) : 0u;
+                run[0] += k < 3 ? one : 0u;
+                run[1] += k >= 3 ? one : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < ITEMS; ++r) {
+                before_cls[r] = 0;
+#pragma unroll
+                for (int k = 1; k <= K2_CLASSES; ++k) {
+                    const unsigned long long m = __ballot(cls_of[r] == k);
+                    if (cls_of[r] == k) before_cls[r] = tot[k - 1] + (unsigned int)__popcll(m & lane_lt);
+                    tot[k - 1] += (unsigned int)__popcll(m);
+                }
             }
         }
-        static_assert(K2_CLASSES == 6 && K2_QUEUES == 4, "lane k reserves class k; the sixth class is wave-local");
         const unsigned int my_tot = lane == 0 ? tot[0] : (lane == 1 ? tot[1] : (lane == 2 ? tot[2] : (lane == 3 ? tot[3] : tot[4])));
         unsigned int my_base = 0;
         if (lane <= K2_QUEUES && my_tot) my_base = atomicAdd(&cnt[lane], my_tot);
@@ -983,16 +1053,6 @@ __global__ __launch_bounds__(K2_THREADS) void k2h_generic(K2Params P, const QEnt
     H.flush(P.top_hist);
 }
 
-// the class thresholds of every count 0..max_count for the two binomials of a pass (dev::cls_row): one thread per (binomial, count)
-__global__ void k2_class_tables(double n_intra, double n_inter, int max_count, dev::ClsRow* __restrict__ intra,
-                                dev::ClsRow* __restrict__ inter) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > 2 * max_count + 1) return;
-    const bool e = i > max_count;
-    const int c = e ? i - (max_count + 1) : i;
-    (e ? inter : intra)[c] = dev::cls_row(e ? n_inter : n_intra, c);
-}
-
 // test hook: class of (count, prior) by the table and by bdtrc_class's arithmetic, and the five thresholds of the count
 __global__ void k_debug_classify(double n_total, const int32_t* __restrict__ count, const double* __restrict__ prior, int64_t n,
                                  int32_t* __restrict__ by_table, int32_t* __restrict__ by_arith, double* __restrict__ thr5) {
@@ -1317,12 +1377,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restr
                 v[2 * h + 1] = w.y;
                 keep0 = (w.x == w.x) && (pvalue_key(w.x) < cutoff);        // false for NaN; p >= 1 stays when nothing saturates
                 keep1 = (w.y == w.y) && (pvalue_key(w.y) < cutoff);
-                if (!keep0 && !keep1) {
-                    q2[i >> 1] = make_double2((w.x == w.x) ? 1.0 : w.x, (w.y == w.y) ? 1.0 : w.y);
-                } else {
-                    if (!keep0) q[i] = (w.x == w.x) ? 1.0 : w.x;
-                    if (!keep1) q[i + 1] = (w.y == w.y) ? 1.0 : w.y;
-                }
+                // both q of the pair in one 16-byte store, kept rows included: bh_apply overwrites those later on this stream
+                // (partial 8-byte stores around every kept row cost 0.13 ms per 1.2e8 rows with 12 % of them kept)
+                q2[i >> 1] = make_double2((w.x == w.x) ? 1.0 : w.x, (w.y == w.y) ? 1.0 : w.y);
             } else if (i < n) {                                            // the last row of an odd count
                 v[2 * h] = p[i];
                 keep0 = (v[2 * h] == v[2 * h]) && (pvalue_key(v[2 * h]) < cutoff);
@@ -1417,53 +1474,35 @@ __global__ __launch_bounds__(SORT_BLOCKS) void rs_scan(unsigned int* __restrict_
     if (live) row[threadIdx.x] = wsum[wave] + incl - mine;
 }
 
-// RADIX-entry exclusive scan held in LDS by the whole workgroup (RADIX / SORT_THREADS consecutive entries per thread);
-// returns the total through *total_out (LDS) when given
-__device__ __forceinline__ void block_exclusive_scan_radix(unsigned int* a, unsigned int* wave_tmp) {
-    constexpr int PER = RADIX / SORT_THREADS;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned int v[PER];
-    unsigned int mine = 0;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        v[k] = a[threadIdx.x * PER + k];
-        mine += v[k];
-    }
-    unsigned int incl = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned int o = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += o;
-    }
-    if (lane == 63) wave_tmp[wave] = incl;
-    __syncthreads();
-    unsigned int excl = incl - mine;
-    for (int w = 0; w < wave; ++w) excl += wave_tmp[w];
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        a[threadIdx.x * PER + k] = excl;
-        excl += v[k];
-    }
-    __syncthreads();
-}
-
 // stable scatter of one radix pass.  Each wave owns a contiguous sub-range of the tile and ranks its keys
 // with wave-private LDS digit counters (no atomics: one leader lane per distinct digit, found with RADIX_BITS+1
 // ballots); the tile is then reordered through LDS so that the global writes of equal-digit runs are contiguous.
-__global__ __launch_bounds__(SORT_THREADS) void rs_scatter(const unsigned long long* __restrict__ keys_in,
-                                                           const unsigned int* __restrict__ vals_in,
-                                                           unsigned long long* __restrict__ keys_out,
-                                                           unsigned int* __restrict__ vals_out,
-                                                           const unsigned long long* __restrict__ n_ptr, int shift,
-                                                           const unsigned int* __restrict__ block_hist,
-                                                           const unsigned int* __restrict__ digit_total) {
-    __shared__ unsigned short wave_digit[SORT_WAVES][RADIX];   // per-wave digit counts (<= 1024) -> exclusive offsets
+//
+// LDS decides how many workgroups a CU holds, and with them how much of the ranking's latency (dependent LDS reads and writes,
+// 12 ballots per key) is hidden.  Round 3's layout - counters 16 KB + keys 32 KB + payloads 16 KB + two offset tables - came to
+// 81 936 B: ONE 256-thread workgroup per CU, one wave per SIMD, 271 us per pass over 1.5e7 keys (1.3 TB/s,
+// profiles/r04_b_od1_kernel_stats.txt).  Now 512 threads per tile of 4096 keys and the per-wave counters share their 32 KB with
+// the staged keys (a key's slot is in a register by the time the counters die): 64 KB, two workgroups = 16 waves per CU.
+// (Measured and dropped, profiles/r04_e_rs_ab.txt: no staging at all - keys written straight from registers to
+// global_base[digit] + rank - is 45 % slower, the tile-wide reordering is what coalesces the writes of the passes over the
+// exponent bits; squeezing the kernel to 80 VGPRs for a third workgroup per CU spills and is slower still.)
+constexpr int SCAT_ITEMS = 8;                                   // keys per thread; a tile = SCAT_THREADS x 8 keys
+
+template <int SCAT_THREADS, int WPE>
+__global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void rs_scatter(
+    const unsigned long long* __restrict__ keys_in, const unsigned int* __restrict__ vals_in, unsigned long long* __restrict__ keys_out,
+    unsigned int* __restrict__ vals_out, const unsigned long long* __restrict__ n_ptr, int shift,
+    const unsigned int* __restrict__ block_hist, const unsigned int* __restrict__ digit_total) {
+    constexpr int SCAT_WAVES = SCAT_THREADS / 64, TILE = SCAT_THREADS * SCAT_ITEMS, PER = RADIX / SCAT_THREADS;
+    static_assert(SORT_TILE % TILE == 0, "a workgroup's chunk (a multiple of SORT_TILE keys) is whole tiles");
+    static_assert(SCAT_WAVES * RADIX * 2 <= TILE * 8, "the per-wave counters fit the block that later stages the keys");
+    __shared__ __attribute__((aligned(16))) unsigned char stage_raw[TILE * 8];      // per-wave counters, then the tile's keys
+    __shared__ unsigned int s_vals[TILE];
     __shared__ unsigned int tile_start[RADIX];                 // first tile-local slot of each digit
     __shared__ unsigned int global_base[RADIX];                // running global offset of each digit
-    __shared__ unsigned int wave_tmp[SORT_WAVES];
-    __shared__ unsigned long long s_keys[SORT_TILE];
-    __shared__ unsigned int s_vals[SORT_TILE];
-    constexpr int PER = RADIX / SORT_THREADS;
+    __shared__ unsigned int wave_tmp[SCAT_WAVES];
+    unsigned short (*wave_digit)[RADIX] = reinterpret_cast<unsigned short (*)[RADIX]>(stage_raw);   // counts (<= 512) -> exclusive offsets over the waves
+    unsigned long long* s_keys = reinterpret_cast<unsigned long long*>(stage_raw);
     const int64_t n = (int64_t)*n_ptr;
     const int64_t nblk = gridDim.x;
     const int64_t chunk = ((n + nblk - 1) / nblk + SORT_TILE - 1) / SORT_TILE * SORT_TILE;
@@ -1471,31 +1510,49 @@ __global__ __launch_bounds__(SORT_THREADS) void rs_scatter(const unsigned long l
     if (beg >= end) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
-    for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) tile_start[d] = digit_total[d];
-    __syncthreads();
-    block_exclusive_scan_radix(tile_start, wave_tmp);
-    for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS)
-        global_base[d] = tile_start[d] + block_hist[(size_t)d * nblk + blockIdx.x];
-    __syncthreads();
-    for (int64_t tile = beg; tile < end; tile += SORT_TILE) {
-        for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) {
+    // exclusive scan of RADIX entries of `a` (PER consecutive ones per thread); two barriers inside
+    auto scan_radix = [&](unsigned int* a) {
+        unsigned int v[PER];
+        unsigned int mine = 0;
 #pragma unroll
-            for (int w = 0; w < SORT_WAVES; ++w) wave_digit[w][d] = 0;
+        for (int k = 0; k < PER; ++k) {
+            v[k] = a[threadIdx.x * PER + k];
+            mine += v[k];
+        }
+        const unsigned int incl = wave_incl_sum_u32(mine);
+        if (lane == 63) wave_tmp[wave] = incl;
+        __syncthreads();
+        unsigned int excl = incl - mine;
+        for (int w = 0; w < wave; ++w) excl += wave_tmp[w];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            a[threadIdx.x * PER + k] = excl;
+            excl += v[k];
         }
         __syncthreads();
-        unsigned long long key[SORT_ITEMS];
-        unsigned int val[SORT_ITEMS];
-        unsigned short rank[SORT_ITEMS];
-        const int64_t wave_base = tile + (int64_t)wave * (64 * SORT_ITEMS);
+    };
+    for (int d = threadIdx.x; d < RADIX; d += SCAT_THREADS) tile_start[d] = digit_total[d];
+    __syncthreads();
+    scan_radix(tile_start);
+    for (int d = threadIdx.x; d < RADIX; d += SCAT_THREADS)
+        global_base[d] = tile_start[d] + block_hist[(size_t)d * nblk + blockIdx.x];
+    __syncthreads();
+    for (int64_t tile = beg; tile < end; tile += TILE) {
+        for (int i = threadIdx.x; i < SCAT_WAVES * RADIX / 2; i += SCAT_THREADS) reinterpret_cast<unsigned int*>(stage_raw)[i] = 0u;
+        unsigned long long key[SCAT_ITEMS];
+        unsigned int val[SCAT_ITEMS];
+        unsigned int slot[SCAT_ITEMS];
+        const int64_t wave_base = tile + (int64_t)wave * (64 * SCAT_ITEMS);
 #pragma unroll
-        for (int r = 0; r < SORT_ITEMS; ++r) {
+        for (int r = 0; r < SCAT_ITEMS; ++r) {
             const int64_t i = wave_base + r * 64 + lane;
             const bool live = i < end;
             key[r] = live ? keys_in[i] : ~0ull;
             val[r] = live ? vals_in[i] : 0u;
         }
+        __syncthreads();
 #pragma unroll
-        for (int r = 0; r < SORT_ITEMS; ++r) {
+        for (int r = 0; r < SCAT_ITEMS; ++r) {
             const bool live = (wave_base + r * 64 + lane) < end;
             const unsigned int digit = (unsigned int)(key[r] >> shift) & (RADIX - 1);
             // lanes holding the same digit (dead lanes form their own group through the extra bit)
@@ -1509,7 +1566,7 @@ __global__ __launch_bounds__(SORT_THREADS) void rs_scatter(const unsigned long l
             const unsigned int before = __popcll(same & lane_lt);
             unsigned int old = 0;
             if (live) old = wave_digit[wave][digit];          // every lane of the group reads the same counter ...
-            rank[r] = (unsigned short)(old + before);
+            slot[r] = old + before;                           // rank among the wave's keys of this digit, so far
             __builtin_amdgcn_wave_barrier();
             if (live && before == 0) wave_digit[wave][digit] = (unsigned short)(old + __popcll(same));   // ... its leader bumps it
             __builtin_amdgcn_wave_barrier();
@@ -1519,7 +1576,7 @@ __global__ __launch_bounds__(SORT_THREADS) void rs_scatter(const unsigned long l
         for (int d = threadIdx.x * PER; d < (threadIdx.x + 1) * PER; ++d) {
             unsigned int acc = 0;
 #pragma unroll
-            for (int w = 0; w < SORT_WAVES; ++w) {
+            for (int w = 0; w < SCAT_WAVES; ++w) {
                 const unsigned int c = wave_digit[w][d];
                 wave_digit[w][d] = (unsigned short)acc;
                 acc += c;
@@ -1527,29 +1584,35 @@ __global__ __launch_bounds__(SORT_THREADS) void rs_scatter(const unsigned long l
             tile_start[d] = acc;                              // digit total for now
         }
         __syncthreads();
-        block_exclusive_scan_radix(tile_start, wave_tmp);
-        const int live_in_tile = (int)min<int64_t>(SORT_TILE, end - tile);
+        scan_radix(tile_start);
+        const int live_in_tile = (int)min<int64_t>(TILE, end - tile);
 #pragma unroll
-        for (int r = 0; r < SORT_ITEMS; ++r) {
-            const int64_t i = wave_base + r * 64 + lane;
-            if (i < end) {
-                const unsigned int digit = (unsigned int)(key[r] >> shift) & (RADIX - 1);
-                const unsigned int slot = tile_start[digit] + wave_digit[wave][digit] + rank[r];
-                s_keys[slot] = key[r];
-                s_vals[slot] = val[r];
+        for (int r = 0; r < SCAT_ITEMS; ++r) {
+            const unsigned int digit = (unsigned int)(key[r] >> shift) & (RADIX - 1);
+            if (wave_base + r * 64 + lane < end) slot[r] += tile_start[digit] + wave_digit[wave][digit];
+        }
+        __syncthreads();                                      // the counters are dead: their block now stages the keys
+#pragma unroll
+        for (int r = 0; r < SCAT_ITEMS; ++r)
+            if (wave_base + r * 64 + lane < end) {
+                s_keys[slot[r]] = key[r];
+                s_vals[slot[r]] = val[r];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SCAT_ITEMS; ++j) {
+            const int s = threadIdx.x + j * SCAT_THREADS;
+            if (s < live_in_tile) {
+                const unsigned long long k = s_keys[s];
+                const unsigned int digit = (unsigned int)(k >> shift) & (RADIX - 1);
+                const unsigned int dst = global_base[digit] + (s - tile_start[digit]);
+                keys_out[dst] = k;
+                vals_out[dst] = s_vals[s];
             }
         }
         __syncthreads();
-        for (int s = threadIdx.x; s < live_in_tile; s += SORT_THREADS) {
-            const unsigned long long k = s_keys[s];
-            const unsigned int digit = (unsigned int)(k >> shift) & (RADIX - 1);
-            const unsigned int dst = global_base[digit] + (s - tile_start[digit]);
-            keys_out[dst] = k;
-            vals_out[dst] = s_vals[s];
-        }
-        __syncthreads();
         // advance the running global offsets by this tile's digit totals
-        for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) {
+        for (int d = threadIdx.x; d < RADIX; d += SCAT_THREADS) {
             const unsigned int nxt = (d + 1 < RADIX) ? tile_start[d + 1] : (unsigned int)live_in_tile;
             global_base[d] += nxt - tile_start[d];
         }
@@ -1675,10 +1738,189 @@ __global__ __launch_bounds__(BH_THREADS) void bh_apply(const unsigned long long*
         if (i < n) {
             const double qv = fmax(v[r], carry);
             if (vals)
-                q_out[vals[i]] = qv;
+                __builtin_nontemporal_store(qv, q_out + vals[i]);       // one 8-byte store into a line nobody else touches soon: no allocate
             else
                 q_out[i] = qv;
         }
+    }
+}
+
+// ---- small survivor sets: the six radix passes and the BH scan in ONE launch --------------------------------------------
+// On Hi-C data whose counts follow the model closely (C3-synth: 77 k of 1.5e8 rows below the cutoff) and on every shard of a
+// strong-scaling run the sort is all fixed cost: 18 launches + 3 for the BH pass, ~9 us each back to back, for microseconds of
+// work (0.17 + 0.05 ms per pass).  Up to K3S_MAX_KEYS survivors run through k3_small instead: 64 workgroups that stay resident
+// and meet at a device-wide barrier between the phases.  A workgroup owns one tile of 4096 keys, so a pass needs no separate
+// counting read: the digit counts of its tile are what the ranking step of the scatter produces anyway (keys, payloads, ranks
+// and the per-wave counters stay in registers / LDS across the barriers).  Per pass: rank + publish counts | scan the 2048 x 64
+// count matrix (32 digits per workgroup) | write; then the BH values, their running maximum per tile, and q scattered to rows.
+// Same arithmetic and the same stable order as rs_* / bh_*: bit-identical results (tests: every BH fixture goes through it).
+constexpr int K3S_BLOCKS = 64;
+constexpr int K3S_THREADS = 512;
+constexpr int K3S_TILE = K3S_THREADS * SCAT_ITEMS;              // 4096
+constexpr int K3S_MAX_KEYS = K3S_BLOCKS * K3S_TILE;             // 262 144
+static_assert(K3S_TILE == SORT_TILE && RADIX % K3S_BLOCKS == 0, "one tile per workgroup; whole digit rows per workgroup");
+
+// all workgroups of the launch (they are co-resident: 64 of them on 256 CUs, nothing else runs on the stream's device while a
+// pass is in flight); *bar counts arrivals and is zeroed before the launch
+__device__ __forceinline__ void k3s_grid_barrier(unsigned int* bar, unsigned int& epoch) {
+    __threadfence();
+    __syncthreads();
+    ++epoch;
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int want = epoch * gridDim.x;
+        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    __threadfence();
+}
+
+__device__ __forceinline__ unsigned int k3s_load(const unsigned int* p) {      // written by another workgroup of this launch
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(K3S_THREADS) void k3_small(unsigned long long* keys_a, unsigned int* vals_a, unsigned long long* keys_b,
+                                                        unsigned int* vals_b, const unsigned long long* __restrict__ n_ptr,
+                                                        unsigned int* block_hist, unsigned int* digit_total, unsigned int* bar,
+                                                        double n_tests, double* tile_max, double* __restrict__ q_out) {
+    constexpr int WAVES = K3S_THREADS / 64, PER = RADIX / K3S_THREADS, NBLK = K3S_BLOCKS;
+    __shared__ unsigned short wave_digit[WAVES][RADIX];
+    __shared__ unsigned int tile_total[RADIX];
+    __shared__ unsigned int wave_tmp[WAVES];
+    __shared__ double wmax[WAVES];
+    const int64_t n = (int64_t)*n_ptr;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int blk = (int)blockIdx.x;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    const int64_t beg = (int64_t)blk * K3S_TILE, end = min(n, beg + (int64_t)K3S_TILE);
+    unsigned int epoch = 0;
+    unsigned long long* kin = keys_a;
+    unsigned int* vin = vals_a;
+    unsigned long long* kout = keys_b;
+    unsigned int* vout = vals_b;
+    for (int pass = 0; pass < SORT_PASSES; ++pass) {
+        const int shift = pass * RADIX_BITS;
+        // ---- rank this workgroup's tile, publish its digit counts ----
+        for (int i = threadIdx.x; i < WAVES * RADIX / 2; i += K3S_THREADS) reinterpret_cast<unsigned int*>(&wave_digit[0][0])[i] = 0u;
+        unsigned long long key[SCAT_ITEMS];
+        unsigned int val[SCAT_ITEMS], rank[SCAT_ITEMS];
+        const int64_t wave_base = beg + (int64_t)wave * (64 * SCAT_ITEMS);
+#pragma unroll
+        for (int r = 0; r < SCAT_ITEMS; ++r) {
+            const int64_t i = wave_base + r * 64 + lane;
+            const bool live = i < end;
+            key[r] = live ? kin[i] : ~0ull;
+            val[r] = live ? vin[i] : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SCAT_ITEMS; ++r) {
+            const bool live = (wave_base + r * 64 + lane) < end;
+            const unsigned int digit = (unsigned int)(key[r] >> shift) & (RADIX - 1);
+            unsigned long long same = ~0ull;
+            const unsigned int tag = digit | (live ? 0u : RADIX);
+#pragma unroll
+            for (int b = 0; b <= RADIX_BITS; ++b) {
+                const unsigned long long m = __ballot((tag >> b) & 1u);
+                same &= ((tag >> b) & 1u) ? m : ~m;
+            }
+            const unsigned int before = __popcll(same & lane_lt);
+            unsigned int old = 0;
+            if (live) old = wave_digit[wave][digit];
+            rank[r] = old + before;
+            __builtin_amdgcn_wave_barrier();
+            if (live && before == 0) wave_digit[wave][digit] = (unsigned short)(old + __popcll(same));
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        for (int d = threadIdx.x * PER; d < (threadIdx.x + 1) * PER; ++d) {
+            unsigned int acc = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                const unsigned int c = wave_digit[w][d];
+                wave_digit[w][d] = (unsigned short)acc;
+                acc += c;
+            }
+            block_hist[(size_t)d * NBLK + blk] = acc;                  // digit-major, as rs_count writes it
+        }
+        k3s_grid_barrier(bar, epoch);
+        // ---- exclusive scan of 32 digit rows (64 entries: one per lane), their totals ----
+        for (int k = wave; k < RADIX / NBLK; k += WAVES) {
+            const int d = blk * (RADIX / NBLK) + k;
+            const unsigned int v = k3s_load(&block_hist[(size_t)d * NBLK + lane]);
+            const unsigned int incl = wave_incl_sum_u32(v);
+            block_hist[(size_t)d * NBLK + lane] = incl - v;
+            if (lane == 63) digit_total[d] = incl;
+        }
+        k3s_grid_barrier(bar, epoch);
+        // ---- where each digit starts, then the keys to their places ----
+        {
+            unsigned int v[PER];
+            unsigned int mine = 0;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                v[k] = k3s_load(&digit_total[threadIdx.x * PER + k]);
+                mine += v[k];
+            }
+            const unsigned int incl = wave_incl_sum_u32(mine);
+            if (lane == 63) wave_tmp[wave] = incl;
+            __syncthreads();
+            unsigned int excl = incl - mine;
+            for (int w = 0; w < wave; ++w) excl += wave_tmp[w];
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int d = threadIdx.x * PER + k;
+                tile_total[d] = excl + k3s_load(&block_hist[(size_t)d * NBLK + blk]);     // = global_base of rs_scatter
+                excl += v[k];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SCAT_ITEMS; ++r) {
+            if (wave_base + r * 64 + lane < end) {
+                const unsigned int digit = (unsigned int)(key[r] >> shift) & (RADIX - 1);
+                const unsigned int dst = tile_total[digit] + wave_digit[wave][digit] + rank[r];
+                kout[dst] = key[r];
+                vout[dst] = val[r];
+            }
+        }
+        k3s_grid_barrier(bar, epoch);
+        unsigned long long* tk = kin; kin = kout; kout = tk;
+        unsigned int* tv = vin; vin = vout; vout = tv;
+    }
+    // ---- Benjamini-Hochberg over the sorted keys (now in kin / vin): bh_tile_max, bh_scan_tiles and bh_apply in one ----
+    constexpr int ITEMS = SCAT_ITEMS;
+    const int64_t first = beg + (int64_t)threadIdx.x * ITEMS;          // blocked: a thread owns 8 consecutive sorted positions
+    double v[ITEMS];
+    double run = 0.0;
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const int64_t i = first + r;
+        const double b = (i < n) ? bh_value(kin[i], n_tests, (double)(i + 1)) : 0.0;
+        run = fmax(run, b);
+        v[r] = run;
+    }
+    const double incl = wave_incl_max(run, lane);
+    double excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 0.0;
+    if (lane == 63) wmax[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = wmax[0];
+        for (int w = 1; w < WAVES; ++w) t = fmax(t, wmax[w]);
+        tile_max[blk] = t;
+    }
+    k3s_grid_barrier(bar, epoch);
+    double carry = 0.0;
+    for (int t = lane; t < blk; t += 64) carry = fmax(carry, __hip_atomic_load(&tile_max[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) carry = fmax(carry, __shfl_xor(carry, off, 64));
+    for (int w = 0; w < wave; ++w) carry = fmax(carry, wmax[w]);
+    carry = fmax(carry, excl);
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const int64_t i = first + r;
+        if (i < n) __builtin_nontemporal_store(fmax(v[r], carry), q_out + vin[i]);
     }
 }
 
@@ -2062,9 +2304,6 @@ struct fhx_ctx {
     long long *d_stats_stage = nullptr, *h_stats_stage = nullptr;   // K1's sums + histogram window: device block, pinned host copy
     size_t stats_stage_cap = 0;
     int k2_shards = 0;                                // shards (= k2_classify workgroups) of the last fhx_pvalues
-    dev::ClsRow* d_cls_tab = nullptr;                 // class thresholds: (max_count + 1) rows for the intra binomial, then the inter one
-    int64_t cls_tab_counts = 0;                       // rows per binomial it was built for, with these totals:
-    double cls_tab_n[2] = {-1.0, -1.0};
     unsigned int* d_k2h_off = nullptr;                // K2H_BUCKETS + 1 bucket starts
     unsigned char* d_memo = nullptr;                  // no-bias table path: virtual rows, table, overflow list (kept across passes)
     size_t memo_bytes = 0;
@@ -2305,6 +2544,13 @@ int sort_blocks_for(int64_t n_hint) {
     return (int)std::max<int64_t>(64, std::min<int64_t>(SORT_BLOCKS, (want + 63) / 64 * 64));
 }
 
+// one scatter pass
+void launch_rs_scatter(fhx_ctx* ctx, int nblk, const unsigned long long* keys_in, const unsigned int* vals_in, unsigned long long* keys_out,
+                       unsigned int* vals_out, const unsigned long long* counter, int shift) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_scatter<512, 4>), dim3(nblk), dim3(512), 0, ctx->stream, keys_in, vals_in, keys_out, vals_out,
+                       counter, shift, (const unsigned int*)ctx->d_block_hist, (const unsigned int*)ctx->d_digit_total);
+}
+
 int radix_sort_pairs(fhx_ctx* ctx, unsigned long long* keys[2], unsigned int* vals[2], const unsigned long long* counter,
                      int passes, int* result_buf, int64_t n_hint = -1) {
     const int nblk = sort_blocks_for(n_hint);
@@ -2314,8 +2560,7 @@ int radix_sort_pairs(fhx_ctx* ctx, unsigned long long* keys[2], unsigned int* va
         hipLaunchKernelGGL(rs_count, dim3(nblk), dim3(SORT_THREADS), 0, ctx->stream, keys[src], counter, shift,
                            ctx->d_block_hist);
         hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3((nblk + 63) / 64 * 64), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total, nblk);
-        hipLaunchKernelGGL(rs_scatter, dim3(nblk), dim3(SORT_THREADS), 0, ctx->stream, keys[src], vals[src],
-                           keys[1 - src], vals[1 - src], counter, shift, ctx->d_block_hist, ctx->d_digit_total);
+        launch_rs_scatter(ctx, nblk, keys[src], vals[src], keys[1 - src], vals[1 - src], counter, shift);
         src = 1 - src;
     }
     FHX_HIP(hipGetLastError());
@@ -2646,7 +2891,6 @@ void fhx_destroy(fhx_ctx* ctx) {
         dev_free(ctx->d_top_hist);
         dev_free(ctx->d_k2_hist);
         dev_free(ctx->d_cf_tab);
-        dev_free(ctx->d_cls_tab);
         dev_free(ctx->d_stats_stage);
         if (ctx->h_stats_stage) (void)hipHostFree(ctx->h_stats_stage);
         dev_free(ctx->d_k2h_off);
@@ -3105,28 +3349,6 @@ int fhx_pvalues(fhx_ctx* ctx) {
     }
     K2Params P = make_k2_params(ctx);
     FHX_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
-    static const int cl_table = std::getenv("FHX_CL_TABLE") ? std::atoi(std::getenv("FHX_CL_TABLE")) : 0;     // measurements only
-    if (cl_table == 1 || cl_table == 2) {
-        // class thresholds per count for this pass's two binomials (kept while the totals and the largest count stay the same): only
-        // the table variants of k2_classify read them - the default kernel evaluates incbet's predicates per row and needs no table
-        const int64_t mc = std::max<int64_t>(ctx->stats.max_count, 1);
-        if (mc >= INT32_MAX / 2) return fail(ctx, FHX_ERR_UNSUPPORTED, "FHX_CL_TABLE: contact counts beyond 2^30");
-        if (!ctx->d_cls_tab || ctx->cls_tab_counts != mc + 1 || ctx->cls_tab_n[0] != P.intra.n || ctx->cls_tab_n[1] != P.inter.n) {
-            if (ctx->cls_tab_counts < mc + 1 || !ctx->d_cls_tab) {
-                FHX_HIP(hipStreamSynchronize(ctx->stream));
-                dev_free(ctx->d_cls_tab);
-                FHX_HIP(hipMalloc(&ctx->d_cls_tab, (size_t)(2 * (mc + 1)) * sizeof(dev::ClsRow)));
-            }
-            ctx->cls_tab_counts = mc + 1;
-            ctx->cls_tab_n[0] = P.intra.n;
-            ctx->cls_tab_n[1] = P.inter.n;
-            hipLaunchKernelGGL(k2_class_tables, dim3(grid_for(2 * (mc + 1), 128)), dim3(128), 0, ctx->stream, P.intra.n, P.inter.n, (int)mc,
-                               ctx->d_cls_tab, ctx->d_cls_tab + (mc + 1));
-            FHX_HIP(hipGetLastError());
-        }
-        P.cls_intra = ctx->d_cls_tab;
-        P.cls_inter = ctx->d_cls_tab + (mc + 1);
-    }
     // no bias table, fixed-size loci: evaluate a (distance, count) table instead of every row (see k2_memo_rows)
     int32_t *v_loc1 = nullptr, *v_loc2 = nullptr, *v_count = nullptr;
     double* v_table = nullptr;
@@ -3210,25 +3432,23 @@ int fhx_pvalues(fhx_ctx* ctx) {
     // (no reset of the counters: every workgroup of k2_classify writes its own shard's counts)
     {
         const dim3 cgrid(k2_classify_grid(k2_n)), cblock(K2_THREADS);
-        static const int wpe = std::getenv("FHX_CL_WAVES") ? std::atoi(std::getenv("FHX_CL_WAVES")) : 0;        // measurements only
-        const int table = cl_table;
-        static const int cl_hoist = std::getenv("FHX_CL_HOIST") ? std::atoi(std::getenv("FHX_CL_HOIST")) : 1;    // 0: measurements (row-by-row gathers)
+        // FHX_CL_BASE=1: round 3's kernel (gathers row by row, 24 ballots, the division per row) for A/B runs; FHX_CL_PACK=0 /
+        // FHX_CL_TB=0 switch the two later steps off one at a time
+        static const bool cl_base = std::getenv("FHX_CL_BASE") != nullptr;
+        static const bool cl_pack = !(std::getenv("FHX_CL_PACK") && std::atoi(std::getenv("FHX_CL_PACK")) == 0);
+        static const bool cl_tb = !(std::getenv("FHX_CL_TB") && std::atoi(std::getenv("FHX_CL_TB")) == 0);
         if (P.nonfixed)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<1, 4, 0>), cgrid, cblock, 0, ctx->stream, P, Q);
-        else if (table == 1 && wpe == 6)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, 6, 1>), cgrid, cblock, 0, ctx->stream, P, Q);
-        else if (table == 1)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, 4, 1>), cgrid, cblock, 0, ctx->stream, P, Q);
-        else if (table == 2 && wpe == 6)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, 6, 2>), cgrid, cblock, 0, ctx->stream, P, Q);
-        else if (table == 2)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, 4, 2>), cgrid, cblock, 0, ctx->stream, P, Q);
-        else if (wpe == 6)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, 6, 0>), cgrid, cblock, 0, ctx->stream, P, Q);
-        else if (cl_hoist == 0)   // 4 waves/SIMD (98 VGPRs, no scratch): 1.85 ms against 1.95 at 6 (80 VGPRs + 44 B of scratch), profiles/r03_e_*
+        else if (cl_base)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, 4, 0>), cgrid, cblock, 0, ctx->stream, P, Q);
+        else if (cl_pack && cl_tb)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, 4, 3, true, true>), cgrid, cblock, 0, ctx->stream, P, Q);
+        else if (cl_pack)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, 4, 0, true, true>), cgrid, cblock, 0, ctx->stream, P, Q);
+        else if (cl_tb)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, 4, 3, true, false>), cgrid, cblock, 0, ctx->stream, P, Q);
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, 4, 0, true>), cgrid, cblock, 0, ctx->stream, P, Q);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, 4, 0, true, false>), cgrid, cblock, 0, ctx->stream, P, Q);
     }
     const dim3 qgrid(256 * 8), qblock(K2_THREADS);
     hipLaunchKernelGGL(k2_closed, qgrid, qblock, 0, ctx->stream, P, Q.q[K2_CLOSED - 1]);
@@ -3372,9 +3592,9 @@ static int auto_cutoff(fhx_ctx* ctx, const double* d_p, int64_t n, double n_tota
     return FHX_OK;
 }
 
-static int sort_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned long long* keys[2], unsigned int* vals[2],
-                        double* d_q, unsigned long long* counter, const unsigned long long* d_cutoff, int* sorted_buf,
-                        int64_t* n_sorted_out = nullptr) {
+// rows below the cutoff -> keys[0] / vals[0] (their number in *counter and, read back, in *n_kept); every other row gets its q here
+static int compact_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned long long* keys[2], unsigned int* vals[2], double* d_q,
+                           unsigned long long* counter, const unsigned long long* d_cutoff, int64_t* n_kept_out) {
     FHX_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
     // one workgroup per tile, not a resident grid walking the column: 0.507 -> 0.451 ms on C3 (profiles/r03_x_k3_grid.txt); the
     // plain copy kernel of profiles/hbm_rate.hip shows the same (4.9 TB/s with 2048 grid-striding workgroups, 5.6 with one per
@@ -3386,8 +3606,14 @@ static int sort_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned lon
     unsigned long long n_kept = 0;
     FHX_HIP(hipMemcpyAsync(&n_kept, counter, sizeof(n_kept), hipMemcpyDeviceToHost, ctx->stream));
     FHX_HIP(hipStreamSynchronize(ctx->stream));
-    if (n_sorted_out) *n_sorted_out = (int64_t)n_kept;
-    const int nblk = sort_blocks_for((int64_t)n_kept);
+    *n_kept_out = (int64_t)n_kept;
+    return FHX_OK;
+}
+
+// the six radix passes over the n_kept compacted keys; the result is in buffer pair *sorted_buf
+static int sort_kept(fhx_ctx* ctx, unsigned long long* keys[2], unsigned int* vals[2], const unsigned long long* counter, int64_t n_kept,
+                     int* sorted_buf) {
+    const int nblk = sort_blocks_for(n_kept);
     int src = 0;
     // p < 1 means the IEEE exponent field is <= 1022: bits 62 and 63 are always clear, 62 bits to sort
     for (int pass = 0; pass < SORT_PASSES; ++pass) {
@@ -3395,13 +3621,22 @@ static int sort_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned lon
         hipLaunchKernelGGL(rs_count, dim3(nblk), dim3(SORT_THREADS), 0, ctx->stream, keys[src], counter, shift,
                            ctx->d_block_hist);
         hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3((nblk + 63) / 64 * 64), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total, nblk);
-        hipLaunchKernelGGL(rs_scatter, dim3(nblk), dim3(SORT_THREADS), 0, ctx->stream, keys[src], vals[src],
-                           keys[1 - src], vals[1 - src], counter, shift, ctx->d_block_hist, ctx->d_digit_total);
+        launch_rs_scatter(ctx, nblk, keys[src], vals[src], keys[1 - src], vals[1 - src], counter, shift);
         src = 1 - src;
     }
     FHX_HIP(hipGetLastError());
     *sorted_buf = src;
     return FHX_OK;
+}
+
+static int sort_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned long long* keys[2], unsigned int* vals[2],
+                        double* d_q, unsigned long long* counter, const unsigned long long* d_cutoff, int* sorted_buf,
+                        int64_t* n_sorted_out = nullptr) {
+    int64_t n_kept = 0;
+    const int rc = compact_pvalues(ctx, d_p, n, keys, vals, d_q, counter, d_cutoff, &n_kept);
+    if (rc != FHX_OK) return rc;
+    if (n_sorted_out) *n_sorted_out = n_kept;
+    return sort_kept(ctx, keys, vals, counter, n_kept, sorted_buf);
 }
 
 static int bh_from_sorted(fhx_ctx* ctx, const unsigned long long* keys, const unsigned int* vals, int64_t n_rows,
@@ -3415,6 +3650,31 @@ static int bh_from_sorted(fhx_ctx* ctx, const unsigned long long* keys, const un
                        n_total_tests, 0.0, tile_max, (const double*)nullptr, d_q);
     FHX_HIP(hipGetLastError());
     return FHX_OK;
+}
+
+// compaction, sort and BH of one p column -> q in row order.  Survivor sets of up to K3S_MAX_KEYS keys take the single-launch
+// path (k3_small); FHX_K3_SMALL=0 keeps the launch-per-step path for A/B runs.
+static int rank_and_adjust(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned long long* keys[2], unsigned int* vals[2], double* d_q,
+                           unsigned long long* counter, const unsigned long long* d_cutoff, double n_total_tests, double* tile_max,
+                           int* sorted_buf, int64_t* n_sorted_out) {
+    int64_t n_kept = 0;
+    int rc = compact_pvalues(ctx, d_p, n, keys, vals, d_q, counter, d_cutoff, &n_kept);
+    if (rc != FHX_OK) return rc;
+    if (n_sorted_out) *n_sorted_out = n_kept;
+    static const bool small_off = std::getenv("FHX_K3_SMALL") && std::atoi(std::getenv("FHX_K3_SMALL")) == 0;
+    if (n_kept <= K3S_MAX_KEYS && !small_off) {
+        *sorted_buf = 0;                                           // an even number of passes: the sorted keys end where they began
+        if (n_kept == 0) return FHX_OK;
+        unsigned int* bar = reinterpret_cast<unsigned int*>(ctx->d_misc + 64);     // (slots 8..58 hold the 51 FDR buckets at other times)
+        FHX_HIP(hipMemsetAsync(bar, 0, sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(k3_small, dim3(K3S_BLOCKS), dim3(K3S_THREADS), 0, ctx->stream, keys[0], vals[0], keys[1], vals[1],
+                           (const unsigned long long*)counter, ctx->d_block_hist, ctx->d_digit_total, bar, n_total_tests, tile_max, d_q);
+        FHX_HIP(hipGetLastError());
+        return FHX_OK;
+    }
+    rc = sort_kept(ctx, keys, vals, counter, n_kept, sorted_buf);
+    if (rc != FHX_OK) return rc;
+    return bh_from_sorted(ctx, keys[*sorted_buf], vals[*sorted_buf], n, counter, n_total_tests, tile_max, d_q);
 }
 
 static int ensure_sort_scratch(fhx_ctx* ctx) {
@@ -3622,8 +3882,7 @@ int fhx_bh_array(fhx_ctx* ctx, const double* p, int64_t n, double n_total_tests,
     unsigned long long* counter = ctx->d_misc + 2;
     unsigned long long* cutoff = ctx->d_misc + 7;
     rc = auto_cutoff(ctx, d_p, n, n_total_tests, cutoff);
-    if (rc == FHX_OK) rc = sort_pvalues(ctx, d_p, n, keys, vals, d_q, counter, cutoff, &buf);
-    if (rc == FHX_OK) rc = bh_from_sorted(ctx, keys[buf], vals[buf], n, counter, n_total_tests, tile_max, d_q);
+    if (rc == FHX_OK) rc = rank_and_adjust(ctx, d_p, n, keys, vals, d_q, counter, cutoff, n_total_tests, tile_max, &buf, nullptr);
     if (rc == FHX_OK) {
         FHX_HIP(hipMemcpyAsync(q, d_q, cap * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         FHX_HIP(hipStreamSynchronize(ctx->stream));
@@ -3640,12 +3899,11 @@ int fhx_bh(fhx_ctx* ctx, double n_total_tests) {
     FHX_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
     int rc = auto_cutoff(ctx, ctx->d_p, ctx->n_rows, n_total_tests, ctx->d_misc + 6);
     if (rc != FHX_OK) return rc;
-    rc = fhx_bh_local_sort(ctx);
+    int64_t kept = 0;
+    rc = rank_and_adjust(ctx, ctx->d_p, ctx->n_rows, ctx->d_keys, ctx->d_vals, ctx->d_q, ctx->d_misc, ctx->d_misc + 6, n_total_tests,
+                         ctx->d_tile_max, &ctx->sorted_buf, &kept);
     if (rc != FHX_OK) return rc;
-    const int s = ctx->sorted_buf;
-    const int rc2 = bh_from_sorted(ctx, ctx->d_keys[s], ctx->d_vals[s], ctx->n_rows, ctx->d_misc, n_total_tests,
-                                   ctx->d_tile_max, ctx->d_q);
-    if (rc2 != FHX_OK) return rc2;
+    ctx->n_sorted = kept;
     FHX_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
     ctx->ev_valid[2] = true;
     ctx->have_q = true;
@@ -3706,8 +3964,7 @@ int fhx_sort_u64(fhx_ctx* ctx, const void* d_keys_in, int64_t n, void* d_keys_ou
         hipLaunchKernelGGL(rs_count, dim3(nblk), dim3(SORT_THREADS), 0, ctx->stream, keys[src], counter, shift,
                            ctx->d_block_hist);
         hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3((nblk + 63) / 64 * 64), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total, nblk);
-        hipLaunchKernelGGL(rs_scatter, dim3(nblk), dim3(SORT_THREADS), 0, ctx->stream, keys[src], vals[src],
-                           keys[1 - src], vals[1 - src], counter, shift, ctx->d_block_hist, ctx->d_digit_total);
+        launch_rs_scatter(ctx, nblk, keys[src], vals[src], keys[1 - src], vals[1 - src], counter, shift);
         src = 1 - src;
     }
     FHX_HIP(hipGetLastError());
@@ -4041,6 +4298,22 @@ int fhx_k2_heavy_launch(fhx_ctx* ctx, double* seconds, int64_t* rows) {
     }
     if (seconds) *seconds = ms * 1e-3;
     if (rows) *rows = (int64_t)n;
+    return FHX_OK;
+}
+
+int fhx_k2_class_rows(fhx_ctx* ctx, int64_t* out5) {
+    if (!ctx || !out5) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (!ctx->d_k2_counts || ctx->k2_shards <= 0 || !ctx->ev_valid[1]) return fail(ctx, FHX_ERR_ARG, "fhx_pvalues has not run");
+    FHX_HIP(hipSetDevice(ctx->device));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<unsigned long long> part((size_t)(K2_QUEUES + 1) * K2_MAX_SHARDS);
+    FHX_HIP(hipMemcpy(part.data(), ctx->d_k2_counts, part.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int k = 0; k <= K2_QUEUES; ++k) {
+        unsigned long long n = 0;
+        for (int sh = 0; sh < ctx->k2_shards; ++sh) n += part[(size_t)k * K2_MAX_SHARDS + sh];
+        out5[k] = (int64_t)n;
+    }
     return FHX_OK;
 }
 

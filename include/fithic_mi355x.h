@@ -229,6 +229,11 @@ int fhx_kernel_seconds(fhx_ctx* ctx, double* k1, double* k2, double* k3);
 /* Duration (HIP events on the context's stream) and row count of the dominant launch of the last fhx_pvalues: the queue
  * of rows whose continued fraction runs to Cephes' 300-iteration cap (k2_queue<BC_CF_SWAPPED>). */
 int fhx_k2_heavy_launch(fhx_ctx* ctx, double* seconds, int64_t* rows);
+/* Rows the last fhx_pvalues queued per branch class of incbet (the per-pair branch table of fithic/fithic.py:1057-1116 followed
+ * into Cephes): out5 = power series, converging incbcf, incbd, swapped incbcf (the 300-iteration class), closed form with
+ * prior >= 0.01.  Every other row was finished by the classification launch itself (constants, closed form with a small prior).
+ * Measurement aid: per-kernel bytes and rows of bench.py / profiles. */
+int fhx_k2_class_rows(fhx_ctx* ctx, int64_t* out5);
 
 /* myStats.benjamini_hochberg_correction(p_values, num_total_tests) on an arbitrary host array (fithic/myStats.py:24-48):
  * copies p to the GPU, runs the K3 kernels, copies q back (input order). */
@@ -323,6 +328,11 @@ int fhx_next_pass_distributed(fhx_ctx* ctx, int64_t* n_outliers_total);
 /* host wall seconds per stage of the last fhx_run_pass_distributed: k1 + stats exchange, host fit, K2 launch, cutoff +
  * local sort + splitters (up to the count exchange), key exchange + slice sort + scan + q return */
 int fhx_dist_stage_seconds(fhx_ctx* ctx, double* out5);
+/* The collectives this context issued since the communicator was made (or since the last call with clear != 0), one text line
+ * each: "<step> <kind> <size>" with the step ids, kinds and size units of fithic_amd/csrc/fhx_dist_schedule.def - the one list
+ * of what a sharded pass exchanges.  Recorded only when FHX_DIST_TRACE=1 was set at fhx_comm_init(_custom) time.  *n_bytes
+ * receives the length of the text; nothing is copied (or cleared) when capacity is smaller. */
+int fhx_dist_trace(fhx_ctx* ctx, char* buf, int64_t capacity, int64_t* n_bytes, int clear);
 /* plain copies between host and this context's GPU (plumbing for custom transports): kind 0 = host to device,
  * 1 = device to host, 2 = device to device; waits for completion */
 int fhx_copy(fhx_ctx* ctx, void* dst, const void* src, int64_t bytes, int kind);

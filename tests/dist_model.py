@@ -24,10 +24,20 @@ make global (section 8e):
 
 All per-GPU compute goes through `LocalOps` (the C ABI); the exchange logic itself is backend-agnostic so that the
 world_size-2 gloo tests exercise the same code with a checker-backed LocalOps.
+
+ONE list of collectives for both statements of the schedule: fithic_amd/csrc/fhx_dist_schedule.def.  Every collective below
+names the row of that table it is (`step=`) and `Comm.trace` records (step, kind, size) in the table's units, exactly as the
+library does under FHX_DIST_TRACE=1 (fhx_dist_trace); tests/dist_schedule.py holds both traces against the table
+(tests/test_dist_gloo.py here on CPU, tests/test_gpu_native_dist.py for the library) - a change on one side only fails a test.
 """
 import numpy as np
 
-SAMPLES_PER_RANK = 1024
+DIST_MAX_SAMPLES = 8192                  # fhx_dist.inc: world x samples per rank, sorted by one workgroup
+
+
+def samples_per_rank(world):
+    """fhx_bh_distributed: s = max(1, min(128, DIST_MAX_SAMPLES / world))"""
+    return max(1, min(128, DIST_MAX_SAMPLES // world))
 
 
 class Comm:
@@ -41,6 +51,11 @@ class Comm:
         self.td, self.torch, self.device = td, torch, device
         self.compute_device = compute_device if compute_device is not None else device
         self.rank, self.world = td.get_rank(), td.get_world_size()
+        self.trace = []                  # (step id, kind, size) of every schedule collective, in fhx_dist_schedule.def's units
+
+    def note(self, step, kind, size):
+        if step is not None:
+            self.trace.append((step, kind, int(size)))
 
     def barrier(self):
         self.td.barrier()
@@ -51,42 +66,46 @@ class Comm:
         if self.device.type == "cuda":
             self.torch.cuda.current_stream(self.device).synchronize()
 
-    def all_reduce_i64(self, arr, op="sum"):
+    def all_reduce_i64(self, arr, op="sum", step=None):
         t = self.torch.as_tensor(np.ascontiguousarray(arr, np.int64)).to(self.device)
-        self.td.all_reduce(t, op=self.td.ReduceOp.SUM if op == "sum" else self.td.ReduceOp.MAX)
+        self.note(step, {"sum": "ALL_REDUCE_SUM", "max": "ALL_REDUCE_MAX", "min": "ALL_REDUCE_MIN"}[op], t.numel())
+        self.td.all_reduce(t, op={"sum": self.td.ReduceOp.SUM, "max": self.td.ReduceOp.MAX, "min": self.td.ReduceOp.MIN}[op])
         return t.cpu().numpy()
 
-    def all_gather_i64(self, t):
+    def all_gather_i64(self, t, step=None):
         t = t.to(self.device)
+        self.note(step, "ALL_GATHER", 8 * t.numel())
         out = [self.torch.empty_like(t) for _ in range(self.world)]
         self.td.all_gather(out, t)
         self._done()
         return [o.to(self.compute_device) for o in out]
 
-    def all_gather_v_i64(self, arr):
-        """Variable-length all-gather of int64 host arrays -> list of numpy arrays, one per rank."""
+    def gather_lists_i64(self, arr, width):
+        """fhx_dist.inc dist_gather_lists: one variable-length list of `width`-tuples per rank -> list of numpy arrays.  Lengths
+        first (NF_LENGTHS), then every list padded to the longest (NF_LISTS)."""
         arr = np.ascontiguousarray(arr, np.int64)
-        sizes = self.all_reduce_i64(np.eye(self.world, dtype=np.int64)[self.rank] * len(arr))
-        width = int(sizes.max()) if self.world else 0
-        if width == 0:
+        n_mine = len(arr) // width
+        lens = [int(t.item()) for t in self.all_gather_i64(self.torch.tensor([n_mine], dtype=self.torch.int64), step="NF_LENGTHS")]
+        longest = max(lens)
+        if longest == 0:
             return [np.zeros(0, np.int64) for _ in range(self.world)]
-        pad = np.zeros(width, np.int64)
+        pad = np.zeros(longest * width, np.int64)
         pad[:len(arr)] = arr
-        t = self.torch.as_tensor(pad).to(self.device)
-        out = [self.torch.empty_like(t) for _ in range(self.world)]
-        self.td.all_gather(out, t)
-        return [o.cpu().numpy()[:int(n)] for o, n in zip(out, sizes)]
+        out = self.all_gather_i64(self.torch.as_tensor(pad), step="NF_LISTS")
+        return [o.cpu().numpy()[:n * width] for o, n in zip(out, lens)]
 
-    def all_gather_f64_scalar(self, v):
+    def all_gather_f64_scalar(self, v, step=None):
         t = self.torch.tensor([float(v)], dtype=self.torch.float64, device=self.device)
+        self.note(step, "ALL_GATHER", 8)
         out = [self.torch.empty_like(t) for _ in range(self.world)]
         self.td.all_gather(out, t)
         return [float(o.item()) for o in out]
 
-    def all_reduce_device_i64(self, ptr, n):
+    def all_reduce_device_i64(self, ptr, n, step=None):
         """In-place SUM all-reduce of n int64 values living at device address `ptr` (the engine's own buffer): wrapped as a
         torch tensor without a copy.  With a host transport (gloo in the tests) it is staged through the host."""
         torch = self.torch
+        self.note(step, "ALL_REDUCE_SUM", n)
 
         class _View:                                    # minimal __cuda_array_interface__ carrier
             __cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
@@ -101,17 +120,12 @@ class Comm:
             t.copy_(h)
             torch.cuda.current_stream(self.compute_device).synchronize()
 
-    def all_to_all_v(self, send, send_counts, dtype=None, recv_counts=None):
-        """send: 1-D tensor laid out rank-major; returns (recv tensor, recv_counts).  recv_counts, when the caller already
-        knows them (the return leg of an exchange), saves the count exchange."""
+    def all_to_all_v(self, send, send_counts, recv_counts, step=None):
+        """send: 1-D tensor of 8-byte elements laid out rank-major; both count vectors are known to the caller (they come out of
+        the all-gathered count matrix, as in the library); returns (recv tensor, recv_counts)."""
         torch = self.torch
-        if recv_counts is None:
-            sc = torch.tensor(send_counts, dtype=torch.int64, device=self.device)
-            rc = torch.empty_like(sc)
-            self.td.all_to_all_single(rc, sc)
-            recv_counts = [int(v) for v in rc.cpu().tolist()]
-        else:
-            recv_counts = [int(v) for v in recv_counts]
+        recv_counts = [int(v) for v in recv_counts]
+        self.note(step, "ALL_TO_ALL_V", sum(int(v) for v in send_counts))
         send = send.to(self.device).contiguous()
         recv = torch.empty(sum(recv_counts), dtype=send.dtype, device=self.device)
         self.td.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=[int(v) for v in send_counts])
@@ -270,7 +284,7 @@ def choose_splitters(torch, samples_sorted, world):
 
 
 def distributed_bh(comm, ops, n_tests, timings=None):
-    """Global BH over the p-values of all ranks; leaves q in row order on every rank."""
+    """Global BH over the p-values of all ranks; leaves q in row order on every rank (fhx_bh_distributed)."""
     import time
     torch = comm.torch
     t_last = [time.perf_counter()]
@@ -284,41 +298,42 @@ def distributed_bh(comm, ops, n_tests, timings=None):
     # exact early cutoff: rows whose q is provably 1 are neither sorted nor exchanged (needs the GLOBAL key histogram)
     if hasattr(ops, "top_hist_device") and comm.compute_device.type == "cuda":
         ptr, length = ops.top_hist_device()              # histogram stays in HBM: all-reduce in place, cutoff on the device
-        comm.all_reduce_device_i64(ptr, length)
+        comm.all_reduce_device_i64(ptr, length, step="TOP_HIST")
         ops.set_cutoff_device(n_tests)
     else:
-        ops.set_cutoff(comm.all_reduce_i64(ops.top_hist()), n_tests)
+        ops.set_cutoff(comm.all_reduce_i64(ops.top_hist(), step="TOP_HIST"), n_tests)
     lap("bh_cutoff")
     keys = ops.local_sorted_keys()
     n = keys.numel()
     lap("bh_local_sort")
     # regular samples -> common splitters
-    s = SAMPLES_PER_RANK
+    s = samples_per_rank(comm.world)
     if n:
         idx = torch.clamp(((torch.arange(1, s + 1, device=keys.device, dtype=torch.int64) * n) // (s + 1)), max=n - 1)
         samples = keys[idx]
     else:
         samples = torch.full((s,), (1 << 62), dtype=torch.int64, device=keys.device)      # sorts after every real key
-    gathered = torch.cat(comm.all_gather_i64(samples))
+    gathered = torch.cat(comm.all_gather_i64(samples, step="SAMPLES"))
     gathered = gathered[gathered < (1 << 62)]
     splitters = choose_splitters(torch, torch.sort(gathered).values, comm.world)
-    # cut the local run at the splitters and exchange
+    # cut the local run at the splitters; the count matrix (who sends how much to whom) goes to everybody
     if splitters.numel():
         cuts = torch.searchsorted(keys, splitters, right=False).cpu().tolist()
     else:
         cuts = [n] * (comm.world - 1)
     bounds = [0] + [int(c) for c in cuts] + [n]
     send_counts = [bounds[r + 1] - bounds[r] for r in range(comm.world)]
+    matrix = [t.cpu().tolist() for t in comm.all_gather_i64(torch.tensor(send_counts, dtype=torch.int64), step="COUNT_MATRIX")]
+    recv_counts = [int(matrix[src][comm.rank]) for src in range(comm.world)]
+    rank0 = sum(int(matrix[src][dst]) for dst in range(comm.rank) for src in range(comm.world))
     lap("bh_splitters")
-    recv, recv_counts = comm.all_to_all_v(keys, send_counts)
+    recv, _ = comm.all_to_all_v(keys, send_counts, recv_counts, step="KEYS")
     lap("bh_exchange_keys")
-    # my slice of the global order: sort the received runs, remember where each element came from
+    # my slice of the global order: merge the received runs (ties keep sender order), remember where each element came from
     mine_sorted, perm = ops.sort_keys(recv)
     m = mine_sorted.numel()
-    counts = [int(t.item()) for t in comm.all_gather_i64(torch.tensor([m], dtype=torch.int64))]
-    rank0 = sum(counts[:comm.rank])
     _, seg_max = ops.bh_segment(mine_sorted, rank0, 0.0, n_tests, want_q=False)
-    maxima = comm.all_gather_f64_scalar(seg_max)
+    maxima = comm.all_gather_f64_scalar(seg_max, step="SLICE_MAX")
     carry = max([0.0] + maxima[:comm.rank])
     q_sorted, _ = ops.bh_segment(mine_sorted, rank0, carry, n_tests, want_q=True)
     lap("bh_slice")
@@ -326,7 +341,7 @@ def distributed_bh(comm, ops, n_tests, timings=None):
     q_arrival = torch.empty_like(q_sorted)
     if m:
         q_arrival[perm.to(torch.int64)] = q_sorted
-    q_back, back_counts = comm.all_to_all_v(q_arrival, recv_counts, recv_counts=send_counts)
+    q_back, _ = comm.all_to_all_v(q_arrival, recv_counts, send_counts, step="Q_BACK")
     ops.scatter_q(q_back)
     lap("bh_return")
     return n, m
@@ -351,8 +366,8 @@ class DistributedPass:
         self.timings["k1"] = self.timings.get("k1", 0.0) + time.perf_counter() - t0
         if getattr(ops, "nonfixed", False):
             return self._run_nonfixed(st, hist_cc, hist_np)
-        if self.n_dist_global is None:
-            self.n_dist_global = int(comm.all_reduce_i64(np.array([len(hist_cc)]), op="max")[0])
+        if self.n_dist_global is None:                   # once per loaded row set (dist_agree_n_dist)
+            self.n_dist_global = int(comm.all_reduce_i64(np.array([len(hist_cc)]), op="max", step="NDIST_AGREE")[0])
         nd = self.n_dist_global
         a, b = ops.hist_span(nd) if hasattr(ops, "hist_span") else (0, nd)      # the window that can be non-zero
         w = b - a
@@ -366,7 +381,7 @@ class DistributedPass:
         pack[8 + comm.rank] = st.max_count
         pack[8 + comm.world:8 + comm.world + w] = full_cc[a:b]
         pack[8 + comm.world + w:] = full_np[a:b]
-        pack = comm.all_reduce_i64(pack)
+        pack = comm.all_reduce_i64(pack, step="STATS_PACK")
         (st.inter_count, st.inter_sum, st.intra_all_count, st.intra_all_sum, st.in_range_count, st.in_range_sum,
          st.n_skipped) = [int(v) for v in pack[:7]]
         st.max_count = int(pack[8:8 + comm.world].max())
@@ -386,19 +401,31 @@ class DistributedPass:
         return info
 
     def _run_nonfixed(self, st, hist_cc, hist_np):
-        """-r 0: the histogram is keyed by the distinct distances, which differ between ranks: gather keys and values
-        (a few thousand int64 per rank), merge on every host, then the same fit / K2 / distributed BH as fixed-size runs."""
+        """-r 0: the histogram is keyed by the distinct distances, which differ between ranks: every rank's (distance, sum of
+        counts, rows) triples travel as one padded list with the seven sums and the largest count in front
+        (dist_pass_stats_nonfixed), are merged by distance on every host, then the same fit / K2 / distributed BH as fixed-size runs."""
         comm, ops = self.comm, self.ops
-        keys = ops.local_dist_keys()
-        k_all = comm.all_gather_v_i64(keys)
-        cc_all = comm.all_gather_v_i64(np.asarray(hist_cc, np.int64)[:len(keys)])
-        np_all = comm.all_gather_v_i64(np.asarray(hist_np, np.int64)[:len(keys)])
+        if self.n_dist_global is None:                   # the agreement of dist_agree_n_dist also carries "explicit distances here"
+            comm.all_reduce_i64(np.array([1 << 62]), op="max", step="NDIST_AGREE")
+            self.n_dist_global = 0
+        keys = np.asarray(ops.local_dist_keys(), np.int64)
+        head = [st.inter_count, st.inter_sum, st.intra_all_count, st.intra_all_sum, st.in_range_count, st.in_range_sum, st.n_skipped,
+                st.max_count, 0]
+        body = np.stack([keys, np.asarray(hist_cc, np.int64)[:len(keys)], np.asarray(hist_np, np.int64)[:len(keys)]], axis=1).reshape(-1)
+        lists = comm.gather_lists_i64(np.concatenate([np.array(head, np.int64), body]), width=3)
+        sums = np.zeros(7, np.int64)
+        max_count = 0
+        k_all, cc_all, np_all = [], [], []
+        for L in lists:
+            sums += L[:7]
+            max_count = max(max_count, int(L[7]))
+            t = L[9:].reshape(-1, 3)
+            k_all.append(t[:, 0])
+            cc_all.append(t[:, 1])
+            np_all.append(t[:, 2])
         gkeys, gcc, gnp = merge_keyed_histograms(k_all, cc_all, np_all)
-        pack = comm.all_reduce_i64(np.array([st.inter_count, st.inter_sum, st.intra_all_count, st.intra_all_sum, st.in_range_count,
-                                             st.in_range_sum, st.n_skipped], np.int64))
-        max_count = int(comm.all_reduce_i64(np.array([st.max_count]), op="max")[0])
         (st.inter_count, st.inter_sum, st.intra_all_count, st.intra_all_sum, st.in_range_count, st.in_range_sum,
-         st.n_skipped) = [int(v) for v in pack]
+         st.n_skipped) = [int(v) for v in sums]
         st.max_count = max_count
         if len(gkeys) == 0:                                # no in-range row anywhere: keep one key so that the C ABI accepts it
             gkeys, gcc, gnp = np.zeros(1, np.int64), np.zeros(1, np.int64), np.zeros(1, np.int64)
@@ -415,19 +442,24 @@ class DistributedPass:
         self.ops._outlier_local = np.zeros(0, np.int64)
 
     def next_pass(self):
-        """Fold outliers locally, then make the outlier-distance multiset genome-wide."""
+        """Fold outliers locally, then make the outlier-distance multiset genome-wide (fhx_next_pass_distributed)."""
         n_local, hist = self.ops.next_pass_local()
+        cap = 1 << 62
         if getattr(self.ops, "nonfixed", False):           # `hist` is this rank's cumulative list of outlier distances
-            merged = np.sort(np.concatenate(self.comm.all_gather_v_i64(hist)))
-            self.ops.set_outlier_dists(merged)
-            limit = -int(self.comm.all_reduce_i64(np.array([-min(self.ops.get_skip_limit(), (1 << 62))]), op="max")[0])
-            self.ops.set_skip_limit(limit if limit < (1 << 62) else (1 << 63) - 1)
-            return self.comm.sum_int(n_local)
-        nd = max(self.n_dist_global or 0, int(self.comm.all_reduce_i64(np.array([len(hist)]), op="max")[0]))
-        buf = np.zeros(nd, np.int64)
-        buf[:len(hist)] = hist
-        self.ops.set_outlier_hist(self.comm.all_reduce_i64(buf))
+            send = np.concatenate([np.array([n_local, min(self.ops.get_skip_limit(), cap)], np.int64), np.asarray(hist, np.int64)])
+            lists = self.comm.gather_lists_i64(send, width=1)
+            total = sum(int(L[0]) for L in lists)
+            limit = min(int(L[1]) for L in lists)
+            self.ops.set_outlier_dists(np.sort(np.concatenate([L[2:] for L in lists])))
+            self.ops.set_skip_limit(limit if limit < cap else (1 << 63) - 1)
+            return total
+        nd = int(self.n_dist_global)
+        buf = np.zeros(nd + 1, np.int64)                   # the multiset of outlier distances + this rank's outlier total
+        buf[:min(len(hist), nd)] = hist[:nd]
+        buf[nd] = n_local
+        buf = self.comm.all_reduce_i64(buf, step="OUTLIER_HIST")
+        self.ops.set_outlier_hist(buf[:nd])
         # first duplicated outlier LINE of the whole file (-p >= 3 semantics): min over ranks, in file positions
-        limit = -int(self.comm.all_reduce_i64(np.array([-min(self.ops.get_skip_limit(), (1 << 62))]), op="max")[0])
-        self.ops.set_skip_limit(limit if limit < (1 << 62) else (1 << 63) - 1)
-        return self.comm.sum_int(n_local)
+        limit = int(self.comm.all_reduce_i64(np.array([min(self.ops.get_skip_limit(), cap)]), op="min", step="SKIP_LIMIT")[0])
+        self.ops.set_skip_limit(limit if limit < cap else (1 << 63) - 1)
+        return int(buf[nd])

@@ -215,6 +215,23 @@ def _worker(rank, world, port, case, passes, result_dir):
             if total != r.n_outlier_lines_total:
                 ok = False
                 msgs.append("outlier count %d vs %d" % (total, r.n_outlier_lines_total))
+    # the collectives the model issued == the rows of csrc/fhx_dist_schedule.def, in order, with the table's sizes (the same table
+    # the library's trace is held against in tests/test_gpu_native_dist.py): the model cannot drift from fhx_dist.inc unnoticed
+    import dist_schedule
+    try:
+        s_per = dist.samples_per_rank(world)
+        if res == 0:
+            phases = ["LOAD", "STATS_NF", "BH"] + ["NEXT_NF", "STATS_NF", "BH"] * (passes - 1)
+            envs = [dict(world=world, s=s_per, width=(1 if ph == "NEXT_NF" else 3)) for ph in phases]
+        else:
+            nd = runner.n_dist_global
+            a, b = ops.hist_span(nd) if hasattr(ops, "hist_span") else (0, nd)
+            phases = ["LOAD", "STATS", "BH"] + ["NEXT", "STATS", "BH"] * (passes - 1)
+            envs = [dict(world=world, s=s_per, w=b - a, nd=nd) for _ in phases]
+        dist_schedule.check(comm.trace, phases, envs)
+    except AssertionError as e:
+        ok = False
+        msgs.append("schedule: %s" % e)
     with open(os.path.join(result_dir, "rank%d.txt" % rank), "w") as f:
         f.write("OK" if ok else "FAIL: " + "; ".join(msgs))
     td.destroy_process_group()
@@ -308,3 +325,24 @@ def test_bench_sharded_verification_hashes_over_gloo(tmp_path):
     for r in range(2):
         with open(os.path.join(str(tmp_path), "rank%d.txt" % r)) as f:
             assert f.read() == "OK"
+
+
+def test_schedule_check_catches_drift():
+    """tests/dist_schedule.py against csrc/fhx_dist_schedule.def: the right trace passes; a collective left out, an extra one, a
+    wrong kind or a wrong size is named."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dist_schedule
+    ids = [r[0] for r in dist_schedule.steps()]
+    assert ids[:2] == ["NDIST_AGREE", "STATS_PACK"] and "KEYS" in ids and len(set(ids)) == len(ids)
+    env = dict(world=2, w=10, s=128, nd=50, n_local=7, m=9)
+    good = ([("NDIST_AGREE", "ALL_REDUCE_MAX", 1), ("STATS_PACK", "ALL_REDUCE_SUM", 30), ("TOP_HIST", "ALL_REDUCE_SUM", 8192),
+             ("SAMPLES", "ALL_GATHER", 1024), ("COUNT_MATRIX", "ALL_GATHER", 16), ("KEYS", "ALL_TO_ALL_V", 7),
+             ("SLICE_MAX", "ALL_GATHER", 8), ("Q_BACK", "ALL_TO_ALL_V", 9), ("OUTLIER_HIST", "ALL_REDUCE_SUM", 51),
+             ("SKIP_LIMIT", "ALL_REDUCE_MIN", 1)])
+    phases = ["LOAD", "STATS", "BH", "NEXT"]
+    dist_schedule.check(good, phases, [env] * 4)
+    for bad in (good[:4] + good[5:], good[:3] + [("SLICE_MAX", "ALL_GATHER", 8)] + good[3:],
+                [("STATS_PACK", "ALL_REDUCE_MAX", 30) if r[0] == "STATS_PACK" else r for r in good],
+                [("SAMPLES", "ALL_GATHER", 8192) if r[0] == "SAMPLES" else r for r in good]):
+        with pytest.raises(AssertionError):
+            dist_schedule.check(bad, phases, [env] * 4)

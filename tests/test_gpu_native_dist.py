@@ -89,10 +89,13 @@ def _rank_main(rank, world, conns, case, passes, split, result_path):
         local.set_global_rows(mine)                   # file positions (the -p >= 3 semantics)
         from fithic_amd.sharded import PipeTransport
         tr = PipeTransport(local, rank, world, conns)
+        os.environ["FHX_DIST_TRACE"] = "1"             # the library records every collective it issues (fhx_dist_trace)
         local.comm_init_custom(tr.struct, rank, world)
         assert local.comm_info()[:2] == (rank, world)
+        n_sorted = []
         for pi in range(passes):
             info = local.run_pass_distributed()
+            n_sorted.append(local.n_sorted())
             got = local.fetch(len(mine))
             for key, ref in (("p", want[pi][0]), ("q", want[pi][1])):
                 if not _same(got[key], ref[mine]):
@@ -105,12 +108,43 @@ def _rank_main(rank, world, conns, case, passes, split, result_path):
                 tot = local.next_pass_distributed()
                 if tot != want[pi][2]:
                     msgs.append("outliers %d vs %d" % (tot, want[pi][2]))
+        msgs += _schedule_errors(local, kw, world, passes, n_sorted)
         local.close()
     except Exception as e:
         import traceback
         msgs.append("exception: %r\n%s" % (e, traceback.format_exc()))
     with open(result_path, "w") as f:
         f.write("OK" if not msgs else "FAIL: " + "; ".join(msgs))
+
+
+def _schedule_errors(ctx, kw, world, passes, n_sorted):
+    """The collectives the library issued (FHX_DIST_TRACE=1) against csrc/fhx_dist_schedule.def - the list the Python model of the
+    schedule is held to as well (tests/test_dist_gloo.py): ids, order, kinds and every size the test can name."""
+    import dist_schedule
+    trace = ctx.dist_trace()
+    explicit = any(step == "NF_LENGTHS" for step, _, _ in trace)        # -r 0 / off-grid loci anywhere: distances travel as lists
+    s_per = max(1, min(128, 8192 // world))
+    phases, envs = ["LOAD"], [dict(world=world)]
+    res = kw["resolution"]
+    nd = int(ctx.stats().n_dist)
+    for pi in range(passes):
+        if pi:
+            phases.append("NEXT_NF" if explicit else "NEXT")
+            envs.append(dict(world=world, nd=nd, width=1))
+        phases.append("STATS_NF" if explicit else "STATS")
+        if explicit:
+            envs.append(dict(world=world, width=3))
+        else:
+            a = min(max(0, int(kw["L"]) // res), nd)
+            b = nd if kw["U"] == float("inf") else max(a, min(nd, int(kw["U"]) // res + 2))
+            envs.append(dict(world=world, w=b - a))
+        phases.append("BH")
+        envs.append(dict(world=world, s=s_per, n_local=n_sorted[pi]))
+    try:
+        dist_schedule.check(trace, phases, envs)
+    except AssertionError as e:
+        return ["schedule: %s" % e]
+    return []
 
 
 def _run_world(world, case, passes, split, tmp_path):
@@ -208,12 +242,15 @@ def _rccl_single_rank(case, passes, result_path):
         want = _single_gpu_passes(single, n, passes)
         single.close()
         local = _make_ctx(kw, chroms, frag, bias, con, np.arange(n))
+        os.environ["FHX_DIST_TRACE"] = "1"
         local.comm_init(_capi.comm_unique_id(), 0, 1)
+        n_sorted = []
         rank, world, version = local.comm_info()
         if (rank, world) != (0, 1) or version <= 0:
             msgs.append("comm_info %r" % ((rank, world, version),))
         for pi in range(passes):
             local.run_pass_distributed()
+            n_sorted.append(local.n_sorted())
             got = local.fetch(n)
             for key, ref in (("p", want[pi][0]), ("q", want[pi][1])):
                 if not _same(got[key], ref):
@@ -223,6 +260,7 @@ def _rccl_single_rank(case, passes, result_path):
         stages = local.dist_stage_seconds()
         if not all(v >= 0 for v in stages.values()):
             msgs.append("stage clocks %r" % (stages,))
+        msgs += _schedule_errors(local, kw, 1, passes, n_sorted)
         local.close()
     except Exception as e:
         import traceback
