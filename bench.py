@@ -224,9 +224,14 @@ def main():
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the additional weak-scaling measurement")
     ap.add_argument("--overdispersion", type=float, default=0.0,
                     help="0 = synth-v1 (Poisson around the model); s > 0 adds lognormal rate noise: heavier small-p tail, like real maps")
+    ap.add_argument("--no-k3-stress", action="store_true",
+                    help="N = 1: skip the second workload (lognormal rate noise s = 1.0: a heavy small-p tail, where K3's sort works)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--max-chroms", type=int, default=0, help="use only the first k chromosomes")
+    ap.add_argument("--shard-of", type=int, default=0,
+                    help="scaling model: run, alone on this GPU, the LARGEST shard an N-way chromosome sharding of the workload gives "
+                         "(the chromosomes synth.assign_chromosomes hands the fullest rank); profiles/scaling_model.py")
     ap.add_argument("--path", choices=["fithic", "kr", "cni"], default="fithic",
                     help="fithic (default): the headline pass.  kr / cni: the neighbouring steps (Knight-Ruiz bias vectors, merging of "
                          "nearby contacts) measured by profiles/kr_bench.py / profiles/cni_bench.py, plus their cpu_baseline")
@@ -300,8 +305,14 @@ def main():
     base_lengths = cfg["lengths"] if cfg["lengths"] is not None else synth.HG19_AUTOSOMES
     if args.max_chroms:
         base_lengths = base_lengths[:args.max_chroms]
+    if args.shard_of > 1:
+        g_all = synth.Genome(res, base_lengths)
+        owner_all = synth.assign_chromosomes(g_all, args.shard_of)
+        fullest = max(range(args.shard_of), key=lambda r: sum(g_all.n_loci[c] for c in range(len(g_all)) if owner_all[c] == r))
+        base_lengths = [base_lengths[c] for c in range(len(g_all)) if owner_all[c] == fullest]
+        del g_all
 
-    def measure(replicas, with_cpu_leg, solo=False, want_hashes=False, steps=None, warmup=None):
+    def measure(replicas, with_cpu_leg, solo=False, want_hashes=False, steps=None, warmup=None, overdispersion=None):
         """Generate, load, warm up, time `steps` steps.  Returns the result pieces of this workload.
         solo: this process alone takes the whole genome through the plain single-GPU path (the verification run of rank 0)."""
         world, rank, comm = (1, 0, None) if solo else (world_all, rank_all, comm_all)
@@ -311,7 +322,8 @@ def main():
         owner = synth.assign_chromosomes(genome, world)
         mine = [c for c in range(len(genome)) if owner[c] == rank]
         t_gen = time.time()
-        cols, n_local, n_cis_local, n_trans = build_rows(synth, torch, cfg, genome, mine, rank, world, device, args.overdispersion)
+        cols, n_local, n_cis_local, n_trans = build_rows(synth, torch, cfg, genome, mine, rank, world, device,
+                                                         args.overdispersion if overdispersion is None else overdispersion)
         torch.cuda.synchronize()
         log("[rank %d] generated %d rows (%d cis on %d chromosomes, %d of %d trans) in %.1f s" %
             (rank, n_local, n_cis_local, len(mine), n_local - n_cis_local, n_trans, time.time() - t_gen))
@@ -423,7 +435,7 @@ def main():
     weak_headline = args.weak and world > 1
     replicas = args.replicas if args.replicas > 0 else (world if weak_headline else 1)
     # the f14 fixture of this workload (the real reference's fit on it) applies when the run IS that workload
-    canonical = (args.keep == 0 and args.max_chroms == 0 and args.overdispersion == 0 and replicas == 1)
+    canonical = (args.keep == 0 and args.max_chroms == 0 and args.shard_of <= 1 and args.overdispersion == 0 and replicas == 1)
     fixture_name = args.config if canonical and os.path.exists(os.path.join(ROOT, "tests", "golden", "f14_%s_fit.npz" % args.config)) else None
     verify_sharded = comm is not None and not args.no_parity_check         # N > 1 (or FHX_FORCE_DIST): compare with one GPU
     want_digest = bool(os.environ.get("FHX_BENCH_HASH"))          # A/B of kernel variants: a digest of every p and q in the result line
@@ -537,6 +549,26 @@ def main():
     eng.close()
     del M
     torch.cuda.empty_cache()
+    if rank == 0 and comm is None and args.path == "fithic" and args.overdispersion == 0 and not args.no_k3_stress and args.config == "C3":
+        # K3 where it works: on synth-v1 the exact cutoff leaves < 0.1 % of the rows to sort; with lognormal rate noise (s = 1.0)
+        # 12 % of the rows carry a small p, as on real (over-dispersed) maps.  A second, labelled measurement - never the headline.
+        try:
+            S = measure(replicas, with_cpu_leg=False, steps=max(2, min(args.steps, 5)), warmup=1, overdispersion=1.0)
+            k3_s = max(r[2] for r in S["k_all"])
+            result["k3_stress"] = {
+                "workload": "the same genome and depth, Poisson rates multiplied by lognormal noise (s = 1.0): synth-v1 + overdispersion 1.0",
+                "pairs": int(S["n_total"]), "rows_sorted": S["bh_sorted"], "k3_ms": 1e3 * k3_s,
+                "sorted_keys_per_s": (S["bh_sorted"] / k3_s) if (S["bh_sorted"] and k3_s > 0) else None,
+                "ms_per_step": 1e3 * S["elapsed"] / S["steps"], "pairs_per_s": S["n_total"] * passes * S["steps"] / S["elapsed"],
+                "kernels_ms": {"k1_classify_hist": 1e3 * max(r[0] for r in S["k_all"]), "k2_pvalue": 1e3 * max(r[1] for r in S["k_all"]),
+                               "k3_bh_sort_scan": 1e3 * k3_s},
+                "k3_hbm_frac": (ALGO_BYTES_K3 * S["n_total"] / k3_s) / (HBM_PEAK_GBS * 1e9) if k3_s > 0 else None}
+            S["eng"].close()
+            del S
+        except Exception as e:                                   # noqa: BLE001 - the headline line must not be lost to the extra workload
+            log("k3_stress failed: %r" % (e,))
+            result["k3_stress"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
     if verify_sharded:
         # Every p and q of the sharded pass against ONE GPU: the ranks' hash tables are summed (a chromosome's cis rows live on
         # one rank, the trans rows are spread: the sum is what one GPU holding everything computes); rank 0 then takes the whole

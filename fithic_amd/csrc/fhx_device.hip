@@ -1053,6 +1053,14 @@ __global__ __launch_bounds__(K2_THREADS) void k2h_generic(K2Params P, const QEnt
     H.flush(P.top_hist);
 }
 
+// (Measured and dropped in round 4, profiles/r04_h_cfu_ab.txt: the two CONVERGING classes through the heavy class's machinery -
+// counting-sorted by (binomial, orientation, count), iteration constants from a table row per iteration through scalar loads,
+// four rows per lane, the loop stopped in blocks of eight iterations.  Bit-identical (same digest of all p and q), and the
+// loop kernels were 15 % (incbcf: 1.12 -> 0.95 ms) and 2 % (incbd: 0.96 -> 0.94 ms) faster than k2_queue_by_count - a wave of 256
+// rows runs until its slowest row converges, 16-32 iterations where a row needs 9 on average, and the transcendental epilogue is
+// the same - but the count sort in front of them (count 0.10-0.11 ms, scatter 0.14-0.18 ms, tables, offsets per class) costs more
+// than that: 12.2-12.4 ms per pass against 11.9.)
+
 // test hook: class of (count, prior) by the table and by bdtrc_class's arithmetic, and the five thresholds of the count
 __global__ void k_debug_classify(double n_total, const int32_t* __restrict__ count, const double* __restrict__ prior, int64_t n,
                                  int32_t* __restrict__ by_table, int32_t* __restrict__ by_arith, double* __restrict__ thr5) {
@@ -1745,184 +1753,11 @@ __global__ __launch_bounds__(BH_THREADS) void bh_apply(const unsigned long long*
     }
 }
 
-// ---- small survivor sets: the six radix passes and the BH scan in ONE launch --------------------------------------------
-// On Hi-C data whose counts follow the model closely (C3-synth: 77 k of 1.5e8 rows below the cutoff) and on every shard of a
-// strong-scaling run the sort is all fixed cost: 18 launches + 3 for the BH pass, ~9 us each back to back, for microseconds of
-// work (0.17 + 0.05 ms per pass).  Up to K3S_MAX_KEYS survivors run through k3_small instead: 64 workgroups that stay resident
-// and meet at a device-wide barrier between the phases.  A workgroup owns one tile of 4096 keys, so a pass needs no separate
-// counting read: the digit counts of its tile are what the ranking step of the scatter produces anyway (keys, payloads, ranks
-// and the per-wave counters stay in registers / LDS across the barriers).  Per pass: rank + publish counts | scan the 2048 x 64
-// count matrix (32 digits per workgroup) | write; then the BH values, their running maximum per tile, and q scattered to rows.
-// Same arithmetic and the same stable order as rs_* / bh_*: bit-identical results (tests: every BH fixture goes through it).
-constexpr int K3S_BLOCKS = 64;
-constexpr int K3S_THREADS = 512;
-constexpr int K3S_TILE = K3S_THREADS * SCAT_ITEMS;              // 4096
-constexpr int K3S_MAX_KEYS = K3S_BLOCKS * K3S_TILE;             // 262 144
-static_assert(K3S_TILE == SORT_TILE && RADIX % K3S_BLOCKS == 0, "one tile per workgroup; whole digit rows per workgroup");
-
-// all workgroups of the launch (they are co-resident: 64 of them on 256 CUs, nothing else runs on the stream's device while a
-// pass is in flight); *bar counts arrivals and is zeroed before the launch
-__device__ __forceinline__ void k3s_grid_barrier(unsigned int* bar, unsigned int& epoch) {
-    __threadfence();
-    __syncthreads();
-    ++epoch;
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned int want = epoch * gridDim.x;
-        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
-    }
-    __syncthreads();
-    __threadfence();
-}
-
-__device__ __forceinline__ unsigned int k3s_load(const unsigned int* p) {      // written by another workgroup of this launch
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__global__ __launch_bounds__(K3S_THREADS) void k3_small(unsigned long long* keys_a, unsigned int* vals_a, unsigned long long* keys_b,
-                                                        unsigned int* vals_b, const unsigned long long* __restrict__ n_ptr,
-                                                        unsigned int* block_hist, unsigned int* digit_total, unsigned int* bar,
-                                                        double n_tests, double* tile_max, double* __restrict__ q_out) {
-    constexpr int WAVES = K3S_THREADS / 64, PER = RADIX / K3S_THREADS, NBLK = K3S_BLOCKS;
-    __shared__ unsigned short wave_digit[WAVES][RADIX];
-    __shared__ unsigned int tile_total[RADIX];
-    __shared__ unsigned int wave_tmp[WAVES];
-    __shared__ double wmax[WAVES];
-    const int64_t n = (int64_t)*n_ptr;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int blk = (int)blockIdx.x;
-    const unsigned long long lane_lt = (1ull << lane) - 1ull;
-    const int64_t beg = (int64_t)blk * K3S_TILE, end = min(n, beg + (int64_t)K3S_TILE);
-    unsigned int epoch = 0;
-    unsigned long long* kin = keys_a;
-    unsigned int* vin = vals_a;
-    unsigned long long* kout = keys_b;
-    unsigned int* vout = vals_b;
-    for (int pass = 0; pass < SORT_PASSES; ++pass) {
-        const int shift = pass * RADIX_BITS;
-        // ---- rank this workgroup's tile, publish its digit counts ----
-        for (int i = threadIdx.x; i < WAVES * RADIX / 2; i += K3S_THREADS) reinterpret_cast<unsigned int*>(&wave_digit[0][0])[i] = 0u;
-        unsigned long long key[SCAT_ITEMS];
-        unsigned int val[SCAT_ITEMS], rank[SCAT_ITEMS];
-        const int64_t wave_base = beg + (int64_t)wave * (64 * SCAT_ITEMS);
-#pragma unroll
-        for (int r = 0; r < SCAT_ITEMS; ++r) {
-            const int64_t i = wave_base + r * 64 + lane;
-            const bool live = i < end;
-            key[r] = live ? kin[i] : ~0ull;
-            val[r] = live ? vin[i] : 0u;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < SCAT_ITEMS; ++r) {
-            const bool live = (wave_base + r * 64 + lane) < end;
-            const unsigned int digit = (unsigned int)(key[r] >> shift) & (RADIX - 1);
-            unsigned long long same = ~0ull;
-            const unsigned int tag = digit | (live ? 0u : RADIX);
-#pragma unroll
-            for (int b = 0; b <= RADIX_BITS; ++b) {
-                const unsigned long long m = __ballot((tag >> b) & 1u);
-                same &= ((tag >> b) & 1u) ? m : ~m;
-            }
-            const unsigned int before = __popcll(same & lane_lt);
-            unsigned int old = 0;
-            if (live) old = wave_digit[wave][digit];
-            rank[r] = old + before;
-            __builtin_amdgcn_wave_barrier();
-            if (live && before == 0) wave_digit[wave][digit] = (unsigned short)(old + __popcll(same));
-            __builtin_amdgcn_wave_barrier();
-        }
-        __syncthreads();
-        for (int d = threadIdx.x * PER; d < (threadIdx.x + 1) * PER; ++d) {
-            unsigned int acc = 0;
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) {
-                const unsigned int c = wave_digit[w][d];
-                wave_digit[w][d] = (unsigned short)acc;
-                acc += c;
-            }
-            block_hist[(size_t)d * NBLK + blk] = acc;                  // digit-major, as rs_count writes it
-        }
-        k3s_grid_barrier(bar, epoch);
-        // ---- exclusive scan of 32 digit rows (64 entries: one per lane), their totals ----
-        for (int k = wave; k < RADIX / NBLK; k += WAVES) {
-            const int d = blk * (RADIX / NBLK) + k;
-            const unsigned int v = k3s_load(&block_hist[(size_t)d * NBLK + lane]);
-            const unsigned int incl = wave_incl_sum_u32(v);
-            block_hist[(size_t)d * NBLK + lane] = incl - v;
-            if (lane == 63) digit_total[d] = incl;
-        }
-        k3s_grid_barrier(bar, epoch);
-        // ---- where each digit starts, then the keys to their places ----
-        {
-            unsigned int v[PER];
-            unsigned int mine = 0;
-#pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                v[k] = k3s_load(&digit_total[threadIdx.x * PER + k]);
-                mine += v[k];
-            }
-            const unsigned int incl = wave_incl_sum_u32(mine);
-            if (lane == 63) wave_tmp[wave] = incl;
-            __syncthreads();
-            unsigned int excl = incl - mine;
-            for (int w = 0; w < wave; ++w) excl += wave_tmp[w];
-#pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                const int d = threadIdx.x * PER + k;
-                tile_total[d] = excl + k3s_load(&block_hist[(size_t)d * NBLK + blk]);     // = global_base of rs_scatter
-                excl += v[k];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < SCAT_ITEMS; ++r) {
-            if (wave_base + r * 64 + lane < end) {
-                const unsigned int digit = (unsigned int)(key[r] >> shift) & (RADIX - 1);
-                const unsigned int dst = tile_total[digit] + wave_digit[wave][digit] + rank[r];
-                kout[dst] = key[r];
-                vout[dst] = val[r];
-            }
-        }
-        k3s_grid_barrier(bar, epoch);
-        unsigned long long* tk = kin; kin = kout; kout = tk;
-        unsigned int* tv = vin; vin = vout; vout = tv;
-    }
-    // ---- Benjamini-Hochberg over the sorted keys (now in kin / vin): bh_tile_max, bh_scan_tiles and bh_apply in one ----
-    constexpr int ITEMS = SCAT_ITEMS;
-    const int64_t first = beg + (int64_t)threadIdx.x * ITEMS;          // blocked: a thread owns 8 consecutive sorted positions
-    double v[ITEMS];
-    double run = 0.0;
-#pragma unroll
-    for (int r = 0; r < ITEMS; ++r) {
-        const int64_t i = first + r;
-        const double b = (i < n) ? bh_value(kin[i], n_tests, (double)(i + 1)) : 0.0;
-        run = fmax(run, b);
-        v[r] = run;
-    }
-    const double incl = wave_incl_max(run, lane);
-    double excl = __shfl_up(incl, 1, 64);
-    if (lane == 0) excl = 0.0;
-    if (lane == 63) wmax[wave] = incl;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = wmax[0];
-        for (int w = 1; w < WAVES; ++w) t = fmax(t, wmax[w]);
-        tile_max[blk] = t;
-    }
-    k3s_grid_barrier(bar, epoch);
-    double carry = 0.0;
-    for (int t = lane; t < blk; t += 64) carry = fmax(carry, __hip_atomic_load(&tile_max[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) carry = fmax(carry, __shfl_xor(carry, off, 64));
-    for (int w = 0; w < wave; ++w) carry = fmax(carry, wmax[w]);
-    carry = fmax(carry, excl);
-#pragma unroll
-    for (int r = 0; r < ITEMS; ++r) {
-        const int64_t i = first + r;
-        if (i < n) __builtin_nontemporal_store(fmax(v[r], carry), q_out + vin[i]);
-    }
-}
+// (Measured and dropped in round 4, profiles/r04_f_small_ab.txt: ONE resident launch for small survivor sets - 64 workgroups,
+// a tile each, the six passes and the BH scan separated by device-wide barriers instead of 21 launches.  The kernels of a small
+// sort already run back to back without gaps (profiles/r03_z_c2_timeline.txt); what a launch boundary costs is what a
+// device-scope barrier costs too - the eight XCDs' L2s are made coherent by writing them back - and 19 such barriers took
+// 0.58 ms where the 21 launches take 0.22 ms for the same 77 k keys.)
 
 // ===================================================================================================
 // non-fixed-size mode (-r 0): loci and distances are arbitrary integers, so the dense index arithmetic of the
@@ -3652,8 +3487,7 @@ static int bh_from_sorted(fhx_ctx* ctx, const unsigned long long* keys, const un
     return FHX_OK;
 }
 
-// compaction, sort and BH of one p column -> q in row order.  Survivor sets of up to K3S_MAX_KEYS keys take the single-launch
-// path (k3_small); FHX_K3_SMALL=0 keeps the launch-per-step path for A/B runs.
+// compaction, sort and BH of one p column -> q in row order
 static int rank_and_adjust(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned long long* keys[2], unsigned int* vals[2], double* d_q,
                            unsigned long long* counter, const unsigned long long* d_cutoff, double n_total_tests, double* tile_max,
                            int* sorted_buf, int64_t* n_sorted_out) {
@@ -3661,17 +3495,6 @@ static int rank_and_adjust(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned 
     int rc = compact_pvalues(ctx, d_p, n, keys, vals, d_q, counter, d_cutoff, &n_kept);
     if (rc != FHX_OK) return rc;
     if (n_sorted_out) *n_sorted_out = n_kept;
-    static const bool small_off = std::getenv("FHX_K3_SMALL") && std::atoi(std::getenv("FHX_K3_SMALL")) == 0;
-    if (n_kept <= K3S_MAX_KEYS && !small_off) {
-        *sorted_buf = 0;                                           // an even number of passes: the sorted keys end where they began
-        if (n_kept == 0) return FHX_OK;
-        unsigned int* bar = reinterpret_cast<unsigned int*>(ctx->d_misc + 64);     // (slots 8..58 hold the 51 FDR buckets at other times)
-        FHX_HIP(hipMemsetAsync(bar, 0, sizeof(unsigned long long), ctx->stream));
-        hipLaunchKernelGGL(k3_small, dim3(K3S_BLOCKS), dim3(K3S_THREADS), 0, ctx->stream, keys[0], vals[0], keys[1], vals[1],
-                           (const unsigned long long*)counter, ctx->d_block_hist, ctx->d_digit_total, bar, n_total_tests, tile_max, d_q);
-        FHX_HIP(hipGetLastError());
-        return FHX_OK;
-    }
     rc = sort_kept(ctx, keys, vals, counter, n_kept, sorted_buf);
     if (rc != FHX_OK) return rc;
     return bh_from_sorted(ctx, keys[*sorted_buf], vals[*sorted_buf], n, counter, n_total_tests, tile_max, d_q);

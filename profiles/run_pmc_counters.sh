@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 : > "$ROOT/gpurun_out/${TAG}_counters.txt"
 for C in "$@"; do
   rm -rf /tmp/pmcc_${T}_$C
-  rocprofv3 --kernel-trace --pmc $C -d /tmp/pmcc_${T}_$C -o run -- python "$ROOT/bench.py" --no-cpu-baseline --steps 3 > /tmp/pmcc_${T}_$C.log 2>&1 || { echo "$C: failed"; tail -3 /tmp/pmcc_${T}_$C.log; continue; }
+  rocprofv3 --kernel-trace --pmc $C -d /tmp/pmcc_${T}_$C -o run -- python "$ROOT/bench.py" --no-cpu-baseline --no-k3-stress --steps 3 > /tmp/pmcc_${T}_$C.log 2>&1 || { echo "$C: failed"; tail -3 /tmp/pmcc_${T}_$C.log; continue; }
   DB=$(find /tmp/pmcc_${T}_$C -name '*.db' | head -1)
   python - "$DB" "$C" >> "$ROOT/gpurun_out/${TAG}_counters.txt" <<'PY'
 import sqlite3, sys, re

@@ -10,7 +10,7 @@ mkdir -p "$ROOT/gpurun_out"
 python bench.py "$@" > "$ROOT/gpurun_out/${TAG}_bench.json" 2> "$ROOT/gpurun_out/${TAG}_bench.err"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$T
-rocprofv3 --kernel-trace --stats -d /tmp/prof_$T -o run -- python "$ROOT/bench.py" "$@" --no-cpu-baseline > /tmp/prof_$T.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/prof_$T -o run -- python "$ROOT/bench.py" "$@" --no-cpu-baseline --no-k3-stress > /tmp/prof_$T.log 2>&1
 DB=$(find /tmp/prof_$T -name '*.db' | head -1)
 python "$ROOT/profiles/summarize_rocprof.py" "$DB" > "$ROOT/gpurun_out/${TAG}_kernel_stats.txt"
 cat "$ROOT/gpurun_out/${TAG}_kernel_stats.txt"
