@@ -181,17 +181,46 @@ SYMBOLS = {
     "fhx_cni_get_records": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, _I64P]),
 }
 
-BUILD_CMD = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-             "-fno-fast-math", "-pthread", "-o", os.path.join(_PKG, "libfithic_mi355x.so"), os.path.join(CSRC, "fhx_device.hip"),
-             os.path.join(CSRC, "fhx_kr.hip"), os.path.join(CSRC, "fhx_cni.hip"), os.path.join(CSRC, "fhx_host.cpp"), os.path.join(CSRC, "fhx_io.cpp"), os.path.join(CSRC, "fhx_gunzip.cpp"), "-lz", "-ldl"]
+# One object per translation unit (fithic_amd/csrc/_obj/, git-ignored), compiled in parallel, then one link: a change in K2 does
+# not recompile K1, K3, the Knight-Ruiz path or the host stages.  Flags are the same for every unit - -ffp-contract=off matters
+# for bit-exactness on the host (FITPACK, lgamma tables) as much as on the device (fhx_bdtrc.hpp).
+SOURCES = ["fhx_device.hip", "fhx_k1.hip", "fhx_k2.hip", "fhx_k3.hip", "fhx_kr.hip", "fhx_cni.hip", "fhx_host.cpp", "fhx_io.cpp", "fhx_gunzip.cpp"]
+COMPILE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-pthread"]
+LINK_FLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-lz", "-ldl"]
+OBJ_DIR = os.path.join(CSRC, "_obj")
+
+
+def build_commands():
+    """[(compile command per unit)], link command - what build() runs (INTEGRATION.md quotes it)"""
+    objs = [os.path.join(OBJ_DIR, os.path.splitext(f)[0] + ".o") for f in SOURCES]
+    compiles = [["hipcc"] + COMPILE_FLAGS + ["-c", "-o", o, os.path.join(CSRC, f)] for f, o in zip(SOURCES, objs)]
+    link = ["hipcc"] + objs + LINK_FLAGS + ["-o", LIB_PATH]
+    return compiles, link
 
 
 def build(force=False):
     """Compile the HIP kernels + host stages for gfx950 into the in-tree shared library."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(os.path.dirname(_PKG), "include", "fithic_mi355x.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
-        return LIB_PATH
-    subprocess.check_call(BUILD_CMD)
+    from concurrent.futures import ThreadPoolExecutor
+    shared = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc", ".def", ".h"))]
+    shared.append(os.path.join(os.path.dirname(_PKG), "include", "fithic_mi355x.h"))
+    newest_shared = max(os.path.getmtime(p) for p in shared)
+    compiles, link = build_commands()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    stale = []
+    for f, cmd in zip(SOURCES, compiles):
+        obj, src = cmd[-2], cmd[-1]
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_shared):
+            stale.append(cmd)
+    if stale:
+        def run(cmd):
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("%s failed:\n%s" % (" ".join(cmd[-4:]), r.stderr[-4000:]))
+        with ThreadPoolExecutor(max_workers=min(len(stale), os.cpu_count() or 4)) as ex:
+            list(ex.map(run, stale))
+    objs = [cmd[-2] for cmd in compiles]
+    if stale or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(o) for o in objs):
+        subprocess.check_call(link)
     return LIB_PATH
 
 

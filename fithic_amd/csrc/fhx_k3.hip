@@ -1,0 +1,907 @@
+// fhx_k3.hip - K3: myStats.benjamini_hochberg_correction (fithic/myStats.py:24-48) - exact early cutoff, compaction of the surviving p,
+// LSD radix sort of their IEEE bit patterns, min(p*N/rank, 1), inclusive max-scan, scatter to row order
+// (one of the device translation units of libfithic_mi355x.so; shared declarations: fhx_ctx.hpp)
+#include "fhx_ctx.hpp"
+
+namespace fhx {
+
+// ===================================================================================================
+// K3: Benjamini-Hochberg as the reference defines it
+// ===================================================================================================
+// ---- early cutoff -----------------------------------------------------------------------------------------------
+// The reference's monotonisation is a FORWARD running max of min(p*N/rank, 1) over ascending p (fithic/myStats.py:31-46):
+// once one element reaches 1 every later element has q = 1.  An element with p >= t whose rank is at most C certainly has
+// fl(fl(p*N)/rank) >= fl(fl(t*N)/C) (rounding is monotone), so from a coarse histogram of the keys (top 14 bits: sign,
+// exponent, 2 mantissa bits) we can name a key T* such that every element >= T* has q = 1 exactly - those rows are not
+// sorted at all.  On Hi-C data N (possible pairs) exceeds the number of observed rows, so only the enriched small-p tail
+// (typically 10-20 % of the rows) survives the cutoff.  The result is bit-identical to sorting everything.
+// Every value that is not NaN is counted (NaN rows take no rank: they sort last and get q = NaN).  p == 1.0 - most rows of
+// a Hi-C run - goes through a per-thread counter instead of 64 lanes hitting one LDS word.  Negative values do not occur
+// (fhx_bh_array rejects them; bdtrc never returns one); a stray sign bit is clamped into the last bin rather than indexing
+// past the table.
+__device__ __forceinline__ void top_hist_one(double v, unsigned int* h, unsigned int& ones) {
+    if (v == 1.0)
+        ++ones;
+    else if (v == v)
+        atomicAdd(&h[min((unsigned int)(pvalue_key(v) >> TOP_SHIFT), (unsigned int)TOP_BINS - 1u)], 1u);
+}
+
+__global__ __launch_bounds__(512) void k3_top_hist(const double* __restrict__ p, int64_t n, unsigned long long* __restrict__ hist) {
+    __shared__ unsigned int h[TOP_BINS];
+    for (int i = threadIdx.x; i < TOP_BINS; i += 512) h[i] = 0;
+    __syncthreads();
+    const int64_t n2 = n >> 1;
+    const double2* p2 = reinterpret_cast<const double2*>(p);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned int ones = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        const double2 v = p2[i];
+        top_hist_one(v.x, h, ones);
+        top_hist_one(v.y, h, ones);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) top_hist_one(p[n - 1], h, ones);
+    ones = (unsigned int)wave_sum_i64((long long)ones);
+    if ((threadIdx.x & 63) == 0 && ones) atomicAdd(&h[KEY_ONE >> TOP_SHIFT], ones);
+    __syncthreads();
+    for (int i = threadIdx.x; i < TOP_BINS; i += 512)
+        if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+}
+
+// smallest bin b (non-empty) with fl(fl(lower_edge(b) * N) / (#keys in bins 0..b)) >= 1 -> cutoff key = b << TOP_SHIFT
+__host__ __device__ inline bool bin_saturates(int b, unsigned long long cum_incl, double n_tests) {
+    const unsigned long long edge_bits = (unsigned long long)b << TOP_SHIFT;
+    double edge;
+    memcpy(&edge, &edge_bits, sizeof(edge));
+    const double v = edge * n_tests / (double)cum_incl;
+    return v >= 1.0;
+}
+
+__global__ __launch_bounds__(1024) void k3_cutoff(const unsigned long long* __restrict__ hist, double n_tests,
+                                                  unsigned long long* __restrict__ cutoff_key) {
+    __shared__ unsigned long long part[1024];
+    __shared__ unsigned int best;
+    constexpr int PER = TOP_BINS / 1024;
+    unsigned long long local[PER];
+    unsigned long long sum = 0;
+    for (int k = 0; k < PER; ++k) {
+        local[k] = hist[threadIdx.x * PER + k];
+        sum += local[k];
+    }
+    part[threadIdx.x] = sum;
+    if (threadIdx.x == 0) best = TOP_BINS;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long acc = 0;
+        for (int i = 0; i < 1024; ++i) {
+            const unsigned long long c = part[i];
+            part[i] = acc;
+            acc += c;
+        }
+    }
+    __syncthreads();
+    unsigned long long cum = part[threadIdx.x];
+    for (int k = 0; k < PER; ++k) {
+        cum += local[k];
+        const int b = threadIdx.x * PER + k;
+        if (local[k] && bin_saturates(b, cum, n_tests)) atomicMin(&best, (unsigned int)b);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        *cutoff_key = (best < (unsigned int)TOP_BINS) ? ((unsigned long long)best << TOP_SHIFT) : KEY_KEEP_ALL;
+}
+
+// compaction: keys of the rows below the cutoff key (IEEE bit pattern: all p are >= 0, so unsigned order is
+// numeric order); rows at or above it get q = 1 and NaN rows get q = NaN right here.
+__global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restrict__ p, int64_t n,
+                                                           unsigned long long* __restrict__ keys,
+                                                           unsigned int* __restrict__ vals, double* __restrict__ q,
+                                                           unsigned long long* __restrict__ counter,
+                                                           const unsigned long long* __restrict__ cutoff_key) {
+    // rows at or above the cutoff key (see above) have q = 1 and are not sorted; NaN rows get q = NaN.
+    // one global atomic per 4096-row tile (a same-address atomic per 256 rows capped this kernel at ~88 M atomics/s)
+    __shared__ unsigned int wave_cnt[SORT_WAVES];
+    __shared__ unsigned long long block_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    const int64_t tiles = (n + SORT_TILE - 1) / SORT_TILE;
+    const unsigned long long cutoff = *cutoff_key;
+    const double2* p2 = reinterpret_cast<const double2*>(p);
+    double2* q2 = reinterpret_cast<double2*>(q);
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int64_t wave_base = t * SORT_TILE + (int64_t)wave * (64 * SORT_ITEMS);
+        // two consecutive rows per lane and step: 16-byte loads of p and (for the rows that are not ranked: nearly all) 16-byte
+        // stores of q
+        double v[SORT_ITEMS];
+        unsigned int before[SORT_ITEMS];
+        unsigned long long keepmask = 0;          // bit r: this lane keeps item r
+        unsigned int run = 0;
+#pragma unroll
+        for (int h = 0; h < SORT_ITEMS / 2; ++h) {
+            const int64_t i = wave_base + (int64_t)(h * 64 + lane) * 2;
+            bool keep0 = false, keep1 = false;
+            v[2 * h] = v[2 * h + 1] = 1.0;
+            if (i + 1 < n) {
+                const double2 w = p2[i >> 1];
+                v[2 * h] = w.x;
+                v[2 * h + 1] = w.y;
+                keep0 = (w.x == w.x) && (pvalue_key(w.x) < cutoff);        // false for NaN; p >= 1 stays when nothing saturates
+                keep1 = (w.y == w.y) && (pvalue_key(w.y) < cutoff);
+                // both q of the pair in one 16-byte store, kept rows included: bh_apply overwrites those later on this stream
+                // (partial 8-byte stores around every kept row cost 0.13 ms per 1.2e8 rows with 12 % of them kept)
+                q2[i >> 1] = make_double2((w.x == w.x) ? 1.0 : w.x, (w.y == w.y) ? 1.0 : w.y);
+            } else if (i < n) {                                            // the last row of an odd count
+                v[2 * h] = p[i];
+                keep0 = (v[2 * h] == v[2 * h]) && (pvalue_key(v[2 * h]) < cutoff);
+                if (!keep0) q[i] = (v[2 * h] == v[2 * h]) ? 1.0 : v[2 * h];
+            }
+            const unsigned long long m0 = __ballot(keep0), m1 = __ballot(keep1);
+            before[2 * h] = run + __popcll(m0 & lane_lt);
+            run += __popcll(m0);
+            before[2 * h + 1] = run + __popcll(m1 & lane_lt);
+            run += __popcll(m1);
+            if (keep0) keepmask |= (1ull << (2 * h));
+            if (keep1) keepmask |= (1ull << (2 * h + 1));
+        }
+        if (lane == 0) wave_cnt[wave] = run;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned int tot = 0;
+            for (int w = 0; w < SORT_WAVES; ++w) {
+                const unsigned int c = wave_cnt[w];
+                wave_cnt[w] = tot;
+                tot += c;
+            }
+            block_base = tot ? atomicAdd(counter, (unsigned long long)tot) : 0ull;
+        }
+        __syncthreads();
+        const unsigned long long base = block_base + wave_cnt[wave];
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            if ((keepmask >> r) & 1ull) {
+                keys[base + before[r]] = pvalue_key(v[r]);
+                vals[base + before[r]] = (unsigned int)(wave_base + (int64_t)((r >> 1) * 64 + lane) * 2 + (r & 1));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// per-workgroup digit counts for one radix pass; workgroup b owns the contiguous chunk [b*chunk, (b+1)*chunk)
+__global__ __launch_bounds__(SORT_THREADS) void rs_count(const unsigned long long* __restrict__ keys,
+                                                         const unsigned long long* __restrict__ n_ptr, int shift,
+                                                         unsigned int* __restrict__ block_hist) {
+    __shared__ unsigned int h[RADIX];
+    const int64_t n = (int64_t)*n_ptr;
+    const int64_t nblk = gridDim.x;                   // the launch decides how many chunks there are (sort_blocks_for)
+    const int64_t chunk = ((n + nblk - 1) / nblk + SORT_TILE - 1) / SORT_TILE * SORT_TILE;
+    const int64_t beg = (int64_t)blockIdx.x * chunk, end = min(n, beg + chunk);
+    for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) h[d] = 0;
+    __syncthreads();
+    // two keys per lane per step (16-byte loads); chunk starts are multiples of SORT_TILE, so they are aligned
+    const int64_t len = end > beg ? end - beg : 0;           // workgroups past the end own nothing
+    const int64_t n2 = len >> 1;
+    const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(keys + beg);
+    for (int64_t i = threadIdx.x; i < n2; i += SORT_THREADS) {
+        const ulonglong2 k = k2[i];
+        atomicAdd(&h[(k.x >> shift) & (RADIX - 1)], 1u);
+        atomicAdd(&h[(k.y >> shift) & (RADIX - 1)], 1u);
+    }
+    if (threadIdx.x == 0 && (len & 1)) atomicAdd(&h[(keys[end - 1] >> shift) & (RADIX - 1)], 1u);
+    __syncthreads();
+    for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) block_hist[(size_t)d * nblk + blockIdx.x] = h[d];   // digit-major
+}
+
+// exclusive scan of the digit-major (RADIX x SORT_BLOCKS) count matrix along the workgroup axis: one
+// workgroup per digit, one thread per sorting workgroup (coalesced row access); digit totals go to
+// digit_total[], their own exclusive scan is folded into rs_scatter's prologue.
+__global__ __launch_bounds__(SORT_BLOCKS) void rs_scan(unsigned int* __restrict__ block_hist,
+                                                       unsigned int* __restrict__ digit_total, int nblk) {
+    __shared__ unsigned int wsum[SORT_BLOCKS / 64];
+    unsigned int* row = block_hist + (size_t)blockIdx.x * nblk;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool live = (int)threadIdx.x < nblk;         // blockDim.x = nblk rounded up to whole waves
+    const unsigned int mine = live ? row[threadIdx.x] : 0u;
+    unsigned int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int acc = 0;
+        const int waves = (blockDim.x + 63) / 64;
+        for (int w = 0; w < waves; ++w) {
+            const unsigned int c = wsum[w];
+            wsum[w] = acc;
+            acc += c;
+        }
+        digit_total[blockIdx.x] = acc;
+    }
+    __syncthreads();
+    if (live) row[threadIdx.x] = wsum[wave] + incl - mine;
+}
+
+// stable scatter of one radix pass.  Each wave owns a contiguous sub-range of the tile and ranks its keys
+// with wave-private LDS digit counters (no atomics: one leader lane per distinct digit, found with RADIX_BITS+1
+// ballots); the tile is then reordered through LDS so that the global writes of equal-digit runs are contiguous.
+//
+// LDS decides how many workgroups a CU holds, and with them how much of the ranking's latency (dependent LDS reads and writes,
+// 12 ballots per key) is hidden.  Round 3's layout - counters 16 KB + keys 32 KB + payloads 16 KB + two offset tables - came to
+// 81 936 B: ONE 256-thread workgroup per CU, one wave per SIMD, 271 us per pass over 1.5e7 keys (1.3 TB/s,
+// profiles/r04_b_od1_kernel_stats.txt).  Now 512 threads per tile of 4096 keys and the per-wave counters share their 32 KB with
+// the staged keys (a key's slot is in a register by the time the counters die): 64 KB, two workgroups = 16 waves per CU.
+// (Measured and dropped, profiles/r04_e_rs_ab.txt: no staging at all - keys written straight from registers to
+// global_base[digit] + rank - is 45 % slower, the tile-wide reordering is what coalesces the writes of the passes over the
+// exponent bits; squeezing the kernel to 80 VGPRs for a third workgroup per CU spills and is slower still.)
+
+template <int SCAT_THREADS, int WPE>
+__global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void rs_scatter(
+    const unsigned long long* __restrict__ keys_in, const unsigned int* __restrict__ vals_in, unsigned long long* __restrict__ keys_out,
+    unsigned int* __restrict__ vals_out, const unsigned long long* __restrict__ n_ptr, int shift,
+    const unsigned int* __restrict__ block_hist, const unsigned int* __restrict__ digit_total) {
+    constexpr int SCAT_WAVES = SCAT_THREADS / 64, TILE = SCAT_THREADS * SCAT_ITEMS, PER = RADIX / SCAT_THREADS;
+    static_assert(SORT_TILE % TILE == 0, "a workgroup's chunk (a multiple of SORT_TILE keys) is whole tiles");
+    static_assert(SCAT_WAVES * RADIX * 2 <= TILE * 8, "the per-wave counters fit the block that later stages the keys");
+    __shared__ __attribute__((aligned(16))) unsigned char stage_raw[TILE * 8];      // per-wave counters, then the tile's keys
+    __shared__ unsigned int s_vals[TILE];
+    __shared__ unsigned int tile_start[RADIX];                 // first tile-local slot of each digit
+    __shared__ unsigned int global_base[RADIX];                // running global offset of each digit
+    __shared__ unsigned int wave_tmp[SCAT_WAVES];
+    unsigned short (*wave_digit)[RADIX] = reinterpret_cast<unsigned short (*)[RADIX]>(stage_raw);   // counts (<= 512) -> exclusive offsets over the waves
+    unsigned long long* s_keys = reinterpret_cast<unsigned long long*>(stage_raw);
+    const int64_t n = (int64_t)*n_ptr;
+    const int64_t nblk = gridDim.x;
+    const int64_t chunk = ((n + nblk - 1) / nblk + SORT_TILE - 1) / SORT_TILE * SORT_TILE;
+    const int64_t beg = (int64_t)blockIdx.x * chunk, end = min(n, beg + chunk);
+    if (beg >= end) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    // exclusive scan of RADIX entries of `a` (PER consecutive ones per thread); two barriers inside
+    auto scan_radix = [&](unsigned int* a) {
+        unsigned int v[PER];
+        unsigned int mine = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            v[k] = a[threadIdx.x * PER + k];
+            mine += v[k];
+        }
+        const unsigned int incl = wave_incl_sum_u32(mine);
+        if (lane == 63) wave_tmp[wave] = incl;
+        __syncthreads();
+        unsigned int excl = incl - mine;
+        for (int w = 0; w < wave; ++w) excl += wave_tmp[w];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            a[threadIdx.x * PER + k] = excl;
+            excl += v[k];
+        }
+        __syncthreads();
+    };
+    for (int d = threadIdx.x; d < RADIX; d += SCAT_THREADS) tile_start[d] = digit_total[d];
+    __syncthreads();
+    scan_radix(tile_start);
+    for (int d = threadIdx.x; d < RADIX; d += SCAT_THREADS)
+        global_base[d] = tile_start[d] + block_hist[(size_t)d * nblk + blockIdx.x];
+    __syncthreads();
+    for (int64_t tile = beg; tile < end; tile += TILE) {
+        for (int i = threadIdx.x; i < SCAT_WAVES * RADIX / 2; i += SCAT_THREADS) reinterpret_cast<unsigned int*>(stage_raw)[i] = 0u;
+        unsigned long long key[SCAT_ITEMS];
+        unsigned int val[SCAT_ITEMS];
+        unsigned int slot[SCAT_ITEMS];
+        const int64_t wave_base = tile + (int64_t)wave * (64 * SCAT_ITEMS);
+#pragma unroll
+        for (int r = 0; r < SCAT_ITEMS; ++r) {
+            const int64_t i = wave_base + r * 64 + lane;
+            const bool live = i < end;
+            key[r] = live ? keys_in[i] : ~0ull;
+            val[r] = live ? vals_in[i] : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SCAT_ITEMS; ++r) {
+            const bool live = (wave_base + r * 64 + lane) < end;
+            const unsigned int digit = (unsigned int)(key[r] >> shift) & (RADIX - 1);
+            // lanes holding the same digit (dead lanes form their own group through the extra bit)
+            unsigned long long same = ~0ull;
+            const unsigned int tag = digit | (live ? 0u : RADIX);
+#pragma unroll
+            for (int b = 0; b <= RADIX_BITS; ++b) {
+                const unsigned long long m = __ballot((tag >> b) & 1u);
+                same &= ((tag >> b) & 1u) ? m : ~m;
+            }
+            const unsigned int before = __popcll(same & lane_lt);
+            unsigned int old = 0;
+            if (live) old = wave_digit[wave][digit];          // every lane of the group reads the same counter ...
+            slot[r] = old + before;                           // rank among the wave's keys of this digit, so far
+            __builtin_amdgcn_wave_barrier();
+            if (live && before == 0) wave_digit[wave][digit] = (unsigned short)(old + __popcll(same));   // ... its leader bumps it
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        // exclusive offsets: per digit across waves, then across digits
+        for (int d = threadIdx.x * PER; d < (threadIdx.x + 1) * PER; ++d) {
+            unsigned int acc = 0;
+#pragma unroll
+            for (int w = 0; w < SCAT_WAVES; ++w) {
+                const unsigned int c = wave_digit[w][d];
+                wave_digit[w][d] = (unsigned short)acc;
+                acc += c;
+            }
+            tile_start[d] = acc;                              // digit total for now
+        }
+        __syncthreads();
+        scan_radix(tile_start);
+        const int live_in_tile = (int)min<int64_t>(TILE, end - tile);
+#pragma unroll
+        for (int r = 0; r < SCAT_ITEMS; ++r) {
+            const unsigned int digit = (unsigned int)(key[r] >> shift) & (RADIX - 1);
+            if (wave_base + r * 64 + lane < end) slot[r] += tile_start[digit] + wave_digit[wave][digit];
+        }
+        __syncthreads();                                      // the counters are dead: their block now stages the keys
+#pragma unroll
+        for (int r = 0; r < SCAT_ITEMS; ++r)
+            if (wave_base + r * 64 + lane < end) {
+                s_keys[slot[r]] = key[r];
+                s_vals[slot[r]] = val[r];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SCAT_ITEMS; ++j) {
+            const int s = threadIdx.x + j * SCAT_THREADS;
+            if (s < live_in_tile) {
+                const unsigned long long k = s_keys[s];
+                const unsigned int digit = (unsigned int)(k >> shift) & (RADIX - 1);
+                const unsigned int dst = global_base[digit] + (s - tile_start[digit]);
+                keys_out[dst] = k;
+                vals_out[dst] = s_vals[s];
+            }
+        }
+        __syncthreads();
+        // advance the running global offsets by this tile's digit totals
+        for (int d = threadIdx.x; d < RADIX; d += SCAT_THREADS) {
+            const unsigned int nxt = (d + 1 < RADIX) ? tile_start[d + 1] : (unsigned int)live_in_tile;
+            global_base[d] += nxt - tile_start[d];
+        }
+        __syncthreads();
+    }
+}
+
+// BH value of sorted position i (0-based, global rank = rank0 + i + 1): min(p*N/rank, 1), myStats.py:35-38
+__device__ __forceinline__ double bh_value(unsigned long long key_bits, double n_tests, double rank) {
+    const double pv = __longlong_as_double((long long)key_bits);
+    double v = pv * n_tests / rank;           // (p*N)/(i+1): mul then div, never fused
+    if (1.0 < v || pv == 1.0) v = 1.0;        // min(bh, 1); p == 1.0 is 1.0 whatever N / rank says (myStats.py:33-34)
+    // The reference's running maximum starts at 0 (myStats.py:30): invisible while N > 0, but fit_Spline can pass a NEGATIVE
+    // number of tests (possible-pair counts go negative with unmappable loci) and then every bh value is negative
+    // and every q is 0 (tests/golden/f12_bh_nonpositive_N.npz).  Clamping the values is the same running maximum.
+    if (v < 0.0) v = 0.0;
+    return v;
+}
+
+
+__device__ __forceinline__ double wave_incl_max(double v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_up(v, off, 64);
+        if (lane >= off) v = fmax(v, o);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(BH_THREADS) void bh_tile_max(const unsigned long long* __restrict__ keys,
+                                                          const unsigned long long* __restrict__ n_ptr, int64_t n_fixed,
+                                                          double n_tests, double rank0, double* __restrict__ tile_max) {
+    __shared__ double wmax[BH_THREADS / 64];
+    const int64_t n = n_ptr ? (int64_t)*n_ptr : n_fixed;
+    const int64_t base = (int64_t)blockIdx.x * BH_TILE;
+    if (base >= n) return;
+    double m = 0.0;
+#pragma unroll
+    for (int r = 0; r < BH_ITEMS; ++r) {
+        const int64_t i = base + r * BH_THREADS + threadIdx.x;
+        if (i < n) m = fmax(m, bh_value(keys[i], n_tests, rank0 + (double)(i + 1)));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = wmax[0];
+        for (int w = 1; w < BH_THREADS / 64; ++w) t = fmax(t, wmax[w]);
+        tile_max[blockIdx.x] = t;
+    }
+}
+
+// exclusive running max over the tile maxima (carry-in of every tile); one workgroup
+__global__ __launch_bounds__(1024) void bh_scan_tiles(double* __restrict__ tile_max,
+                                                      const unsigned long long* __restrict__ n_ptr, int64_t n_fixed,
+                                                      double carry_in, double* __restrict__ total_max) {
+    __shared__ double part[1024];
+    const int64_t n = n_ptr ? (int64_t)*n_ptr : n_fixed;
+    const int64_t tiles = (n + BH_TILE - 1) / BH_TILE;
+    const int64_t per = (tiles + 1023) / 1024;
+    const int64_t beg = (int64_t)threadIdx.x * per, end = min(tiles, beg + per);
+    double m = 0.0;
+    for (int64_t t = beg; t < end; ++t) m = fmax(m, tile_max[t]);
+    part[threadIdx.x] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double run = carry_in;
+        for (int i = 0; i < 1024; ++i) {
+            const double c = part[i];
+            part[i] = run;
+            run = fmax(run, c);
+        }
+        if (total_max) *total_max = run;
+    }
+    __syncthreads();
+    double run = part[threadIdx.x];
+    for (int64_t t = beg; t < end; ++t) {
+        const double c = tile_max[t];
+        tile_max[t] = run;
+        run = fmax(run, c);
+    }
+}
+
+// q = inclusive running max of the BH values; written either scattered to row order (vals != null)
+// or in sorted order (distributed path)
+__global__ __launch_bounds__(BH_THREADS) void bh_apply(const unsigned long long* __restrict__ keys,
+                                                       const unsigned int* __restrict__ vals,
+                                                       const unsigned long long* __restrict__ n_ptr, int64_t n_fixed,
+                                                       double n_tests, double rank0, const double* __restrict__ tile_carry,
+                                                       const double* __restrict__ extra_carry, double* __restrict__ q_out) {
+    __shared__ double wtot[BH_THREADS / 64];
+    const int64_t n = n_ptr ? (int64_t)*n_ptr : n_fixed;
+    const int64_t base = (int64_t)blockIdx.x * BH_TILE;
+    if (base >= n) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // blocked arrangement: thread t owns BH_ITEMS consecutive sorted positions
+    const int64_t first = base + (int64_t)threadIdx.x * BH_ITEMS;
+    double v[BH_ITEMS];
+    double run = 0.0;
+#pragma unroll
+    for (int r = 0; r < BH_ITEMS; ++r) {
+        const int64_t i = first + r;
+        const double b = (i < n) ? bh_value(keys[i], n_tests, rank0 + (double)(i + 1)) : 0.0;
+        run = fmax(run, b);
+        v[r] = run;
+    }
+    const double incl = wave_incl_max(run, lane);
+    double excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 0.0;
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    double carry = tile_carry[blockIdx.x];
+    if (extra_carry) carry = fmax(carry, *extra_carry);          // sharded runs: the running max of the lower ranks' slices
+    for (int w = 0; w < wave; ++w) carry = fmax(carry, wtot[w]);
+    carry = fmax(carry, excl);
+#pragma unroll
+    for (int r = 0; r < BH_ITEMS; ++r) {
+        const int64_t i = first + r;
+        if (i < n) {
+            const double qv = fmax(v[r], carry);
+            if (vals)
+                __builtin_nontemporal_store(qv, q_out + vals[i]);       // one 8-byte store into a line nobody else touches soon: no allocate
+            else
+                q_out[i] = qv;
+        }
+    }
+}
+
+// (Measured and dropped in round 4, profiles/r04_f_small_ab.txt: ONE resident launch for small survivor sets - 64 workgroups,
+// a tile each, the six passes and the BH scan separated by device-wide barriers instead of 21 launches.  The kernels of a small
+// sort already run back to back without gaps (profiles/r03_z_c2_timeline.txt); what a launch boundary costs is what a
+// device-scope barrier costs too - the eight XCDs' L2s are made coherent by writing them back - and 19 such barriers took
+// 0.58 ms where the 21 launches take 0.22 ms for the same 77 k keys.)
+
+__global__ void k_iota_u32(unsigned int* __restrict__ v, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) v[i] = (unsigned int)i;
+}
+
+__global__ void k_scatter_q(const unsigned int* __restrict__ rows, const double* __restrict__ q_sorted,
+                            const unsigned long long* __restrict__ n_ptr, double* __restrict__ q) {
+    const int64_t n = (int64_t)*n_ptr;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) q[rows[i]] = q_sorted[i];
+}
+
+// plot_qvalues' 51 buckets (fithic.py:1235-1254): counts of floor(q/0.001), NaN -> bucket of 1.0
+__global__ void k_fdr_hist(const double* __restrict__ q, int64_t n, unsigned long long* __restrict__ buckets) {
+    __shared__ unsigned int h[64];
+    if (threadIdx.x < 64) h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double v = q[i];
+        if (v != v) v = 1.0;
+        const double b = floor(v / 0.001);
+        if (b < 51.0) atomicAdd(&h[(int)b], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 51 && h[threadIdx.x]) atomicAdd(&buckets[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+
+// ---- host side ----------------------------------------------------------------------------------------------------------
+// LSD radix sort of (u64 key, u32 payload) pairs over the low `passes`*11 key bits; n lives in *counter (device)
+// Chunks (= workgroups) of a sort of about n keys: a count matrix of RADIX x blocks is scanned in every pass, so a small sort
+// must not pay for 1024 of them (6 passes over ~10^6 keys: 0.26 ms with 1024 blocks, a third of that with 64).  n_hint < 0:
+// the size is only known on the device.
+int sort_blocks_for(int64_t n_hint) {
+    if (n_hint < 0) return SORT_BLOCKS;
+    const int64_t want = (n_hint + 4 * SORT_TILE - 1) / (4 * SORT_TILE);          // >= four tiles per workgroup
+    return (int)std::max<int64_t>(64, std::min<int64_t>(SORT_BLOCKS, (want + 63) / 64 * 64));
+}
+
+// one scatter pass
+void launch_rs_scatter(fhx_ctx* ctx, int nblk, const unsigned long long* keys_in, const unsigned int* vals_in, unsigned long long* keys_out,
+                       unsigned int* vals_out, const unsigned long long* counter, int shift) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_scatter<512, 4>), dim3(nblk), dim3(512), 0, ctx->stream, keys_in, vals_in, keys_out, vals_out,
+                       counter, shift, (const unsigned int*)ctx->d_block_hist, (const unsigned int*)ctx->d_digit_total);
+}
+
+int radix_sort_pairs(fhx_ctx* ctx, unsigned long long* keys[2], unsigned int* vals[2], const unsigned long long* counter,
+                     int passes, int* result_buf, int64_t n_hint) {
+    const int nblk = sort_blocks_for(n_hint);
+    int src = 0;
+    for (int pass = 0; pass < passes; ++pass) {
+        const int shift = pass * RADIX_BITS;
+        hipLaunchKernelGGL(rs_count, dim3(nblk), dim3(SORT_THREADS), 0, ctx->stream, keys[src], counter, shift,
+                           ctx->d_block_hist);
+        hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3((nblk + 63) / 64 * 64), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total, nblk);
+        launch_rs_scatter(ctx, nblk, keys[src], vals[src], keys[1 - src], vals[1 - src], counter, shift);
+        src = 1 - src;
+    }
+    FHX_HIP(hipGetLastError());
+    *result_buf = src;
+    return FHX_OK;
+}
+
+
+// launches for the other translation units (the sharded schedule, the heavy class's bucket sort, the FDR counts)
+void launch_rs_scan(fhx_ctx* ctx, int nblk) {
+    hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3((nblk + 63) / 64 * 64), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total, nblk);
+}
+void launch_k3_cutoff(fhx_ctx* ctx, double n_tests, unsigned long long* d_cutoff) {
+    hipLaunchKernelGGL(k3_cutoff, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long*)ctx->d_top_hist, n_tests, d_cutoff);
+}
+void launch_bh_tile_max(fhx_ctx* ctx, int tiles, const unsigned long long* keys, const unsigned long long* n_ptr, int64_t n_fixed,
+                        double n_tests, double rank0, double* tile_max) {
+    hipLaunchKernelGGL(bh_tile_max, dim3(tiles), dim3(BH_THREADS), 0, ctx->stream, keys, n_ptr, n_fixed, n_tests, rank0, tile_max);
+}
+void launch_bh_scan_tiles(fhx_ctx* ctx, double* tile_max, const unsigned long long* n_ptr, int64_t n_fixed, double carry_in,
+                          double* total_max) {
+    hipLaunchKernelGGL(bh_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, tile_max, n_ptr, n_fixed, carry_in, total_max);
+}
+void launch_bh_apply(fhx_ctx* ctx, int tiles, const unsigned long long* keys, const unsigned int* vals, const unsigned long long* n_ptr,
+                     int64_t n_fixed, double n_tests, double rank0, const double* tile_carry, const double* extra_carry, double* q_out) {
+    hipLaunchKernelGGL(bh_apply, dim3(tiles), dim3(BH_THREADS), 0, ctx->stream, keys, vals, n_ptr, n_fixed, n_tests, rank0, tile_carry,
+                       extra_carry, q_out);
+}
+void launch_scatter_q(fhx_ctx* ctx, int64_t n_rows, const unsigned int* rows, const double* q_sorted, const unsigned long long* n_ptr,
+                      double* q) {
+    hipLaunchKernelGGL(k_scatter_q, dim3(grid_for(n_rows, 256)), dim3(256), 0, ctx->stream, rows, q_sorted, n_ptr, q);
+}
+void launch_fdr_hist(fhx_ctx* ctx, const double* q, int64_t n, unsigned long long* buckets) {
+    hipLaunchKernelGGL(k_fdr_hist, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, q, n, buckets);
+}
+
+}  // namespace fhx
+
+// ---- C ABI -----------------------------------------------------------------------------------------------------------------
+// compact p < 1 and LSD-radix-sort (key, row); returns the index (0/1) of the buffer pair holding the result
+// cutoff key from a device-local histogram of the p-values (single-GPU path; sharded runs all-reduce the histogram)
+// d_top_hist <- key histogram of the context's p: what K2 gathered while storing them, else one more read of p
+int fhx::fill_top_hist(fhx_ctx* ctx) {
+    if (ctx->k2_hist_valid) {
+        FHX_HIP(hipMemcpyAsync(ctx->d_top_hist, ctx->d_k2_hist, TOP_BINS * sizeof(unsigned long long), hipMemcpyDeviceToDevice, ctx->stream));
+        return FHX_OK;
+    }
+    FHX_HIP(hipMemsetAsync(ctx->d_top_hist, 0, TOP_BINS * sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(k3_top_hist, dim3(grid_for((ctx->n_rows + 1) / 2, 512, 256 * 4)), dim3(512), 0, ctx->stream, ctx->d_p,
+                       ctx->n_rows, ctx->d_top_hist);
+    FHX_HIP(hipGetLastError());
+    return FHX_OK;
+}
+
+static int auto_cutoff(fhx_ctx* ctx, const double* d_p, int64_t n, double n_total_tests, unsigned long long* d_cutoff) {
+    if (d_p == ctx->d_p) {
+        const int rc = fill_top_hist(ctx);
+        if (rc != FHX_OK) return rc;
+    } else {
+        FHX_HIP(hipMemsetAsync(ctx->d_top_hist, 0, TOP_BINS * sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(k3_top_hist, dim3(grid_for((n + 1) / 2, 512, 256 * 4)), dim3(512), 0, ctx->stream, d_p, n, ctx->d_top_hist);
+    }
+    hipLaunchKernelGGL(k3_cutoff, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long*)ctx->d_top_hist, n_total_tests,
+                       d_cutoff);
+    FHX_HIP(hipGetLastError());
+    return FHX_OK;
+}
+
+// rows below the cutoff -> keys[0] / vals[0] (their number in *counter and, read back, in *n_kept); every other row gets its q here
+static int compact_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned long long* keys[2], unsigned int* vals[2], double* d_q,
+                           unsigned long long* counter, const unsigned long long* d_cutoff, int64_t* n_kept_out) {
+    FHX_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
+    // one workgroup per tile, not a resident grid walking the column: 0.507 -> 0.451 ms on C3 (profiles/r03_x_k3_grid.txt); the
+    // plain copy kernel of profiles/hbm_rate.hip shows the same (4.9 TB/s with 2048 grid-striding workgroups, 5.6 with one per
+    // chunk).  FHX_K3_GRID caps the grid for measurements.
+    static const int k3_cap = std::getenv("FHX_K3_GRID") ? std::atoi(std::getenv("FHX_K3_GRID")) : (1 << 30);
+    hipLaunchKernelGGL(k3_compact, dim3(grid_for(n, SORT_TILE, k3_cap)), dim3(SORT_THREADS), 0, ctx->stream, d_p, n,
+                       keys[0], vals[0], d_q, counter, d_cutoff);
+    // how many keys survived decides the shape of the sort (one 8-byte read back: ~20 us against ~190 us of fixed cost saved)
+    unsigned long long n_kept = 0;
+    FHX_HIP(hipMemcpyAsync(&n_kept, counter, sizeof(n_kept), hipMemcpyDeviceToHost, ctx->stream));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    *n_kept_out = (int64_t)n_kept;
+    return FHX_OK;
+}
+
+// the six radix passes over the n_kept compacted keys; the result is in buffer pair *sorted_buf
+static int sort_kept(fhx_ctx* ctx, unsigned long long* keys[2], unsigned int* vals[2], const unsigned long long* counter, int64_t n_kept,
+                     int* sorted_buf) {
+    const int nblk = sort_blocks_for(n_kept);
+    int src = 0;
+    // p < 1 means the IEEE exponent field is <= 1022: bits 62 and 63 are always clear, 62 bits to sort
+    for (int pass = 0; pass < SORT_PASSES; ++pass) {
+        const int shift = pass * RADIX_BITS;
+        hipLaunchKernelGGL(rs_count, dim3(nblk), dim3(SORT_THREADS), 0, ctx->stream, keys[src], counter, shift,
+                           ctx->d_block_hist);
+        hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3((nblk + 63) / 64 * 64), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total, nblk);
+        launch_rs_scatter(ctx, nblk, keys[src], vals[src], keys[1 - src], vals[1 - src], counter, shift);
+        src = 1 - src;
+    }
+    FHX_HIP(hipGetLastError());
+    *sorted_buf = src;
+    return FHX_OK;
+}
+
+static int sort_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned long long* keys[2], unsigned int* vals[2],
+                        double* d_q, unsigned long long* counter, const unsigned long long* d_cutoff, int* sorted_buf,
+                        int64_t* n_sorted_out = nullptr) {
+    int64_t n_kept = 0;
+    const int rc = compact_pvalues(ctx, d_p, n, keys, vals, d_q, counter, d_cutoff, &n_kept);
+    if (rc != FHX_OK) return rc;
+    if (n_sorted_out) *n_sorted_out = n_kept;
+    return sort_kept(ctx, keys, vals, counter, n_kept, sorted_buf);
+}
+
+static int bh_from_sorted(fhx_ctx* ctx, const unsigned long long* keys, const unsigned int* vals, int64_t n_rows,
+                          const unsigned long long* counter, double n_total_tests, double* tile_max, double* d_q) {
+    const int tiles = (int)std::max<int64_t>(1, (n_rows + BH_TILE - 1) / BH_TILE);
+    hipLaunchKernelGGL(bh_tile_max, dim3(tiles), dim3(BH_THREADS), 0, ctx->stream, keys, counter, (int64_t)0, n_total_tests,
+                       0.0, tile_max);
+    hipLaunchKernelGGL(bh_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, tile_max, counter, (int64_t)0, 0.0,
+                       (double*)nullptr);
+    hipLaunchKernelGGL(bh_apply, dim3(tiles), dim3(BH_THREADS), 0, ctx->stream, keys, vals, counter, (int64_t)0,
+                       n_total_tests, 0.0, tile_max, (const double*)nullptr, d_q);
+    FHX_HIP(hipGetLastError());
+    return FHX_OK;
+}
+
+// compaction, sort and BH of one p column -> q in row order
+static int rank_and_adjust(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned long long* keys[2], unsigned int* vals[2], double* d_q,
+                           unsigned long long* counter, const unsigned long long* d_cutoff, double n_total_tests, double* tile_max,
+                           int* sorted_buf, int64_t* n_sorted_out) {
+    int64_t n_kept = 0;
+    int rc = compact_pvalues(ctx, d_p, n, keys, vals, d_q, counter, d_cutoff, &n_kept);
+    if (rc != FHX_OK) return rc;
+    if (n_sorted_out) *n_sorted_out = n_kept;
+    rc = sort_kept(ctx, keys, vals, counter, n_kept, sorted_buf);
+    if (rc != FHX_OK) return rc;
+    return bh_from_sorted(ctx, keys[*sorted_buf], vals[*sorted_buf], n, counter, n_total_tests, tile_max, d_q);
+}
+
+int fhx::ensure_sort_scratch(fhx_ctx* ctx) {
+    if (!ctx->d_block_hist) FHX_HIP(hipMalloc(&ctx->d_block_hist, (size_t)RADIX * SORT_BLOCKS * sizeof(unsigned int)));
+    if (!ctx->d_digit_total) FHX_HIP(hipMalloc(&ctx->d_digit_total, RADIX * sizeof(unsigned int)));
+    if (!ctx->d_misc) FHX_HIP(hipMalloc(&ctx->d_misc, 192 * sizeof(unsigned long long)));
+    if (!ctx->d_top_hist) FHX_HIP(hipMalloc(&ctx->d_top_hist, TOP_BINS * sizeof(unsigned long long)));
+    return FHX_OK;
+}
+
+int fhx_bh_top_hist(fhx_ctx* ctx, int64_t* hist_out, int64_t capacity) {
+    if (!ctx || !hist_out || capacity < TOP_BINS) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (!ctx->have_p) return fail(ctx, FHX_ERR_ARG, "fhx_pvalues must run first");
+    FHX_HIP(hipSetDevice(ctx->device));
+    {
+        const int rc = fill_top_hist(ctx);
+        if (rc != FHX_OK) return rc;
+    }
+    FHX_HIP(hipMemcpyAsync(hist_out, ctx->d_top_hist, TOP_BINS * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    return FHX_OK;
+}
+
+// Device-resident variant for sharded runs: the histogram stays in HBM (fhx_device_ptr(ctx, 4)), the caller all-reduces it
+// in place (RCCL) and fhx_bh_set_cutoff_device derives the cutoff from it - no host round trip of the 64 KiB table.
+int fhx_bh_top_hist_device(fhx_ctx* ctx) {
+    if (!ctx) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (!ctx->have_p) return fail(ctx, FHX_ERR_ARG, "fhx_pvalues must run first");
+    FHX_HIP(hipSetDevice(ctx->device));
+    {
+        const int rc = fill_top_hist(ctx);
+        if (rc != FHX_OK) return rc;
+    }
+    FHX_HIP(hipStreamSynchronize(ctx->stream));           // the caller's collective runs on another stream
+    return FHX_OK;
+}
+
+int fhx_bh_set_cutoff_device(fhx_ctx* ctx, double n_total_tests) {
+    if (!ctx || !(n_total_tests > 0)) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    FHX_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k3_cutoff, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long*)ctx->d_top_hist, n_total_tests,
+                       ctx->d_misc + 6);
+    FHX_HIP(hipGetLastError());
+    return FHX_OK;
+}
+
+int fhx_bh_set_cutoff(fhx_ctx* ctx, const int64_t* global_hist, int64_t n_bins, double n_total_tests) {
+    if (!ctx || !global_hist || n_bins != TOP_BINS || !(n_total_tests > 0)) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    FHX_HIP(hipSetDevice(ctx->device));
+    unsigned long long cutoff = KEY_KEEP_ALL, cum = 0;
+    for (int b = 0; b < TOP_BINS; ++b) {
+        cum += (unsigned long long)global_hist[b];
+        if (global_hist[b] > 0 && bin_saturates(b, cum, n_total_tests)) {
+            cutoff = (unsigned long long)b << TOP_SHIFT;
+            break;
+        }
+    }
+    FHX_HIP(hipMemcpyAsync(ctx->d_misc + 6, &cutoff, sizeof(cutoff), hipMemcpyHostToDevice, ctx->stream));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    return FHX_OK;
+}
+
+int fhx_bh_local_sort(fhx_ctx* ctx) {
+    if (!ctx) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (!ctx->have_p) return fail(ctx, FHX_ERR_ARG, "fhx_pvalues must run first");
+    FHX_HIP(hipSetDevice(ctx->device));
+    int64_t kept = 0;
+    const int rc = sort_pvalues(ctx, ctx->d_p, ctx->n_rows, ctx->d_keys, ctx->d_vals, ctx->d_q, ctx->d_misc, ctx->d_misc + 6,
+                                &ctx->sorted_buf, &kept);
+    if (rc != FHX_OK) return rc;
+    ctx->n_sorted = kept;
+    return FHX_OK;
+}
+
+int fhx_bh_array(fhx_ctx* ctx, const double* p, int64_t n, double n_total_tests, double* q) {
+    if (!ctx || !p || !q || n < 0) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (n == 0) return FHX_OK;
+    if (n >= (1ll << 32)) return fail(ctx, FHX_ERR_UNSUPPORTED, "more than 2^32 p-values");
+    if (!std::isfinite(n_total_tests)) return fail(ctx, FHX_ERR_ARG, "number of tests must be finite");
+    for (int64_t i = 0; i < n; ++i)
+        if (p[i] < 0.0) return fail(ctx, FHX_ERR_ARG, "negative p-value at index " + std::to_string(i) + " (p-values must be >= 0 or NaN)");
+    FHX_HIP(hipSetDevice(ctx->device));
+    int rc = ensure_sort_scratch(ctx);
+    if (rc != FHX_OK) return rc;
+    double *d_p = nullptr, *d_q = nullptr, *tile_max = nullptr;
+    unsigned long long* keys[2] = {nullptr, nullptr};
+    unsigned int* vals[2] = {nullptr, nullptr};
+    DeviceScratch tmp;
+    const size_t cap = (size_t)n;
+    FHX_HIP(tmp.get(&d_p, cap * sizeof(double)));
+    FHX_HIP(tmp.get(&d_q, cap * sizeof(double)));
+    FHX_HIP(tmp.get(&tile_max, (cap / BH_TILE + 2) * sizeof(double)));
+    for (int b = 0; b < 2; ++b) {
+        FHX_HIP(tmp.get(&keys[b], cap * sizeof(unsigned long long)));
+        FHX_HIP(tmp.get(&vals[b], cap * sizeof(unsigned int)));
+    }
+    FHX_HIP(hipMemcpyAsync(d_p, p, cap * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    int buf = 0;
+    unsigned long long* counter = ctx->d_misc + 2;
+    unsigned long long* cutoff = ctx->d_misc + 7;
+    rc = auto_cutoff(ctx, d_p, n, n_total_tests, cutoff);
+    if (rc == FHX_OK) rc = rank_and_adjust(ctx, d_p, n, keys, vals, d_q, counter, cutoff, n_total_tests, tile_max, &buf, nullptr);
+    if (rc == FHX_OK) {
+        FHX_HIP(hipMemcpyAsync(q, d_q, cap * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        FHX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return rc;
+}
+
+int fhx_bh(fhx_ctx* ctx, double n_total_tests) {
+    if (!ctx) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (!ctx->have_p) return fail(ctx, FHX_ERR_ARG, "fhx_pvalues must run first");
+    if (!std::isfinite(n_total_tests)) return fail(ctx, FHX_ERR_ARG, "number of tests must be finite");
+    FHX_HIP(hipSetDevice(ctx->device));
+    FHX_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+    int rc = auto_cutoff(ctx, ctx->d_p, ctx->n_rows, n_total_tests, ctx->d_misc + 6);
+    if (rc != FHX_OK) return rc;
+    int64_t kept = 0;
+    rc = rank_and_adjust(ctx, ctx->d_p, ctx->n_rows, ctx->d_keys, ctx->d_vals, ctx->d_q, ctx->d_misc, ctx->d_misc + 6, n_total_tests,
+                         ctx->d_tile_max, &ctx->sorted_buf, &kept);
+    if (rc != FHX_OK) return rc;
+    ctx->n_sorted = kept;
+    FHX_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
+    ctx->ev_valid[2] = true;
+    ctx->have_q = true;
+    return FHX_OK;
+}
+
+int fhx_bh_apply_sorted(fhx_ctx* ctx, const void* d_sorted_keys, int64_t n, int64_t global_rank0, double carry_in,
+                        double n_total_tests, void* d_q_sorted, double* block_max_out) {
+    if (!ctx || n < 0) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    FHX_HIP(hipSetDevice(ctx->device));
+    if (n == 0) {
+        if (block_max_out) *block_max_out = carry_in;
+        return FHX_OK;
+    }
+    const int tiles = (int)((n + BH_TILE - 1) / BH_TILE);
+    double* tile_max = nullptr;
+    FHX_HIP(hipMalloc(&tile_max, ((size_t)tiles + 1) * sizeof(double)));
+    const unsigned long long* keys = (const unsigned long long*)d_sorted_keys;
+    hipLaunchKernelGGL(bh_tile_max, dim3(tiles), dim3(BH_THREADS), 0, ctx->stream, keys, (const unsigned long long*)nullptr, n,
+                       n_total_tests, (double)global_rank0, tile_max);
+    hipLaunchKernelGGL(bh_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, tile_max, (const unsigned long long*)nullptr, n,
+                       carry_in, tile_max + tiles);
+    if (d_q_sorted)
+        hipLaunchKernelGGL(bh_apply, dim3(tiles), dim3(BH_THREADS), 0, ctx->stream, keys, (const unsigned int*)nullptr,
+                           (const unsigned long long*)nullptr, n, n_total_tests, (double)global_rank0, tile_max,
+                           (const double*)nullptr, (double*)d_q_sorted);
+    double total = 0.0;
+    FHX_HIP(hipMemcpyAsync(&total, tile_max + tiles, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    dev_free(tile_max);
+    if (block_max_out) *block_max_out = total;
+    return FHX_OK;
+}
+
+int fhx_sort_u64(fhx_ctx* ctx, const void* d_keys_in, int64_t n, void* d_keys_out, void* d_perm_out) {
+    if (!ctx || n < 0 || (n > 0 && (!d_keys_in || !d_keys_out || !d_perm_out))) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (n == 0) return FHX_OK;
+    if (n >= (1ll << 32)) return fail(ctx, FHX_ERR_UNSUPPORTED, "more than 2^32 keys");
+    FHX_HIP(hipSetDevice(ctx->device));
+    int rc = ensure_sort_scratch(ctx);
+    if (rc != FHX_OK) return rc;
+    unsigned long long* keys[2] = {nullptr, (unsigned long long*)d_keys_out};
+    unsigned int* vals[2] = {nullptr, (unsigned int*)d_perm_out};
+    FHX_HIP(hipMalloc(&keys[0], (size_t)n * sizeof(unsigned long long)));
+    FHX_HIP(hipMalloc(&vals[0], (size_t)n * sizeof(unsigned int)));
+    unsigned long long* counter = ctx->d_misc + 3;
+    const unsigned long long n_host = (unsigned long long)n;
+    FHX_HIP(hipMemcpyAsync(counter, &n_host, sizeof(n_host), hipMemcpyHostToDevice, ctx->stream));
+    // an even number of ping-pong passes: start in the caller's output pair so that the result lands there
+    FHX_HIP(hipMemcpyAsync(keys[1], d_keys_in, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, vals[1], n);
+    const int nblk = sort_blocks_for(n);
+    int src = 1;
+    for (int pass = 0; pass < SORT_PASSES; ++pass) {
+        const int shift = pass * RADIX_BITS;
+        hipLaunchKernelGGL(rs_count, dim3(nblk), dim3(SORT_THREADS), 0, ctx->stream, keys[src], counter, shift,
+                           ctx->d_block_hist);
+        hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3((nblk + 63) / 64 * 64), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total, nblk);
+        launch_rs_scatter(ctx, nblk, keys[src], vals[src], keys[1 - src], vals[1 - src], counter, shift);
+        src = 1 - src;
+    }
+    FHX_HIP(hipGetLastError());
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    dev_free(keys[0]);
+    dev_free(vals[0]);
+    return FHX_OK;                                   // even number of swaps: the result is in pair [1]
+}
+
+int fhx_bh_scatter(fhx_ctx* ctx, const void* d_q_sorted_local) {
+    if (!ctx) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (ctx->n_sorted == -1) return fail(ctx, FHX_ERR_ARG, "fhx_bh_local_sort must run first");
+    FHX_HIP(hipSetDevice(ctx->device));
+    if (d_q_sorted_local)                       // NULL is legal when this rank holds no p < 1 at all
+        hipLaunchKernelGGL(k_scatter_q, dim3(grid_for(ctx->n_rows, 256)), dim3(256), 0, ctx->stream, ctx->d_vals[ctx->sorted_buf],
+                       (const double*)d_q_sorted_local, ctx->d_misc, ctx->d_q);
+    FHX_HIP(hipGetLastError());
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->have_q = true;
+    return FHX_OK;
+}
+

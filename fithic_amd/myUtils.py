@@ -2,7 +2,7 @@
 (`from fithic import myUtils` -> `from fithic_amd import myUtils`).
 
 On the engine's path these are not called per row - K1 / K2 classify every contact row on the GPU
-(fithic_amd/csrc/fhx_device.hip: k1_classify_hist, row_prior) with the same predicates; the Python forms exist for callers that
+(fithic_amd/csrc/fhx_k1.hip: k1_classify_hist; fhx_k2.hip: row_prior) with the same predicates; the Python forms exist for callers that
 used them on their own rows.  Thresholds follow the reference's convention: -1 = no bound on that side.
 
     in_range_check(interactionDistance, distLowThres, distUpThres)      fithic/myUtils.py:85-92

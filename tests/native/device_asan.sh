@@ -22,7 +22,7 @@ echo "== 2. the library, instrumented"
 SRC="$ROOT/fithic_amd/csrc"
 if [ -f "$ROOT/ab/libfithic_mi355x_asan.so" ]; then echo "(prebuilt in the build container with the command below: ab/libfithic_mi355x_asan.so)"; cp "$ROOT/ab/libfithic_mi355x_asan.so" $OUT/; else
 ( time hipcc -fsanitize=address -shared-libsan -g --offload-arch=gfx950:xnack+ -O1 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -pthread \
-    -o $OUT/libfithic_mi355x_asan.so $SRC/fhx_device.hip $SRC/fhx_kr.hip $SRC/fhx_cni.hip $SRC/fhx_host.cpp $SRC/fhx_io.cpp $SRC/fhx_gunzip.cpp -lz -ldl ) 2>&1 | grep -v "warning\|^ *[0-9]* |\|\^" | tail -8
+    -o $OUT/libfithic_mi355x_asan.so $SRC/fhx_device.hip $SRC/fhx_k1.hip $SRC/fhx_k2.hip $SRC/fhx_k3.hip $SRC/fhx_kr.hip $SRC/fhx_cni.hip $SRC/fhx_host.cpp $SRC/fhx_io.cpp $SRC/fhx_gunzip.cpp -lz -ldl ) 2>&1 | grep -v "warning\|^ *[0-9]* |\|\^" | tail -8
 fi
 ls -la $OUT/libfithic_mi355x_asan.so 2>&1
 echo "-- one small pass through ctypes (LD_PRELOAD of the sanitizer runtime: python itself is not instrumented)"
