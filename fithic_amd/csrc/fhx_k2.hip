@@ -499,20 +499,16 @@ __global__ __launch_bounds__(1024) void k2h_offsets(const unsigned int* __restri
     __shared__ unsigned int part[1024];
     const unsigned int g1 = granule - 1u;
     const unsigned int a = (digit_total[2 * threadIdx.x] + g1) / granule * granule, b = (digit_total[2 * threadIdx.x + 1] + g1) / granule * granule;
-    part[threadIdx.x] = a + b;
+    // exclusive prefix over the 1024 threads: wave scan + the 16 wave totals (was one thread walking all 1024)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned int incl = wave_incl_sum_u32(a + b);
+    if (lane == 63) part[wave] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned int acc = 0;
-        for (int i = 0; i < 1024; ++i) {
-            const unsigned int c = part[i];
-            part[i] = acc;
-            acc += c;
-        }
-        off[K2H_BUCKETS] = acc;
-    }
-    __syncthreads();
-    off[2 * threadIdx.x] = part[threadIdx.x];
-    off[2 * threadIdx.x + 1] = part[threadIdx.x] + a;
+    unsigned int excl = incl - (a + b);
+    for (int w = 0; w < wave; ++w) excl += part[w];
+    if (threadIdx.x == 1023) off[K2H_BUCKETS] = excl + a + b;
+    off[2 * threadIdx.x] = excl;
+    off[2 * threadIdx.x + 1] = excl + a;
 }
 
 __global__ __launch_bounds__(K2H_THREADS) void k2h_scatter(QSpan q, const unsigned int* __restrict__ block_hist,

@@ -67,19 +67,20 @@ __global__ __launch_bounds__(1024) void k3_cutoff(const unsigned long long* __re
         local[k] = hist[threadIdx.x * PER + k];
         sum += local[k];
     }
-    part[threadIdx.x] = sum;
+    // exclusive prefix of the 1024 partial sums: wave scan + the 16 wave totals (one thread walking all 1024 took 12 of this
+    // kernel's 16 us - a fixed cost of every pass)
     if (threadIdx.x == 0) best = TOP_BINS;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long acc = 0;
-        for (int i = 0; i < 1024; ++i) {
-            const unsigned long long c = part[i];
-            part[i] = acc;
-            acc += c;
-        }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
     }
+    if (lane == 63) part[wave] = incl;
     __syncthreads();
-    unsigned long long cum = part[threadIdx.x];
+    unsigned long long cum = incl - sum;
+    for (int w = 0; w < wave; ++w) cum += part[w];
     for (int k = 0; k < PER; ++k) {
         cum += local[k];
         const int b = threadIdx.x * PER + k;
@@ -368,6 +369,134 @@ __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(WP
     }
 }
 
+// ---- small survivor sets: two launches instead of eighteen ---------------------------------------------------------------
+// On Hi-C data whose counts follow the model closely (C3-synth: 77 k of 1.5e8 rows below the cutoff) and on every shard of a
+// strong-scaling run the radix sort is all fixed cost: 18 launches of 5-15 us for microseconds of work (0.16 ms per pass,
+// profiles/r03_z_c2_timeline.txt - the launches already run back to back, it is the kernels' own floor).  Up to KS_MAX_KEYS
+// survivors are instead sorted tile by tile in LDS (ks_tile_sort: a bitonic network over 4096 (key, row) pairs, the strides
+// below 8 in registers) and the sorted tiles merged by rank (ks_merge_tiles: an element's place is its position in its own tile
+// plus, for every other tile, the number of elements below it - at or below it for earlier tiles).  Neither step is stable and
+// neither needs to be: equal p-values share one q whatever their order (the first of them has the largest p*N/rank and the
+// running maximum carries it over the rest), and no later pass depends on the order - unlike the passes of the LSD sort.
+constexpr int KS_TILE = 4096;
+constexpr int KS_THREADS = 512;
+constexpr int KS_PER = KS_TILE / KS_THREADS;                    // 8 consecutive elements per thread in the register stages
+constexpr int KS_MAX_TILES = 32;
+constexpr int KS_MAX_KEYS = KS_MAX_TILES * KS_TILE;             // 131 072
+
+__global__ __launch_bounds__(KS_THREADS) void ks_tile_sort(const unsigned long long* __restrict__ keys_in, const unsigned int* __restrict__ vals_in,
+                                                           const unsigned long long* __restrict__ n_ptr, unsigned long long* __restrict__ keys_out,
+                                                           unsigned int* __restrict__ vals_out) {
+    // The tile lives in LDS; a compare-exchange at stride j pairs element i with i + j.  Strides of 8 and more: four pairs per
+    // thread and a barrier per stride; the strides 4, 2, 1 that end every block size: one visit of a thread's eight consecutive
+    // elements, in registers.  (Measured, profiles/r04_l_small_ab.txt: keeping the elements in registers throughout and reaching
+    // the partner lane with wave shuffles for strides 8..256 - 39 of the 78 stages without a barrier - is slower, 75 us
+    // against 45 for three tiles: 24 ds_bpermute per stage cost more than the barriers they save.)
+    __shared__ unsigned long long sk[KS_TILE];
+    __shared__ unsigned int sv[KS_TILE];
+    const int64_t n = (int64_t)*n_ptr;
+    const int64_t base = (int64_t)blockIdx.x * KS_TILE;
+    if (base >= n) return;
+#pragma unroll
+    for (int r = 0; r < KS_PER; ++r) {
+        const int s = threadIdx.x + r * KS_THREADS;
+        const bool live = base + s < n;
+        sk[s] = live ? keys_in[base + s] : ~0ull;                // padding sorts last (keys are IEEE patterns of p >= 0: never all ones)
+        sv[s] = live ? vals_in[base + s] : 0u;
+    }
+    __syncthreads();
+    auto register_stages = [&](int k) {
+        unsigned long long a[KS_PER];
+        unsigned int b[KS_PER];
+        const int first = threadIdx.x * KS_PER;
+#pragma unroll
+        for (int e = 0; e < KS_PER; ++e) {
+            a[e] = sk[first + e];
+            b[e] = sv[first + e];
+        }
+#pragma unroll
+        for (int j = KS_PER / 2; j > 0; j >>= 1) {
+            if (j < k) {
+#pragma unroll
+                for (int e = 0; e < KS_PER; ++e) {
+                    if ((e & j) == 0) {
+                        const bool up = ((first + e) & k) == 0;
+                        if ((a[e] > a[e + j]) == up) {
+                            const unsigned long long ta = a[e]; a[e] = a[e + j]; a[e + j] = ta;
+                            const unsigned int tb = b[e]; b[e] = b[e + j]; b[e + j] = tb;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < KS_PER; ++e) {
+            sk[first + e] = a[e];
+            sv[first + e] = b[e];
+        }
+    };
+    for (int k = 2; k <= KS_TILE; k <<= 1) {
+        for (int j = k >> 1; j >= KS_PER; j >>= 1) {             // partners in other threads: through LDS, four pairs per thread
+#pragma unroll
+            for (int r = 0; r < KS_PER / 2; ++r) {
+                const int t = threadIdx.x + r * KS_THREADS;
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i + j;
+                const unsigned long long x = sk[i], y = sk[l];
+                const bool up = (i & k) == 0;
+                if ((x > y) == up) {
+                    sk[i] = y;
+                    sk[l] = x;
+                    const unsigned int vx = sv[i];
+                    sv[i] = sv[l];
+                    sv[l] = vx;
+                }
+            }
+            __syncthreads();
+        }
+        register_stages(k);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < KS_PER; ++r) {
+        const int s = threadIdx.x + r * KS_THREADS;
+        if (base + s < n) {
+            keys_out[base + s] = sk[s];
+            vals_out[base + s] = sv[s];
+        }
+    }
+}
+
+// sorted tiles of KS_TILE elements -> one sorted array
+__global__ __launch_bounds__(256) void ks_merge_tiles(const unsigned long long* __restrict__ keys_in, const unsigned int* __restrict__ vals_in,
+                                                      const unsigned long long* __restrict__ n_ptr, unsigned long long* __restrict__ keys_out,
+                                                      unsigned int* __restrict__ vals_out) {
+    const int64_t n = (int64_t)*n_ptr;
+    const int tiles = (int)((n + KS_TILE - 1) / KS_TILE);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long k = keys_in[i];
+        const int mine = (int)(i / KS_TILE);
+        int64_t pos = i - (int64_t)mine * KS_TILE;
+        for (int t = 0; t < tiles; ++t) {
+            if (t == mine) continue;
+            int64_t lo = (int64_t)t * KS_TILE, hi = min(n, lo + (int64_t)KS_TILE);
+            const int64_t first = lo;
+            const bool take_equal = t < mine;                    // equal keys: the earlier tile's come first
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                const unsigned long long v = keys_in[mid];
+                if (v < k || (take_equal && v == k))
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            pos += lo - first;
+        }
+        keys_out[pos] = k;
+        vals_out[pos] = vals_in[i];
+    }
+}
+
 // BH value of sorted position i (0-based, global rank = rank0 + i + 1): min(p*N/rank, 1), myStats.py:35-38
 __device__ __forceinline__ double bh_value(unsigned long long key_bits, double n_tests, double rank) {
     const double pv = __longlong_as_double((long long)key_bits);
@@ -425,19 +554,16 @@ __global__ __launch_bounds__(1024) void bh_scan_tiles(double* __restrict__ tile_
     const int64_t beg = (int64_t)threadIdx.x * per, end = min(tiles, beg + per);
     double m = 0.0;
     for (int64_t t = beg; t < end; ++t) m = fmax(m, tile_max[t]);
-    part[threadIdx.x] = m;
+    // exclusive running max over the 1024 partial maxima (wave scan + the 16 wave maxima; was one thread walking all of them)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double incl = wave_incl_max(m, lane);
+    if (lane == 63) part[wave] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double run = carry_in;
-        for (int i = 0; i < 1024; ++i) {
-            const double c = part[i];
-            part[i] = run;
-            run = fmax(run, c);
-        }
-        if (total_max) *total_max = run;
-    }
-    __syncthreads();
-    double run = part[threadIdx.x];
+    double run = __shfl_up(incl, 1, 64);
+    if (lane == 0) run = 0.0;
+    run = fmax(run, carry_in);
+    for (int w = 0; w < wave; ++w) run = fmax(run, part[w]);
+    if (total_max && threadIdx.x == 1023) *total_max = fmax(run, m);
     for (int64_t t = beg; t < end; ++t) {
         const double c = tile_max[t];
         tile_max[t] = run;
@@ -642,6 +768,20 @@ static int compact_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned 
 // the six radix passes over the n_kept compacted keys; the result is in buffer pair *sorted_buf
 static int sort_kept(fhx_ctx* ctx, unsigned long long* keys[2], unsigned int* vals[2], const unsigned long long* counter, int64_t n_kept,
                      int* sorted_buf) {
+    static const bool small_off = std::getenv("FHX_K3_SMALL") && std::atoi(std::getenv("FHX_K3_SMALL")) == 0;       // A/B runs
+    if (n_kept <= KS_MAX_KEYS && !small_off) {                     // tile sort in LDS + merge by rank: two launches (see ks_tile_sort)
+        const int tiles = (int)std::max<int64_t>(1, (n_kept + KS_TILE - 1) / KS_TILE);
+        if (n_kept > 0) {
+            hipLaunchKernelGGL(ks_tile_sort, dim3(tiles), dim3(KS_THREADS), 0, ctx->stream, (const unsigned long long*)keys[0],
+                               (const unsigned int*)vals[0], counter, keys[1], vals[1]);
+            if (tiles > 1)
+                hipLaunchKernelGGL(ks_merge_tiles, dim3(grid_for(n_kept, 256)), dim3(256), 0, ctx->stream, (const unsigned long long*)keys[1],
+                                   (const unsigned int*)vals[1], counter, keys[0], vals[0]);
+        }
+        FHX_HIP(hipGetLastError());
+        *sorted_buf = (n_kept > 0 && tiles == 1) ? 1 : 0;
+        return FHX_OK;
+    }
     const int nblk = sort_blocks_for(n_kept);
     int src = 0;
     // p < 1 means the IEEE exponent field is <= 1022: bits 62 and 63 are always clear, 62 bits to sort
@@ -668,9 +808,10 @@ static int sort_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned lon
     return sort_kept(ctx, keys, vals, counter, n_kept, sorted_buf);
 }
 
-static int bh_from_sorted(fhx_ctx* ctx, const unsigned long long* keys, const unsigned int* vals, int64_t n_rows,
+// n_keys: the number of sorted keys when the host knows it (the grids then cover the keys, not the rows), else an upper bound
+static int bh_from_sorted(fhx_ctx* ctx, const unsigned long long* keys, const unsigned int* vals, int64_t n_keys,
                           const unsigned long long* counter, double n_total_tests, double* tile_max, double* d_q) {
-    const int tiles = (int)std::max<int64_t>(1, (n_rows + BH_TILE - 1) / BH_TILE);
+    const int tiles = (int)std::max<int64_t>(1, (n_keys + BH_TILE - 1) / BH_TILE);
     hipLaunchKernelGGL(bh_tile_max, dim3(tiles), dim3(BH_THREADS), 0, ctx->stream, keys, counter, (int64_t)0, n_total_tests,
                        0.0, tile_max);
     hipLaunchKernelGGL(bh_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, tile_max, counter, (int64_t)0, 0.0,
@@ -691,7 +832,7 @@ static int rank_and_adjust(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned 
     if (n_sorted_out) *n_sorted_out = n_kept;
     rc = sort_kept(ctx, keys, vals, counter, n_kept, sorted_buf);
     if (rc != FHX_OK) return rc;
-    return bh_from_sorted(ctx, keys[*sorted_buf], vals[*sorted_buf], n, counter, n_total_tests, tile_max, d_q);
+    return bh_from_sorted(ctx, keys[*sorted_buf], vals[*sorted_buf], n_kept, counter, n_total_tests, tile_max, d_q);
 }
 
 int fhx::ensure_sort_scratch(fhx_ctx* ctx) {
