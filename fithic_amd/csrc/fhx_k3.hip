@@ -768,7 +768,8 @@ static int compact_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned 
 // the six radix passes over the n_kept compacted keys; the result is in buffer pair *sorted_buf
 static int sort_kept(fhx_ctx* ctx, unsigned long long* keys[2], unsigned int* vals[2], const unsigned long long* counter, int64_t n_kept,
                      int* sorted_buf) {
-    static const bool small_off = std::getenv("FHX_K3_SMALL") && std::atoi(std::getenv("FHX_K3_SMALL")) == 0;       // A/B runs
+    const char* small_env = std::getenv("FHX_K3_SMALL");          // "0": the radix passes whatever the size (A/B runs, tests)
+    const bool small_off = small_env && std::atoi(small_env) == 0;
     if (n_kept <= KS_MAX_KEYS && !small_off) {                     // tile sort in LDS + merge by rank: two launches (see ks_tile_sort)
         const int tiles = (int)std::max<int64_t>(1, (n_kept + KS_TILE - 1) / KS_TILE);
         if (n_kept > 0) {

@@ -202,6 +202,27 @@ def test_bh_ragged_sizes_bit_exact(ctx, n):
     assert bits_equal(ctx.bh_array(allone, 5.0), allone)          # nothing to sort at all
 
 
+@pytest.mark.parametrize("n", [4095, 4096, 4097, 12288, 50000, 131072, 131073, 300000])
+def test_bh_tile_sort_and_radix_sort_agree_with_the_oracle(ctx, n, monkeypatch):
+    """Survivor sets of up to 131 072 keys are sorted in LDS tiles and merged by rank (ks_tile_sort / ks_merge_tiles), larger ones
+    by the six radix passes; FHX_K3_SMALL=0 forces the radix passes.  Many ties (values drawn from 1 000 levels), some NaN, every
+    value below the cutoff (N = 1: nothing saturates, all n values are ranked): both paths must give the oracle's q bit for bit."""
+    from oracle import fithic_oracle as fo
+    rng = np.random.default_rng(n)
+    p = rng.choice(rng.random(1000) * 1e-3, n)
+    p[rng.integers(0, n, max(1, n // 500))] = np.nan
+    p[rng.integers(0, n, 5)] = 0.0
+    want = fo.benjamini_hochberg(p, 1.0)
+    for env in (None, "0"):
+        if env is None:
+            monkeypatch.delenv("FHX_K3_SMALL", raising=False)
+        else:
+            monkeypatch.setenv("FHX_K3_SMALL", env)
+        got = ctx.bh_array(p, 1.0)
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        assert bits_equal(np.nan_to_num(got, nan=-1.0), np.nan_to_num(want, nan=-1.0)), (n, env)
+
+
 def test_bh_values_above_one_and_few_tests_follow_the_reference(ctx):
     """myStats.benjamini_hochberg_correction takes any numbers: with N < rank a p > 1 yields min(p*N/rank, 1) < 1, and only
     p == 1.0 exactly is pinned to 1.0 (myStats.py:33-38).  Nothing saturates for small N, so every row is ranked."""

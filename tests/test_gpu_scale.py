@@ -228,6 +228,9 @@ def test_count_homogeneous_waves_equal_the_per_lane_kernel(monkeypatch):
             res_passes.append(eng.fetch())
             _, heavy_rows = eng.ctx.k2_heavy_launch()
             assert heavy_rows > n // 20                                          # the class under test is populated
+            by_class = eng.ctx.k2_class_rows()                                   # fhx_k2_class_rows: what each class kernel worked on
+            assert by_class["cf_swapped"] == heavy_rows and all(v >= 0 for v in by_class.values())
+            assert 0 < by_class["cf_bcf"] + by_class["cf_bd"] + by_class["pseries"] < len(cols[0])
             eng.next_pass()
         out[tag] = res_passes
         eng.close()
