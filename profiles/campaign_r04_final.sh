@@ -17,3 +17,8 @@ head -28 gpurun_out/r04/z_kernel_stats.txt
 for f in z z_c2 z_c3w z_c5 z_forced_dist; do python -c "
 import json
 d=json.loads(open('gpurun_out/r04/${f}_bench.json').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['kernels_ms'], (d.get('parity_check') or {}).get('ok'), d.get('strong_efficiency'))"; done
+# second call of the round's end: the scaling model (largest shard of an N-way sharding alone on this GPU, plain and under
+# FHX_FORCE_DIST=1) and K3 under a heavy small-p tail with its kernel summary and PMC traffic
+python profiles/scaling_model.py --config C3 --steps 40 > gpurun_out/r04/z_scaling_model.txt 2>&1
+bash profiles/run_profile.sh r04/z_od1 --steps 10 --warmup 3 --overdispersion 1.0 --no-cpu-baseline > gpurun_out/r04/z_od1_profile.log 2>&1
+bash profiles/run_pmc.sh r04/z_od1 --steps 3 --warmup 1 --overdispersion 1.0 --no-parity-check > gpurun_out/r04/z_od1_pmc.log 2>&1
