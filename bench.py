@@ -3,6 +3,8 @@
 K3 Benjamini-Hochberg) on synthetic human contacts, with the inputs resident in HBM.
 
     python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py --gpus N --steps K --warmup W          (no launcher: the script starts its N ranks itself; fewer than N visible
+                                                            GPUs -> one JSON diagnostic line with "value": null, exit code 2)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
@@ -24,7 +26,11 @@ Workloads (`--config`, BASELINE.json configs):
       (`--max-chroms k` takes the first k chromosomes; the trans rows scale with the loci).
 With N > 1 GPUs the headline is STRONG scaling (BASELINE configs[3]: the one genome sharded by chromosome over the ranks,
 distance histogram all-reduced, BH ranking global over RCCL); the weak-scaling figure (genome replicated N times, N x the
-rows) is measured afterwards and reported under `weak_scaling` (`--no-weak` skips it, `--weak` makes it the headline).
+rows) is measured afterwards and reported under `weak_scaling` (`--no-weak` skips it, `--weak` makes it the headline).  The N > 1
+line also carries `per_rank` (rows and kernel times of every rank), `single_gpu_ms_per_step` / `strong_speedup` / `strong_efficiency`
+(against the one-GPU pass rank 0 times in the same run while it verifies) and `predicted_ms` (profiles/scaling_model.json).
+At N = 1 on C3 a second, labelled workload follows the headline: `k3_stress` - the same genome with lognormal rate noise, where
+12 % of the rows fall below the BH cutoff and K3's sort has work to do (`--no-k3-stress` skips it; it never enters `value`).
 """
 import argparse
 import json
