@@ -168,9 +168,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restr
 }
 
 // per-workgroup digit counts for one radix pass; workgroup b owns the contiguous chunk [b*chunk, (b+1)*chunk)
+template <int BITS>
 __global__ __launch_bounds__(SORT_THREADS) void rs_count(const unsigned long long* __restrict__ keys,
                                                          const unsigned long long* __restrict__ n_ptr, int shift,
                                                          unsigned int* __restrict__ block_hist) {
+    constexpr int RADIX = 1 << BITS;                  // (shadows the header's 11-bit constant)
     __shared__ unsigned int h[RADIX];
     const int64_t n = (int64_t)*n_ptr;
     const int64_t nblk = gridDim.x;                   // the launch decides how many chunks there are (sort_blocks_for)
@@ -237,12 +239,13 @@ __global__ __launch_bounds__(SORT_BLOCKS) void rs_scan(unsigned int* __restrict_
 // global_base[digit] + rank - is 45 % slower, the tile-wide reordering is what coalesces the writes of the passes over the
 // exponent bits; squeezing the kernel to 80 VGPRs for a third workgroup per CU spills and is slower still.)
 
-template <int SCAT_THREADS, int WPE>
+template <int SCAT_THREADS, int WPE, int BITS>
 __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void rs_scatter(
     const unsigned long long* __restrict__ keys_in, const unsigned int* __restrict__ vals_in, unsigned long long* __restrict__ keys_out,
     unsigned int* __restrict__ vals_out, const unsigned long long* __restrict__ n_ptr, int shift,
     const unsigned int* __restrict__ block_hist, const unsigned int* __restrict__ digit_total) {
-    constexpr int SCAT_WAVES = SCAT_THREADS / 64, TILE = SCAT_THREADS * SCAT_ITEMS, PER = RADIX / SCAT_THREADS;
+    constexpr int RADIX = 1 << BITS, RADIX_BITS = BITS;       // (shadow the header's 11-bit constants)
+    constexpr int SCAT_WAVES = SCAT_THREADS / 64, TILE = SCAT_THREADS * SCAT_ITEMS, PER = RADIX >= SCAT_THREADS ? RADIX / SCAT_THREADS : 1;
     static_assert(SORT_TILE % TILE == 0, "a workgroup's chunk (a multiple of SORT_TILE keys) is whole tiles");
     static_assert(SCAT_WAVES * RADIX * 2 <= TILE * 8, "the per-wave counters fit the block that later stages the keys");
     __shared__ __attribute__((aligned(16))) unsigned char stage_raw[TILE * 8];      // per-wave counters, then the tile's keys
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(WP
         unsigned int mine = 0;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            v[k] = a[threadIdx.x * PER + k];
+            v[k] = (int)threadIdx.x * PER + k < RADIX ? a[threadIdx.x * PER + k] : 0u;
             mine += v[k];
         }
         const unsigned int incl = wave_incl_sum_u32(mine);
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(WP
         for (int w = 0; w < wave; ++w) excl += wave_tmp[w];
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            a[threadIdx.x * PER + k] = excl;
+            if ((int)threadIdx.x * PER + k < RADIX) a[threadIdx.x * PER + k] = excl;
             excl += v[k];
         }
         __syncthreads();
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(WP
         }
         __syncthreads();
         // exclusive offsets: per digit across waves, then across digits
-        for (int d = threadIdx.x * PER; d < (threadIdx.x + 1) * PER; ++d) {
+        for (int d = threadIdx.x * PER; d < (threadIdx.x + 1) * PER && d < RADIX; ++d) {
             unsigned int acc = 0;
 #pragma unroll
             for (int w = 0; w < SCAT_WAVES; ++w) {
@@ -662,23 +665,28 @@ int sort_blocks_for(int64_t n_hint) {
     return (int)std::max<int64_t>(64, std::min<int64_t>(SORT_BLOCKS, (want + 63) / 64 * 64));
 }
 
-// one scatter pass
-void launch_rs_scatter(fhx_ctx* ctx, int nblk, const unsigned long long* keys_in, const unsigned int* vals_in, unsigned long long* keys_out,
-                       unsigned int* vals_out, const unsigned long long* counter, int shift) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_scatter<512, 4>), dim3(nblk), dim3(512), 0, ctx->stream, keys_in, vals_in, keys_out, vals_out,
-                       counter, shift, (const unsigned int*)ctx->d_block_hist, (const unsigned int*)ctx->d_digit_total);
-}
-
-int radix_sort_pairs(fhx_ctx* ctx, unsigned long long* keys[2], unsigned int* vals[2], const unsigned long long* counter,
-                     int passes, int* result_buf, int64_t n_hint) {
-    const int nblk = sort_blocks_for(n_hint);
-    int src = 0;
+// LSD radix passes over the low `key_bits` bits of the keys, `bits` bits per pass (8..11), starting in buffer pair `src`;
+// *result_buf = the pair that holds the sorted keys and payloads
+static int radix_passes(fhx_ctx* ctx, unsigned long long* keys[2], unsigned int* vals[2], const unsigned long long* counter, int nblk,
+                        int key_bits, int bits, int src, int* result_buf) {
+    const int passes = (key_bits + bits - 1) / bits;
     for (int pass = 0; pass < passes; ++pass) {
-        const int shift = pass * RADIX_BITS;
-        hipLaunchKernelGGL(rs_count, dim3(nblk), dim3(SORT_THREADS), 0, ctx->stream, keys[src], counter, shift,
-                           ctx->d_block_hist);
-        hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3((nblk + 63) / 64 * 64), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total, nblk);
-        launch_rs_scatter(ctx, nblk, keys[src], vals[src], keys[1 - src], vals[1 - src], counter, shift);
+        const int shift = pass * bits;
+#define FHX_RS_PASS(B)                                                                                                               \
+    do {                                                                                                                             \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_count<B>), dim3(nblk), dim3(SORT_THREADS), 0, ctx->stream, keys[src], counter, shift,    \
+                           ctx->d_block_hist);                                                                                       \
+        hipLaunchKernelGGL(rs_scan, dim3(1 << B), dim3((nblk + 63) / 64 * 64), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total, \
+                           nblk);                                                                                                    \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_scatter<512, 4, B>), dim3(nblk), dim3(512), 0, ctx->stream, keys[src], vals[src],        \
+                           keys[1 - src], vals[1 - src], counter, shift, (const unsigned int*)ctx->d_block_hist,                      \
+                           (const unsigned int*)ctx->d_digit_total);                                                                 \
+    } while (0)
+        if (bits == 8) FHX_RS_PASS(8);
+        else if (bits == 9) FHX_RS_PASS(9);
+        else if (bits == 10) FHX_RS_PASS(10);
+        else FHX_RS_PASS(11);
+#undef FHX_RS_PASS
         src = 1 - src;
     }
     FHX_HIP(hipGetLastError());
@@ -686,6 +694,10 @@ int radix_sort_pairs(fhx_ctx* ctx, unsigned long long* keys[2], unsigned int* va
     return FHX_OK;
 }
 
+int radix_sort_pairs(fhx_ctx* ctx, unsigned long long* keys[2], unsigned int* vals[2], const unsigned long long* counter,
+                     int passes, int* result_buf, int64_t n_hint) {
+    return radix_passes(ctx, keys, vals, counter, sort_blocks_for(n_hint), passes * RADIX_BITS, RADIX_BITS, 0, result_buf);
+}
 
 // launches for the other translation units (the sharded schedule, the heavy class's bucket sort, the FDR counts)
 void launch_rs_scan(fhx_ctx* ctx, int nblk) {
@@ -783,20 +795,11 @@ static int sort_kept(fhx_ctx* ctx, unsigned long long* keys[2], unsigned int* va
         *sorted_buf = (n_kept > 0 && tiles == 1) ? 1 : 0;
         return FHX_OK;
     }
-    const int nblk = sort_blocks_for(n_kept);
-    int src = 0;
-    // p < 1 means the IEEE exponent field is <= 1022: bits 62 and 63 are always clear, 62 bits to sort
-    for (int pass = 0; pass < SORT_PASSES; ++pass) {
-        const int shift = pass * RADIX_BITS;
-        hipLaunchKernelGGL(rs_count, dim3(nblk), dim3(SORT_THREADS), 0, ctx->stream, keys[src], counter, shift,
-                           ctx->d_block_hist);
-        hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3((nblk + 63) / 64 * 64), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total, nblk);
-        launch_rs_scatter(ctx, nblk, keys[src], vals[src], keys[1 - src], vals[1 - src], counter, shift);
-        src = 1 - src;
-    }
-    FHX_HIP(hipGetLastError());
-    *sorted_buf = src;
-    return FHX_OK;
+    // p < 1 means the IEEE exponent field is <= 1022: bits 62 and 63 are always clear, 62 bits to sort.  FHX_RS_BITS: digit width
+    // of these passes (measurements)
+    const char* be = std::getenv("FHX_RS_BITS");
+    const int bits = (be && std::atoi(be) >= 8 && std::atoi(be) <= 11) ? std::atoi(be) : SORT_BITS_LARGE;
+    return radix_passes(ctx, keys, vals, counter, sort_blocks_for(n_kept), 62, bits, 0, sorted_buf);
 }
 
 static int sort_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned long long* keys[2], unsigned int* vals[2],
@@ -1016,17 +1019,9 @@ int fhx_sort_u64(fhx_ctx* ctx, const void* d_keys_in, int64_t n, void* d_keys_ou
     // an even number of ping-pong passes: start in the caller's output pair so that the result lands there
     FHX_HIP(hipMemcpyAsync(keys[1], d_keys_in, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, vals[1], n);
-    const int nblk = sort_blocks_for(n);
-    int src = 1;
-    for (int pass = 0; pass < SORT_PASSES; ++pass) {
-        const int shift = pass * RADIX_BITS;
-        hipLaunchKernelGGL(rs_count, dim3(nblk), dim3(SORT_THREADS), 0, ctx->stream, keys[src], counter, shift,
-                           ctx->d_block_hist);
-        hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3((nblk + 63) / 64 * 64), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total, nblk);
-        launch_rs_scatter(ctx, nblk, keys[src], vals[src], keys[1 - src], vals[1 - src], counter, shift);
-        src = 1 - src;
-    }
-    FHX_HIP(hipGetLastError());
+    int where = 1;
+    rc = radix_passes(ctx, keys, vals, counter, sort_blocks_for(n), SORT_PASSES * RADIX_BITS, RADIX_BITS, 1, &where);   // six passes: back in pair [1]
+    if (rc != FHX_OK) return rc;
     FHX_HIP(hipStreamSynchronize(ctx->stream));
     dev_free(keys[0]);
     dev_free(vals[0]);
