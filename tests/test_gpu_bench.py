@@ -33,6 +33,9 @@ def test_single_gpu_line_is_checked_against_the_oracle():
     assert pc["ok"] and pc["max_dp"] <= 1e-10 and pc["max_dq"] == 0.0 and pc["rows_q"] == out["config"]["pairs"]
     assert "fit_vs_reference" not in pc                     # two chromosomes are not the workload the f14 fixture was made on
     assert out["n_gpus"] == 1 and out["roofline"]["frac"] > 0 and out["value"] > 1e8
+    ks = out["k3_stress"]                                   # the second, labelled workload: K3 with a heavy small-p tail
+    assert ks["rows_sorted"] > out["bh_rows_sorted_rank0"] and ks["rows_sorted"] > ks["pairs"] // 50 and ks["k3_ms"] > 0
+    assert sum(out["k2_class_rows_rank0"].values()) < out["config"]["pairs"]
 
 
 def test_sharded_schedule_over_rccl_is_verified_against_one_gpu():
@@ -80,5 +83,19 @@ def test_more_gpus_than_the_node_has_yields_one_diagnostic_line():
 
 
 def test_single_gpu_line_says_strong_scaling():
-    out = _plain({}, "--max-chroms", "2", "--no-cpu-baseline", "--no-parity-check")
-    assert out["scaling"] == "strong" and out["n_gpus"] == 1 and out["value"] > 1e8
+    out = _plain({}, "--max-chroms", "2", "--no-cpu-baseline", "--no-parity-check", "--no-k3-stress")
+    assert out["scaling"] == "strong" and out["n_gpus"] == 1 and out["value"] > 1e8 and "k3_stress" not in out
+
+
+def test_shard_of_runs_the_fullest_rank_of_an_n_way_sharding():
+    """--shard-of N (profiles/scaling_model.py): the chromosomes the fullest of N ranks would hold, alone on this GPU."""
+    import bench
+    from fithic_amd import synth
+    g = synth.Genome(5000, synth.HG19_AUTOSOMES[:6])
+    owner = synth.assign_chromosomes(g, 3)
+    loads = [sum(g.n_loci[c] for c in range(6) if owner[c] == r) for r in range(3)]
+    out = _plain({}, "--max-chroms", "6", "--shard-of", "3", "--no-cpu-baseline", "--no-k3-stress")
+    assert out["parity_check"]["ok"] and "fit_vs_reference" not in out["parity_check"]
+    whole = _plain({}, "--max-chroms", "6", "--no-cpu-baseline", "--no-parity-check", "--no-k3-stress")
+    frac = out["config"]["pairs"] / whole["config"]["pairs"]
+    assert abs(frac - max(loads) / sum(loads)) < 0.03

@@ -68,6 +68,33 @@ def _engine_with_case(case):
     return eng, kw, chroms, con
 
 
+def test_device_writer_writes_through_links_and_replaces_plain_files(tmp_path):
+    """The writer publishes a plain file by renaming a finished temporary over it (an earlier output survives a failure), but a
+    target that is a symlink or a device node is written THROUGH, as fopen(path, "wb") did - renaming over it would replace the node."""
+    eng, kw, chroms, con = _engine_with_case("f2_all")
+    eng.run_pass(collect=False)
+    plain = str(tmp_path / "plain.gz")
+    rows, nbytes = eng.ctx.write_significances_device(plain, chroms.names)
+    with open(plain, "rb") as f:
+        want = f.read()
+    with open(plain, "wb") as f:
+        f.write(b"an older, longer output" * 100)               # replaced as a whole
+    assert eng.ctx.write_significances_device(plain, chroms.names) == (rows, nbytes)
+    real, link = str(tmp_path / "real.gz"), str(tmp_path / "link.gz")
+    with open(real, "wb") as f:
+        f.write(b"x")
+    os.symlink(real, link)
+    assert eng.ctx.write_significances_device(link, chroms.names) == (rows, nbytes)
+    assert os.path.islink(link) and os.readlink(link) == real
+    for path in (plain, real):
+        with open(path, "rb") as f:
+            assert f.read() == want
+    assert eng.ctx.write_significances_device("/dev/null", chroms.names) == (rows, nbytes)
+    assert os.path.exists("/dev/null") and not os.path.isfile("/dev/null")
+    assert sorted(os.listdir(str(tmp_path))) == ["link.gz", "plain.gz", "real.gz"]      # no temporary left behind
+    eng.close()
+
+
 @pytest.mark.parametrize("case", ["f1_bias", "f2_all", "f2_intra", "f6_quirk_all", "f11_offgrid_all", "f8_nonfixed_all"])
 def test_device_writer_equals_python_formatting_on_the_golden_inputs(case, tmp_path):
     from fithic_amd import _capi
