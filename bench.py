@@ -392,17 +392,20 @@ def main():
             runner.timings.clear()
         kt = np.zeros(3)
         heavy = np.zeros(2)                                # seconds, rows of the dominant launch (the 300-iteration class)
+        eng.ctx.kernel_seconds_total(reset=True)           # the library sums its HIP events per pass from here on
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         info = None
         for _ in range(steps):
-            info = one_step(timed=True)
-            kt += np.array(eng.kernel_seconds())          # HIP events on the engine's stream (syncs it); last pass of the step
-            heavy += np.array(eng.ctx.k2_heavy_launch(), dtype=np.float64)
-        torch.cuda.synchronize()
+            info = one_step(timed=True)                    # nothing but the K passes in the timed region: the events are read by the
+        torch.cuda.synchronize()                           # library where it waits for its stream anyway (fhx_kernel_seconds_total)
         barrier()
         elapsed = time.perf_counter() - t0
+        ev_s, ev_n = eng.ctx.kernel_seconds_total()        # seconds of K1, K2, K3 and the heavy launch over ev_n passes of the region
+        per_pass = [ev_s[k] / ev_n[k] if ev_n[k] else 0.0 for k in range(4)]
+        kt = np.array(per_pass[:3])
+        heavy = np.array([per_pass[3], float(eng.ctx.k2_heavy_launch()[1])])      # rows of the launch: the last pass's
         if comm:
             elapsed = comm.max_float(elapsed)
             n_total = comm.sum_int(n_local)
@@ -413,8 +416,6 @@ def main():
             stage_ms = {k: 1e3 * v / max(steps * passes, 1) for k, v in runner.timings.items()}
             if rank == 0:
                 log("[rank 0] host wall per pass of the distributed stages (ms): " + ", ".join("%s %.2f" % kv for kv in stage_ms.items()))
-        kt /= max(steps, 1)
-        heavy /= max(steps, 1)
         mine_row = list(kt) + [float(n_local)] + list(heavy)
         k_all = comm.gather_floats(mine_row) if comm else [mine_row]
         hashes = None

@@ -108,6 +108,7 @@ SYMBOLS = {
     "fhx_device_ptr": (_P, [_P, ctypes.c_int]),
     "fhx_n_sorted": (ctypes.c_int64, [_P]),
     "fhx_kernel_seconds": (ctypes.c_int, [_P, _F64P, _F64P, _F64P]),
+    "fhx_kernel_seconds_total": (ctypes.c_int, [_P, _F64P, _I64P, ctypes.c_int]),
     "fhx_k2_heavy_launch": (ctypes.c_int, [_P, _F64P, _I64P]),
     "fhx_k2_class_rows": (ctypes.c_int, [_P, _I64P]),
     "fhx_bdtrc_array": (ctypes.c_int, [_P, ctypes.c_double, _I32P, _F64P, ctypes.c_int64, _F64P]),
@@ -570,6 +571,13 @@ class Context:
         k = [ctypes.c_double(0) for _ in range(3)]
         self._check(self._L.fhx_kernel_seconds(self._h, *[ctypes.byref(v) for v in k]))
         return tuple(v.value for v in k)
+
+    def kernel_seconds_total(self, reset=False):
+        """(seconds[4], passes[4]) of K1, K2, K3 and the heavy K2 launch summed since the last reset (waits for the stream once)."""
+        s = (ctypes.c_double * 4)()
+        n = (ctypes.c_int64 * 4)()
+        self._check(self._L.fhx_kernel_seconds_total(self._h, s, n, 1 if reset else 0))
+        return list(s), list(n)
 
     def k2_heavy_launch(self):
         sec, rows = ctypes.c_double(0), ctypes.c_int64(0)

@@ -18,6 +18,7 @@
 #include <unistd.h>
 #include <deque>
 #include <mutex>
+#include <map>
 #include <condition_variable>
 #include <algorithm>
 #include <cmath>
@@ -159,6 +160,11 @@ constexpr int K2H_BUCKETS = 2048;                       // == RADIX: the radix s
 constexpr int K2H_BLOCKS = 1024;                        // == SORT_BLOCKS
 __device__ __forceinline__ int k2h_bucket(int signed_count);
 
+// words of fhx_ctx::d_misc that K2's class kernels use, zeroed together before they are launched
+constexpr int MISC_K2_REDO = 64;                         // rows k2h_heavy handed back
+constexpr int MISC_K2_NEXT = 65;                         // + 0: k2h_heavy's next task; + class (1..K2_QUEUES): that kernel's next piece
+constexpr int MISC_K2_WORDS = 8;
+
 constexpr int K2_CL_ITEMS = 4;
 constexpr int K2_CL_TILE = K2_THREADS * K2_CL_ITEMS;     // 1024 rows per workgroup step: four waves of 256 consecutive rows
 
@@ -232,6 +238,12 @@ struct fhx_ctx {
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [6],[7]: around the heavy K2 launch
     long long n_heavy_last = 0;
     bool ev_valid[3] = {false, false, false};
+    // sums over the passes since the last reset: K1, K2, K3 and the heavy K2 launch.  A pair is added once, at a point where the
+    // stream is known to have passed it (fold_kernel_events), so that a caller timing many passes does not have to stop the
+    // stream after each one to read its events
+    double ev_sum[4] = {0.0, 0.0, 0.0, 0.0};
+    long long ev_count[4] = {0, 0, 0, 0};
+    bool ev_folded[4] = {true, true, true, true};
     std::string err;
     fhx_params prm{};
     bool have_params = false;
@@ -430,6 +442,7 @@ int ingest_device_rows(fhx_ctx* ctx, const int32_t* c1, const int32_t* m1, const
                        int64_t n);
 int pass_stats_nonfixed(fhx_ctx* ctx, fhx_stats* out);
 int launch_k1(fhx_ctx* ctx);
+void fold_kernel_events(fhx_ctx* ctx);        // after a stream synchronisation only
 // fhx_k2.hip
 K2Params make_k2_params(fhx_ctx* c);
 void launch_k2_extras(fhx_ctx* ctx, const K2Params& P, int64_t n_rows, double* d_expcc, double* d_b1, double* d_b2);

@@ -546,6 +546,23 @@ int fhx_kernel_seconds(fhx_ctx* ctx, double* k1, double* k2, double* k3) {
     return FHX_OK;
 }
 
+int fhx_kernel_seconds_total(fhx_ctx* ctx, double* sums4, int64_t* counts4, int reset) {
+    if (!ctx) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    FHX_HIP(hipSetDevice(ctx->device));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    fold_kernel_events(ctx);
+    for (int k = 0; k < 4; ++k) {
+        if (sums4) sums4[k] = ctx->ev_sum[k];
+        if (counts4) counts4[k] = ctx->ev_count[k];
+        if (reset) {
+            ctx->ev_sum[k] = 0.0;
+            ctx->ev_count[k] = 0;
+        }
+    }
+    return FHX_OK;
+}
+
 #include "fhx_dist.inc"
 #include "fhx_emit.inc"
 #include "fhx_inflate.inc"

@@ -853,8 +853,11 @@ int fhx::pass_stats_nonfixed(fhx_ctx* ctx, fhx_stats* out) {
         FHX_HIP(hipStreamSynchronize(ctx->stream));
     } else {
         FHX_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+        FHX_HIP(hipStreamSynchronize(ctx->stream));
     }
     ctx->ev_valid[0] = true;
+    ctx->ev_folded[0] = false;
+    fold_kernel_events(ctx);
     fhx_stats& st = ctx->stats;
     st.n_rows = ctx->n_rows;
     st.inter_count = s.inter_count;
@@ -907,7 +910,22 @@ int fhx::launch_k1(fhx_ctx* ctx) {
     FHX_HIP(hipGetLastError());
     FHX_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     ctx->ev_valid[0] = true;
+    ctx->ev_folded[0] = false;
     return FHX_OK;
+}
+
+// Adds the event pairs that have not been counted yet to the context's sums.  The caller has just synchronised the stream, and
+// every pair recorded so far lies before that point.
+void fhx::fold_kernel_events(fhx_ctx* ctx) {
+    for (int k = 0; k < 4; ++k) {
+        if (ctx->ev_folded[k] || !ctx->ev_valid[k < 3 ? k : 1]) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ev[k < 3 ? 2 * k : 6], ctx->ev[k < 3 ? 2 * k + 1 : 7]) == hipSuccess) {
+            ctx->ev_sum[k] += (double)ms * 1e-3;
+            ctx->ev_count[k] += 1;
+        }
+        ctx->ev_folded[k] = true;
+    }
 }
 
 int fhx_pass_stats(fhx_ctx* ctx, fhx_stats* out) {
@@ -942,6 +960,7 @@ int fhx_pass_stats(fhx_ctx* ctx, fhx_stats* out) {
     FHX_HIP(hipGetLastError());
     FHX_HIP(hipMemcpyAsync(ctx->h_stats_stage, ctx->d_stats_stage, pack_len * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
     FHX_HIP(hipStreamSynchronize(ctx->stream));
+    fold_kernel_events(ctx);               // this pass's K1 and, behind it on the stream, the previous pass's K2 and K3
     const long long* pk = ctx->h_stats_stage;
     ctx->h_hist_cc.assign((size_t)nd, 0);
     ctx->h_hist_np.assign((size_t)nd, 0);

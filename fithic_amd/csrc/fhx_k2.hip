@@ -382,21 +382,116 @@ __global__ __launch_bounds__(K2_THREADS) void k2_closed(K2Params P, QSpan q) {
     H.flush(P.top_hist);
 }
 
+// A class queue seen as ONE dense list across its shards (round 4).  Until then a consumer workgroup took whole shards: 2048
+// workgroups on the 1280 (or fewer) the chip holds at a time ran as 1.6 rounds, the second one on a 60 % full chip, and every
+// shard ended in a partial tile - 12 % of the class kernels' time on C3 and a third of it on a 1/8 shard of C3
+// (profiles/r04_tl_shard8.txt).  Now every consumer workgroup builds the exclusive prefix of the shard counts in LDS (2048
+// counts, one DPP scan) and takes dense pieces of that list.  The launches are sized to what the chip holds at a time
+// (`resident_grid`).  How the pieces are handed out follows from what a returning atomic on ONE address costs here - 11 ns,
+// whoever asks (profiles/r02_s_classify_variants.txt): a counter for every 256 entries of the power-series class took twice the
+// time of the kernel it fed (0.67 against 0.35 ms, profiles/r04_p_kernel_stats.txt), so that class is cut into one contiguous
+// range per wave; the 1024-entry tiles of the converging classes and the 300-iteration tasks of k2h_heavy are few enough
+// for a counter, and each taker's FIRST piece is its own number, so that nobody queues for the counter at the start.
+struct QDense {
+    // LDS is what limits the residency of the class kernels (16 KB of tile + 16 KB of fused histogram: four workgroups per CU),
+    // so the table holds one word per PAIR of shards and the second shard of a pair is told from the first one's count
+    static constexpr int PAIRS = K2_MAX_SHARDS / 2;
+    unsigned int* prefix;              // LDS, PAIRS + 1 words: entries in front of shard 2 i; [PAIRS] = all entries
+    const unsigned long long* count;
+    // all K2_THREADS threads of the workgroup; ends with a barrier
+    __device__ __forceinline__ void build(const QSpan& q, unsigned int* prefix_lds, unsigned int* wave_tot) {
+        static_assert(PAIRS % K2_THREADS == 0, "whole pairs per thread");
+        constexpr int PER = PAIRS / K2_THREADS;
+        prefix = prefix_lds;
+        count = q.count;
+        unsigned int c[PER], s = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int sh = 2 * ((int)threadIdx.x * PER + k);
+            c[k] = (sh < q.n_shards ? (unsigned int)q.count[sh] : 0u) + (sh + 1 < q.n_shards ? (unsigned int)q.count[sh + 1] : 0u);
+            s += c[k];
+        }
+        const unsigned int incl = wave_incl_sum_u32(s);
+        if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        unsigned int run = incl - s;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += wave_tot[w];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            prefix_lds[threadIdx.x * PER + k] = run;
+            run += c[k];
+        }
+        if (threadIdx.x == K2_THREADS - 1) prefix_lds[PAIRS] = run;
+        __syncthreads();
+    }
+    __device__ __forceinline__ unsigned int total() const { return prefix[PAIRS]; }
+    // the pair that holds entry v < total(): the last i with prefix[i] <= v (empty pairs share their successor's start)
+    __device__ __forceinline__ int pair_of(unsigned int v) const {
+        int lo = 0, hi = PAIRS;                        // prefix[lo] <= v < prefix[hi]
+#pragma unroll 1
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (prefix[mid] <= v)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        return lo;
+    }
+    // a reader's place in the list: pair `pr` holds entries [base, end), the first `c0` of them in its first shard
+    struct Cursor {
+        int pr;
+        unsigned int base, end, c0;
+    };
+    __device__ __forceinline__ void load(Cursor& c) const {
+        c.base = prefix[c.pr];
+        c.end = prefix[c.pr + 1];
+        c.c0 = (unsigned int)count[2 * c.pr];
+    }
+    __device__ __forceinline__ Cursor open(unsigned int v) const {
+        Cursor c;
+        c.pr = pair_of(v);
+        load(c);
+        return c;
+    }
+    // entry v of the dense list, v at or behind the cursor's pair (consecutive pieces of a thread: the same pair, or a step on)
+    __device__ __forceinline__ const QEntry* at(const QSpan& q, Cursor& c, unsigned int v) const {
+        if (v >= c.end) {
+            do ++c.pr;
+            while (v >= prefix[c.pr + 1]);
+            load(c);
+        }
+        const unsigned int u = v - c.base;
+        return u < c.c0 ? qentry(q, 2 * c.pr, (long long)u) : qentry(q, 2 * c.pr + 1, (long long)(u - c.c0));
+    }
+};
+constexpr int K2_WAVES = K2_THREADS / 64;
+
+// one class, one lane per row: every wave takes one contiguous range of the dense list (whole multiples of 64 entries)
 template <int CLS, bool SMALL_N>
 __global__ __launch_bounds__(K2_THREADS) void k2_queue(K2Params P, QSpan q) {
     __shared__ unsigned int hist_lds[K2_HIST_BINS];
+    __shared__ unsigned int prefix_lds[QDense::PAIRS + 1], wave_tot[K2_WAVES];
     FusedHist H;
     H.init(hist_lds, P.top_hist);
-    for (int sh = blockIdx.x; sh < q.n_shards; sh += gridDim.x) {
-        const long long n = (long long)q.count[sh];
-        for (long long j = threadIdx.x; j < n; j += blockDim.x) {
-            const QEntry e = *qentry(q, sh, j);
-            const bool is_inter = e.count < 0;
-            const int c = is_inter ? -e.count : e.count;
-            const double pv = dev::bdtrc_count_class<CLS, SMALL_N>(c, is_inter ? P.inter : P.intra, e.prior);
-            store_p<false>(P.p + e.row, pv);
-            H.add(pv);
-        }
+    QDense D;
+    D.build(q, prefix_lds, wave_tot);
+    const unsigned long long total = D.total();
+    const unsigned int lane = threadIdx.x & 63;
+    const unsigned long long n_waves = (unsigned long long)gridDim.x * K2_WAVES;
+    const unsigned long long share = ((total + n_waves - 1) / n_waves + 63ull) & ~63ull;
+    const unsigned long long begin = ((unsigned long long)blockIdx.x * K2_WAVES + (threadIdx.x >> 6)) * share;
+    const unsigned long long end = min(total, begin + share);
+    QDense::Cursor cur{0, 0u, 0u, 0u};
+    if (begin + lane < end) cur = D.open((unsigned int)(begin + lane));
+#pragma unroll 1
+    for (unsigned long long v = begin + lane; v < end; v += 64) {
+        const QEntry e = *D.at(q, cur, (unsigned int)v);
+        const bool is_inter = e.count < 0;
+        const int c = is_inter ? -e.count : e.count;
+        const double pv = dev::bdtrc_count_class<CLS, SMALL_N>(c, is_inter ? P.inter : P.intra, e.prior);
+        store_p<false>(P.p + e.row, pv);
+        H.add(pv);
     }
     H.flush(P.top_hist);
 }
@@ -405,31 +500,55 @@ __global__ __launch_bounds__(K2_THREADS) void k2_queue(K2Params P, QSpan q) {
 // wave waits for its slowest lane (measured: mean 9.3 iterations, mean of the per-wave maximum 20.3).  Each workgroup
 // therefore takes a tile of 1024 entries, counting-sorts it by min(count, 31) in LDS (one LDS atomic per entry) and hands
 // every wave 64 neighbours of that order (per-wave maximum 11.4).  Results go to P.p[row], so the order is free.
+// Tiles are pieces of the dense list (QDense): a workgroup's first tile is its own number, the others come from the launch's
+// counter (`quarters` 1..4 fixes the tile at that many times 256 entries: measurements).
 constexpr int K2_SORT_TILE = 1024;
 constexpr int K2_SORT_BUCKETS = 32;
 template <int CLS, bool SMALL_N, int WPE>
-__global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE))) void k2_queue_by_count(K2Params P, QSpan q) {
+__global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE))) void k2_queue_by_count(K2Params P, QSpan q,
+                                                                                                         unsigned int* next_tile,
+                                                                                                         int quarters) {
     static_assert(K2_SORT_TILE == 4 * K2_THREADS, "four entries per thread");
     __shared__ QEntry tile[K2_SORT_TILE];
     __shared__ unsigned int bucket_cnt[K2_SORT_BUCKETS], bucket_off[K2_SORT_BUCKETS];
     __shared__ unsigned int hist_lds[K2_HIST_BINS];
+    __shared__ unsigned int prefix_lds[QDense::PAIRS + 1], wave_tot[K2_WAVES], tile_lds;
     FusedHist H;
     H.init(hist_lds, P.top_hist);
-    for (int sh = blockIdx.x; sh < q.n_shards; sh += gridDim.x) {
-      const int64_t n = (int64_t)q.count[sh];
-      const int64_t tiles = (n + K2_SORT_TILE - 1) / K2_SORT_TILE;
-      for (int64_t t = 0; t < tiles; ++t) {
+    QDense D;
+    D.build(q, prefix_lds, wave_tot);
+    const unsigned int total = D.total();
+    // tile: at most 1024 entries, and such that the workgroups' shares are whole tiles - a 1/8 shard of C3 has 2.6 tiles of 1024
+    // per workgroup, i.e. three rounds of which the last is 60 % full; three tiles of 896 each fill them all
+    unsigned int tile_n = (unsigned int)quarters * K2_THREADS;
+    if (quarters < 1 || quarters > 4) {
+        const unsigned int share = (total + gridDim.x - 1) / gridDim.x;
+        const unsigned int rounds = max(1u, (share + K2_SORT_TILE - 1) / K2_SORT_TILE);
+        tile_n = min((unsigned int)K2_SORT_TILE, ((share + rounds - 1) / rounds + 63u) & ~63u);
+        tile_n = max(tile_n, 64u);
+    }
+    const unsigned int tiles = (total + tile_n - 1) / tile_n;
+    unsigned int mine = blockIdx.x;
+    for (;;) {
         if (threadIdx.x < K2_SORT_BUCKETS) bucket_cnt[threadIdx.x] = 0;
+        if (threadIdx.x == 0) tile_lds = mine;
         __syncthreads();
+        const unsigned int t = tile_lds;
+        if (t >= tiles) break;
+        if (threadIdx.x == 0) mine = gridDim.x + atomicAdd(next_tile, 1u);      // the next tile's number arrives while this one is worked on
+        const unsigned int v0 = t * tile_n;
+        const int m = (int)min(tile_n, total - v0);
         QEntry e[4];
         int bucket[4];
         unsigned int slot[4];
+        QDense::Cursor cur{0, 0u, 0u, 0u};
+        if ((int)threadIdx.x < m) cur = D.open(v0 + threadIdx.x);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int64_t j = t * K2_SORT_TILE + r * K2_THREADS + threadIdx.x;
+            const int idx = r * K2_THREADS + (int)threadIdx.x;
             bucket[r] = -1;
-            if (j < n) {
-                e[r] = *qentry(q, sh, j);
+            if (idx < m) {
+                e[r] = *D.at(q, cur, v0 + idx);
                 const int c = e[r].count < 0 ? -e[r].count : e[r].count;
                 bucket[r] = c < K2_SORT_BUCKETS - 1 ? c : K2_SORT_BUCKETS - 1;
                 slot[r] = atomicAdd(&bucket_cnt[bucket[r]], 1u);
@@ -446,7 +565,6 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE)
         for (int r = 0; r < 4; ++r)
             if (bucket[r] >= 0) tile[bucket_off[bucket[r]] + slot[r]] = e[r];
         __syncthreads();
-        const int m = (int)min((int64_t)K2_SORT_TILE, n - t * K2_SORT_TILE);
 #pragma unroll 1
         for (int r = 0; r < 4; ++r) {
             const int idx = r * K2_THREADS + threadIdx.x;
@@ -460,7 +578,6 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE)
             }
         }
         __syncthreads();
-      }
     }
     H.flush(P.top_hist);
 }
@@ -551,7 +668,7 @@ template <int R, int WPE, bool SMALL_N>
 __global__ __launch_bounds__(K2H_THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k2h_heavy(
     K2HeavyParams P, const QEntry* __restrict__ sorted, const unsigned int* __restrict__ off,
     const unsigned int* __restrict__ digit_total, const dev::CfRow* __restrict__ tab, QEntry* __restrict__ redo,
-    unsigned long long* __restrict__ n_redo) {
+    unsigned long long* __restrict__ n_redo, unsigned int* __restrict__ next_task) {
     static_assert(R >= 1 && R <= K2H_MAX_ROWS, "the sorted queue is padded for at most K2H_MAX_ROWS rows per lane");
     __shared__ unsigned int hist_lds[K2_HIST_BINS];
     FusedHist H;
@@ -560,8 +677,11 @@ __global__ __launch_bounds__(K2H_THREADS) __attribute__((amdgpu_waves_per_eu(WPE
     const int lane = threadIdx.x & 63;
     constexpr unsigned int TASK = 64u * R;
     const unsigned int n_tasks = off[K2H_GENERIC] / TASK;        // tasks in front of the generic bucket
-    const unsigned int stride = gridDim.x * (K2H_THREADS / 64);
-    for (unsigned int task = blockIdx.x * (K2H_THREADS / 64) + wave; task < n_tasks; task += stride) {
+    // tasks are handed out by a counter (round 4): with a fixed stride a 1/8 shard of C3 gave 27 % of the waves four tasks and
+    // the others three - the launch took 4/3.3 of its share of the full-size one (profiles/r04_tl_shard8.txt).  One returning
+    // atomic per 300 x 92 instructions of work.
+    const unsigned int n_waves = gridDim.x * (K2H_THREADS / 64);
+    for (unsigned int task = blockIdx.x * (K2H_THREADS / 64) + wave; task < n_tasks;) {
         const unsigned int first = task * TASK;
         // bucket of this task: the last b with off[b] <= first (empty buckets share their successor's start: skip them)
         int lo = 0, hi = K2H_GENERIC;                             // invariant: off[lo] <= first < off[hi]
@@ -610,6 +730,9 @@ __global__ __launch_bounds__(K2H_THREADS) __attribute__((amdgpu_waves_per_eu(WPE
             }
             H.add_wave_min(pv, mine);
         }
+        unsigned int next = 0;
+        if (lane == 0) next = atomicAdd(next_task, 1u);
+        task = n_waves + (unsigned int)__builtin_amdgcn_readfirstlane((int)next);
     }
     H.flush(P.top_hist);
 }
@@ -894,6 +1017,22 @@ void launch_k2_extras(fhx_ctx* ctx, const K2Params& P, int64_t n_rows, double* d
 }  // namespace fhx
 
 // ---- C ABI -----------------------------------------------------------------------------------------------------------------
+// workgroups of `kernel` (K2_THREADS threads, its static LDS) that the device holds at a time: the class kernels cut their queue into
+// that many shares, or take pieces from a counter - a larger grid would run its surplus on a part-empty chip
+template <typename K>
+static int resident_grid(fhx_ctx* ctx, K kernel) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, int> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    const std::pair<int, const void*> key(ctx->device, (const void*)kernel);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, K2_THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus < 1) cus = 256;
+    return cache[key] = per_cu * cus;
+}
+
 int fhx_pvalues(fhx_ctx* ctx) {
     if (!ctx) return FHX_ERR_ARG;
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
@@ -1014,22 +1153,27 @@ int fhx_pvalues(fhx_ctx* ctx) {
 #define FHX_LAUNCH_QUEUE(CLS)                                                                                         \
     do {                                                                                                              \
         if (small_n)                                                                                                  \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue<CLS, true>), qgrid, qblock, 0, ctx->stream, P, Q.q[(CLS) - 1]);  \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue<CLS, true>), dim3(resident_grid(ctx, k2_queue<CLS, true>)), qblock, 0,      \
+                               ctx->stream, P, Q.q[(CLS) - 1]);                                                       \
         else                                                                                                          \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue<CLS, false>), qgrid, qblock, 0, ctx->stream, P, Q.q[(CLS) - 1]); \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue<CLS, false>), dim3(resident_grid(ctx, k2_queue<CLS, false>)), qblock, 0,    \
+                               ctx->stream, P, Q.q[(CLS) - 1]);                                                       \
     } while (0)
     const bool legacy_heavy = getenv("FHX_K2_LEGACY") != nullptr;      // A/B and tests: the per-lane kernel of round 1
+    // the handed-back rows' counter and the work counters of the class kernels (k2h_heavy's tasks, one per class queue)
+    unsigned long long* n_redo = ctx->d_misc + MISC_K2_REDO;
+    unsigned long long* k2_next = ctx->d_misc + MISC_K2_NEXT;
+    FHX_HIP(hipMemsetAsync(n_redo, 0, MISC_K2_WORDS * sizeof(unsigned long long), ctx->stream));
     if (legacy_heavy) {
         FHX_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
         FHX_LAUNCH_QUEUE(dev::BC_CF_SWAPPED);            // longest-running class first
         FHX_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
+        ctx->ev_folded[3] = false;
     } else {
         static_assert(K2H_BUCKETS == RADIX && K2H_BLOCKS == SORT_BLOCKS, "the radix sort's count matrix and scan are reused");
         const QSpan hs = Q.q[dev::BC_CF_SWAPPED - 1];
         QEntry* hq = ctx->d_queue[0];                    // the handed-back rows: this buffer is dead once it is scattered and the
                                                          // power-series class (its other tenant) has run
-        unsigned long long* n_redo = ctx->d_misc + 11;
-        FHX_HIP(hipMemsetAsync(n_redo, 0, sizeof(unsigned long long), ctx->stream));
         if (!Q.heavy_hist)              // otherwise k2_classify has counted while it queued
             hipLaunchKernelGGL(k2h_count, dim3(K2H_BLOCKS), dim3(K2H_THREADS), 0, ctx->stream, hs, ctx->d_block_hist);
         launch_rs_scan(ctx, (int)SORT_BLOCKS);
@@ -1054,7 +1198,7 @@ int fhx_pvalues(fhx_ctx* ctx) {
 #define FHX_HEAVY_N(R, W, S)                                                                                                        \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k2h_heavy<R, W, S>), dim3(256 * W), dim3(K2H_THREADS), 0, ctx->stream, HP,                     \
                        (const QEntry*)ctx->d_queue_sorted, (const unsigned int*)ctx->d_k2h_off, (const unsigned int*)ctx->d_digit_total, \
-                       (const dev::CfRow*)ctx->d_cf_tab, hq, n_redo)
+                       (const dev::CfRow*)ctx->d_cf_tab, hq, n_redo, (unsigned int*)k2_next)
 #define FHX_HEAVY(R, W)           \
     do {                          \
         if (small_n)              \
@@ -1069,19 +1213,27 @@ int fhx_pvalues(fhx_ctx* ctx) {
 #undef FHX_HEAVY
 #undef FHX_HEAVY_N
         FHX_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
+        ctx->ev_folded[3] = false;
         hipLaunchKernelGGL(k2h_generic, dim3(256 * 4), dim3(K2_THREADS), 0, ctx->stream, P, (const QEntry*)ctx->d_queue_sorted,
                            (const unsigned int*)ctx->d_k2h_off, (const unsigned int*)ctx->d_digit_total, (const QEntry*)hq,
                            (const unsigned long long*)n_redo);
     }
     static const int cf_wpe = std::getenv("FHX_CF_WAVES") ? std::atoi(std::getenv("FHX_CF_WAVES")) : 0;              // measurements
+    static const int cf_quarters = std::getenv("FHX_CF_QUARTERS") ? std::atoi(std::getenv("FHX_CF_QUARTERS")) : 0;   // 1..4: measurements
 #define FHX_LAUNCH_QUEUE_BY_COUNT(CLS)                                                                                                \
     do {                                                                                                                              \
         if (small_n)                                                                                                                  \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue_by_count<CLS, true, 4>), qgrid, qblock, 0, ctx->stream, P, Q.q[(CLS) - 1]);      \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue_by_count<CLS, true, 4>), dim3(resident_grid(ctx, k2_queue_by_count<CLS, true, 4>)), \
+                               qblock, 0, ctx->stream, P, Q.q[(CLS) - 1],          \
+                               (unsigned int*)(k2_next + (CLS)), cf_quarters);     \
         else if (cf_wpe == 4)                                                                                                         \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue_by_count<CLS, false, 4>), qgrid, qblock, 0, ctx->stream, P, Q.q[(CLS) - 1]);     \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue_by_count<CLS, false, 4>), dim3(resident_grid(ctx, k2_queue_by_count<CLS, false, 4>)), \
+                               qblock, 0, ctx->stream, P, Q.q[(CLS) - 1],          \
+                               (unsigned int*)(k2_next + (CLS)), cf_quarters);     \
         else                                                                                                                          \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue_by_count<CLS, false, 5>), qgrid, qblock, 0, ctx->stream, P, Q.q[(CLS) - 1]);     \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue_by_count<CLS, false, 5>), dim3(resident_grid(ctx, k2_queue_by_count<CLS, false, 5>)), \
+                               qblock, 0, ctx->stream, P, Q.q[(CLS) - 1],          \
+                               (unsigned int*)(k2_next + (CLS)), cf_quarters);     \
     } while (0)
     FHX_LAUNCH_QUEUE_BY_COUNT(dev::BC_CF_BD);
     FHX_LAUNCH_QUEUE_BY_COUNT(dev::BC_CF_BCF);
@@ -1109,6 +1261,7 @@ int fhx_pvalues(fhx_ctx* ctx) {
     FHX_HIP(hipGetLastError());
     FHX_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
     ctx->ev_valid[1] = true;
+    ctx->ev_folded[1] = false;
     ctx->have_p = true;
     ctx->have_q = false;
     ctx->n_sorted = -1;
@@ -1368,7 +1521,7 @@ int fhx_k2_heavy_launch(fhx_ctx* ctx, double* seconds, int64_t* rows) {
     for (unsigned long long v : part) n += v;
     if (std::getenv("FHX_DEBUG_HEAVY")) {                  // how many rows the uniform kernel handed back to the per-lane loop
         unsigned long long redo = 0;
-        FHX_HIP(hipMemcpy(&redo, ctx->d_misc + 11, sizeof(redo), hipMemcpyDeviceToHost));
+        FHX_HIP(hipMemcpy(&redo, ctx->d_misc + MISC_K2_REDO, sizeof(redo), hipMemcpyDeviceToHost));
         std::fprintf(stderr, "k2h_heavy: %.3f ms, %llu rows in the class, %llu handed back\n", ms, n, redo);
     }
     if (seconds) *seconds = ms * 1e-3;

@@ -968,6 +968,7 @@ int fhx_bh(fhx_ctx* ctx, double n_total_tests) {
     ctx->n_sorted = kept;
     FHX_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
     ctx->ev_valid[2] = true;
+    ctx->ev_folded[2] = false;
     ctx->have_q = true;
     return FHX_OK;
 }

@@ -226,6 +226,12 @@ void* fhx_device_ptr(fhx_ctx* ctx, int which);
 int64_t fhx_n_sorted(fhx_ctx* ctx);
 /* Seconds the kernels of the last pass took on the context's stream (HIP events): k1, k2, k3. */
 int fhx_kernel_seconds(fhx_ctx* ctx, double* k1, double* k2, double* k3);
+/* The same summed over the passes since the last reset, without stopping the stream after each of them: sums4 = seconds of K1, K2,
+ * K3 and of the heavy K2 launch (fhx_k2_heavy_launch), counts4 = how many passes each sum holds (either may be NULL).  The library
+ * reads a pass's events at the next point where it waits for the stream anyway (the statistics of the following pass), this call
+ * waits for the stream and reads the rest; reset != 0 clears the sums afterwards.  A timing harness calls it once with reset
+ * before and once after its timed passes. */
+int fhx_kernel_seconds_total(fhx_ctx* ctx, double* sums4, int64_t* counts4, int reset);
 /* Duration (HIP events on the context's stream) and row count of the dominant launch of the last fhx_pvalues: the queue
  * of rows whose continued fraction runs to Cephes' 300-iteration cap (k2_queue<BC_CF_SWAPPED>). */
 int fhx_k2_heavy_launch(fhx_ctx* ctx, double* seconds, int64_t* rows);
