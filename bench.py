@@ -402,6 +402,9 @@ def main():
         torch.cuda.synchronize()                           # library where it waits for its stream anyway (fhx_kernel_seconds_total)
         barrier()
         elapsed = time.perf_counter() - t0
+        if eng.call_seconds is not None and eng.call_seconds[4]:
+            log("host seconds per pass inside pass_stats / fit / pvalues / bh (FHX_CALL_TIMES): " +
+                " / ".join("%.1f us" % (1e6 * v / eng.call_seconds[4]) for v in eng.call_seconds[:4]))
         ev_s, ev_n = eng.ctx.kernel_seconds_total()        # seconds of K1, K2, K3 and the heavy launch over ev_n passes of the region
         per_pass = [ev_s[k] / ev_n[k] if ev_n[k] else 0.0 for k in range(4)]
         kt = np.array(per_pass[:3])

@@ -294,11 +294,15 @@ int fhx_fit(fhx_ctx* ctx, fhx_fit_info* out) {
     if (!ctx) return FHX_ERR_ARG;
     if (!ctx->have_params || !ctx->have_frags) return fail(ctx, FHX_ERR_ARG, "parameters and fragments must be loaded");
     if (!ctx->have_stats) return fail(ctx, FHX_ERR_ARG, "fhx_pass_stats (or fhx_set_global_stats) must run first");
+    static const bool fit_times = std::getenv("FHX_FIT_TIMES") != nullptr;      // measurements: where the host part of a pass goes
+    const auto t0 = std::chrono::steady_clock::now();
     PassInputs in;
     fill_pass_inputs(ctx, in);
     std::string err;
     const int rc = run_host_pass(in, ctx->frags, ctx->fit, err);
     if (rc != FHX_OK) return fail(ctx, rc, err);
+    const auto t1 = std::chrono::steady_clock::now();
+    auto t2 = t1;
     ctx->have_fit = true;
     ctx->have_bins = true;
     const PassFit& f = ctx->fit;
@@ -314,6 +318,7 @@ int fhx_fit(fhx_ctx* ctx, fhx_fit_info* out) {
         std::vector<double> lb_a, ib_a, lb_e, ib_e;
         build_lbeta_table((double)ctx->stats.in_range_sum, mc, lb_a, ib_a);
         build_lbeta_table((double)ctx->stats.inter_sum, mc, lb_e, ib_e);
+        t2 = std::chrono::steady_clock::now();
         const size_t n_lut = std::max<size_t>(f.prior_lut.size(), 1), n_tab = (size_t)(mc + 1);
         const size_t n_xy = ctx->nonfixed ? std::max<size_t>(f.table_x.size(), 1) : 0;
         const size_t need = n_lut + 4 * n_tab + 2 * n_xy;
@@ -349,6 +354,14 @@ int fhx_fit(fhx_ctx* ctx, fhx_fit_info* out) {
         }
         FHX_HIP(hipMemcpyAsync(ctx->d_fit_tables, h, at * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         FHX_HIP(hipEventRecord(ctx->ev_fit_copy, ctx->stream));
+    }
+    if (fit_times) {
+        const auto t3 = std::chrono::steady_clock::now();
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double, std::micro>(b - a).count();
+        };
+        std::fprintf(stderr, "fhx_fit: bins + spline + isotonic %.1f us, per-count tables (max count %lld) %.1f us, staging + copy %.1f us\n",
+                     us(t0, t1), (long long)ctx->stats.max_count, us(t1, t2), us(t2, t3));
     }
     if (out) {
         std::memset(out, 0, sizeof(*out));

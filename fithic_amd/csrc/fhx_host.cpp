@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -810,8 +811,15 @@ void make_bins_stage(const PassInputs& in, PassFit& out) {
     for (auto& b : out.bins) b.poss0 = b.poss;
 }
 
+
 int run_host_pass(const PassInputs& in, const FragTable& frags, PassFit& out, std::string& err) {
+    static const bool stage_times = std::getenv("FHX_FIT_TIMES") != nullptr;      // measurements
+    double tm[8] = {0};
+    int tk = 0;
+    auto tlast = std::chrono::steady_clock::now();
+    auto T = [&]() { const auto n = std::chrono::steady_clock::now(); if (tk < 8) tm[tk++] = std::chrono::duration<double, std::micro>(n - tlast).count(); tlast = n; };
     make_bins_stage(in, out);
+    T();
     const int64_t res = in.resolution;
 
     // ---- generate_FragPairs ---------------------------------------------------------------------------
@@ -1001,6 +1009,7 @@ int run_host_pass(const PassInputs& in, const FragTable& frags, PassFit& out, st
         out.baseline_intra_prob = poss_intra_all > 0 ? 1.0 / poss_intra_all : 0.0;
     }
 
+    T();
     // ---- calculateProbabilities (fithic.py:869-908) -------------------------------------------------
     out.x.clear();
     out.y.clear();
@@ -1055,6 +1064,7 @@ int run_host_pass(const PassInputs& in, const FragTable& frags, PassFit& out, st
         err = "spline fit rejected its input";
         return FHX_ERR_REFERENCE_EXIT;
     }
+    T();
     out.min_x = xs.front();
     out.max_x = xs.back();
     // splineX: observed distances d with min(x) <= d <= max(x) (int vs float comparison is exact here)
@@ -1075,6 +1085,7 @@ int run_host_pass(const PassInputs& in, const FragTable& frags, PassFit& out, st
     }
     out.table_y0.resize(tx.size());
     spline_eval(out.spline, tx.data(), static_cast<int64_t>(tx.size()), out.table_y0.data());
+    T();
     out.table_y.resize(tx.size());
     pava_decreasing(out.table_y0.data(), static_cast<int64_t>(tx.size()), out.table_y.data());
     {
@@ -1086,6 +1097,7 @@ int run_host_pass(const PassInputs& in, const FragTable& frags, PassFit& out, st
         }
         out.residual = numpy_sum(sq.data(), m);
     }
+    T();
     // dense LUT over distance indices: clamp, bisect_left, cap (fithic.py:1066-1069); with explicit distance keys (-r 0,
     // or -r N on off-grid loci) the device does the same search per row
     if (res > 0 && !in.dist_keys) {
@@ -1099,6 +1111,7 @@ int run_host_pass(const PassInputs& in, const FragTable& frags, PassFit& out, st
             out.prior_lut[static_cast<size_t>(i)] = out.table_y[std::min(pos, nt - 1)];
         }
     }
+    if (stage_times) { T(); std::fprintf(stderr, "run_host_pass: bins %.1f us, possible pairs %.1f, spline fit %.1f, table eval %.1f, isotonic + residual %.1f, lut %.1f\n", tm[0], tm[1], tm[2], tm[3], tm[4], tm[5]); }
     return FHX_OK;
 }
 

@@ -1030,6 +1030,7 @@ static int resident_grid(fhx_ctx* ctx, K kernel) {
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, K2_THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 4;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus < 1) cus = 256;
+    if (std::getenv("FHX_DEBUG_GRID")) std::fprintf(stderr, "resident_grid: %d workgroups per CU x %d CUs\n", per_cu, cus);
     return cache[key] = per_cu * cus;
 }
 
@@ -1150,13 +1151,16 @@ int fhx_pvalues(fhx_ctx* ctx) {
     // totals below 171: the kernels that carry Cephes' pow branch (a binomial without a single contact - no inter-chromosomal
     // rows - classifies every row as trivial and reaches no class kernel: it does not count)
     const bool small_n = (P.intra.small_n && P.intra.n >= 1.0) || (P.inter.small_n && P.inter.n >= 1.0);
+    // one range per wave of TWICE the resident workgroups: the ranges are cut by entries, not by work, and the second half
+    // evens the first one out (C3: 376 us at 1 x, 358 at 2.3 x, 362 at 4.7 x, profiles/r04_t_ps.txt); FHX_PS_GRID: measurements
+    static const int ps_grid = std::getenv("FHX_PS_GRID") ? std::atoi(std::getenv("FHX_PS_GRID")) : 0;
 #define FHX_LAUNCH_QUEUE(CLS)                                                                                         \
     do {                                                                                                              \
         if (small_n)                                                                                                  \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue<CLS, true>), dim3(resident_grid(ctx, k2_queue<CLS, true>)), qblock, 0,      \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue<CLS, true>), dim3(2 * resident_grid(ctx, k2_queue<CLS, true>)), qblock, 0,      \
                                ctx->stream, P, Q.q[(CLS) - 1]);                                                       \
         else                                                                                                          \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue<CLS, false>), dim3(resident_grid(ctx, k2_queue<CLS, false>)), qblock, 0,    \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_queue<CLS, false>), dim3(ps_grid > 0 ? ps_grid : 2 * resident_grid(ctx, k2_queue<CLS, false>)), qblock, 0,    \
                                ctx->stream, P, Q.q[(CLS) - 1]);                                                       \
     } while (0)
     const bool legacy_heavy = getenv("FHX_K2_LEGACY") != nullptr;      // A/B and tests: the per-lane kernel of round 1
@@ -1182,10 +1186,13 @@ int fhx_pvalues(fhx_ctx* ctx) {
         // rows per lane: 4 at 4 waves/SIMD - C3 (2.7e7 rows in the class) 7.43 -> 6.66 ms, a 1/18 shard (1.5e6 rows) 0.87 -> 0.78 ms of
         // K2 against one row per lane at 8 waves/SIMD; 2 x 8, 3 x 5 and 4 x 3 are within 3 % (profiles/r03_c_*heavy_variants.txt).
         // FHX_K2H_ROWS (1, 2) / FHX_K2H_WAVES (3) select the instantiations kept for measurements.
-        static const int heavy_rows = std::getenv("FHX_K2H_ROWS") ? std::atoi(std::getenv("FHX_K2H_ROWS")) : 4;
+        const char* heavy_rows_env = std::getenv("FHX_K2H_ROWS");                 // read per call: the tests run every instantiation
+        const int heavy_rows = heavy_rows_env ? std::atoi(heavy_rows_env) : 0;
         static const int heavy_wpe = std::getenv("FHX_K2H_WAVES") ? std::atoi(std::getenv("FHX_K2H_WAVES")) : 0;
-        const int hr = (heavy_rows == 1 || heavy_rows == 2) ? heavy_rows : 4;     // the instantiations below: 1, 2 or 4 rows per lane - the
-                                                                                   // bucket granule must be the launched kernel's task size
+        // a small input (a shard of a strong-scaling run) has a handful of 256-entry tasks per wave and ends with most waves idle:
+        // two rows per lane at eight waves per SIMD halves the task (a 1/8 shard of C3: 876 -> 829 us, profiles/r04_t_rows.txt)
+        const int hr = (heavy_rows == 1 || heavy_rows == 2) ? heavy_rows       // the instantiations below: 1, 2 or 4 rows per lane - the
+                       : (heavy_rows == 0 && k2_n < 32000000) ? 2 : 4;         // bucket granule must be the launched kernel's task size
         hipLaunchKernelGGL(k2h_offsets, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned int*)ctx->d_digit_total, ctx->d_k2h_off,
                            64u * (unsigned int)hr);
         hipLaunchKernelGGL(k2h_tables, dim3(K2H_GENERIC), dim3(K2H_TABLE_THREADS), 0, ctx->stream, (const unsigned int*)ctx->d_digit_total,

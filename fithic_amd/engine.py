@@ -10,6 +10,9 @@
 
 There is no CPU implementation behind this class: without the built library or without a GPU it raises.
 """
+import os
+import time
+
 import numpy as np
 
 from . import _capi
@@ -33,6 +36,9 @@ class Engine:
         self.n_rows = 0
         self.mode = "intraOnly"
         self.pass_no = 0
+        # FHX_CALL_TIMES=1 (measurements): host seconds inside pass_stats / fit / pvalues / bh summed over run_pass calls, then the
+        # number of calls - where a small pass's wall time goes that its kernels do not explain
+        self.call_seconds = [0.0, 0.0, 0.0, 0.0, 0] if os.environ.get("FHX_CALL_TIMES") else None
 
     def close(self):
         self.ctx.close()
@@ -78,10 +84,24 @@ class Engine:
     def run_pass(self, collect=True):
         """K1 -> host fit -> K2 -> K3, all on this context's stream.  Returns a PassOutput."""
         out = PassOutput()
-        st = self.ctx.pass_stats()
-        info = self.ctx.fit()
-        self.ctx.pvalues()
-        self.ctx.bh(info.bh_total_tests)
+        if self.call_seconds is None:
+            st = self.ctx.pass_stats()
+            info = self.ctx.fit()
+            self.ctx.pvalues()
+            self.ctx.bh(info.bh_total_tests)
+        else:                                   # measurements: host wall time of each of the four calls, summed
+            t = [time.perf_counter()]
+            st = self.ctx.pass_stats()
+            t.append(time.perf_counter())
+            info = self.ctx.fit()
+            t.append(time.perf_counter())
+            self.ctx.pvalues()
+            t.append(time.perf_counter())
+            self.ctx.bh(info.bh_total_tests)
+            t.append(time.perf_counter())
+            for k in range(4):
+                self.call_seconds[k] += t[k + 1] - t[k]
+            self.call_seconds[4] += 1
         out.stats, out.info = st.as_dict(), info.as_dict()
         if collect:
             self.ctx.sync()

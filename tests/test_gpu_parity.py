@@ -386,6 +386,37 @@ def test_three_passes_match_oracle(name):
     eng.close()
 
 
+@pytest.mark.parametrize("name", ["f1_bias", "f8_nonfixed_all"])
+def test_kernel_seconds_summed_over_passes(name):
+    """fhx_kernel_seconds_total: the library adds every pass's HIP-event durations (K1, K2, K3, the heavy launch) to its sums at
+    points where it waits for the stream anyway, so that a timing harness does not stop the stream after each pass.  Three passes
+    give three samples of each, the sums are at least the last pass's own durations, and a reset clears them."""
+    from fithic_amd import tables
+    from fithic_amd.engine import Engine
+    meta, g = load_case(name)
+    kw = case_args(meta)
+    chroms = tables.ChromIndex()
+    con = tables.read_contacts(kw["contacts"], chroms)
+    eng = Engine(0)
+    eng.configure(kw["resolution"], kw["L"], kw["U"], kw["n_bins"], kw["mapp_thres"], kw["mode"], kw["tL"], kw["tU"])
+    eng.load_fragments(*tables.read_fragments(kw["frags"], chroms), chroms.sort_rank())
+    if kw["bias_path"]:
+        eng.load_bias(*tables.read_bias(kw["bias_path"], chroms))
+    eng.load_contacts(con.chr1, con.mid1, con.chr2, con.mid2, con.count)
+    eng.run_pass(collect=False)
+    eng.ctx.kernel_seconds_total(reset=True)
+    assert eng.ctx.kernel_seconds_total() == ([0.0] * 4, [0] * 4)
+    for _ in range(3):
+        eng.run_pass(collect=False)
+    last = eng.kernel_seconds()
+    sums, counts = eng.ctx.kernel_seconds_total()
+    assert counts == [3, 3, 3, 3]
+    assert all(s >= l > 0.0 for s, l in zip(sums[:3], last)) and 0.0 < sums[3] <= sums[1]
+    assert eng.ctx.kernel_seconds_total(reset=True)[1] == [3, 3, 3, 3]      # nothing is counted twice
+    assert eng.ctx.kernel_seconds_total()[1] == [0, 0, 0, 0]
+    eng.close()
+
+
 @pytest.mark.parametrize("name", ["f1_nobias", "f1_bias", "f2_all", "f6_quirk_all", "f7_pfal_all", "f8_nonfixed_hESC", "f8_nonfixed_all",
                                   "f13_all_p3", "f13_quirk_p4", "f13_hESC_p3"])
 def test_cli_writes_the_reference_files(name, tmp_path, capsys):

@@ -192,7 +192,8 @@ def test_count_homogeneous_waves_equal_the_per_lane_kernel(monkeypatch):
     """The 300-iteration class runs in waves of one (binomial, count) with table-fed iteration constants and a uniform
     renormalisation schedule (k2h_heavy / cf_swapped_uniform); FHX_K2_LEGACY=1 selects round 1's per-lane kernel, which is
     itself bit-exact against the oracle's Cephes.  Both must give the same bits: intra + inter binomials, counts beyond the
-    table cap (generic bucket), 2 passes (different totals)."""
+    table cap (generic bucket), 2 passes (different totals).  Every instantiation of the wave kernel is compared: 4 rows per lane
+    (what a C3-sized input runs), 2 (what an input below 3.2e7 rows runs: this one, by default) and 1 (FHX_K2H_ROWS)."""
     import torch
     from fithic_amd import synth
     from fithic_amd.engine import Engine
@@ -212,11 +213,13 @@ def test_count_homogeneous_waves_equal_the_per_lane_kernel(monkeypatch):
     inter = [c1, rng.integers(0, nl[c1]) * res + res // 2, c2, rng.integers(0, nl[c2]) * res + res // 2, 1 + rng.poisson(0.7, m)]
     cols = [np.concatenate([a, b]).astype(np.int32) for a, b in zip(cols, inter)]
     out = {}
-    for tag in ("uniform", "legacy"):
+    for tag in ("uniform", "rows4", "rows2", "rows1", "legacy"):
+        monkeypatch.delenv("FHX_K2_LEGACY", raising=False)
+        monkeypatch.delenv("FHX_K2H_ROWS", raising=False)
         if tag == "legacy":
             monkeypatch.setenv("FHX_K2_LEGACY", "1")
-        else:
-            monkeypatch.delenv("FHX_K2_LEGACY", raising=False)
+        elif tag.startswith("rows"):
+            monkeypatch.setenv("FHX_K2H_ROWS", tag[4:])
         eng = Engine(0)
         eng.configure(res, 20000, 2000000, n_bins=100, mapp_thres=1, mode="All")
         eng.load_fragments(*genome.fragments(), genome.sort_rank())
@@ -234,10 +237,11 @@ def test_count_homogeneous_waves_equal_the_per_lane_kernel(monkeypatch):
             eng.next_pass()
         out[tag] = res_passes
         eng.close()
-    for a, b in zip(out["uniform"], out["legacy"]):
-        for key in ("p", "q"):
-            same = (a[key].view(np.int64) == b[key].view(np.int64)) | (np.isnan(a[key]) & np.isnan(b[key]))
-            assert same.all(), (key, int((~same).sum()), float(np.nanmax(np.abs(a[key] - b[key]))))
+    for tag in ("uniform", "rows4", "rows2", "rows1"):
+        for a, b in zip(out[tag], out["legacy"]):
+            for key in ("p", "q"):
+                same = (a[key].view(np.int64) == b[key].view(np.int64)) | (np.isnan(a[key]) & np.isnan(b[key]))
+                assert same.all(), (tag, key, int((~same).sum()), float(np.nanmax(np.abs(a[key] - b[key]))))
 
 
 def _bench_rows(cfg, lengths, device):
