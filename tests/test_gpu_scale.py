@@ -188,6 +188,48 @@ def test_no_bias_table_path_equals_per_row_evaluation(monkeypatch):
     assert np.nanmin(out["table"][0]["p"]) < 1e-6
 
 
+@pytest.mark.parametrize("n_rows", [5000, 6100, 66000, 2047 * 1024 + 13, 2048 * 1024 + 1, 2049 * 1024 + 5, 5000001])
+def test_class_queues_read_as_dense_lists_do_not_depend_on_row_order(n_rows):
+    """The class kernels read the queues k2_classify wrote - one shard per workgroup: 5, 6, 65, 2047 or 2048 shards here, the last
+    ones ragged - as ONE dense list (QDense: prefix over pairs of shards, pieces from a counter or one range per wave).  p is a
+    function of the row alone and q of the multiset of p, so the same rows in reverse order must give the same bits row for row:
+    an entry dropped, read twice or taken from a neighbouring shard at any of those seams shows up as a difference; q of the whole
+    column is checked against the oracle's BH as well (p against the oracle's Cephes: the parity files)."""
+    import torch
+    from fithic_amd import synth
+    from fithic_amd.engine import Engine
+    from oracle import fithic_oracle as fo
+    res = 5000
+    genome = synth.Genome(res, lengths=synth.HG19_AUTOSOMES[20:22])
+    amp = synth.solve_amplitude(0.66, 4, 400)
+    dev = torch.device("cuda", 0)
+    parts = [synth.cis_contacts(genome, c, 4, 400, amp, device=dev) for c in range(2)]
+    cols = [torch.cat([p[k] for p in parts]).cpu().numpy() for k in range(5)]
+    assert len(cols[0]) >= n_rows
+    pick = np.sort(np.random.default_rng(n_rows).choice(len(cols[0]), n_rows, replace=False))
+    cols = [c[pick].astype(np.int32) for c in cols]
+    out = []
+    for order in (slice(None), slice(None, None, -1)):
+        eng = Engine(0)
+        eng.configure(res, 20000, 2000000, n_bins=100, mapp_thres=1, mode="intraOnly")
+        eng.load_fragments(*genome.fragments(), genome.sort_rank())
+        eng.load_bias(*genome.bias_table())
+        eng.load_contacts(*[np.ascontiguousarray(c[order]) for c in cols])
+        o = eng.run_pass()
+        v = eng.fetch()
+        classes = eng.ctx.k2_class_rows()
+        out.append((o, {k: v[k][order] for k in ("p", "q")}, classes))
+        eng.close()
+    (o, a, ca), (_, b, cb) = out
+    populated = sum(ca[k] > 0 for k in ("pseries", "cf_bcf", "cf_bd", "cf_swapped"))
+    assert ca == cb and populated >= (4 if n_rows > 1000000 else 1)      # a thin sample of the map leaves some classes empty
+    for key in ("p", "q"):
+        same = (a[key].view(np.int64) == b[key].view(np.int64)) | (np.isnan(a[key]) & np.isnan(b[key]))
+        assert same.all(), (key, int((~same).sum()))
+    q_ref = fo.benjamini_hochberg(a["p"], o.info["bh_total_tests"])
+    assert max_abs_diff(a["q"], q_ref) <= TOL
+
+
 def test_count_homogeneous_waves_equal_the_per_lane_kernel(monkeypatch):
     """The 300-iteration class runs in waves of one (binomial, count) with table-fed iteration constants and a uniform
     renormalisation schedule (k2h_heavy / cf_swapped_uniform); FHX_K2_LEGACY=1 selects round 1's per-lane kernel, which is
