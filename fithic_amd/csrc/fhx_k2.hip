@@ -382,16 +382,17 @@ __global__ __launch_bounds__(K2_THREADS) void k2_closed(K2Params P, QSpan q) {
     H.flush(P.top_hist);
 }
 
-// A class queue seen as ONE dense list across its shards (round 4).  Until then a consumer workgroup took whole shards: 2048
-// workgroups on the 1280 (or fewer) the chip holds at a time ran as 1.6 rounds, the second one on a 60 % full chip, and every
-// shard ended in a partial tile - 12 % of the class kernels' time on C3 and a third of it on a 1/8 shard of C3
-// (profiles/r04_tl_shard8.txt).  Now every consumer workgroup builds the exclusive prefix of the shard counts in LDS (2048
-// counts, one DPP scan) and takes dense pieces of that list.  The launches are sized to what the chip holds at a time
+// A class queue seen as ONE dense list across its shards (round 4).  Until then a consumer workgroup took whole shards - 2048
+// workgroups where the chip holds 1024 (converging classes) to 1536 (power series) at a time, each with whatever its shard held
+// and a partial tile at every shard's end; the timeline of a 1/8 shard of C3 (profiles/r04_tl_shard8.txt) had these kernels a
+// third over their share of the full-size run.  Now every consumer workgroup builds the exclusive prefix of the shard counts in
+// LDS (one DPP scan) and takes dense pieces of that list, and the launches are sized to what the chip holds at a time
 // (`resident_grid`).  How the pieces are handed out follows from what a returning atomic on ONE address costs here - 11 ns,
 // whoever asks (profiles/r02_s_classify_variants.txt): a counter for every 256 entries of the power-series class took twice the
 // time of the kernel it fed (0.67 against 0.35 ms, profiles/r04_p_kernel_stats.txt), so that class is cut into one contiguous
 // range per wave; the 1024-entry tiles of the converging classes and the 300-iteration tasks of k2h_heavy are few enough
 // for a counter, and each taker's FIRST piece is its own number, so that nobody queues for the counter at the start.
+// C3: converging classes 1.11 + 0.96 -> 1.02 + 0.89 ms, k2h_heavy 6.47 -> 5.69 ms (profiles/r04_z_kernel_stats.txt).
 struct QDense {
     // LDS is what limits the residency of the class kernels (16 KB of tile + 16 KB of fused histogram: four workgroups per CU),
     // so the table holds one word per PAIR of shards and the second shard of a pair is told from the first one's count
