@@ -131,8 +131,8 @@ struct QEntry {
 // atomics/s on this chip, and the two block barriers around that round trip left the kernel at 29 % of HBM and 49 % VALU busy -
 // bound by neither, profiles/r02_z_pmc.txt.)  A shard's tiles are known in advance (tile t belongs to workgroup t % grid), so a
 // region of ceil(tiles / grid) tiles per shard can never overflow; two classes share a buffer, growing towards each other
-// inside every shard's region.  Consumers walk the queue shard by shard (a consumer workgroup takes whole shards: no index
-// arithmetic over shard boundaries).
+// inside every shard's region.  The class kernels read a queue as one dense list over its shards (QDense, fhx_k2.hip: a prefix
+// of the shard counts in LDS); k2h_scatter and k2_closed take whole shards.
 constexpr int K2_MAX_SHARDS = 2048;                      // the largest k2_classify grid: 256 CUs x 8
 
 struct QSpan {
