@@ -583,6 +583,13 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE)
     H.flush(P.top_hist);
 }
 
+// Measured and dropped (round 4, profiles/r04_v_cf_split_ab.txt, profiles/ab_cf_split.sh): the same two classes as a LOOP kernel
+// (count-sorted tile, no histogram, continued fraction only: 72-86 VGPRs, 7 workgroups per CU, result through 8 B per entry) and a
+// FINISH kernel (queue order, Cephes' three logs and exp, histogram: 7 per CU).  Bit-identical, and slower: loop 0.80 + 0.65 ms,
+// finish 0.44 + 0.44 ms against 1.03 + 0.90 ms fused - compiled for 5 or 7 waves per SIMD the loop kernel takes the same time
+// (it waits on its own dependent chains and on the slowest lane of a wave, not on registers), and the finish on its own is bound
+// by the scattered 8-byte p stores that the fused kernel hides under the loop.
+
 // ---- the 300-iteration class in count-homogeneous waves -----------------------------------------------------------
 // The swapped-continued-fraction queue is counting-sorted by (binomial, contact count) so that every wave of k2h_heavy
 // holds 64 rows of ONE count: all per-iteration constants of Cephes' loop then come from a table row per iteration
