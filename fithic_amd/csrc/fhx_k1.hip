@@ -875,14 +875,28 @@ int fhx::pass_stats_nonfixed(fhx_ctx* ctx, fhx_stats* out) {
     return FHX_OK;
 }
 
+namespace fhx {
+__global__ __launch_bounds__(256) void k1_zero(unsigned long long* __restrict__ hist_cc, unsigned long long* __restrict__ hist_np, int64_t n_dist,
+                                               K1Sums* __restrict__ sums) {
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = i0; i < n_dist; i += (int64_t)gridDim.x * blockDim.x) {
+        hist_cc[i] = 0ull;
+        hist_np[i] = 0ull;
+    }
+    static_assert(sizeof(K1Sums) % sizeof(unsigned long long) == 0, "K1Sums is a block of 8-byte words");
+    if (i0 < (int64_t)(sizeof(K1Sums) / sizeof(unsigned long long))) reinterpret_cast<unsigned long long*>(sums)[i0] = 0ull;
+}
+}  // namespace fhx
+
 // K1 of the fixed-size path on the context's stream: histograms and sums stay in HBM
 int fhx::launch_k1(fhx_ctx* ctx) {
     const int64_t res = ctx->prm.resolution;
     const int64_t lo = (ctx->prm.dist_low + res - 1) / res;
     const int64_t hi = std::min<int64_t>(ctx->prm.dist_up / res, ctx->n_dist - 1);
-    FHX_HIP(hipMemsetAsync(ctx->d_hist_cc, 0, ctx->n_dist * sizeof(unsigned long long), ctx->stream));
-    FHX_HIP(hipMemsetAsync(ctx->d_hist_np, 0, ctx->n_dist * sizeof(unsigned long long), ctx->stream));
-    FHX_HIP(hipMemsetAsync(ctx->d_sums, 0, sizeof(K1Sums), ctx->stream));
+    // both histograms and the sums zeroed by ONE launch (three memsets were three fill kernels of ~4.5 us each in front of K1, and
+    // three enqueues on the host while the GPU waits for the pass to start)
+    hipLaunchKernelGGL(k1_zero, dim3(grid_for(std::max<int64_t>(ctx->n_dist, 1), 256, 256)), dim3(256), 0, ctx->stream, ctx->d_hist_cc,
+                       ctx->d_hist_np, (int64_t)ctx->n_dist, ctx->d_sums);
     FHX_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     const uint8_t* skip = ctx->skip_active ? ctx->d_skip : (const uint8_t*)nullptr;
     const long long* grow = (ctx->skip_limit != INT64_MAX) ? (const long long*)ctx->d_grow : (const long long*)nullptr;

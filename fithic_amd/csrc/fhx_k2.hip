@@ -366,8 +366,10 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE,
 }
 
 // count == 1: p = 1 - (1 - prior)^n through Cephes' log1p / expm1 (or pow): bdtrc_closed_form
-__global__ __launch_bounds__(K2_THREADS) void k2_closed(K2Params P, QSpan q) {
+// (also zeroes the counters of the class kernels that follow it on the stream - `zero_words`: instead of a memset of their own)
+__global__ __launch_bounds__(K2_THREADS) void k2_closed(K2Params P, QSpan q, unsigned long long* __restrict__ zero_words) {
     __shared__ unsigned int hist_lds[K2_HIST_BINS];
+    if (blockIdx.x == 0 && threadIdx.x < MISC_K2_WORDS) zero_words[threadIdx.x] = 0ull;
     FusedHist H;
     H.init(hist_lds, P.top_hist);
     for (int sh = blockIdx.x; sh < q.n_shards; sh += gridDim.x) {
@@ -1155,7 +1157,7 @@ int fhx_pvalues(fhx_ctx* ctx) {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, 4, 0, true, false>), cgrid, cblock, 0, ctx->stream, P, Q);
     }
     const dim3 qgrid(256 * 8), qblock(K2_THREADS);
-    hipLaunchKernelGGL(k2_closed, qgrid, qblock, 0, ctx->stream, P, Q.q[K2_CLOSED - 1]);
+    hipLaunchKernelGGL(k2_closed, qgrid, qblock, 0, ctx->stream, P, Q.q[K2_CLOSED - 1], ctx->d_misc + MISC_K2_REDO);
     // totals below 171: the kernels that carry Cephes' pow branch (a binomial without a single contact - no inter-chromosomal
     // rows - classifies every row as trivial and reaches no class kernel: it does not count)
     const bool small_n = (P.intra.small_n && P.intra.n >= 1.0) || (P.inter.small_n && P.inter.n >= 1.0);
@@ -1174,8 +1176,7 @@ int fhx_pvalues(fhx_ctx* ctx) {
     const bool legacy_heavy = getenv("FHX_K2_LEGACY") != nullptr;      // A/B and tests: the per-lane kernel of round 1
     // the handed-back rows' counter and the work counters of the class kernels (k2h_heavy's tasks, one per class queue)
     unsigned long long* n_redo = ctx->d_misc + MISC_K2_REDO;
-    unsigned long long* k2_next = ctx->d_misc + MISC_K2_NEXT;
-    FHX_HIP(hipMemsetAsync(n_redo, 0, MISC_K2_WORDS * sizeof(unsigned long long), ctx->stream));
+    unsigned long long* k2_next = ctx->d_misc + MISC_K2_NEXT;                 // both zeroed by k2_closed above
     if (legacy_heavy) {
         FHX_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
         FHX_LAUNCH_QUEUE(dev::BC_CF_SWAPPED);            // longest-running class first
