@@ -223,6 +223,34 @@ def test_bh_tile_sort_and_radix_sort_agree_with_the_oracle(ctx, n, monkeypatch):
         assert bits_equal(np.nan_to_num(got, nan=-1.0), np.nan_to_num(want, nan=-1.0)), (n, env)
 
 
+@pytest.mark.parametrize("n,shape", [(131073, "uniform"), (1000003, "skewed"), (5000011, "cluster"), (16000000, "uniform"),
+                                     (3000000, "levels"), (2000000, "equal")])
+def test_bh_large_survivor_sets_bit_exact_vs_oracle(ctx, n, shape):
+    """The eight radix passes on 1.3e5 .. 1.6e7 survivors (N = 1: every value is ranked) in the shapes real p-value columns
+    take: uniform; p = u^8 (the exponent-heavy skew of small p); a narrow cluster holding a third of the values beside a wide
+    background; 1 000 levels and one single value (ties).  q must be the oracle's bit for bit."""
+    from oracle import fithic_oracle as fo
+    rng = np.random.default_rng(n)
+    if shape == "uniform":
+        p = rng.random(n) * 1e-2
+    elif shape == "skewed":
+        p = rng.random(n) ** 8
+    elif shape == "cluster":
+        p = rng.random(n) * 1e-3
+        k = n // 3
+        p[rng.integers(0, n, k)] = 3.1e-7 * (1.0 + 1e-9 * rng.random(k))
+    elif shape == "levels":
+        p = rng.choice(rng.random(1000) * 1e-3, n)
+    else:
+        p = np.full(n, 1.25e-5)
+    p[rng.integers(0, n, 7)] = np.nan
+    p[rng.integers(0, n, 5)] = 0.0
+    want = fo.benjamini_hochberg(p, 1.0)
+    got = ctx.bh_array(p, 1.0)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert bits_equal(np.nan_to_num(got, nan=-1.0), np.nan_to_num(want, nan=-1.0)), (n, shape)
+
+
 def test_bh_values_above_one_and_few_tests_follow_the_reference(ctx):
     """myStats.benjamini_hochberg_correction takes any numbers: with N < rank a p > 1 yields min(p*N/rank, 1) < 1, and only
     p == 1.0 exactly is pinned to 1.0 (myStats.py:33-38).  Nothing saturates for small N, so every row is ranked."""
