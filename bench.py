@@ -521,7 +521,7 @@ def main():
                          "fp64_valu_issue_frac": (fp64_instr / hv_s) / fp64_issue_peak if hv_s > 0 else None,
                          "fp64_note": "loop instructions only, against the nominal 2.4 GHz; by the SQ counters (profiles/r04_z_counters.txt: 3.18e9 VALU "
                                       "wave-instructions per launch = 25.4 per row-iteration all told, 1.28e7 cycles) the launch fills 97 % of the VALU "
-                                      "issue slots (one wave instruction per 4 cycles and SIMD) at the 2.24 GHz it runs at"},
+                                      "issue slots (one wave instruction per 4 cycles and SIMD) at the 2.15-2.24 GHz the boxes run it at"},
             "kernels_ms": {"k1_classify_hist": 1e3 * worst[0], "k2_pvalue": 1e3 * worst[1], "k3_bh_sort_scan": 1e3 * worst[2]},
             "bh_rows_sorted_rank0": M.get("bh_sorted"),
             "k2_class_rows_rank0": M.get("class_rows"),
