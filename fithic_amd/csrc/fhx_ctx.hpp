@@ -424,7 +424,14 @@ inline int grid_for(int64_t n, int threads, int max_blocks = 256 * 8) {
 
 // k2_classify over n rows: workgroup b of `grid` takes tiles b, b + grid, ... and queues into shard b, so a shard receives at
 // most ceil(tiles / grid) tiles of rows, whatever their classes
-inline int k2_classify_grid(int64_t n) { return grid_for(n, K2_CL_TILE, K2_MAX_SHARDS); }
+inline int k2_classify_grid(int64_t n) {
+    static const int cap = [] {                      // FHX_CL_SHARDS: measurements (a smaller grid = fewer, longer queue shards)
+        const char* e = std::getenv("FHX_CL_SHARDS");
+        const int v = e ? std::atoi(e) : 0;
+        return v >= 1 && v <= K2_MAX_SHARDS ? v : K2_MAX_SHARDS;
+    }();
+    return grid_for(n, K2_CL_TILE, cap);
+}
 inline long long k2_shard_capacity(int64_t n) {              // entries per shard region: the rows one workgroup of k2_classify can meet
     const long long tiles = std::max<long long>(1, (n + K2_CL_TILE - 1) / K2_CL_TILE), grid = k2_classify_grid(n);
     return ((tiles + grid - 1) / grid) * (long long)K2_CL_TILE;
