@@ -282,26 +282,44 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:                     # the launcher's world is what runs; the line reports it as n_gpus
         log("[bench] --gpus %d but the launcher started %d rank(s): running with %d" % (args.gpus, world, world))
-    if torch.cuda.device_count() <= local_rank:
-        diagnostic(json_fd, args, "rank %d finds %d visible GPU(s)" % (rank, torch.cuda.device_count()), visible_devices=torch.cuda.device_count())
+    # FHX_BENCH_TRANSPORT=pipes (tests only): the ranks share the GPUs that exist (rank r on device r % visible) and the library's
+    # collectives go through fhx_comm_init_custom + sharded.PipeTransport (host-staged, what `fithic --gpus N` uses in its tests)
+    # instead of RCCL, which refuses two ranks on one GPU; torch.distributed runs on gloo.  Everything else in the N > 1 branch
+    # is the code an RCCL run executes.  The line of such a run carries "value": null: its timings say nothing about xGMI.
+    pipes = transport_kind() == "pipes"
+    n_vis = torch.cuda.device_count()
+    if n_vis <= (0 if pipes else local_rank):
+        diagnostic(json_fd, args, "rank %d finds %d visible GPU(s)" % (rank, n_vis), visible_devices=n_vis)
         raise SystemExit(2)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % n_vis if pipes else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     comm = None
     rccl = None
+    mesh = None
     if world > 1 or os.environ.get("FHX_FORCE_DIST"):      # FHX_FORCE_DIST=1: run the RCCL path with a single rank
         import datetime
         import torch.distributed as td
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # nccl == RCCL on ROCm; the long timeout covers rank 0's single-GPU verification run, during which the others wait
-        td.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(minutes=45))
-        comm = TorchComm(td, torch, device)
-        try:
-            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
-        except Exception:
-            ver = None
-        rccl = {"world": td.get_world_size(), "backend": td.get_backend(), "torch_rccl_version": ver,
-                "driver": "library communicator: fhx_comm_init + fhx_run_pass_distributed (collectives on the engine's stream)"}
+        # the long timeout covers rank 0's single-GPU verification run, during which the others wait
+        if pipes:
+            from fithic_amd import sharded
+            td.init_process_group("gloo", timeout=datetime.timedelta(minutes=45))
+            comm = TorchComm(td, torch, torch.device("cpu"))
+            mesh = sharded.socket_mesh(rank, world, os.environ.get("MASTER_PORT", "0"), comm.barrier)
+            rccl = {"world": td.get_world_size(), "backend": td.get_backend(), "torch_rccl_version": None,
+                    "transport": "pipes", "devices_shared": n_vis < world,
+                    "driver": "library communicator: fhx_comm_init_custom (sharded.PipeTransport: collectives staged through host "
+                              "memory over a socket mesh) + fhx_run_pass_distributed - NOT RCCL, timings are not xGMI timings"}
+        else:
+            td.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(minutes=45))      # nccl == RCCL on ROCm
+            comm = TorchComm(td, torch, device)
+            try:
+                ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                ver = None
+            rccl = {"world": td.get_world_size(), "backend": td.get_backend(), "torch_rccl_version": ver, "transport": "rccl",
+                    "driver": "library communicator: fhx_comm_init + fhx_run_pass_distributed (collectives on the engine's stream)"}
 
     comm_all = comm
     cfg = dict(CONFIGS[args.config])
@@ -333,7 +351,7 @@ def main():
         torch.cuda.synchronize()
         log("[rank %d] generated %d rows (%d cis on %d chromosomes, %d of %d trans) in %.1f s" %
             (rank, n_local, n_cis_local, len(mine), n_local - n_cis_local, n_trans, time.time() - t_gen))
-        eng = Engine(local_rank)
+        eng = Engine(dev_index)
         eng.configure(res, L, U, n_bins=100, mapp_thres=1, mode=cfg["mode"])
         eng.load_fragments(*genome.fragments(), genome.sort_rank())
         if not args.no_bias:
@@ -353,7 +371,13 @@ def main():
         torch.cuda.empty_cache()
 
         runner = None
-        if comm:                                                 # the library's own RCCL communicator on the engine's stream
+        if comm and pipes:                                       # tests: the caller-provided transport of `fithic --gpus N`
+            from fithic_amd import sharded
+            pt = sharded.PipeTransport(eng.ctx, rank, world, mesh)
+            eng.ctx.comm_init_custom(pt.struct, rank, world)
+            runner = NativeRunner(eng)
+            runner.transport = pt                                # the callbacks live as long as the runner
+        elif comm:                                               # the library's own RCCL communicator on the engine's stream
             import torch.distributed as td
             uid = [_capi_mod().comm_unique_id() if rank == 0 else None]
             td.broadcast_object_list(uid, src=0)                 # torch.distributed only carries the 128-byte id
@@ -529,6 +553,10 @@ def main():
         }
         if passes > 1:
             result["ms_per_pass"] = [float(v) for v in M["pass_ms"]]
+        if pipes and rccl:
+            result["value_over_pipes"], result["value"] = result["value"], None
+            result["value_note"] = ("FHX_BENCH_TRANSPORT=pipes: %d rank(s) on %d GPU(s), collectives staged through host memory - a test of "
+                                    "bench.py's N > 1 branch, not a measurement; every time in this line is labelled by rccl.transport" % (world, n_vis))
         if rccl:
             r_, w_, v_ = eng.ctx.comm_info()
             rccl.update(world_in_library=w_, library_rccl_version_code=v_)
@@ -592,7 +620,7 @@ def main():
                 for g_ in gathered[1:]:
                     total += g_.to(total.device)
                 V = measure(replicas, with_cpu_leg=True, solo=True, want_hashes=True, steps=max(2, min(args.steps, 5)), warmup=1)
-                same = (V["hashes"] == total)
+                same = (V["hashes"] == total.to(V["hashes"].device))     # (gloo gathers on the host)
                 chk = checked(V["eng"], V["genome"], V["sample"], V["info"], fixture_name)
                 n_bad_p, n_bad_q = int((~same[0]).sum()), int((~same[1]).sum())
                 names = V["genome"].names
@@ -648,6 +676,14 @@ def diagnostic(fd, args, message, **extra):
     os.write(fd, (json.dumps(line) + "\n").encode())
 
 
+def transport_kind():
+    """"rccl" (what a measurement uses) or "pipes" (FHX_BENCH_TRANSPORT=pipes: tests of the N > 1 branch on a box with one GPU)"""
+    t = os.environ.get("FHX_BENCH_TRANSPORT", "rccl")
+    if t not in ("rccl", "pipes"):
+        raise SystemExit("FHX_BENCH_TRANSPORT must be rccl or pipes")
+    return t
+
+
 def visible_gpus():
     """GPUs this process could use, without creating a HIP context here (the ranks are separate processes)."""
     try:
@@ -663,7 +699,7 @@ def self_launch(args):
     import socket
     import subprocess
     n_vis = visible_gpus()
-    if n_vis < args.gpus:
+    if n_vis < (1 if transport_kind() == "pipes" else args.gpus):        # pipes: the ranks share the GPUs there are
         diagnostic(1, args, "--gpus %d asked for, %d GPU(s) visible on this node: nothing was run" % (args.gpus, n_vis), visible_devices=n_vis)
         return 2
     s = socket.socket()

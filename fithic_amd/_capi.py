@@ -109,6 +109,7 @@ SYMBOLS = {
     "fhx_n_sorted": (ctypes.c_int64, [_P]),
     "fhx_kernel_seconds": (ctypes.c_int, [_P, _F64P, _F64P, _F64P]),
     "fhx_kernel_seconds_total": (ctypes.c_int, [_P, _F64P, _I64P, ctypes.c_int]),
+    "fhx_kernel_events_dropped": (ctypes.c_int, [_P, _I64P]),
     "fhx_k2_heavy_launch": (ctypes.c_int, [_P, _F64P, _I64P]),
     "fhx_k2_class_rows": (ctypes.c_int, [_P, _I64P]),
     "fhx_bdtrc_array": (ctypes.c_int, [_P, ctypes.c_double, _I32P, _F64P, ctypes.c_int64, _F64P]),
@@ -203,9 +204,16 @@ def build(force=False):
     """Compile the HIP kernels + host stages for gfx950 into the in-tree shared library."""
     from concurrent.futures import ThreadPoolExecutor
     shared = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc", ".def", ".h"))]
-    shared.append(os.path.join(os.path.dirname(_PKG), "include", "fithic_mi355x.h"))
+    header = os.path.join(os.path.dirname(_PKG), "include", "fithic_mi355x.h")
+    if os.path.exists(header):                         # an installed package ships csrc/ but not include/
+        shared.append(header)
     newest_shared = max(os.path.getmtime(p) for p in shared)
     compiles, link = build_commands()
+    # a library newer than every source and header is current whatever csrc/_obj holds: the objects are git- and gpurun-ignored,
+    # so a fresh checkout or the GPU box has the .so without them and must not recompile nine units to find that out
+    newest_src = max([newest_shared] + [os.path.getmtime(os.path.join(CSRC, f)) for f in SOURCES])
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest_src:
+        return LIB_PATH
     os.makedirs(OBJ_DIR, exist_ok=True)
     stale = []
     for f, cmd in zip(SOURCES, compiles):
@@ -578,6 +586,12 @@ class Context:
         n = (ctypes.c_int64 * 4)()
         self._check(self._L.fhx_kernel_seconds_total(self._h, s, n, 1 if reset else 0))
         return list(s), list(n)
+
+    def kernel_events_dropped(self):
+        """passes of K1, K2, K3, heavy launch whose events were overwritten unread since the last reset (0 = the sums are complete)"""
+        n = (ctypes.c_int64 * 4)()
+        self._check(self._L.fhx_kernel_events_dropped(self._h, n))
+        return list(n)
 
     def k2_heavy_launch(self):
         sec, rows = ctypes.c_double(0), ctypes.c_int64(0)

@@ -244,6 +244,7 @@ struct fhx_ctx {
     double ev_sum[4] = {0.0, 0.0, 0.0, 0.0};
     long long ev_count[4] = {0, 0, 0, 0};
     bool ev_folded[4] = {true, true, true, true};
+    long long ev_dropped[4] = {0, 0, 0, 0};      // pairs re-recorded before they could be read (see before_rerecord)
     std::string err;
     fhx_params prm{};
     bool have_params = false;
@@ -450,6 +451,7 @@ int ingest_device_rows(fhx_ctx* ctx, const int32_t* c1, const int32_t* m1, const
 int pass_stats_nonfixed(fhx_ctx* ctx, fhx_stats* out);
 int launch_k1(fhx_ctx* ctx);
 void fold_kernel_events(fhx_ctx* ctx);        // after a stream synchronisation only
+void before_rerecord(fhx_ctx* ctx, int group);   // in front of the hipEventRecord that starts group 0 (K1), 1 (K2 + heavy), 2 (K3)
 // fhx_k2.hip
 K2Params make_k2_params(fhx_ctx* c);
 void launch_k2_extras(fhx_ctx* ctx, const K2Params& P, int64_t n_rows, double* d_expcc, double* d_b1, double* d_b2);

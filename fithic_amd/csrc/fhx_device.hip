@@ -571,8 +571,15 @@ int fhx_kernel_seconds_total(fhx_ctx* ctx, double* sums4, int64_t* counts4, int 
         if (reset) {
             ctx->ev_sum[k] = 0.0;
             ctx->ev_count[k] = 0;
+            ctx->ev_dropped[k] = 0;
         }
     }
+    return FHX_OK;
+}
+
+int fhx_kernel_events_dropped(fhx_ctx* ctx, int64_t* dropped4) {
+    if (!ctx || !dropped4) return FHX_ERR_ARG;
+    for (int k = 0; k < 4; ++k) dropped4[k] = ctx->ev_dropped[k];
     return FHX_OK;
 }
 

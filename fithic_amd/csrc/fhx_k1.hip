@@ -819,6 +819,7 @@ int fhx::pass_stats_nonfixed(fhx_ctx* ctx, fhx_stats* out) {
     unsigned long long* counter = ctx->d_misc + 10;
     FHX_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
     FHX_HIP(hipMemsetAsync(ctx->d_sums, 0, sizeof(K1Sums), ctx->stream));
+    before_rerecord(ctx, 0);
     FHX_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     hipLaunchKernelGGL(nf_k1_classify, dim3(grid_for(ctx->n_rows, SORT_TILE, 256 * 8)), dim3(SORT_THREADS), 0, ctx->stream,
                        ctx->d_loc1, ctx->d_loc2, ctx->d_count, ctx->skip_active ? ctx->d_skip : (const uint8_t*)nullptr,
@@ -897,6 +898,7 @@ int fhx::launch_k1(fhx_ctx* ctx) {
     // three enqueues on the host while the GPU waits for the pass to start)
     hipLaunchKernelGGL(k1_zero, dim3(grid_for(std::max<int64_t>(ctx->n_dist, 1), 256, 256)), dim3(256), 0, ctx->stream, ctx->d_hist_cc,
                        ctx->d_hist_np, (int64_t)ctx->n_dist, ctx->d_sums);
+    before_rerecord(ctx, 0);
     FHX_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     const uint8_t* skip = ctx->skip_active ? ctx->d_skip : (const uint8_t*)nullptr;
     const long long* grow = (ctx->skip_limit != INT64_MAX) ? (const long long*)ctx->d_grow : (const long long*)nullptr;
@@ -937,6 +939,26 @@ void fhx::fold_kernel_events(fhx_ctx* ctx) {
         if (hipEventElapsedTime(&ms, ctx->ev[k < 3 ? 2 * k : 6], ctx->ev[k < 3 ? 2 * k + 1 : 7]) == hipSuccess) {
             ctx->ev_sum[k] += (double)ms * 1e-3;
             ctx->ev_count[k] += 1;
+        }
+        ctx->ev_folded[k] = true;
+    }
+}
+
+// Each kernel group has ONE event pair, recorded again by every pass.  A caller that runs a group twice without a statistics call
+// or fhx_kernel_seconds_total in between (pvalues() repeated, bh re-run) would overwrite a pair nobody has read: the pair is
+// read here if the stream has passed it (no waiting), else counted in ev_dropped - fhx_kernel_events_dropped tells a timing
+// harness that its mean covers fewer passes than it ran.
+void fhx::before_rerecord(fhx_ctx* ctx, int group) {
+    for (int k : {group, group == 1 ? 3 : -1}) {
+        if (k < 0 || ctx->ev_folded[k] || !ctx->ev_valid[k < 3 ? k : 1]) continue;
+        hipEvent_t a = ctx->ev[k < 3 ? 2 * k : 6], b = ctx->ev[k < 3 ? 2 * k + 1 : 7];
+        float ms = 0.f;
+        if (hipEventQuery(b) == hipSuccess && hipEventElapsedTime(&ms, a, b) == hipSuccess) {
+            ctx->ev_sum[k] += (double)ms * 1e-3;
+            ctx->ev_count[k] += 1;
+        } else {
+            (void)hipGetLastError();               // hipErrorNotReady is not an error of the pass
+            ctx->ev_dropped[k] += 1;
         }
         ctx->ev_folded[k] = true;
     }

@@ -1054,6 +1054,7 @@ int fhx_pvalues(fhx_ctx* ctx) {
         if (r2 != FHX_OK) return r2;
     }
     K2Params P = make_k2_params(ctx);
+    before_rerecord(ctx, 1);
     FHX_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
     // no bias table, fixed-size loci: evaluate a (distance, count) table instead of every row (see k2_memo_rows)
     int32_t *v_loc1 = nullptr, *v_loc2 = nullptr, *v_count = nullptr;

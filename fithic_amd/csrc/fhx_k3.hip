@@ -958,6 +958,7 @@ int fhx_bh(fhx_ctx* ctx, double n_total_tests) {
     if (!ctx->have_p) return fail(ctx, FHX_ERR_ARG, "fhx_pvalues must run first");
     if (!std::isfinite(n_total_tests)) return fail(ctx, FHX_ERR_ARG, "number of tests must be finite");
     FHX_HIP(hipSetDevice(ctx->device));
+    before_rerecord(ctx, 2);
     FHX_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
     int rc = auto_cutoff(ctx, ctx->d_p, ctx->n_rows, n_total_tests, ctx->d_misc + 6);
     if (rc != FHX_OK) return rc;
@@ -1012,8 +1013,9 @@ int fhx_sort_u64(fhx_ctx* ctx, const void* d_keys_in, int64_t n, void* d_keys_ou
     if (rc != FHX_OK) return rc;
     unsigned long long* keys[2] = {nullptr, (unsigned long long*)d_keys_out};
     unsigned int* vals[2] = {nullptr, (unsigned int*)d_perm_out};
-    FHX_HIP(hipMalloc(&keys[0], (size_t)n * sizeof(unsigned long long)));
-    FHX_HIP(hipMalloc(&vals[0], (size_t)n * sizeof(unsigned int)));
+    DeviceScratch tmp;                               // freed on every return path
+    FHX_HIP(tmp.get(&keys[0], (size_t)n * sizeof(unsigned long long)));
+    FHX_HIP(tmp.get(&vals[0], (size_t)n * sizeof(unsigned int)));
     unsigned long long* counter = ctx->d_misc + 3;
     const unsigned long long n_host = (unsigned long long)n;
     FHX_HIP(hipMemcpyAsync(counter, &n_host, sizeof(n_host), hipMemcpyHostToDevice, ctx->stream));
@@ -1024,8 +1026,6 @@ int fhx_sort_u64(fhx_ctx* ctx, const void* d_keys_in, int64_t n, void* d_keys_ou
     rc = radix_passes(ctx, keys, vals, counter, sort_blocks_for(n), SORT_PASSES * RADIX_BITS, RADIX_BITS, 1, &where);   // six passes: back in pair [1]
     if (rc != FHX_OK) return rc;
     FHX_HIP(hipStreamSynchronize(ctx->stream));
-    dev_free(keys[0]);
-    dev_free(vals[0]);
     return FHX_OK;                                   // even number of swaps: the result is in pair [1]
 }
 

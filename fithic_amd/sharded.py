@@ -110,6 +110,34 @@ def make_mesh(ctxmp, world):
     return conns
 
 
+def socket_mesh(rank, world, tag, barrier, directory=None):
+    """The same full mesh between processes that do NOT share a parent (bench.py's ranks are started by torch.distributed.run):
+    every rank listens on an AF_UNIX socket named after `tag` (the rendezvous port: unique per launch), `barrier()` (the
+    launcher's own process group) separates "all listen" from "all connect", the higher rank of a pair connects to the lower
+    and says who it is.  Returns {peer: Connection} - what PipeTransport takes."""
+    import tempfile
+    from multiprocessing.connection import Client, Listener
+    directory = directory or tempfile.gettempdir()
+    addr = lambda r: os.path.join(directory, "fhx_mesh_%s_%d.sock" % (tag, r))
+    if os.path.exists(addr(rank)):
+        os.unlink(addr(rank))
+    listener = Listener(addr(rank), family="AF_UNIX", backlog=max(world, 1))
+    conns = {}
+    try:
+        barrier()
+        for peer in range(rank):                           # lower ranks listen for me
+            c = Client(addr(peer), family="AF_UNIX")
+            c.send(rank)
+            conns[peer] = c
+        for _ in range(rank + 1, world):                   # higher ranks come to me
+            c = listener.accept()
+            conns[int(c.recv())] = c
+        barrier()
+    finally:
+        listener.close()                                   # unlinks the socket file
+    return conns
+
+
 class _Rank:
     """One rank's engine + communicator; the same object serves rank 0 (in process) and the workers' command loop."""
 

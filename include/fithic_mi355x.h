@@ -232,6 +232,10 @@ int fhx_kernel_seconds(fhx_ctx* ctx, double* k1, double* k2, double* k3);
  * waits for the stream and reads the rest; reset != 0 clears the sums afterwards.  A timing harness calls it once with reset
  * before and once after its timed passes. */
 int fhx_kernel_seconds_total(fhx_ctx* ctx, double* sums4, int64_t* counts4, int reset);
+/* Passes whose event pair was recorded again before it could be read (a kernel group run twice with no statistics call and no
+ * fhx_kernel_seconds_total in between, while the stream had not yet passed the first pair): dropped4 = K1, K2, K3, heavy launch,
+ * since the last reset.  Zero means the sums above cover every pass that ran. */
+int fhx_kernel_events_dropped(fhx_ctx* ctx, int64_t* dropped4);
 /* Duration (HIP events on the context's stream) and row count of the dominant launch of the last fhx_pvalues: the queue
  * of rows whose continued fraction runs to Cephes' 300-iteration cap (k2_queue<BC_CF_SWAPPED>). */
 int fhx_k2_heavy_launch(fhx_ctx* ctx, double* seconds, int64_t* rows);

@@ -99,3 +99,32 @@ def test_shard_of_runs_the_fullest_rank_of_an_n_way_sharding():
     whole = _plain({}, "--max-chroms", "6", "--no-cpu-baseline", "--no-parity-check", "--no-k3-stress")
     frac = out["config"]["pairs"] / whole["config"]["pairs"]
     assert abs(frac - max(loads) / sum(loads)) < 0.03
+
+
+@pytest.mark.parametrize("world, chroms", [(2, 3), (4, 5), (8, 8)])
+def test_n_ranks_branch_of_bench_runs_end_to_end_over_the_pipe_transport(world, chroms):
+    """bench.py's whole N > 1 branch with N > 1: `python bench.py --gpus N` starts N ranks that share this
+    box's GPU; torch.distributed runs on gloo and the library's collectives go through fhx_comm_init_custom + the pipe transport
+    of `fithic --gpus N` (RCCL refuses two ranks on one device).  Everything else is what an RCCL run executes: NativeRunner
+    under a world > 1 communicator, the per-rank hash tables gathered and summed, rank 0's solo verification while the others
+    wait, per_rank, predicted_ms, strong_efficiency, the weak-scaling leg - and one JSON line, whose `value` is null because
+    nothing in it measures xGMI."""
+    out = _plain({"FHX_BENCH_TRANSPORT": "pipes"}, "--gpus", str(world), "--max-chroms", str(chroms))
+    assert out["n_gpus"] == world and out["scaling"] == "strong"
+    assert out["value"] is None and out["value_over_pipes"] > 1e6 and "pipes" in out["value_note"]
+    assert out["rccl"]["transport"] == "pipes" and out["rccl"]["backend"] == "gloo" and out["rccl"]["world"] == world
+    assert out["rccl"]["world_in_library"] == world
+    pc = out["parity_check"]
+    assert pc["ok"] and pc["sharded_equals_single_gpu"] and pc["ranks"] == world and pc["chromosomes_hashed"] == chroms
+    assert pc["chromosomes_p_differ"] == [] and pc["chromosomes_q_differ"] == [] and pc["global_stats_equal"] and pc["fit_scalars_equal"]
+    assert pc["rows"] == out["config"]["pairs"] and pc["max_dp"] <= 1e-10 and pc["max_dq"] == 0.0
+    ranks = out["per_rank"]
+    assert len(ranks) == world and [r["rank"] for r in ranks] == list(range(world))
+    assert sum(r["rows"] for r in ranks) == out["config"]["pairs"]
+    assert sum(1 for r in ranks if r["rows"] > 0) == min(world, chroms)        # a chromosome's rows live on one rank
+    assert all(r["k1_ms"] > 0 and r["k2_ms"] > 0 for r in ranks if r["rows"] > 0)
+    assert len(out["stage_ms"]) == 5 and out["single_gpu_ms_per_step"] > 0 and out["strong_efficiency"] > 0
+    assert out["predicted_ms"] is None or out["predicted_ms"]["ms"] > 0
+    w = out["weak_scaling"]
+    # (every replica of the genome draws its own rows: N x the pairs up to sampling noise)
+    assert w["replicas"] == world and abs(w["pairs"] / (world * out["config"]["pairs"]) - 1.0) < 0.01 and w["value"] > 1e6

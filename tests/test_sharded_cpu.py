@@ -132,3 +132,46 @@ def test_a_rank_that_dies_is_reported():
         eng._all("pvalues")
     assert "rank 1" in str(e.value) and eng.broken
     eng.close()
+
+
+_MESH_RANK = r"""
+import os, sys
+import numpy as np
+import torch.distributed as td
+sys.path.insert(0, %r)
+from fithic_amd import sharded
+td.init_process_group("gloo")
+rank, world = td.get_rank(), td.get_world_size()
+mesh = sharded.socket_mesh(rank, world, os.environ["MASTER_PORT"], td.barrier)
+
+class Bare(sharded.PipeTransport):
+    def __init__(self):
+        self.rank, self.world, self.conns = rank, world, mesh
+
+got = Bare()._exchange([np.full(2_000_000 + r, (rank * 16 + r) %% 251, np.uint8) for r in range(world)])
+assert [(int(g[0]), len(g)) for g in got] == [((src * 16 + rank) %% 251, 2_000_000 + rank) for src in range(world)], rank
+td.barrier()
+sys.stdout.write("mesh-ok-%%d\n" %% rank)
+"""
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_socket_mesh_between_ranks_of_a_launcher(world, tmp_path):
+    """bench.py under FHX_BENCH_TRANSPORT=pipes: its ranks are started by torch.distributed.run and share no parent that could hand
+    them pipes; the mesh is made of AF_UNIX sockets named after the rendezvous port, and PipeTransport runs over it unchanged."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "mesh_rank.py"
+    script.write_text(_MESH_RANK % root)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    for k in range(world):                                   # (the ranks share one stdout: lines may interleave)
+        assert r.stdout.count("mesh-ok-%d" % k) == 1, r.stdout
