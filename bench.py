@@ -459,10 +459,14 @@ def main():
         except Exception:                                        # noqa: BLE001 - informational only
             bh_sorted = None
         try:
+            sort_stats = eng.ctx.bh_sort_stats() if bh_sorted else None     # how K3 sorted them (passes, repair, fallback)
+        except Exception:                                        # noqa: BLE001 - informational only
+            sort_stats = None
+        try:
             class_rows = eng.ctx.k2_class_rows()                 # rows per branch class of the last K2 (what each class kernel worked on)
         except Exception:                                        # noqa: BLE001 - informational only
             class_rows = None
-        return dict(class_rows=class_rows, steps=steps, genome=genome, eng=eng, sample=sample, elapsed=elapsed, n_total=n_total, n_local=n_local, k_all=k_all, bh_sorted=bh_sorted,
+        return dict(sort_stats=sort_stats, class_rows=class_rows, steps=steps, genome=genome, eng=eng, sample=sample, elapsed=elapsed, n_total=n_total, n_local=n_local, k_all=k_all, bh_sorted=bh_sorted,
                     stage_ms=stage_ms, pass_ms=pass_ms / max(steps, 1), info=info, n_trans=n_trans, replicas=replicas,
                     hashes=hashes, hashed_pass1=want_hashes and passes > 1)
 
@@ -548,6 +552,7 @@ def main():
                                       "issue slots (one wave instruction per 4 cycles and SIMD) at the 2.15-2.24 GHz the boxes run it at"},
             "kernels_ms": {"k1_classify_hist": 1e3 * worst[0], "k2_pvalue": 1e3 * worst[1], "k3_bh_sort_scan": 1e3 * worst[2]},
             "bh_rows_sorted_rank0": M.get("bh_sorted"),
+            "bh_sort_rank0": M.get("sort_stats"),
             "k2_class_rows_rank0": M.get("class_rows"),
             "whole_pass_hbm_frac": (ALGO_BYTES_K1 + ALGO_BYTES_K2 + ALGO_BYTES_K3) * value / (world * HBM_PEAK_GBS * 1e9),
         }

@@ -107,6 +107,7 @@ SYMBOLS = {
     "fhx_get_array": (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_int64, _I64P]),
     "fhx_device_ptr": (_P, [_P, ctypes.c_int]),
     "fhx_n_sorted": (ctypes.c_int64, [_P]),
+    "fhx_bh_sort_stats": (ctypes.c_int, [_P, _I64P]),
     "fhx_kernel_seconds": (ctypes.c_int, [_P, _F64P, _F64P, _F64P]),
     "fhx_kernel_seconds_total": (ctypes.c_int, [_P, _F64P, _I64P, ctypes.c_int]),
     "fhx_kernel_events_dropped": (ctypes.c_int, [_P, _I64P]),
@@ -586,6 +587,13 @@ class Context:
         n = (ctypes.c_int64 * 4)()
         self._check(self._L.fhx_kernel_seconds_total(self._h, s, n, 1 if reset else 0))
         return list(s), list(n)
+
+    def bh_sort_stats(self):
+        """how the last BH call sorted its survivors (include/fithic_mi355x.h: fhx_bh_sort_stats)"""
+        n = (ctypes.c_int64 * 8)()
+        self._check(self._L.fhx_bh_sort_stats(self._h, n))
+        return dict(zip(("passes", "low_bit", "beyond_lists", "inversions", "runs_by_thread", "long_run_inversions", "segments", "segment_keys"),
+                        [int(v) for v in n]))
 
     def kernel_events_dropped(self):
         """passes of K1, K2, K3, heavy launch whose events were overwritten unread since the last reset (0 = the sums are complete)"""

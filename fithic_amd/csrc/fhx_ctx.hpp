@@ -21,6 +21,7 @@
 #include <map>
 #include <condition_variable>
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -334,6 +335,11 @@ struct fhx_ctx {
     double* d_tile_max = nullptr;
     int sorted_buf = 0;
     int64_t n_sorted = -1;
+    unsigned int* h_k3 = nullptr;                     // pinned: [0..1] survivors by the histogram, [8..15] the sort repair's verdict
+    hipEvent_t ev_k3 = nullptr;                       // the copy into h_k3
+    bool k3_n_is_bound = false;                       // the survivors' number compact_pvalues returned is an upper bound
+    bool k3_kept_by_hist = false;                     // auto_cutoff has put the survivors' number on its way into h_k3[0..1]
+    int64_t sort_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the last large sort of K3 (fhx_bh_sort_stats)
     std::vector<int64_t> fdr_counts;
     fhx::DistState* dist = nullptr;                 // communicator + exchange buffers of sharded runs (fhx_dist.inc)
     bool dist_ndist_agreed = false;                   // sharded runs: the histogram length was made equal on all ranks

@@ -71,6 +71,8 @@ void fhx_destroy(fhx_ctx* ctx) {
         dev_free(ctx->d_fit_tables);            // d_lut, d_lbeta_*, d_invb_*, d_table_x / y point into it
         if (ctx->h_fit_stage) (void)hipHostFree(ctx->h_fit_stage);
         if (ctx->ev_fit_copy) (void)hipEventDestroy(ctx->ev_fit_copy);
+        if (ctx->ev_k3) (void)hipEventDestroy(ctx->ev_k3);
+        if (ctx->h_k3) (void)hipHostFree(ctx->h_k3);
         dev_free(ctx->d_p);
         dev_free(ctx->d_q);
         dev_free(ctx->d_work);

@@ -57,8 +57,9 @@ __host__ __device__ inline bool bin_saturates(int b, unsigned long long cum_incl
 }
 
 __global__ __launch_bounds__(1024) void k3_cutoff(const unsigned long long* __restrict__ hist, double n_tests,
-                                                  unsigned long long* __restrict__ cutoff_key) {
+                                                  unsigned long long* __restrict__ cutoff_key, unsigned long long* __restrict__ n_below) {
     __shared__ unsigned long long part[1024];
+    __shared__ unsigned long long below;
     __shared__ unsigned int best;
     constexpr int PER = TOP_BINS / 1024;
     unsigned long long local[PER];
@@ -69,7 +70,10 @@ __global__ __launch_bounds__(1024) void k3_cutoff(const unsigned long long* __re
     }
     // exclusive prefix of the 1024 partial sums: wave scan + the 16 wave totals (one thread walking all 1024 took 12 of this
     // kernel's 16 us - a fixed cost of every pass)
-    if (threadIdx.x == 0) best = TOP_BINS;
+    if (threadIdx.x == 0) {
+        best = TOP_BINS;
+        below = 0ull;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long incl = sum;
 #pragma unroll
@@ -81,12 +85,24 @@ __global__ __launch_bounds__(1024) void k3_cutoff(const unsigned long long* __re
     __syncthreads();
     unsigned long long cum = incl - sum;
     for (int w = 0; w < wave; ++w) cum += part[w];
+    const unsigned long long cum0 = cum;
     for (int k = 0; k < PER; ++k) {
         cum += local[k];
         const int b = threadIdx.x * PER + k;
         if (local[k] && bin_saturates(b, cum, n_tests)) atomicMin(&best, (unsigned int)b);
     }
     __syncthreads();
+    // the values below the cutoff key = the counts of the bins below the cutoff bin (all counted values when nothing saturates):
+    // what k3_compact will keep, known before it has run (the host sizes the sort while the compaction is still under way)
+    if (n_below) {
+        unsigned long long mine = 0;
+        cum = cum0;
+        for (int k = 0; k < PER; ++k)
+            if ((unsigned int)(threadIdx.x * PER + k) < best) mine += local[k];
+        if (mine) atomicAdd(&below, mine);
+        __syncthreads();
+        if (threadIdx.x == 0) *n_below = below;
+    }
     if (threadIdx.x == 0)
         *cutoff_key = (best < (unsigned int)TOP_BINS) ? ((unsigned long long)best << TOP_SHIFT) : KEY_KEEP_ALL;
 }
@@ -371,6 +387,8 @@ __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(WP
         __syncthreads();
     }
 }
+
+#include "fhx_onesweep.inc"
 
 // ---- small survivor sets: two launches instead of eighteen ---------------------------------------------------------------
 // On Hi-C data whose counts follow the model closely (C3-synth: 77 k of 1.5e8 rows below the cutoff) and on every shard of a
@@ -699,12 +717,233 @@ int radix_sort_pairs(fhx_ctx* ctx, unsigned long long* keys[2], unsigned int* va
     return radix_passes(ctx, keys, vals, counter, sort_blocks_for(n_hint), passes * RADIX_BITS, RADIX_BITS, 0, result_buf);
 }
 
+// ---- one-sweep sort of the top bits + repair of the rest (fhx_onesweep.inc) ---------------------------------------------------
+// ctrl: os_ctrl_words(n, 8) 32-bit words of device scratch.  key_hi: 62 for the engine's own p (bdtrc returns values in [0, 1]:
+// bits 62 and 63 of the pattern are clear), 64 for a caller's array (fhx_bh_array takes whatever is >= 0: 2.0, +inf).
+struct OsPlan {
+    int passes, lo;
+};
+static size_t os_repair_offset(int64_t n) { return (os_ctrl_words(n, OS_MAX_PASSES) + 3) / 4 * 4; }      // words; 16-byte aligned
+static size_t os_scratch_bytes(int64_t n) {          // control block + descriptors of eight passes + the repair's lists
+    return (os_repair_offset(n) + os_repair_words(n)) * sizeof(unsigned int);
+}
+static OsPlan os_plan(int64_t n, int key_hi) {
+    const char* e = std::getenv("FHX_OS_PASSES");    // measurements and tests (8 = all bits, nothing to repair)
+    const int fv = e ? std::atoi(e) : 0;
+    const int forced = (fv >= 1 && fv <= OS_MAX_PASSES) ? fv : 0;
+    int passes = forced ? forced : (n <= 250000000ll ? 5 : 6);
+    passes = std::min(passes, (key_hi + OS_BITS - 1) / OS_BITS);
+    return OsPlan{passes, std::max(0, key_hi - passes * OS_BITS)};
+}
+
+static int os_run_passes(fhx_ctx* ctx, unsigned long long* keys[2], unsigned int* vals[2], const unsigned long long* counter, int64_t n,
+                         OsPlan plan, unsigned int* ctrl, int* src_io, bool n_into_slot = false) {
+    const int tiles = (int)((n + OS_TILE - 1) / OS_TILE);
+    FHX_HIP(hipMemsetAsync(ctrl, 0, os_ctrl_words(n, plan.passes) * sizeof(unsigned int), ctx->stream));
+    if (n_into_slot) {                                     // a segment: its key count lives in the control block
+        unsigned long long* slot = reinterpret_cast<unsigned long long*>(ctrl + OSC_SEG_N);
+        hipLaunchKernelGGL(os_set_n, dim3(1), dim3(1), 0, ctx->stream, slot, (unsigned long long)n);
+        counter = slot;
+    }
+    const int hgrid = std::max(1, std::min(tiles / 2, 1024));
+    switch (plan.passes) {
+#define FHX_OS_HIST(P)                                                                                                             \
+    case P:                                                                                                                        \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(os_hist<P>), dim3(hgrid), dim3(OS_THREADS), 0, ctx->stream, (const unsigned long long*)keys[*src_io], \
+                           counter, plan.lo, ctrl + OSC_HIST);                                                                     \
+        break
+        FHX_OS_HIST(1); FHX_OS_HIST(2); FHX_OS_HIST(3); FHX_OS_HIST(4); FHX_OS_HIST(5); FHX_OS_HIST(6); FHX_OS_HIST(7); FHX_OS_HIST(8);
+#undef FHX_OS_HIST
+    }
+    int src = *src_io;
+    const char* we = std::getenv("FHX_OS_WPE");            // waves per SIMD the scatter is compiled for (measurements): 4 or 6
+    const int wpe = we ? std::atoi(we) : 4;
+    const char* le = std::getenv("FHX_OS_LB");             // descriptors per look-back step: 8 (default), 16, 32
+    const int lb = le ? std::atoi(le) : 8;
+    const bool persist = std::getenv("FHX_OS_PERSIST") != nullptr;      // resident workgroups taking tiles in a loop (measured slower)
+    for (int p = 0; p < plan.passes; ++p) {
+#define FHX_OS_SCATTER(W, P, L)                                                                                                       \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(os_scatter<W, P, L>), dim3(P ? std::min(tiles, 256 * (W / 2)) : tiles), dim3(OS_THREADS), 0, ctx->stream, (const unsigned long long*)keys[src], \
+                       (const unsigned int*)vals[src], keys[1 - src], vals[1 - src], counter, plan.lo + p * OS_BITS,                \
+                       (const unsigned int*)(ctrl + OSC_HIST + p * OS_RADIX), ctrl + OSC_DESC + (size_t)p * tiles * OS_RADIX,        \
+                       ctrl + OSC_TICKET + p, ctrl + OSC_COPY_PASSES)
+        if (wpe == 6) FHX_OS_SCATTER(6, false, 8);
+        else if (persist) FHX_OS_SCATTER(4, true, 8);
+        else if (lb == 8) FHX_OS_SCATTER(4, false, 8);
+        else if (lb == 32) FHX_OS_SCATTER(4, false, 32);
+        else FHX_OS_SCATTER(4, false, 16);
+#undef FHX_OS_SCATTER
+        src = 1 - src;
+    }
+    FHX_HIP(hipGetLastError());
+    *src_io = src;
+    return FHX_OK;
+}
+
+// One-sweep passes + repair, in two halves: onesweep_launch enqueues the passes, the repair and a copy of the repair's verdict
+// into pinned memory; onesweep_finish waits for that copy alone (an event, not the stream) and - rarely - sorts what the repair
+// could not reach.  Between the two a caller may enqueue whatever only READS the sorted keys (the BH scan): it runs while the
+// host looks at the verdict, instead of the GPU idling through a host round trip; *moved tells it to run that work again.
+struct OsPending {
+    bool active = false;
+    OsPlan plan{0, 0};
+    int src = 0, key_hi = 62;
+    int64_t n = 0;
+    unsigned long long* keys[2] = {nullptr, nullptr};
+    unsigned int* vals[2] = {nullptr, nullptr};
+    const unsigned long long* counter = nullptr;
+    unsigned int* ctrl = nullptr;
+};
+
+static int ensure_k3_host(fhx_ctx* ctx) {
+    if (!ctx->h_k3) FHX_HIP(hipHostMalloc((void**)&ctx->h_k3, (20 + RP_SEG_CAP * 4 + 4) * sizeof(unsigned int), hipHostMallocDefault));
+    if (!ctx->ev_k3) FHX_HIP(hipEventCreateWithFlags(&ctx->ev_k3, hipEventDisableTiming));
+    return FHX_OK;
+}
+
+static int onesweep_launch(fhx_ctx* ctx, unsigned long long* keys[2], unsigned int* vals[2], const unsigned long long* counter, int64_t n,
+                           int key_hi, unsigned int* ctrl, OsPending* pend) {
+    int rc = ensure_k3_host(ctx);
+    if (rc != FHX_OK) return rc;
+    key_hi = std::min(64, key_hi + 1);                     // os_spread moves every exponent up by 52: p <= 1 reaches bit 62
+    pend->plan = os_plan(n, key_hi);
+    pend->src = 0;
+    pend->key_hi = key_hi;
+    pend->n = n;
+    pend->counter = counter;
+    pend->ctrl = ctrl;
+    for (int b = 0; b < 2; ++b) {
+        pend->keys[b] = keys[b];
+        pend->vals[b] = vals[b];
+    }
+    rc = os_run_passes(ctx, keys, vals, counter, n, pend->plan, ctrl, &pend->src);
+    if (rc != FHX_OK) return rc;
+    for (int k = 0; k < 8; ++k) ctx->h_k3[8 + k] = 0u;
+    if (pend->plan.lo > 0) {
+        unsigned int* rp = ctrl + os_repair_offset(n);
+        const unsigned int region_cap = (unsigned int)os_region_cap(n);
+        uint2* d_runs = reinterpret_cast<uint2*>(rp);
+        OsFindCounts* d_counts = reinterpret_cast<OsFindCounts*>(rp + (size_t)region_cap * RP_FIND_WGS * 2);
+        unsigned int* d_longs = reinterpret_cast<unsigned int*>(d_counts + RP_FIND_WGS);
+        long long* d_segs = reinterpret_cast<long long*>(d_longs + RP_LONG_CAP);
+        unsigned long long* k = keys[pend->src];
+        unsigned int* v = vals[pend->src];
+        static_assert(RP_FIND_WGS == RP_FIND_GRID, "one count slot and one region per workgroup");
+        hipLaunchKernelGGL(os_find_runs, dim3(RP_FIND_GRID), dim3(256), 0, ctx->stream, (const unsigned long long*)k, counter, pend->plan.lo, ctrl,
+                           d_runs, region_cap, d_counts, d_longs);
+        hipLaunchKernelGGL(os_tally, dim3(1), dim3(RP_FIND_GRID), 0, ctx->stream, (const OsFindCounts*)d_counts, ctrl);
+        hipLaunchKernelGGL(os_fix_runs, dim3(RP_FIND_GRID), dim3(256), 0, ctx->stream, k, v, (const uint2*)d_runs, region_cap,
+                           (const OsFindCounts*)d_counts);
+        hipLaunchKernelGGL(os_long_runs, dim3(64), dim3(512), 0, ctx->stream, (const unsigned long long*)k, counter, pend->plan.lo, ctrl,
+                           (const unsigned int*)d_longs, d_segs);
+        hipLaunchKernelGGL(os_fix_long, dim3(64), dim3(512), 0, ctx->stream, k, v, (const unsigned int*)ctrl, (const long long*)d_segs);
+        FHX_HIP(hipGetLastError());
+        FHX_HIP(hipMemcpyAsync(ctx->h_k3 + 8, ctrl + OSC_FALLBACK, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+        // (n may be the histogram's upper bound, see compact_pvalues: the exact count comes back with the verdict)
+        FHX_HIP(hipMemcpyAsync(ctx->h_k3 + 16, counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        FHX_HIP(hipMemcpyAsync(ctx->h_k3 + 20, d_segs, RP_SEG_CAP * 2 * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+        FHX_HIP(hipEventRecord(ctx->ev_k3, ctx->stream));
+    }
+    pend->active = true;
+    return FHX_OK;
+}
+
+static int onesweep_finish(fhx_ctx* ctx, OsPending* pend, bool* moved) {
+    *moved = false;
+    if (!pend->active) return FHX_OK;
+    pend->active = false;
+    const OsPlan plan = pend->plan;
+    int64_t n = pend->n;                                   // what the launch was sized for: the exact count or an upper bound
+    const int key_hi = pend->key_hi;
+    unsigned int* ctrl = pend->ctrl;
+    int src = pend->src;
+    unsigned int st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t seg_count = 0, seg_keys = 0;
+    bool everything = false;
+    int rc = FHX_OK;
+    if (plan.lo > 0) {
+        FHX_HIP(hipEventSynchronize(ctx->ev_k3));
+        for (int k = 0; k < 8; ++k) st[k] = ctx->h_k3[8 + k];
+        const int64_t n_exact = (int64_t)*reinterpret_cast<volatile unsigned long long*>(ctx->h_k3 + 16);
+        if (n_exact > n) return fail(ctx, FHX_ERR_HIP, "internal: more keys were compacted than the histogram counted");
+        n = n_exact;
+        if (std::getenv("FHX_OS_FORCE_FALLBACK")) st[0] |= 4u;      // tests
+        const unsigned int n_segs = st[OSC_SEGMENTS - OSC_FALLBACK];
+        if (st[0]) everything = true;                      // a list overflowed, a run's ends were out of reach, or forced
+        else if (n_segs) {
+            struct OsSegment {
+                int64_t s, e;
+            };
+            std::vector<OsSegment> segs;
+            const long long* hs = reinterpret_cast<const long long*>(ctx->h_k3 + 20);
+            for (unsigned int k = 0; k < n_segs && k < (unsigned int)RP_SEG_CAP; ++k) {
+                const OsSegment g{hs[2 * k], hs[2 * k + 1]};
+                if (g.s < 0 || g.e > n || g.e <= g.s) return fail(ctx, FHX_ERR_HIP, "internal: a long run's bounds are off");
+                seg_keys += g.e - g.s;
+                ++seg_count;
+                if (g.e - g.s > RP_WG_RUN) segs.push_back(g);      // (the shorter ones are sorted already: os_fix_long)
+            }
+            if (seg_keys > n / 2) everything = true;       // no longer an exception: sort all bits in one go
+            for (size_t i = 0; i < segs.size() && !everything; ++i) {
+                const OsSegment& g = segs[i];
+                if (g.e - g.s < 2) continue;
+                unsigned long long* kk[2] = {pend->keys[src] + g.s, pend->keys[1 - src] + g.s};
+                unsigned int* vv[2] = {pend->vals[src] + g.s, pend->vals[1 - src] + g.s};
+                const int bits = plan.lo;
+                const int64_t m = g.e - g.s;
+                int where = 0;
+                if (m <= KS_MAX_KEYS) {                    // tiles sorted in LDS + merge by rank (whole keys: the run's top bits are equal anyway)
+                    unsigned long long* slot = reinterpret_cast<unsigned long long*>(ctrl + OSC_SEG_N);
+                    hipLaunchKernelGGL(os_set_n, dim3(1), dim3(1), 0, ctx->stream, slot, (unsigned long long)m);
+                    const int tiles = (int)((m + KS_TILE - 1) / KS_TILE);
+                    hipLaunchKernelGGL(ks_tile_sort, dim3(tiles), dim3(KS_THREADS), 0, ctx->stream, (const unsigned long long*)kk[0],
+                                       (const unsigned int*)vv[0], (const unsigned long long*)slot, kk[1], vv[1]);
+                    if (tiles > 1)
+                        hipLaunchKernelGGL(ks_merge_tiles, dim3(grid_for(m, 256)), dim3(256), 0, ctx->stream, (const unsigned long long*)kk[1],
+                                           (const unsigned int*)vv[1], (const unsigned long long*)slot, kk[0], vv[0]);
+                    FHX_HIP(hipGetLastError());
+                    where = tiles > 1 ? 0 : 1;
+                } else {
+                    rc = os_run_passes(ctx, kk, vv, nullptr, m, OsPlan{(bits + OS_BITS - 1) / OS_BITS, 0}, ctrl, &where, true);
+                    if (rc != FHX_OK) return rc;
+                }
+                if (where == 1) {                          // an odd number of passes: back into the array's own buffer
+                    FHX_HIP(hipMemcpyAsync(kk[0], kk[1], (size_t)m * sizeof(unsigned long long), hipMemcpyDeviceToDevice, ctx->stream));
+                    FHX_HIP(hipMemcpyAsync(vv[0], vv[1], (size_t)m * sizeof(unsigned int), hipMemcpyDeviceToDevice, ctx->stream));
+                }
+                *moved = true;
+            }
+        }
+    }
+    ctx->sort_stats[0] = plan.passes;
+    ctx->sort_stats[1] = plan.lo;
+    ctx->sort_stats[2] = (int64_t)st[0] | (everything ? 8 : 0);      // bit 3: every bit of every key was sorted after all
+    ctx->sort_stats[3] = st[OSC_INVERSIONS - OSC_FALLBACK];
+    ctx->sort_stats[4] = st[OSC_SMALL_RUNS - OSC_FALLBACK];
+    ctx->sort_stats[5] = st[OSC_LONG_RUNS - OSC_FALLBACK];
+    if (std::getenv("FHX_OS_DEBUG"))
+        std::fprintf(stderr, "[onesweep] %lld keys, %d passes from bit %d: look-back steps of digit 0 per tile and pass %.2f, inversions %u\n", (long long)n,
+                     plan.passes, plan.lo, (double)st[OSC_LB_STEPS - OSC_FALLBACK] / std::max<double>(1.0, (double)plan.passes * ((n + OS_TILE - 1) / OS_TILE)),
+                     st[OSC_INVERSIONS - OSC_FALLBACK]);
+    ctx->sort_stats[6] = seg_count;
+    ctx->sort_stats[7] = seg_keys;
+    if (everything) {
+        // whatever order the keys are in now is as good a start as any (eight passes: the result is in the same buffer pair)
+        rc = os_run_passes(ctx, pend->keys, pend->vals, pend->counter, pend->n, OsPlan{(key_hi + OS_BITS - 1) / OS_BITS, 0}, ctrl, &src);
+        if (rc != FHX_OK) return rc;
+        *moved = true;
+        if (src != pend->src) return fail(ctx, FHX_ERR_HIP, "internal: the full sort left the keys in the other buffer pair");
+    }
+    return FHX_OK;
+}
+
 // launches for the other translation units (the sharded schedule, the heavy class's bucket sort, the FDR counts)
 void launch_rs_scan(fhx_ctx* ctx, int nblk) {
     hipLaunchKernelGGL(rs_scan, dim3(RADIX), dim3((nblk + 63) / 64 * 64), 0, ctx->stream, ctx->d_block_hist, ctx->d_digit_total, nblk);
 }
 void launch_k3_cutoff(fhx_ctx* ctx, double n_tests, unsigned long long* d_cutoff) {
-    hipLaunchKernelGGL(k3_cutoff, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long*)ctx->d_top_hist, n_tests, d_cutoff);
+    hipLaunchKernelGGL(k3_cutoff, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long*)ctx->d_top_hist, n_tests, d_cutoff,
+                       (unsigned long long*)nullptr);
 }
 void launch_bh_tile_max(fhx_ctx* ctx, int tiles, const unsigned long long* keys, const unsigned long long* n_ptr, int64_t n_fixed,
                         double n_tests, double rank0, double* tile_max) {
@@ -753,9 +992,18 @@ static int auto_cutoff(fhx_ctx* ctx, const double* d_p, int64_t n, double n_tota
         FHX_HIP(hipMemsetAsync(ctx->d_top_hist, 0, TOP_BINS * sizeof(unsigned long long), ctx->stream));
         hipLaunchKernelGGL(k3_top_hist, dim3(grid_for((n + 1) / 2, 512, 256 * 4)), dim3(512), 0, ctx->stream, d_p, n, ctx->d_top_hist);
     }
+    // the survivors' number by the histogram (d_misc[8]) goes to pinned memory right behind the cutoff: compact_pvalues waits for
+    // that copy alone, while the compaction it has already enqueued runs
+    {
+        const int rc = ensure_k3_host(ctx);
+        if (rc != FHX_OK) return rc;
+    }
     hipLaunchKernelGGL(k3_cutoff, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long*)ctx->d_top_hist, n_total_tests,
-                       d_cutoff);
+                       d_cutoff, ctx->d_misc + 8);
     FHX_HIP(hipGetLastError());
+    FHX_HIP(hipMemcpyAsync(ctx->h_k3, ctx->d_misc + 8, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    FHX_HIP(hipEventRecord(ctx->ev_k3, ctx->stream));
+    ctx->k3_kept_by_hist = true;
     return FHX_OK;
 }
 
@@ -769,19 +1017,35 @@ static int compact_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned 
     static const int k3_cap = std::getenv("FHX_K3_GRID") ? std::atoi(std::getenv("FHX_K3_GRID")) : (1 << 30);
     hipLaunchKernelGGL(k3_compact, dim3(grid_for(n, SORT_TILE, k3_cap)), dim3(SORT_THREADS), 0, ctx->stream, d_p, n,
                        keys[0], vals[0], d_q, counter, d_cutoff);
-    // how many keys survived decides the shape of the sort (one 8-byte read back: ~20 us against ~190 us of fixed cost saved)
+    // how many keys survived decides the shape of the sort.  When the cutoff came from this GPU's own histogram (auto_cutoff) the
+    // number is already on its way - the histogram's bins below the cutoff bin hold exactly the rows kept here - and the host goes
+    // on to enqueue the sort while the compaction runs; otherwise (sharded runs: the histogram is the all-reduced one) the counter
+    // is read back behind the compaction.
     unsigned long long n_kept = 0;
-    FHX_HIP(hipMemcpyAsync(&n_kept, counter, sizeof(n_kept), hipMemcpyDeviceToHost, ctx->stream));
-    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->k3_n_is_bound = false;
+    if (ctx->k3_kept_by_hist) {
+        // (an UPPER BOUND when the histogram is K2's: it counts a wave's values in the bin of the smallest, fhx_k2.hip FusedHist -
+        // every launch below takes its true count from the device counter and sizes its grid for the bound)
+        ctx->k3_kept_by_hist = false;
+        FHX_HIP(hipEventSynchronize(ctx->ev_k3));
+        const unsigned long long by_hist = *reinterpret_cast<volatile unsigned long long*>(ctx->h_k3);
+        n_kept = std::min<unsigned long long>(by_hist, (unsigned long long)n);
+        ctx->k3_n_is_bound = true;
+    } else {
+        FHX_HIP(hipMemcpyAsync(&n_kept, counter, sizeof(n_kept), hipMemcpyDeviceToHost, ctx->stream));
+        FHX_HIP(hipStreamSynchronize(ctx->stream));
+    }
     *n_kept_out = (int64_t)n_kept;
     return FHX_OK;
 }
 
-// the six radix passes over the n_kept compacted keys; the result is in buffer pair *sorted_buf
+// sort of the n_kept compacted keys; the result is in buffer pair *sorted_buf.  key_hi: the bits that can be set (62 / 64, see
+// onesweep_sort); ctrl: device scratch of os_ctrl_words(n_kept, 8) words, or nullptr (then the three-launch passes run)
 static int sort_kept(fhx_ctx* ctx, unsigned long long* keys[2], unsigned int* vals[2], const unsigned long long* counter, int64_t n_kept,
-                     int* sorted_buf) {
+                     int* sorted_buf, int key_hi, unsigned int* ctrl, OsPending* defer = nullptr) {
     const char* small_env = std::getenv("FHX_K3_SMALL");          // "0": the radix passes whatever the size (A/B runs, tests)
     const bool small_off = small_env && std::atoi(small_env) == 0;
+    for (int k = 0; k < 8; ++k) ctx->sort_stats[k] = 0;
     if (n_kept <= KS_MAX_KEYS && !small_off) {                     // tile sort in LDS + merge by rank: two launches (see ks_tile_sort)
         const int tiles = (int)std::max<int64_t>(1, (n_kept + KS_TILE - 1) / KS_TILE);
         if (n_kept > 0) {
@@ -795,21 +1059,39 @@ static int sort_kept(fhx_ctx* ctx, unsigned long long* keys[2], unsigned int* va
         *sorted_buf = (n_kept > 0 && tiles == 1) ? 1 : 0;
         return FHX_OK;
     }
-    // p < 1 means the IEEE exponent field is <= 1022: bits 62 and 63 are always clear, 62 bits to sort.  FHX_RS_BITS: digit width
-    // of these passes (measurements)
+    const char* se = std::getenv("FHX_K3_SORT");                  // "legacy": round 4's count / scan / scatter passes (A/B runs)
+    const bool legacy = se && std::strcmp(se, "legacy") == 0;
+    if (ctrl && !legacy && n_kept <= OS_MAX_KEYS) {
+        OsPending mine;
+        OsPending* pend = defer ? defer : &mine;
+        int rc = onesweep_launch(ctx, keys, vals, counter, n_kept, key_hi, ctrl, pend);
+        if (rc != FHX_OK) return rc;
+        *sorted_buf = pend->src;                          // (the finish never changes the buffer pair)
+        if (defer) return FHX_OK;                          // the caller finishes, after enqueueing what only reads the keys
+        bool moved = false;
+        return onesweep_finish(ctx, pend, &moved);
+    }
+    // FHX_RS_BITS: digit width of these passes (measurements)
     const char* be = std::getenv("FHX_RS_BITS");
     const int bits = (be && std::atoi(be) >= 8 && std::atoi(be) <= 11) ? std::atoi(be) : SORT_BITS_LARGE;
-    return radix_passes(ctx, keys, vals, counter, sort_blocks_for(n_kept), 62, bits, 0, sorted_buf);
+    return radix_passes(ctx, keys, vals, counter, sort_blocks_for(n_kept), key_hi, bits, 0, sorted_buf);
 }
 
 static int sort_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned long long* keys[2], unsigned int* vals[2],
                         double* d_q, unsigned long long* counter, const unsigned long long* d_cutoff, int* sorted_buf,
-                        int64_t* n_sorted_out = nullptr) {
+                        int64_t* n_sorted_out, int key_hi, unsigned int* ctrl) {
     int64_t n_kept = 0;
     const int rc = compact_pvalues(ctx, d_p, n, keys, vals, d_q, counter, d_cutoff, &n_kept);
     if (rc != FHX_OK) return rc;
     if (n_sorted_out) *n_sorted_out = n_kept;
-    return sort_kept(ctx, keys, vals, counter, n_kept, sorted_buf);
+    return sort_kept(ctx, keys, vals, counter, n_kept, sorted_buf, key_hi, ctrl);
+}
+
+// The engine's own sort scratch: the workspace behind the K3 view (alloc_row_arrays: K3 uses 24 of its >= 48 bytes per row; the
+// descriptors of eight passes take 2).
+static unsigned int* engine_sort_ctrl(fhx_ctx* ctx) {
+    const size_t cap = std::max<size_t>(4, ((size_t)ctx->n_rows + 3) / 4 * 4);
+    return reinterpret_cast<unsigned int*>(ctx->d_work + cap * 24);
 }
 
 // n_keys: the number of sorted keys when the host knows it (the grids then cover the keys, not the rows), else an upper bound
@@ -829,14 +1111,21 @@ static int bh_from_sorted(fhx_ctx* ctx, const unsigned long long* keys, const un
 // compaction, sort and BH of one p column -> q in row order
 static int rank_and_adjust(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned long long* keys[2], unsigned int* vals[2], double* d_q,
                            unsigned long long* counter, const unsigned long long* d_cutoff, double n_total_tests, double* tile_max,
-                           int* sorted_buf, int64_t* n_sorted_out) {
+                           int* sorted_buf, int64_t* n_sorted_out, int key_hi, unsigned int* ctrl) {
     int64_t n_kept = 0;
     int rc = compact_pvalues(ctx, d_p, n, keys, vals, d_q, counter, d_cutoff, &n_kept);
     if (rc != FHX_OK) return rc;
     if (n_sorted_out) *n_sorted_out = n_kept;
-    rc = sort_kept(ctx, keys, vals, counter, n_kept, sorted_buf);
+    OsPending pend;
+    rc = sort_kept(ctx, keys, vals, counter, n_kept, sorted_buf, key_hi, ctrl, &pend);
     if (rc != FHX_OK) return rc;
-    return bh_from_sorted(ctx, keys[*sorted_buf], vals[*sorted_buf], n_kept, counter, n_total_tests, tile_max, d_q);
+    rc = bh_from_sorted(ctx, keys[*sorted_buf], vals[*sorted_buf], n_kept, counter, n_total_tests, tile_max, d_q);
+    if (rc != FHX_OK) return rc;
+    bool moved = false;
+    rc = onesweep_finish(ctx, &pend, &moved);          // the BH scan above runs while the host reads the repair's verdict
+    if (rc != FHX_OK) return rc;
+    if (moved) rc = bh_from_sorted(ctx, keys[*sorted_buf], vals[*sorted_buf], n_kept, counter, n_total_tests, tile_max, d_q);
+    return rc;
 }
 
 int fhx::ensure_sort_scratch(fhx_ctx* ctx) {
@@ -881,7 +1170,7 @@ int fhx_bh_set_cutoff_device(fhx_ctx* ctx, double n_total_tests) {
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
     FHX_HIP(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k3_cutoff, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long*)ctx->d_top_hist, n_total_tests,
-                       ctx->d_misc + 6);
+                       ctx->d_misc + 6, (unsigned long long*)nullptr);
     FHX_HIP(hipGetLastError());
     return FHX_OK;
 }
@@ -903,6 +1192,12 @@ int fhx_bh_set_cutoff(fhx_ctx* ctx, const int64_t* global_hist, int64_t n_bins, 
     return FHX_OK;
 }
 
+int fhx_bh_sort_stats(fhx_ctx* ctx, int64_t* out8) {
+    if (!ctx || !out8) return FHX_ERR_ARG;
+    for (int k = 0; k < 8; ++k) out8[k] = ctx->sort_stats[k];
+    return FHX_OK;
+}
+
 int fhx_bh_local_sort(fhx_ctx* ctx) {
     if (!ctx) return FHX_ERR_ARG;
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
@@ -910,7 +1205,7 @@ int fhx_bh_local_sort(fhx_ctx* ctx) {
     FHX_HIP(hipSetDevice(ctx->device));
     int64_t kept = 0;
     const int rc = sort_pvalues(ctx, ctx->d_p, ctx->n_rows, ctx->d_keys, ctx->d_vals, ctx->d_q, ctx->d_misc, ctx->d_misc + 6,
-                                &ctx->sorted_buf, &kept);
+                                &ctx->sorted_buf, &kept, 62, engine_sort_ctrl(ctx));
     if (rc != FHX_OK) return rc;
     ctx->n_sorted = kept;
     return FHX_OK;
@@ -939,12 +1234,15 @@ int fhx_bh_array(fhx_ctx* ctx, const double* p, int64_t n, double n_total_tests,
         FHX_HIP(tmp.get(&keys[b], cap * sizeof(unsigned long long)));
         FHX_HIP(tmp.get(&vals[b], cap * sizeof(unsigned int)));
     }
+    // a caller's p may be anything >= 0 (2.0, +inf: the reference ranks them like any other value): all 64 key bits count
+    unsigned int* ctrl = nullptr;
+    if (n > KS_MAX_KEYS && n <= OS_MAX_KEYS) FHX_HIP(tmp.get(&ctrl, os_scratch_bytes(n)));
     FHX_HIP(hipMemcpyAsync(d_p, p, cap * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     int buf = 0;
     unsigned long long* counter = ctx->d_misc + 2;
     unsigned long long* cutoff = ctx->d_misc + 7;
     rc = auto_cutoff(ctx, d_p, n, n_total_tests, cutoff);
-    if (rc == FHX_OK) rc = rank_and_adjust(ctx, d_p, n, keys, vals, d_q, counter, cutoff, n_total_tests, tile_max, &buf, nullptr);
+    if (rc == FHX_OK) rc = rank_and_adjust(ctx, d_p, n, keys, vals, d_q, counter, cutoff, n_total_tests, tile_max, &buf, nullptr, 64, ctrl);
     if (rc == FHX_OK) {
         FHX_HIP(hipMemcpyAsync(q, d_q, cap * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         FHX_HIP(hipStreamSynchronize(ctx->stream));
@@ -964,9 +1262,9 @@ int fhx_bh(fhx_ctx* ctx, double n_total_tests) {
     if (rc != FHX_OK) return rc;
     int64_t kept = 0;
     rc = rank_and_adjust(ctx, ctx->d_p, ctx->n_rows, ctx->d_keys, ctx->d_vals, ctx->d_q, ctx->d_misc, ctx->d_misc + 6, n_total_tests,
-                         ctx->d_tile_max, &ctx->sorted_buf, &kept);
+                         ctx->d_tile_max, &ctx->sorted_buf, &kept, 62, engine_sort_ctrl(ctx));
     if (rc != FHX_OK) return rc;
-    ctx->n_sorted = kept;
+    ctx->n_sorted = ctx->k3_n_is_bound ? -2 : kept;      // -2: fhx_n_sorted reads the device counter when somebody asks
     FHX_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
     ctx->ev_valid[2] = true;
     ctx->ev_folded[2] = false;

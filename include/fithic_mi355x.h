@@ -224,6 +224,12 @@ int fhx_get_array(fhx_ctx* ctx, int which, void* dst, int64_t capacity_elems, in
 /* Raw device pointers for plumbing (torch / RCCL exchange): 0 = p, 1 = q, 2 = sorted keys, 3 = sorted idx */
 void* fhx_device_ptr(fhx_ctx* ctx, int which);
 int64_t fhx_n_sorted(fhx_ctx* ctx);
+/* How the last Benjamini-Hochberg call sorted its surviving p-values (diagnostics, tests): out8 = radix passes of the first
+ * attempt (0: the small in-LDS sort ran), lowest key bit they covered, what the repair of the lower bits could not list (0 =
+ * nothing; bit 0: a run whose ends were out of reach, bit 1: a list overflowed, bit 2: forced by FHX_OS_FORCE_FALLBACK, bit 3:
+ * every bit of every key was sorted after all), inversions met, runs sorted by one thread each, inversions found in runs too
+ * long for that, such runs sorted as segments of their own, keys in them. */
+int fhx_bh_sort_stats(fhx_ctx* ctx, int64_t* out8);
 /* Seconds the kernels of the last pass took on the context's stream (HIP events): k1, k2, k3. */
 int fhx_kernel_seconds(fhx_ctx* ctx, double* k1, double* k2, double* k3);
 /* The same summed over the passes since the last reset, without stopping the stream after each of them: sums4 = seconds of K1, K2,
