@@ -70,7 +70,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_rows(synth, torch, cfg, genome, mine, rank, world, device, overdispersion=0.0):
+def build_rows(synth, torch, cfg, genome, mine, rank, world, device, overdispersion=0.0, hotspots=None):
     """This rank's contact rows as five int32 device columns (one allocation per column, filled chromosome by chromosome)."""
     n_chr = len(genome)
     hi = cfg["hi"]
@@ -88,7 +88,7 @@ def build_rows(synth, torch, cfg, genome, mine, rank, world, device, overdispers
     n = 0
     for c in mine:
         part = synth.cis_contacts(genome, c, cfg["lo"], hi if hi is not None else genome.n_loci[c] - 1, amp, device=device,
-                                  overdispersion=overdispersion)
+                                  overdispersion=overdispersion, hotspots=hotspots)
         m = int(part[0].numel())
         if n + m > est:                                       # estimate too small: grow (rare)
             grow = [torch.empty(int((n + m) * 1.2), dtype=torch.int32, device=device) for _ in range(5)]
@@ -230,6 +230,9 @@ def main():
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the additional weak-scaling measurement")
     ap.add_argument("--overdispersion", type=float, default=0.0,
                     help="0 = synth-v1 (Poisson around the model); s > 0 adds lognormal rate noise: heavier small-p tail, like real maps")
+    ap.add_argument("--hotspots", default="", metavar="PHI:M",
+                    help="variant: a random fraction PHI of the pairs gets M times the model's rate, the rest less (mean kept) - the "
+                         "contrast that puts a third to a half of a real map's rows below the BH cutoff")
     ap.add_argument("--no-k3-stress", action="store_true",
                     help="N = 1: skip the second workload (lognormal rate noise s = 1.0: a heavy small-p tail, where K3's sort works)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -336,7 +339,14 @@ def main():
         base_lengths = [base_lengths[c] for c in range(len(g_all)) if owner_all[c] == fullest]
         del g_all
 
-    def measure(replicas, with_cpu_leg, solo=False, want_hashes=False, steps=None, warmup=None, overdispersion=None):
+    def parse_hotspots(text):
+        if not text:
+            return None
+        phi, m = (float(v) for v in text.split(":"))
+        return phi, m
+
+    def measure(replicas, with_cpu_leg, solo=False, want_hashes=False, steps=None, warmup=None, overdispersion=None, hotspots=None,
+                sample_budget=3.0e7):
         """Generate, load, warm up, time `steps` steps.  Returns the result pieces of this workload.
         solo: this process alone takes the whole genome through the plain single-GPU path (the verification run of rank 0)."""
         world, rank, comm = (1, 0, None) if solo else (world_all, rank_all, comm_all)
@@ -347,7 +357,8 @@ def main():
         mine = [c for c in range(len(genome)) if owner[c] == rank]
         t_gen = time.time()
         cols, n_local, n_cis_local, n_trans = build_rows(synth, torch, cfg, genome, mine, rank, world, device,
-                                                         args.overdispersion if overdispersion is None else overdispersion)
+                                                         args.overdispersion if overdispersion is None else overdispersion,
+                                                         parse_hotspots(args.hotspots) if hotspots is None else (hotspots or None))
         torch.cuda.synchronize()
         log("[rank %d] generated %d rows (%d cis on %d chromosomes, %d of %d trans) in %.1f s" %
             (rank, n_local, n_cis_local, len(mine), n_local - n_cis_local, n_trans, time.time() - t_gen))
@@ -362,7 +373,7 @@ def main():
             # bounded sample for the CPU legs: whole chromosomes, smallest first, up to ~3e7 cis rows (10-15 s of one core),
             # plus every trans row between two sampled chromosomes; a chromosome that alone exceeds the budget (1 kb loci)
             # is cut to its first loci - rows with both ends below the cut - so that the sample is a complete small genome
-            sample = build_sample(torch, cols, n_local, n_cis_local, genome, mine, cfg, res, device)
+            sample = build_sample(torch, cols, n_local, n_cis_local, genome, mine, cfg, res, device, budget=sample_budget)
         keys = chr1 = None
         if want_hashes:                                          # row identities for the sharded-vs-single comparison
             keys = row_keys(torch, synth, cols, n_local)
@@ -473,7 +484,7 @@ def main():
     weak_headline = args.weak and world > 1
     replicas = args.replicas if args.replicas > 0 else (world if weak_headline else 1)
     # the f14 fixture of this workload (the real reference's fit on it) applies when the run IS that workload
-    canonical = (args.keep == 0 and args.max_chroms == 0 and args.shard_of <= 1 and args.overdispersion == 0 and replicas == 1)
+    canonical = (args.keep == 0 and args.max_chroms == 0 and args.shard_of <= 1 and args.overdispersion == 0 and not args.hotspots and replicas == 1)
     fixture_name = args.config if canonical and os.path.exists(os.path.join(ROOT, "tests", "golden", "f14_%s_fit.npz" % args.config)) else None
     verify_sharded = comm is not None and not args.no_parity_check         # N > 1 (or FHX_FORCE_DIST): compare with one GPU
     want_digest = bool(os.environ.get("FHX_BENCH_HASH"))          # A/B of kernel variants: a digest of every p and q in the result line
@@ -512,6 +523,16 @@ def main():
                 traffic_source = tj.get("source")
             except Exception:
                 traffic = None
+        # the bound that matters: every VALU wave-instruction of the pass at one per four cycles and SIMD (counters of the same
+        # command on this tree, profiles/valu_floor.json made by profiles/update_valu_floor.py; scaled by this run's rows)
+        floor_ms = floor_src = None
+        try:
+            vf = json.load(open(os.path.join(ROOT, "profiles", "valu_floor.json"))).get(args.config)
+            if vf and world == 1:
+                floor_ms = vf["floor_ms"] * n_total / vf["pairs"]
+                floor_src = vf["source"]
+        except Exception:                                        # noqa: BLE001 - informational
+            floor_ms = None
         fp64_instr = hv_rows * 300.0 * HEAVY_FP64_INSTR_PER_ITER
         fp64_issue_peak = 256 * 4 * 16 * 2.4e9          # CUs x SIMDs x fp64 lanes/clk x Hz  (= 78.6 TFLOP/s / 2)
         n_chr = len(base_lengths)
@@ -536,7 +557,8 @@ def main():
             "scaling": "weak" if weak_headline else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "name": args.config, "pairs": n_total, "resolution": res,
-                       "generator": "synth-v1" if args.overdispersion == 0 else "synth-v1 + lognormal rate noise s=%g" % args.overdispersion,
+                       "generator": "synth-v1" + ("" if args.overdispersion == 0 else " + lognormal rate noise s=%g" % args.overdispersion) +
+                                    ("" if not args.hotspots else " + hotspots phi:m=%s" % args.hotspots),
                        "parallelism": "chromosome-sharded x%d" % world, "passes": passes, "mode": cfg["mode"],
                        "bias": not args.no_bias},
             "roofline": {"bound": "hbm", "binding_resource": "fp64_valu_issue", "kernel": "k2h_heavy (swapped incbcf, 300 iterations)",
@@ -545,6 +567,8 @@ def main():
                          "note": "HBM is the designated roofline of the path; the dominant launch (rows whose Cephes continued "
                                  "fraction runs all 300 iterations) is bound by fp64 VALU issue, see fp64_valu_issue_frac: "
                                  "algorithmic bytes = 20 B/row (12 read + 8 written), %g fp64 instructions per row-iteration" % HEAVY_FP64_INSTR_PER_ITER,
+                         "valu_issue_floor_ms": floor_ms, "pass_over_floor": (ms / floor_ms) if floor_ms else None,
+                         "valu_issue_floor_source": floor_src,
                          "launch_seconds": hv_s, "rows_per_launch": hv_rows,
                          "fp64_valu_issue_frac": (fp64_instr / hv_s) / fp64_issue_peak if hv_s > 0 else None,
                          "fp64_note": "loop instructions only, against the nominal 2.4 GHz; by the SQ counters (profiles/r04_z_counters.txt: 3.18e9 VALU "
@@ -586,6 +610,11 @@ def main():
             if not args.no_cpu_baseline:
                 try:
                     result["cpu_baseline"] = cpu_baseline(genome, M["sample"], cfg, not args.no_bias)
+                    try:
+                        result["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(genome, M["sample"], cfg, not args.no_bias)
+                    except Exception as e:                       # noqa: BLE001 - informational leg
+                        log("cpu_baseline all_cores failed: %r" % (e,))
+                        result["cpu_baseline"]["all_cores"] = {"value": None, "error": repr(e)}
                 except Exception as e:                           # the GPU line must not be lost to a problem of the CPU leg
                     log("cpu_baseline failed: %r" % (e,))
                     result["cpu_baseline"] = {"value": None, "unit": "contact-pairs/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
@@ -593,26 +622,40 @@ def main():
     eng.close()
     del M
     torch.cuda.empty_cache()
-    if rank == 0 and comm is None and args.path == "fithic" and args.overdispersion == 0 and not args.no_k3_stress and args.config == "C3":
-        # K3 where it works: on synth-v1 the exact cutoff leaves < 0.1 % of the rows to sort; with lognormal rate noise (s = 1.0)
-        # 12 % of the rows carry a small p, as on real (over-dispersed) maps.  A second, labelled measurement - never the headline.
-        try:
-            S = measure(replicas, with_cpu_leg=False, steps=max(2, min(args.steps, 5)), warmup=1, overdispersion=1.0)
-            k3_s = max(r[2] for r in S["k_all"])
-            result["k3_stress"] = {
-                "workload": "the same genome and depth, Poisson rates multiplied by lognormal noise (s = 1.0): synth-v1 + overdispersion 1.0",
-                "pairs": int(S["n_total"]), "rows_sorted": S["bh_sorted"], "k3_ms": 1e3 * k3_s,
-                "sorted_keys_per_s": (S["bh_sorted"] / k3_s) if (S["bh_sorted"] and k3_s > 0) else None,
-                "ms_per_step": 1e3 * S["elapsed"] / S["steps"], "pairs_per_s": S["n_total"] * passes * S["steps"] / S["elapsed"],
-                "kernels_ms": {"k1_classify_hist": 1e3 * max(r[0] for r in S["k_all"]), "k2_pvalue": 1e3 * max(r[1] for r in S["k_all"]),
-                               "k3_bh_sort_scan": 1e3 * k3_s},
-                "k3_hbm_frac": (ALGO_BYTES_K3 * S["n_total"] / k3_s) / (HBM_PEAK_GBS * 1e9) if k3_s > 0 else None}
-            S["eng"].close()
-            del S
-        except Exception as e:                                   # noqa: BLE001 - the headline line must not be lost to the extra workload
-            log("k3_stress failed: %r" % (e,))
-            result["k3_stress"] = {"error": repr(e)}
-        torch.cuda.empty_cache()
+    if (rank == 0 and comm is None and args.path == "fithic" and args.overdispersion == 0 and not args.hotspots and not args.no_k3_stress
+            and args.config == "C3"):
+        # K3 where it works: on synth-v1 the exact cutoff leaves < 0.1 % of the rows to sort.  Three more, labelled workloads on the
+        # same genome put 12 %, 39 % and 55 % of the rows below the BH cutoff - real (over-dispersed, domain-structured) maps sit
+        # at 27-53 % - each measured AND checked like the headline (p of sampled rows against the oracle's Cephes, q of
+        # every row against the oracle's BH of the engine's p).  Never the headline.
+        result["k3_stress"] = []
+        for label, od, hot in (("lognormal rate noise s = 1.0", 1.0, None), ("hotspots phi:m = 0.2:4.5", 0.0, (0.2, 4.5)),
+                               ("hotspots phi:m = 0.25:3.9", 0.0, (0.25, 3.9))):
+            try:
+                S = measure(replicas, with_cpu_leg=not args.no_parity_check, steps=max(2, min(args.steps, 3)), warmup=1, overdispersion=od,
+                            hotspots=hot if hot else (), sample_budget=1.0e7)
+                k3_s = max(r[2] for r in S["k_all"])
+                entry = {
+                    "workload": "the same genome and depth, synth-v1 + " + label,
+                    "pairs": int(S["n_total"]), "rows_sorted": S["bh_sorted"],
+                    "survivor_fraction": (S["bh_sorted"] / S["n_total"]) if S["bh_sorted"] else None, "k3_ms": 1e3 * k3_s,
+                    "sorted_keys_per_s": (S["bh_sorted"] / k3_s) if (S["bh_sorted"] and k3_s > 0) else None,
+                    "sort": S["sort_stats"],
+                    "ms_per_step": 1e3 * S["elapsed"] / S["steps"], "pairs_per_s": S["n_total"] * passes * S["steps"] / S["elapsed"],
+                    "kernels_ms": {"k1_classify_hist": 1e3 * max(r[0] for r in S["k_all"]), "k2_pvalue": 1e3 * max(r[1] for r in S["k_all"]),
+                                   "k3_bh_sort_scan": 1e3 * k3_s},
+                    "k3_hbm_frac": (ALGO_BYTES_K3 * S["n_total"] / k3_s) / (HBM_PEAK_GBS * 1e9) if k3_s > 0 else None}
+                if S["sample"] is not None:
+                    entry["parity_check"] = checked(S["eng"], S["genome"], S["sample"], S["info"], None)
+                else:
+                    entry["parity_check"] = {"ok": None, "skipped": "--no-parity-check"}
+                result["k3_stress"].append(entry)
+                S["eng"].close()
+                del S
+            except Exception as e:                               # noqa: BLE001 - the headline line must not be lost to the extra workloads
+                log("k3_stress (%s) failed: %r" % (label, e))
+                result["k3_stress"].append({"workload": label, "error": repr(e)})
+            torch.cuda.empty_cache()
     if verify_sharded:
         # Every p and q of the sharded pass against ONE GPU: the ranks' hash tables are summed (a chromosome's cis rows live on
         # one rank, the trans rows are spread: the sum is what one GPU holding everything computes); rank 0 then takes the whole
@@ -813,6 +856,52 @@ def cpu_baseline(genome, sample, cfg, with_bias):
             "calibration": dict(cal, reference_over_port=cal["reference_rows_per_s"] / cal["port_rows_per_s"],
                                 estimated_reference_pairs_per_s_here=len(pairs) * cfg["passes"] / dt *
                                 cal["reference_rows_per_s"] / cal["port_rows_per_s"])}
+
+
+def _oracle_one_chromosome(job):
+    """worker of cpu_baseline_all_cores: the oracle on the rows of one sampled chromosome (own fit on it) -> (rows, seconds)"""
+    sys.path.insert(0, ROOT)
+    from oracle import fithic_oracle as fo
+    name, cols, frags, bias_dic, kw = job
+    c1, m1, c2, m2, cnt = cols
+    pairs = fo.Pairs(c1, m1, c2, m2, cnt, [name])
+    fo.build()
+    t0 = time.perf_counter()
+    fo.run(pairs, frags, None, kw["res"], n_bins=100, passes=kw["passes"], mode=kw["mode"], L=kw["L"], U=kw["U"], bias_dic=bias_dic)
+    return len(pairs), time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(genome, sample, cfg, with_bias):
+    """SURVEY 8(d)(ii), "for information": the oracle sharded by chromosome over the host cores - one process per sampled
+    chromosome (its cis rows, a fit of its own), all at once.  -> dict for cpu_baseline["all_cores"]."""
+    import multiprocessing as mp
+    import numpy as np
+    c1, m1, c2, m2, cnt = sample["cols"]
+    jobs = []
+    kw = dict(res=cfg["res"], passes=cfg["passes"], mode="intraOnly", L=cfg["L"], U=cfg["U"])
+    for c in sample["chroms"]:
+        sel = (c1 == c) & (c2 == c)
+        if not sel.any():
+            continue
+        frags, bias_dic = _oracle_tables(genome, [c], cfg["res"], with_bias, sample.get("cut_loci"))
+        z = np.zeros(int(sel.sum()), np.int32)
+        jobs.append((genome.names[c], (z, m1[sel], z, m2[sel], cnt[sel]), frags, bias_dic, kw))
+    if not jobs:
+        return None
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(min(len(jobs), os.cpu_count() or 1)) as pool:
+        done = pool.map(_oracle_one_chromosome, jobs, chunksize=1)
+    wall = time.perf_counter() - t0
+    rows = sum(r for r, _ in done)
+    busy = max(t for _, t in done)
+    one_core = sum(r for r, _ in done) / sum(t for _, t in done)
+    return {"value": rows * cfg["passes"] / busy, "unit": "contact-pairs/s", "cores": min(len(jobs), os.cpu_count() or 1),
+            "host_cores": os.cpu_count(), "rows": rows, "seconds_slowest_worker": busy, "seconds_wall_with_process_start": wall,
+            "per_core_in_this_leg": one_core * cfg["passes"],
+            "projected_on_all_host_cores": one_core * cfg["passes"] * (os.cpu_count() or 1),
+            "how": "one process per sampled chromosome (cis rows, own fit), all at once; value = rows / the slowest worker's oracle time; "
+                   "the projection multiplies the per-core rate of this leg by the host's cores (the genome has 22 chromosomes: more "
+                   "cores than that would need rows split within a chromosome, which the per-pair loop allows)"}
 
 
 def cpu_baseline_kr(genome, cols, perc):

@@ -116,10 +116,13 @@ def solve_amplitude(keep_fraction, lo_idx, hi_idx):
     return math.sqrt(lo * hi)
 
 
-def cis_contacts(genome, chrom, lo_idx, hi_idx, amplitude, device="cpu", max_window=None, overdispersion=0.0):
+def cis_contacts(genome, chrom, lo_idx, hi_idx, amplitude, device="cpu", max_window=None, overdispersion=0.0, hotspots=None):
     """Contact rows of one chromosome as torch int32 tensors (chr1, mid1, chr2, mid2, count) on `device`.
     overdispersion = 0 is synth-v1 (pure Poisson around the model); s > 0 multiplies every pair's rate by
-    exp(s*z - s^2/2), z ~ N(0,1) (gamma-Poisson-like counts, the heavier small-p tail real Hi-C maps show)."""
+    exp(s*z - s^2/2), z ~ N(0,1) (gamma-Poisson-like counts, the heavier small-p tail real Hi-C maps show); hotspots = (phi, m)
+    multiplies the rate of a random fraction phi of the pairs by m and of the rest by (1 - phi*m)/(1 - phi) (mean kept): the
+    contrast of pairs inside and outside domains, which is what puts a third to a half of a real map's rows below the
+    Benjamini-Hochberg cutoff."""
     import torch
     n = genome.n_loci[chrom]
     hi = min(hi_idx, n - 1)
@@ -130,7 +133,9 @@ def cis_contacts(genome, chrom, lo_idx, hi_idx, amplitude, device="cpu", max_win
         z = torch.zeros(0, dtype=torch.int32, device=device)
         return z, z, z, z, z
     gen = None
-    if overdispersion > 0:                                  # variant, not synth-v1: extra rate noise from torch's generator
+    if hotspots is not None and not (0.0 < hotspots[0] < 1.0 and 0.0 < hotspots[0] * hotspots[1] < 1.0):
+        raise ValueError("hotspots = (phi, m) needs 0 < phi < 1 and phi * m < 1")
+    if overdispersion > 0 or hotspots is not None:          # variant, not synth-v1: extra rate noise from torch's generator
         gen = torch.Generator(device=device)
         gen.manual_seed(SEED * 1000 + chrom)
     b = torch.from_numpy(genome.bias(chrom)).to(device)
@@ -158,6 +163,10 @@ def cis_contacts(genome, chrom, lo_idx, hi_idx, amplitude, device="cpu", max_win
             if overdispersion > 0:
                 z = torch.randn(lam.shape, device=device, generator=gen, dtype=torch.float32)
                 lam = lam * torch.exp(overdispersion * z - 0.5 * overdispersion * overdispersion).to(lam.dtype)
+            if hotspots is not None:
+                phi, m = hotspots
+                hot = torch.rand(lam.shape, device=device, generator=gen, dtype=torch.float32) < phi
+                lam = lam * torch.where(hot, torch.full_like(lam, m), torch.full_like(lam, (1.0 - phi * m) / (1.0 - phi)))
             # counter-based uniforms: splitmix64(seed ^ index), index unique per (chromosome, i, delta, stream)
             index = ((chrom * (1 << 22) + i[:, None]) * (1 << shift) + dd[None, :]) * 2
             cnt = _poisson_inverse(torch, lam, _uniform(torch, index))

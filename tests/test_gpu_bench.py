@@ -33,8 +33,12 @@ def test_single_gpu_line_is_checked_against_the_oracle():
     assert pc["ok"] and pc["max_dp"] <= 1e-10 and pc["max_dq"] == 0.0 and pc["rows_q"] == out["config"]["pairs"]
     assert "fit_vs_reference" not in pc                     # two chromosomes are not the workload the f14 fixture was made on
     assert out["n_gpus"] == 1 and out["roofline"]["frac"] > 0 and out["value"] > 1e8
-    ks = out["k3_stress"]                                   # the second, labelled workload: K3 with a heavy small-p tail
-    assert ks["rows_sorted"] > out["bh_rows_sorted_rank0"] and ks["rows_sorted"] > ks["pairs"] // 50 and ks["k3_ms"] > 0
+    ks = out["k3_stress"]                                   # three more, labelled workloads: 12 %, 39 %, 55 % of the rows below the cutoff
+    assert len(ks) == 3 and [k["survivor_fraction"] > f for k, f in zip(ks, (0.08, 0.3, 0.45))] == [True] * 3
+    for k in ks:                                            # each with a verdict of its own
+        pc = k["parity_check"]
+        assert pc["ok"] and pc["max_dp"] <= 1e-10 and pc["max_dq"] == 0.0 and pc["rows_q"] == k["pairs"], k["workload"]
+        assert k["rows_sorted"] > out["bh_rows_sorted_rank0"] and k["k3_ms"] > 0 and k["sort"]["passes"] == 5
     assert sum(out["k2_class_rows_rank0"].values()) < out["config"]["pairs"]
 
 
