@@ -155,6 +155,11 @@ SYMBOLS = {
                                                     ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _I64P]),
     "fhx_write_significances_device": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int32, _I32P, _I32P,
                                                       _I32P, _I32P, _I32P, ctypes.c_int64, _I64P, _I64P]),
+    "fhx_write_significances_device_range": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int32, ctypes.c_int64,
+                                                            ctypes.c_int64, ctypes.c_int32, _I64P, _I64P]),
+    "fhx_ingest_contacts_chr_counts": (ctypes.c_int, [_P, _I64P, ctypes.c_int32]),
+    "fhx_ingest_contacts_commit_shard": (ctypes.c_int, [_P, _I32P, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int32, _I64P]),
+    "fhx_shard_segments": (ctypes.c_int, [_P, _I64P, _I64P, _I64P, ctypes.c_int64, _I64P]),
     "fhx_host_spline_fit": (ctypes.c_int, [_F64P, _F64P, ctypes.c_int32, ctypes.c_double, _F64P, _F64P, _I32P, _F64P, _I32P, _I32P]),
     "fhx_host_spline_eval": (ctypes.c_int, [_F64P, _F64P, ctypes.c_int32, _F64P, ctypes.c_int64, _F64P]),
     "fhx_host_pava_decreasing": (ctypes.c_int, [_F64P, ctypes.c_int64, _F64P]),
@@ -387,6 +392,37 @@ class Context:
         """ids[i] = the run's chromosome id of name i: the parsed rows become the context's contact rows"""
         ids = np.ascontiguousarray(ids, np.int32)
         self._check(self._L.fhx_ingest_contacts_commit(self._h, _ptr(ids, ctypes.c_int32), len(ids)))
+
+    def ingest_contacts_chr_counts(self, n_names):
+        """rows of the parsed text per name, by the chromosome of the first locus"""
+        out = np.zeros(int(n_names), np.int64)
+        self._check(self._L.fhx_ingest_contacts_chr_counts(self._h, _ptr(out, ctypes.c_int64), int(n_names)))
+        return out
+
+    def ingest_contacts_commit_shard(self, ids, mine):
+        """as ingest_contacts_commit, keeping only the rows whose first chromosome has mine[i] set -> rows kept"""
+        ids = np.ascontiguousarray(ids, np.int32)
+        mine = np.ascontiguousarray(mine, np.uint8)
+        n = ctypes.c_int64(0)
+        self._check(self._L.fhx_ingest_contacts_commit_shard(self._h, _ptr(ids, ctypes.c_int32), _ptr(mine, ctypes.c_uint8), len(ids), ctypes.byref(n)))
+        return n.value
+
+    def shard_segments(self, cap=1 << 16):
+        """[(local start, file position, length)] of the stretches of consecutive file positions this rank holds, or None (> cap)"""
+        a, b, c = (np.zeros(int(cap), np.int64) for _ in range(3))
+        n = ctypes.c_int64(0)
+        self._check(self._L.fhx_shard_segments(self._h, _ptr(a, ctypes.c_int64), _ptr(b, ctypes.c_int64), _ptr(c, ctypes.c_int64), int(cap), ctypes.byref(n)))
+        if n.value > cap:
+            return None
+        return [(int(a[i]), int(b[i]), int(c[i])) for i in range(n.value)]
+
+    def write_significances_range(self, path, chr_names, row_begin, row_end, with_header):
+        """rows [row_begin, row_end) of this context as gzip members (header member in front if asked) -> (rows written, bytes)"""
+        arr = (ctypes.c_char_p * len(chr_names))(*[os.fsencode(n) for n in chr_names])
+        rows, nbytes = ctypes.c_int64(0), ctypes.c_int64(0)
+        self._check(self._L.fhx_write_significances_device_range(self._h, os.fsencode(path), arr, len(chr_names), int(row_begin), int(row_end),
+                                                                 1 if with_header else 0, ctypes.byref(rows), ctypes.byref(nbytes)))
+        return rows.value, nbytes.value
 
     def ingest_contacts_discard(self):
         self._L.fhx_ingest_contacts_discard(self._h)

@@ -150,6 +150,7 @@ def read_Interactions(contactCountsFile, biasFile, outliers=None):
             starter.join()
             S.configure()
             return S.engine
+        engine_of.sharded = gpus > 1                       # (known before the engine is up: load_contacts plans by it)
         try:
             S.contacts = tables.load_contacts(contactCountsFile, S.chroms, engine_of)
         finally:
@@ -157,7 +158,7 @@ def read_Interactions(contactCountsFile, biasFile, outliers=None):
         S.contacts_path = contactCountsFile
         if os.environ.get("FHX_TIMING"):
             print("stage: inflate + parse + ingest of %d rows took %.3f s (%s parser)"
-                  % (len(S.contacts), time.time() - t0, "device" if isinstance(S.contacts, tables.DeviceContacts) else "host"))
+                  % (len(S.contacts), time.time() - t0, "device" if hasattr(S.contacts, "rows") else "host"))
         S.pass_started = 0
     elif outliers is not None and S.pass_started >= 1 and S.values is not None:
         if S.outlier_refs is not None and not (outliers is S.outlier_refs[0] and len(outliers) == S.outlier_refs[1]):
@@ -538,7 +539,7 @@ def fit_Spline(mainDic, x, y, yerr, infilename, outfilename, biasDic, outliersli
         rows = np.flatnonzero(flags)
     (outliersline.update if hasattr(outliersline, "add") else outliersline.extend)(rows.tolist())
     # abs(mid1 - mid2) of every outlier line, inter-chromosomal ones included (fithic.py:1217)
-    if isinstance(con, tables.DeviceContacts):
+    if hasattr(con, "rows"):                              # rows resident on the GPU(s): DeviceContacts, sharded.ShardedContacts
         _, out_mid1, _, out_mid2, _ = con.rows(rows)
     else:
         out_mid1, out_mid2 = con.mid1[rows], con.mid2[rows]

@@ -147,6 +147,7 @@ class _Rank:
         self.transport, self.unique_id, self.mesh = transport, unique_id, mesh
         self.comm_ready = False
         self.n_rows = 0
+        self.segments = None
 
     def _ensure_comm(self):
         if self.comm_ready:
@@ -173,6 +174,93 @@ class _Rank:
         self.eng.ctx.set_global_rows(rows)               # file positions: the -p >= 3 semantics
         self.n_rows = len(rows)
         self._ensure_comm()
+
+    # ---- the contacts file read by every rank itself (no rows through rank 0) ----
+    def ingest_file(self, path, threads):
+        """inflate + parse the whole file on this rank's GPU -> ("ok", rows, names, rows per name) or ("unsupported", why)"""
+        ctx = self.eng.ctx
+        text = None
+        try:
+            try:
+                n, names = ctx.ingest_contacts_file(path, threads)
+            except _capi.FhxError as e:
+                if e.code != _capi.FHX_ERR_UNSUPPORTED:
+                    raise
+                if getattr(e, "refused", 1) == 2:
+                    return ("unsupported", str(e))
+                text = _capi.HostText(path, threads)
+                try:
+                    n, names = ctx.ingest_contacts_text(text, threads)
+                except _capi.FhxError as e2:
+                    if e2.code != _capi.FHX_ERR_UNSUPPORTED:
+                        raise
+                    return ("unsupported", str(e2))
+            return ("ok", n, names, ctx.ingest_contacts_chr_counts(len(names)))
+        finally:
+            if text is not None:
+                text.close()
+
+    def ingest_discard(self):
+        self.eng.ctx.ingest_contacts_discard()
+
+    def commit_shard(self, ids, mine):
+        """keep the rows whose first chromosome is this rank's -> (rows kept, [(local start, file position, length)] or None)"""
+        n = self.eng.ctx.ingest_contacts_commit_shard(ids, mine)
+        self.eng.n_rows = int(n)
+        self.eng.pass_no = 0
+        self.n_rows = int(n)
+        self.segments = self.eng.ctx.shard_segments()
+        self._ensure_comm()
+        return self.n_rows, self.segments
+
+    def write_parts(self, name, chr_names):
+        """this rank's stretches of the significances file, one part file each -> ("ok", [(file position, path, bytes)]) or
+        ("unsupported", why): then nothing is left behind"""
+        parts = []
+        try:
+            for local_start, file_start, length in self.segments:
+                path = "%s.part-%015d" % (name, file_start)
+                self.eng.ctx.write_significances_range(path, chr_names, local_start, local_start + length, False)
+                parts.append((file_start, path, os.path.getsize(path)))
+        except _capi.FhxError as e:
+            for _, path, _ in parts:
+                if os.path.exists(path):
+                    os.unlink(path)
+            if e.code == _capi.FHX_ERR_UNSUPPORTED:
+                return ("unsupported", str(e))
+            raise
+        return ("ok", parts)
+
+    def place_parts(self, target, placements):
+        """copy this rank's parts into `target` at their offsets (all ranks at once: the file is put together in parallel)"""
+        fd = os.open(target, os.O_WRONLY)
+        try:
+            for path, offset in placements:
+                with open(path, "rb") as src:
+                    size = os.fstat(src.fileno()).st_size
+                    done = 0
+                    while done < size:
+                        try:
+                            k = os.copy_file_range(src.fileno(), fd, size - done, done, offset + done)
+                        except OSError:                          # file systems without it
+                            k = os.pwrite(fd, os.pread(src.fileno(), min(size - done, 64 << 20), done), offset + done)
+                        if k <= 0:
+                            raise OSError("short copy of %s" % path)
+                        done += k
+                os.unlink(path)
+        finally:
+            os.close(fd)
+
+    def drop_parts(self, paths):
+        for p in paths:
+            if os.path.exists(p):
+                os.unlink(p)
+
+    def outlier_rows(self):
+        return self.eng.ctx.fetch_outlier_rows()
+
+    def fetch_pairs(self, local_rows):
+        return self.eng.ctx.fetch_pairs(rows=local_rows)
 
     def pass_stats(self):
         return self.eng.ctx.pass_stats_distributed().as_dict()
@@ -269,6 +357,77 @@ class _CtxFacade:
     def bh_array(self, p, n_total_tests):
         return self._o.local.eng.ctx.bh_array(p, n_total_tests)
 
+    def fetch_outlier_rows(self):
+        """file positions of the outlier rows of all ranks, ascending (each rank compacts its own on its GPU)"""
+        o = self._o
+        parts = [o.file_rows(r, np.asarray(local, np.int64)) for r, local in enumerate(o._all("outlier_rows"))]
+        return np.sort(np.concatenate(parts)) if parts else np.zeros(0, np.int64)
+
+    def write_significances_device(self, name, chr_names):
+        """The significances file written by all ranks at once: every rank formats and deflates the stretches of the file it holds
+        (gzip members of their own), the sizes give every part its offset, and the ranks copy their parts into place.  Raises
+        FhxError(FHX_ERR_UNSUPPORTED) - nothing written - when the rows did not come from the file reader (the ranks hold no file
+        positions), when a rank's rows are too scattered over the file, or when the device formatter refuses a row."""
+        o = self._o
+        if o.segments is None or any(sg is None for sg in o.segments):
+            raise _capi.FhxError(_capi.FHX_ERR_UNSUPPORTED, "the ranks' rows are not stretches of the file")
+        results = o._all("write_parts", name, list(chr_names))
+        parts = [p for res in results if res[0] == "ok" for p in res[1]]
+        if any(res[0] != "ok" for res in results):
+            o._all("drop_parts", per_rank=[([p[1] for p in (res[1] if res[0] == "ok" else [])],) for res in results])
+            raise _capi.FhxError(_capi.FHX_ERR_UNSUPPORTED, "; ".join(res[1] for res in results if res[0] != "ok"))
+        tmp = "%s.fhx-tmp-%d" % (name, os.getpid())
+        head = tmp + ".head"
+        o.local.eng.ctx.write_significances_range(head, list(chr_names), 0, 0, True)
+        offsets, at = {}, os.path.getsize(head)
+        for file_start, path, nbytes in sorted(parts):
+            offsets[path] = at
+            at += nbytes
+        with open(tmp, "wb") as f, open(head, "rb") as h:
+            f.write(h.read())
+            f.truncate(at)
+        os.unlink(head)
+        per_rank = [(tmp, [(p[1], offsets[p[1]]) for p in (res[1])]) for res in results]
+        o._all("place_parts", per_rank=per_rank)
+        os.replace(tmp, name)
+
+
+class ShardedContacts:
+    """Contact rows that every rank read from the file itself (ShardedEngine.ingest_file): the length is known, identity columns
+    come back from the ranks that hold them - a few rows (the outlier lines) or, for the host writer's fallback, all."""
+
+    raw_count = None
+
+    def __init__(self, owner, n_rows):
+        self._o, self._n, self._cols = owner, int(n_rows), None
+
+    def __len__(self):
+        return self._n
+
+    def rows(self, rows):
+        rows = np.asarray(rows, np.int64)
+        out = [np.empty(len(rows), np.int32) for _ in range(5)]
+        if len(rows) == 0:
+            return out
+        ranks, local = self._o.locate(rows)
+        got = self._o._all("fetch_pairs", per_rank=[(local[ranks == r],) for r in range(self._o.world)])
+        for r, cols in enumerate(got):
+            sel = ranks == r
+            for k in range(5):
+                out[k][sel] = cols[k]
+        return out
+
+    def _all_cols(self):
+        if self._cols is None:
+            self._cols = self.rows(np.arange(self._n, dtype=np.int64))
+        return self._cols
+
+    chr1 = property(lambda self: self._all_cols()[0])
+    mid1 = property(lambda self: self._all_cols()[1])
+    chr2 = property(lambda self: self._all_cols()[2])
+    mid2 = property(lambda self: self._all_cols()[3])
+    count = property(lambda self: self._all_cols()[4])
+
 
 class ShardedEngine:
     """The Engine methods fithic_amd.fithic uses, over `gpus` ranks (see the module docstring)."""
@@ -318,6 +477,7 @@ class ShardedEngine:
             raise
         self.ctx = _CtxFacade(self)
         self.n_rows = 0
+        self.segments = None                                 # file reader mode: per rank [(local start, file position, length)]
         self.rows_of = [np.zeros(0, np.int64) for _ in range(gpus)]
         self.resolution = None
 
@@ -447,7 +607,69 @@ class ShardedEngine:
         cols = [np.asarray(a) for a in (chr1, mid1, chr2, mid2, count)]
         per_rank = [tuple(a[rows] for a in cols) + (rows,) for rows in self.rows_of]
         self._all("load_contacts", per_rank=per_rank)
+        self.segments = None
         self.n_rows = n
+
+    def ingest_file(self, path, chroms, threads=0):
+        """The contacts file read by EVERY rank on its own GPU (inflate + parse of the whole file, then each keeps the rows whose
+        first chromosome is its own): no row travels through this process.  The ranks agree on the owners because they count the
+        same file.  -> a ShardedContacts, or None when the device reader does not take the file (the caller then parses on the
+        host and hands the columns out: load_contacts)."""
+        from . import tables
+        per = max(1, (os.cpu_count() or 1) // self.world) if not threads else threads
+        results = self._all("ingest_file", path, per)
+        if any(res[0] != "ok" for res in results):
+            self._all("ingest_discard")
+            return None
+        _, n, names, counts = results[0]
+        ids = tables._interner(chroms)(names)
+        load = [0] * self.world
+        owner = np.zeros(len(names), np.int64)
+        for k in np.argsort(-np.asarray(counts), kind="stable"):          # greedy by row count, as load_contacts
+            r = min(range(self.world), key=lambda q: load[q])
+            owner[k] = r
+            load[r] += int(counts[k])
+        kept = self._all("commit_shard", per_rank=[(ids, (owner == r).astype(np.uint8)) for r in range(self.world)])
+        if sum(k[0] for k in kept) != n:
+            raise RuntimeError("the ranks kept %d of %d rows" % (sum(k[0] for k in kept), n))
+        self.n_rows = int(n)
+        self.segments = [k[1] for k in kept]
+        self._rows_of = None
+        return ShardedContacts(self, self.n_rows)
+
+    def file_rows(self, rank, local_rows):
+        """file positions of some local rows of a rank"""
+        if self.segments is None or self.segments[rank] is None:
+            return self.rows_of[rank][local_rows]
+        seg = self.segments[rank]
+        if not seg:
+            return np.zeros(0, np.int64)
+        starts = np.array([sg[0] for sg in seg], np.int64)
+        files = np.array([sg[1] for sg in seg], np.int64)
+        k = np.searchsorted(starts, local_rows, side="right") - 1
+        return files[k] + (local_rows - starts[k])
+
+    def locate(self, file_rows):
+        """(rank, local row) of some file positions (file reader mode)"""
+        table = sorted((sg[1], sg[2], r, sg[0]) for r, seg in enumerate(self.segments) for sg in seg)
+        fs = np.array([t[0] for t in table], np.int64)
+        k = np.searchsorted(fs, file_rows, side="right") - 1
+        ranks = np.array([t[2] for t in table], np.int64)[k]
+        local = np.array([t[3] for t in table], np.int64)[k] + (file_rows - fs[k])
+        return ranks, local
+
+    @property
+    def rows_of(self):
+        if self._rows_of is None:                          # file reader mode: rebuilt from the stretches (host-writer fallback, tests)
+            if self.segments is None or any(sg is None for sg in self.segments):
+                raise RuntimeError("the ranks' rows are too scattered over the file to list them")
+            self._rows_of = [np.concatenate([np.arange(f, f + ln, dtype=np.int64) for _, f, ln in seg]) if seg else np.zeros(0, np.int64)
+                             for seg in self.segments]
+        return self._rows_of
+
+    @rows_of.setter
+    def rows_of(self, value):
+        self._rows_of = value
 
     def pass_stats(self):
         return _Info(self._all("pass_stats")[0])

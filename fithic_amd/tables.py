@@ -133,6 +133,16 @@ def load_contacts(path, chroms, engine_of, threads=0):
             ctx.ingest_contacts_discard()
             raise
         return DeviceContacts(ctx, n)
+    # `fithic --gpus N`: every rank reads the file itself on its own GPU (sharded.ShardedEngine.ingest_file); a file the device
+    # reader does not take falls through to the host parser below, whose columns rank 0 hands out
+    if getattr(engine_of, "sharded", False) and not os.environ.get("FHX_HOST_READER") and not os.environ.get("FHX_CLI_FUNNEL"):
+        eng0 = engine_of()
+        if hasattr(eng0, "ingest_file"):
+            got = eng0.ingest_file(path, chroms, threads)
+            mark("every rank: inflate + parse + keep its chromosomes")
+            if got is not None:
+                report()
+                return got
     # a file without member sizes (plain gzip) is inflated by the host cores whatever follows: do that before waiting for the
     # engine, whose start-up (HIP runtime, context) then hides behind it
     text = None

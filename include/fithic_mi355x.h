@@ -170,6 +170,16 @@ int fhx_ingest_contacts_file(fhx_ctx* ctx, const char* path, int32_t n_threads, 
 /* test hook: the text of such a file as the device decoder produces it (n_out = its size; cap = room in out) */
 int fhx_debug_inflate_file(fhx_ctx* ctx, const char* path, void* out, int64_t cap, int64_t* n_out);
 int fhx_ingest_contacts_commit(fhx_ctx* ctx, const int32_t* ids, int32_t n_ids);
+/* `fithic --gpus N` without a funnel (every rank parses the file on its own GPU, fithic/fithic.py:404-417 once per rank):
+ *   fhx_ingest_contacts_chr_counts    rows of the parsed text per name, counted by the FIRST locus's chromosome (what decides which
+ *                                     rank a row belongs to: the ranks agree on the owners because they count the same file)
+ *   fhx_ingest_contacts_commit_shard  as fhx_ingest_contacts_commit, but only the rows whose first chromosome has mine[i] != 0
+ *                                     enter the context, in file order, with their file positions (fhx_set_global_rows)
+ *   fhx_shard_segments                the maximal stretches of consecutive file positions among the loaded rows: local_start,
+ *                                     file_start, length of each, ordered; *n_out > cap: too many (nothing filled in)          */
+int fhx_ingest_contacts_chr_counts(fhx_ctx* ctx, int64_t* counts, int32_t n_names);
+int fhx_ingest_contacts_commit_shard(fhx_ctx* ctx, const int32_t* ids, const uint8_t* mine, int32_t n_ids, int64_t* n_kept);
+int fhx_shard_segments(fhx_ctx* ctx, int64_t* local_start, int64_t* file_start, int64_t* length, int64_t cap, int64_t* n_out);
 void fhx_ingest_contacts_discard(fhx_ctx* ctx);
 /* The identity columns of loaded rows, rebuilt from the resident rows (slot -> chromosome id, midpoint): rows = n row
  * numbers, or NULL for all rows in order (n must then be the loaded row count).  What a caller that ingested on the device
@@ -418,6 +428,11 @@ int fhx_host_write_significances(const char* path, const char* const* chr_names,
 int fhx_write_significances_device(fhx_ctx* ctx, const char* path, const char* const* chr_names, int32_t n_names,
                                    const int32_t* chr1, const int32_t* mid1, const int32_t* chr2, const int32_t* mid2,
                                    const int32_t* count, int64_t n_rows, int64_t* rows_written, int64_t* bytes_written);
+/* A stretch [row_begin, row_end) of the loaded rows written the same way (identity columns rebuilt on the device), as gzip members
+ * of their own, with or without the column-header member in front.  The ranks of `fithic --gpus N` each write the stretches of the
+ * file they hold; concatenated in file order the pieces are the reference's file (fithic/fithic.py:1167-1219). */
+int fhx_write_significances_device_range(fhx_ctx* ctx, const char* path, const char* const* chr_names, int32_t n_names, int64_t row_begin,
+                                         int64_t row_end, int32_t with_header, int64_t* rows_written, int64_t* bytes_written);
 
 /* ---- Knight-Ruiz bias vectors (fithic/utils/HiCKRy.py; SURVEY 8f rank 4, the step before Fit-Hi-C) --------------------
  * One fhx_kr per GPU, independent of fhx_ctx.  Call order: load_loci -> load_pairs -> [remove_sparse] -> balance -> bias.

@@ -34,47 +34,55 @@ def main():
     ap.add_argument("--compare-host-reader", action="store_true",
                     help="run once more with FHX_HOST_READER=1 (contacts parsed on the host cores) and compare the output files' md5")
     ap.add_argument("--dir", default="/tmp/cli_scale", help="where the input and output files go (/dev/shm/... takes the disk out)")
+    ap.add_argument("--reuse", action="store_true", help="take the input files --dir already holds (a run after another with the same --chroms)")
+    ap.add_argument("--md5", action="store_true", help="print the md5 and line count of the decompressed significances file")
+    ap.add_argument("--tag", default="run", help="output sub-directory")
     args = ap.parse_args()
     import numpy as np
-    import torch
     import bench
     from fithic_amd import synth, _capi
     cfg = dict(bench.CONFIGS["C3"])
     res = cfg["res"]
-    genome = synth.Genome(res, synth.HG19_AUTOSOMES[:args.chroms] if args.chroms < 22 else None)
-    dev = torch.device("cuda", 0)
-    cols_t, n, _, _ = bench.build_rows(synth, torch, cfg, genome, list(range(len(genome))), 0, 1, dev)
-    cols = [t[:n].cpu().numpy() for t in cols_t]
-    del cols_t
-    torch.cuda.empty_cache()
     out = args.dir
     os.makedirs(out, exist_ok=True)
-    t0 = time.time()
-    _capi.host_write_contacts(out + "/contacts.gz", genome.names, *cols, gzip_level=1)
-    t_w = time.time() - t0
-    if args.plain:
+    if args.reuse and all(os.path.exists(out + "/" + f) for f in ("contacts.gz", "frags.gz", "bias.gz", "rows.txt")):
+        n = int(open(out + "/rows.txt").read())
+        print("reusing the input files of %s (%d contact rows)" % (out, n))
+    else:
+        import torch
+        genome = synth.Genome(res, synth.HG19_AUTOSOMES[:args.chroms] if args.chroms < 22 else None)
+        dev = torch.device("cuda", 0)
+        cols_t, n, _, _ = bench.build_rows(synth, torch, cfg, genome, list(range(len(genome))), 0, 1, dev)
+        cols = [t[:n].cpu().numpy() for t in cols_t]
+        del cols_t
+        torch.cuda.empty_cache()
         t0 = time.time()
-        subprocess.run("gzip -dc %s/contacts.gz | gzip -1 > %s/contacts_plain.gz && mv %s/contacts_plain.gz %s/contacts.gz" % (out, out, out, out),
-                       shell=True, check=True)
-        print("rewritten as one plain gzip member in %.1f s" % (time.time() - t0))
-    import pandas as pd
-    names = np.array(genome.names)
-    f_chr, f_mid, f_hits = genome.fragments()
-    pd.DataFrame({0: names[f_chr], 1: 0, 2: f_mid, 3: f_hits, 4: 1}).to_csv(out + "/frags.gz", sep="\t", header=False, index=False,
-                                                                          compression="gzip")
-    b_chr, b_mid, b_val = genome.bias_table()
-    pd.DataFrame({0: names[b_chr], 1: b_mid, 2: b_val}).to_csv(out + "/bias.gz", sep="\t", header=False, index=False, compression="gzip")
-    print("wrote %d contact rows (%.1f MB gz, %s) in %.1f s; host cores %d" %
-          (n, os.path.getsize(out + "/contacts.gz") / 1e6, "one plain member" if args.plain else "size-tagged members", t_w, os.cpu_count()))
+        _capi.host_write_contacts(out + "/contacts.gz", genome.names, *cols, gzip_level=1)
+        t_w = time.time() - t0
+        if args.plain:
+            t0 = time.time()
+            subprocess.run("gzip -dc %s/contacts.gz | gzip -1 > %s/contacts_plain.gz && mv %s/contacts_plain.gz %s/contacts.gz" % (out, out, out, out),
+                           shell=True, check=True)
+            print("rewritten as one plain gzip member in %.1f s" % (time.time() - t0))
+        import pandas as pd
+        names = np.array(genome.names)
+        f_chr, f_mid, f_hits = genome.fragments()
+        pd.DataFrame({0: names[f_chr], 1: 0, 2: f_mid, 3: f_hits, 4: 1}).to_csv(out + "/frags.gz", sep="\t", header=False, index=False,
+                                                                              compression="gzip")
+        b_chr, b_mid, b_val = genome.bias_table()
+        pd.DataFrame({0: names[b_chr], 1: b_mid, 2: b_val}).to_csv(out + "/bias.gz", sep="\t", header=False, index=False, compression="gzip")
+        open(out + "/rows.txt", "w").write(str(n))
+        print("wrote %d contact rows (%.1f MB gz, %s) in %.1f s; host cores %d" %
+              (n, os.path.getsize(out + "/contacts.gz") / 1e6, "one plain member" if args.plain else "size-tagged members", t_w, os.cpu_count()))
     for passes in args.passes:
         t0 = time.time()
         cmd = [sys.executable, "-m", "fithic_amd", "-i", out + "/contacts.gz", "-f", out + "/frags.gz", "-t", out + "/bias.gz",
-               "-o", out + "/run", "-r", str(res), "-L", str(cfg["L"]), "-U", str(cfg["U"]), "-p", str(passes)]
+               "-o", out + "/" + args.tag, "-r", str(res), "-L", str(cfg["L"]), "-U", str(cfg["U"]), "-p", str(passes)]
         if args.gpus > 1:
             cmd += ["--gpus", str(args.gpus)]
         r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, env=dict(os.environ, FHX_TIMING="1"))
         dt = time.time() - t0
-        sig = out + "/run/FitHiC.spline_pass%d.res%d.significances.txt.gz" % (passes, res)
+        sig = out + "/" + args.tag + "/FitHiC.spline_pass%d.res%d.significances.txt.gz" % (passes, res)
         print("fithic -p %d%s: wall %.2f s for %d rows (%.2f M rows/s end to end), output %.1f MB gz, rc %d" %
               (passes, " --gpus %d" % args.gpus if args.gpus > 1 else "", dt, n, n / dt / 1e6,
                os.path.getsize(sig) / 1e6 if os.path.exists(sig) else -1, r.returncode))
@@ -84,6 +92,9 @@ def main():
         if r.returncode != 0:
             print(r.stderr[-2000:])
             continue
+        if args.md5:
+            pr = subprocess.run("gzip -dc %s | tee >(wc -l >&2) | md5sum" % sig, shell=True, executable="/bin/bash", capture_output=True, text=True)
+            print("    decompressed output: %s lines, md5 %s" % (pr.stderr.strip(), pr.stdout.split()[0]))
         if args.rocprof:
             env = dict(os.environ, TMPDIR="/tmp")
             rp = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", args.rocprof, "-o", "cli", "--"] + cmd, cwd="/tmp",
@@ -123,7 +134,7 @@ def main():
                     md5s.append(hashlib.md5(fh.read()).hexdigest())
             print("    significances file (compressed bytes) md5: device parser %s, host parser %s -> %s" %
                   (md5s[0], md5s[1], "EQUAL" if md5s[0] == md5s[1] else "DIFFERENT"))
-        if passes == 1 and args.check_rows > 0:
+        if passes == 1 and args.check_rows > 0 and "cols" in dir():       # (not with --reuse: the rows are not in memory)
             # the first rows of the output against the oracle's text for the same rows (p, q, biases, ExpCC from the engine's
             # fetch are formatted by the oracle's Python '%e' / '%f'; the row selection and the order are the reference's)
             from fithic_amd.engine import Engine

@@ -476,7 +476,7 @@ def test_cli_writes_the_reference_files(name, tmp_path, capsys):
 
 @pytest.mark.parametrize("name,gpus", [("f1_bias", 2), ("f2_all", 3), ("f6_quirk_all", 2), ("f13_all_p3", 2), ("f13_quirk_p4", 3),
                                        ("f8_nonfixed_all", 2), ("f8_nonfixed_hESC", 3), ("f11_offgrid_all", 3)])
-def test_cli_gpus_n_writes_the_same_files(name, gpus, tmp_path, monkeypatch):
+def test_cli_gpus_n_writes_the_same_files(name, gpus, tmp_path, monkeypatch, capsys):
     """`fithic --gpus N`: rows sharded by chromosome over N ranks (worker processes), genome-wide steps through the library's
     communicator, rank 0 writes the ONE output set - byte-identical to the reference's.  On this one-GPU box the ranks share
     GPU 0 and the collectives travel over pipes (FHX_CLI_TRANSPORT=pipes; RCCL refuses two ranks on one device)."""
@@ -485,12 +485,17 @@ def test_cli_gpus_n_writes_the_same_files(name, gpus, tmp_path, monkeypatch):
     from fithic_amd import cli
     monkeypatch.setenv("FHX_CLI_TRANSPORT", "pipes")
     monkeypatch.setenv("FHX_CLI_DEVICES", ",".join(["0"] * gpus))
+    monkeypatch.setenv("FHX_TIMING", "1")
     meta, g = load_case(name)
     kw = case_args(meta)
     argv = ["-i", kw["contacts"], "-f", kw["frags"], "-o", str(tmp_path), "-l", "G", "--gpus", str(gpus)] + meta["argv"]
     if kw["bias_path"]:
         argv += ["-t", kw["bias_path"]]
     cli.main(argv)
+    # no row went through rank 0: every rank read the file on its own GPU and wrote its own stretches of the output
+    said = capsys.readouterr().out
+    assert "every rank: inflate + parse + keep its chromosomes" in said and "(device parser)" in said
+    assert not [f for f in os.listdir(str(tmp_path)) if ".part-" in f or ".fhx-tmp" in f]
     tag = ".res%d" % kw["resolution"] if kw["resolution"] else ""          # -r 0: no resolution in the file names
     for pi in range(1, meta["n_passes"] + 1):
         with gzip.open(os.path.join(str(tmp_path), "G.spline_pass%d%s.significances.txt.gz" % (pi, tag)), "rb") as f:
@@ -502,6 +507,28 @@ def test_cli_gpus_n_writes_the_same_files(name, gpus, tmp_path, monkeypatch):
         mine = [ln for ln in f.read().splitlines() if not ln.startswith("Means and error written")]
     want = [ln for ln in meta["log_txt"].splitlines() if not ln.startswith("Means and error written")]
     assert mine == want
+
+
+@pytest.mark.parametrize("name,gpus", [("f2_all", 2), ("f13_quirk_p4", 3)])
+def test_cli_gpus_n_with_rows_handed_out_by_rank_0(name, gpus, tmp_path, monkeypatch):
+    """the older route, still what a file outside the device parser's grammar takes: rank 0 parses on the host, hands the columns
+    out and gathers p, q, ExpCC and the biases for the one writer (FHX_CLI_FUNNEL=1 forces it)"""
+    import gzip
+    import hashlib
+    from fithic_amd import cli
+    monkeypatch.setenv("FHX_CLI_TRANSPORT", "pipes")
+    monkeypatch.setenv("FHX_CLI_DEVICES", ",".join(["0"] * gpus))
+    monkeypatch.setenv("FHX_CLI_FUNNEL", "1")
+    meta, g = load_case(name)
+    kw = case_args(meta)
+    argv = ["-i", kw["contacts"], "-f", kw["frags"], "-o", str(tmp_path), "-l", "G", "--gpus", str(gpus)] + meta["argv"]
+    if kw["bias_path"]:
+        argv += ["-t", kw["bias_path"]]
+    cli.main(argv)
+    tag = ".res%d" % kw["resolution"] if kw["resolution"] else ""
+    for pi in range(1, meta["n_passes"] + 1):
+        with gzip.open(os.path.join(str(tmp_path), "G.spline_pass%d%s.significances.txt.gz" % (pi, tag)), "rb") as f:
+            assert hashlib.md5(f.read()).hexdigest() == meta["sig_md5_pass%d" % pi]
 
 
 def test_cli_visual_flag_writes_figures_and_same_tables(tmp_path):
