@@ -38,7 +38,7 @@ def ptr(a, t):
     return a.ctypes.data_as(ctypes.POINTER(t))
 
 
-def main(lib=LIB):
+def main(lib=LIB, with_inputs=False):
     L = ctypes.CDLL(lib)
     L.fhx_last_error.restype = ctypes.c_char_p
     L.fhx_last_error.argtypes = [ctypes.c_void_p]
@@ -86,6 +86,8 @@ def main(lib=LIB):
     k = np.nanargmin(p)
     print("smallest p %.3e (q %.3e) at row %d: count %d, distance %d" % (p[k], q[k], k, cols[4][k], cols[3][k] - cols[1][k]))
     L.fhx_destroy(ctx)
+    if with_inputs:                          # (the test holds p and q against the oracle run on the same tables)
+        return p, q, dict(cols=cols, f_chr=f_chr, f_mid=f_mid, bias=bias, res=res, L=20000, U=1500000, n_bins=30)
     return p, q
 
 

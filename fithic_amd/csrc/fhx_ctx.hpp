@@ -130,7 +130,7 @@ struct QEntry {
 // workgroup - or for another wave: a wave reserves its slots with one LDS atomic per class and goes on.  (Round 2 took one
 // returning GLOBAL atomic per class and tile, eight counters per class: all workgroups adding to one address retire at ~88 M
 // atomics/s on this chip, and the two block barriers around that round trip left the kernel at 29 % of HBM and 49 % VALU busy -
-// bound by neither, profiles/r02_z_pmc.txt.)  A shard's tiles are known in advance (tile t belongs to workgroup t % grid), so a
+// bound by neither, profiles/history/r02_z_pmc.txt.)  A shard's tiles are known in advance (tile t belongs to workgroup t % grid), so a
 // region of ceil(tiles / grid) tiles per shard can never overflow; two classes share a buffer, growing towards each other
 // inside every shard's region.  The class kernels read a queue as one dense list over its shards (QDense, fhx_k2.hip: a prefix
 // of the shard counts in LDS); k2h_scatter and k2_closed take whole shards.

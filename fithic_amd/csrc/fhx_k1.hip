@@ -72,7 +72,7 @@ constexpr int K1_LDS_BINS = 6144;      // 6144 * (8 + 4) B = 72 KiB -> two workg
 // 24 576 bins as (u32 sum, 15-bit row count + guard bit); a sum that wraps adds 2^32 to the bin in HBM (exactly one thread
 // sees the wrap), a row count that reaches 2^15 sets the guard bit, which cannot carry into the neighbouring half-word, and
 // the thread that set it moves 2^15 to HBM and clears it.  With 12 B/bin only a quarter of the bins of that run were in LDS
-// and the rest took two device-scope atomics per row: K1 24.8 ms per 1.06e9 rows (profiles/r02_p_c3w_bench.json).
+// and the rest took two device-scope atomics per row: K1 24.8 ms per 1.06e9 rows (profiles/history/r02_p_c3w_bench.json).
 constexpr int K1_WIDE_BINS = 24576;
 constexpr int K1_WIDE_THREADS = 1024;
 

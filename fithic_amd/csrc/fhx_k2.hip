@@ -143,7 +143,7 @@ struct FusedHist {
 // rows of a wave are neighbours and the L2 merges their stores into whole lines; the bucket-sorted heavy class scatters them over
 // the whole column, and a plain store then makes the L2 FETCH every line it partially writes (PMC, k2h_heavy: 1639 MB read per
 // launch for 427 MB of entries; 713 MB with nontemporal stores, which write through without allocating - and 0.5 ms less per
-// pass, profiles/r02_y_*).  The queue-order kernels keep plain stores (nontemporal ones cost them 10-28 % more write traffic).
+// pass, profiles/history/r02_y_*).  The queue-order kernels keep plain stores (nontemporal ones cost them 10-28 % more write traffic).
 template <bool SCATTERED>
 __device__ __forceinline__ void store_p(double* dst, double v) {
     if (SCATTERED)
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_closed(K2Params P, QSpan q, uns
 // third over their share of the full-size run.  Now every consumer workgroup builds the exclusive prefix of the shard counts in
 // LDS (one DPP scan) and takes dense pieces of that list, and the launches are sized to what the chip holds at a time
 // (`resident_grid`).  How the pieces are handed out follows from what a returning atomic on ONE address costs here - 11 ns,
-// whoever asks (profiles/r02_s_classify_variants.txt): a counter for every 256 entries of the power-series class took twice the
+// whoever asks (profiles/history/r02_s_classify_variants.txt): a counter for every 256 entries of the power-series class took twice the
 // time of the kernel it fed (0.67 against 0.35 ms, profiles/r04_p_kernel_stats.txt), so that class is cut into one contiguous
 // range per wave; the 1024-entry tiles of the converging classes and the 300-iteration tasks of k2h_heavy are few enough
 // for a counter, and each taker's FIRST piece is its own number, so that nobody queues for the counter at the start.
@@ -1192,9 +1192,9 @@ int fhx_pvalues(fhx_ctx* ctx) {
             hipLaunchKernelGGL(k2h_count, dim3(K2H_BLOCKS), dim3(K2H_THREADS), 0, ctx->stream, hs, ctx->d_block_hist);
         launch_rs_scan(ctx, (int)SORT_BLOCKS);
         // rows per lane: 4 at 4 waves/SIMD (7.43 -> 6.66 ms per 2.7e7 rows against one row per lane at 8 waves/SIMD; 2 x 8, 2 x 6,
-        // 3 x 5, 4 x 3 are within 3 % of each other, profiles/r03_c_heavy_variants.txt); FHX_K2H_ROWS / FHX_K2H_WAVES: measurements
+        // 3 x 5, 4 x 3 are within 3 % of each other, profiles/history/r03_c_heavy_variants.txt); FHX_K2H_ROWS / FHX_K2H_WAVES: measurements
         // rows per lane: 4 at 4 waves/SIMD - C3 (2.7e7 rows in the class) 7.43 -> 6.66 ms, a 1/18 shard (1.5e6 rows) 0.87 -> 0.78 ms of
-        // K2 against one row per lane at 8 waves/SIMD; 2 x 8, 3 x 5 and 4 x 3 are within 3 % (profiles/r03_c_*heavy_variants.txt).
+        // K2 against one row per lane at 8 waves/SIMD; 2 x 8, 3 x 5 and 4 x 3 are within 3 % (profiles/history/r03_c_*heavy_variants.txt).
         // FHX_K2H_ROWS (1, 2) / FHX_K2H_WAVES (3) select the instantiations kept for measurements.
         const char* heavy_rows_env = std::getenv("FHX_K2H_ROWS");                 // read per call: the tests run every instantiation
         const int heavy_rows = heavy_rows_env ? std::atoi(heavy_rows_env) : 0;

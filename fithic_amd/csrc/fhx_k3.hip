@@ -393,7 +393,7 @@ __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(WP
 // ---- small survivor sets: two launches instead of eighteen ---------------------------------------------------------------
 // On Hi-C data whose counts follow the model closely (C3-synth: 77 k of 1.5e8 rows below the cutoff) and on every shard of a
 // strong-scaling run the radix sort is all fixed cost: 18 launches of 5-15 us for microseconds of work (0.16 ms per pass,
-// profiles/r03_z_c2_timeline.txt - the launches already run back to back, it is the kernels' own floor).  Up to KS_MAX_KEYS
+// profiles/history/r03_z_c2_timeline.txt - the launches already run back to back, it is the kernels' own floor).  Up to KS_MAX_KEYS
 // survivors are instead sorted tile by tile in LDS (ks_tile_sort: a bitonic network over 4096 (key, row) pairs, the strides
 // below 8 in registers) and the sorted tiles merged by rank (ks_merge_tiles: an element's place is its position in its own tile
 // plus, for every other tile, the number of elements below it - at or below it for earlier tiles).  Neither step is stable and
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(BH_THREADS) void bh_apply(const unsigned long long*
 
 // (Measured and dropped in round 4, profiles/r04_f_small_ab.txt: ONE resident launch for small survivor sets - 64 workgroups,
 // a tile each, the six passes and the BH scan separated by device-wide barriers instead of 21 launches.  The kernels of a small
-// sort already run back to back without gaps (profiles/r03_z_c2_timeline.txt); what a launch boundary costs is what a
+// sort already run back to back without gaps (profiles/history/r03_z_c2_timeline.txt); what a launch boundary costs is what a
 // device-scope barrier costs too - the eight XCDs' L2s are made coherent by writing them back - and 19 such barriers took
 // 0.58 ms where the 21 launches take 0.22 ms for the same 77 k keys.)
 
@@ -1011,7 +1011,7 @@ static int auto_cutoff(fhx_ctx* ctx, const double* d_p, int64_t n, double n_tota
 static int compact_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned long long* keys[2], unsigned int* vals[2], double* d_q,
                            unsigned long long* counter, const unsigned long long* d_cutoff, int64_t* n_kept_out) {
     FHX_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
-    // one workgroup per tile, not a resident grid walking the column: 0.507 -> 0.451 ms on C3 (profiles/r03_x_k3_grid.txt); the
+    // one workgroup per tile, not a resident grid walking the column: 0.507 -> 0.451 ms on C3 (profiles/history/r03_x_k3_grid.txt); the
     // plain copy kernel of profiles/hbm_rate.hip shows the same (4.9 TB/s with 2048 grid-striding workgroups, 5.6 with one per
     // chunk).  FHX_K3_GRID caps the grid for measurements.
     static const int k3_cap = std::getenv("FHX_K3_GRID") ? std::atoi(std::getenv("FHX_K3_GRID")) : (1 << 30);

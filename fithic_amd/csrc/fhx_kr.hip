@@ -165,7 +165,7 @@ __device__ __forceinline__ double kr_fold(double acc, const KrCells<VT>& k, cons
     return acc;
 }
 
-// Measured on the C3 matrix (2.96e8 cells, 547 332 rows; profiles/r02_n_kr_variants.txt, r02_o_kr_variants.txt): this form
+// Measured on the C3 matrix (2.96e8 cells, 547 332 rows; profiles/history/r02_n_kr_variants.txt, r02_o_kr_variants.txt): this form
 // 0.44-0.47 ms = 4.8-5.1 TB/s (the streaming read ceiling seen on this part; K1 reaches 5.2); 4-byte loads with lane-strided
 // cells 0.50; a wave walking 4 / 8 / 16 rows as a software pipeline (next row's cells and the bounds of the row after it
 // requested before the current row is reduced) 0.56-0.58 - the kernel is not latency bound; cells transposed through LDS so that

@@ -1,7 +1,7 @@
 """Why the 300-iteration class cannot be replaced by a cheaper, more accurate evaluation: in its regime (n ~ 1.5e8, contact counts
 2..40, n * prior of the order of the count) scipy.special.bdtrc - Cephes' swapped continued fraction stopped at its iteration cap -
 is itself several 1e-9 away from the exact binomial tail, so an exact evaluation would MISS the north_star's bar (|p - bdtrc| <= 1e-10)
-that the bit-faithful loop meets.  CPU only (scipy + decimal):  python profiles/cephes_vs_exact.py > profiles/r03_cephes_vs_exact.txt"""
+that the bit-faithful loop meets.  CPU only (scipy + decimal):  python profiles/cephes_vs_exact.py > profiles/history/r03_cephes_vs_exact.txt"""
 from decimal import Decimal as D, getcontext
 
 import numpy as np

@@ -561,16 +561,26 @@ def test_mirror_benjamini_hochberg_signature():
     F.reset_session()
 
 
-def test_ctypes_only_example_runs_and_matches_the_package(tmp_path):
-    """examples/ctypes_minimal.py drives the C ABI with bare ctypes (the binding INTEGRATION.md describes); its p-values
-    are what the package computes on the same rows."""
+def test_ctypes_only_example_matches_the_oracle(tmp_path):
+    """examples/ctypes_minimal.py drives the C ABI with bare ctypes (the binding INTEGRATION.md describes); its p and q are the
+    oracle's on the same tables, within 1e-10."""
     import importlib.util
+    from oracle import fithic_oracle as fo
     spec = importlib.util.spec_from_file_location("ctypes_minimal", os.path.join(os.path.dirname(GOLDEN), "..", "examples", "ctypes_minimal.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    p, q = mod.main()
-    assert len(p) > 10000 and np.nanmin(p) < 1e-3 and np.all((q[~np.isnan(q)] >= 0) & (q[~np.isnan(q)] <= 1))
-    assert np.all(q[~np.isnan(q)] >= p[~np.isnan(q)] - 1e-18)
+    p, q, x = mod.main(with_inputs=True)
+    names = ["c0", "c1"]
+    c1, m1, c2, m2, cnt = x["cols"]
+    pairs = fo.Pairs(c1, m1, c2, m2, cnt, names)
+    frags = [(names[c], int(m), 1) for c, m in zip(x["f_chr"], x["f_mid"])]
+    bias = np.where((x["bias"] < 0.5) | (x["bias"] > 2.0), -1.0, x["bias"])
+    bias_dic = {n: {} for n in names}
+    for c, m, b in zip(x["f_chr"], x["f_mid"], bias):
+        bias_dic[names[c]].setdefault(int(m), float(b))
+    ref = fo.run(pairs, frags, None, x["res"], n_bins=x["n_bins"], passes=1, mode="intraOnly", L=x["L"], U=x["U"], bias_dic=bias_dic)[0]
+    assert len(p) > 10000 and np.nanmin(p) < 1e-3
+    assert max_abs_diff(p, ref.p) <= 1e-10 and max_abs_diff(q, ref.q) <= 1e-10
 
 
 @pytest.mark.parametrize("name", ["f1_bias", "f2_all", "f8_nonfixed_all"])
