@@ -66,8 +66,11 @@ def calibration():
         return json.load(f)
 
 
+_T0 = time.time()
+
+
 def log(*a):
-    print(*a, file=sys.stderr, flush=True)
+    print("[%6.1f s]" % (time.time() - _T0), *a, file=sys.stderr, flush=True)
 
 
 def build_rows(synth, torch, cfg, genome, mine, rank, world, device, overdispersion=0.0, hotspots=None):
@@ -607,9 +610,11 @@ def main():
                     out1 = eng.run_pass(collect=False)
                     M["info"] = (out1.info, out1.stats)
                 result["parity_check"] = checked(eng, genome, M["sample"], M["info"], fixture_name)
+                log("headline checked (%.1f s)" % result["parity_check"].get("seconds", -1))
             if not args.no_cpu_baseline:
                 try:
                     result["cpu_baseline"] = cpu_baseline(genome, M["sample"], cfg, not args.no_bias)
+                    log("cpu_baseline (one core) done")
                     try:
                         result["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(genome, M["sample"], cfg, not args.no_bias)
                     except Exception as e:                       # noqa: BLE001 - informational leg
@@ -650,6 +655,7 @@ def main():
                 else:
                     entry["parity_check"] = {"ok": None, "skipped": "--no-parity-check"}
                 result["k3_stress"].append(entry)
+                log("k3_stress: %s measured%s" % (label, " and checked (%.1f s)" % entry["parity_check"].get("seconds", -1) if S["sample"] is not None else ""))
                 S["eng"].close()
                 del S
             except Exception as e:                               # noqa: BLE001 - the headline line must not be lost to the extra workloads

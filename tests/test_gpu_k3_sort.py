@@ -165,3 +165,49 @@ def test_a_pass_whose_digit_is_constant_only_copies(ctx):
     p = (rng.random(n) + 1.0) * 2.0 ** -20                       # one exponent: the top pass sees a single digit
     st = _check(ctx, p)
     assert st["beyond_lists"] == 0
+
+
+def _fuzz_seeds(default):
+    import os
+    spec = os.environ.get("FHX_FUZZ_SEEDS")
+    if not spec:
+        return list(default)
+    lo, hi = (int(v) for v in spec.split(":"))
+    return list(range(lo, hi))
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds(range(7000, 7008)))
+def test_large_sort_fuzz(ctx, seed):
+    """random columns of 1.3e5 .. 2.5e6 values for the large sort: continuous tails, atoms with copies, runs that share their
+    leading bits (short, long, longer than any list), zeros, subnormals, values of 1 and above, NaN; few or many tests (nothing or
+    most of the column cut off).  q bit for bit the oracle's.  FHX_FUZZ_SEEDS=lo:hi widens the campaign."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(131_073, 2_500_000)) if rng.random() < 0.8 else int(rng.integers(131_073, 140_000))
+    kind = rng.integers(0, 5)
+    if kind == 0:
+        p = rng.random(n) ** rng.integers(1, 12)
+    elif kind == 1:
+        p = rng.choice(rng.random(int(rng.integers(2, 5000))) ** 6, n)
+    elif kind == 2:
+        p = _runs(rng, n, 1, int(rng.integers(1, 40)), low_bits=int(rng.integers(20, 30)))
+    elif kind == 3:
+        lens = [int(v) for v in rng.integers(33, min(n // 4, 300_000), int(rng.integers(1, 6)))]
+        while sum(lens) + 8 * len(lens) > n:
+            lens.pop()
+        p = _with_long_runs(rng, n, lens or [40], distinct_low=None if rng.random() < 0.5 else int(rng.integers(2, 6)))
+    else:
+        p = np.exp(rng.normal(-12.0, 6.0, n))
+        p = np.minimum(p, 1.0)
+    m = n // int(rng.integers(20, 2000))
+    if rng.random() < 0.6:
+        p[rng.integers(0, n, m)] = 0.0
+    if rng.random() < 0.5:
+        p[rng.integers(0, n, m // 4 + 1)] = rng.integers(1, 1 << int(rng.integers(2, 53)), m // 4 + 1).astype(np.uint64).view(np.float64)
+    if rng.random() < 0.5:
+        p[rng.integers(0, n, m)] = 1.0
+    if rng.random() < 0.3:
+        p[rng.integers(0, n, 5)] = rng.uniform(1.0, 1e9, 5)
+    if rng.random() < 0.5:
+        p[rng.integers(0, n, 9)] = np.nan
+    N = float(rng.choice([1.0, 3.0, 0.3 * n, 1.0 * n, 7.5 * n, 1e12]))
+    _check(ctx, p, N)
