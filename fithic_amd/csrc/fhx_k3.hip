@@ -519,9 +519,37 @@ __global__ __launch_bounds__(256) void ks_merge_tiles(const unsigned long long* 
 }
 
 // BH value of sorted position i (0-based, global rank = rank0 + i + 1): min(p*N/rank, 1), myStats.py:35-38
+// x / r when the quotient is subnormal.  The division the compiler expands (v_div_scale / v_rcp / v_div_fmas / v_div_fixup) is
+// correctly rounded for normal quotients; a subnormal one is rounded twice - once at 53 bits, once when v_div_fmas scales it back
+// down - and comes out one unit of 2^-1074 off in a case in some hundreds (the large-sort fuzz found it: p = 1.24e-314, N = 1,
+// rank 1646).  Deep maps put such quotients in the file: the handful of subnormal p above thousands of exact zeros.  Here the
+// quotient is rounded ONCE, in integers: with g = 2^-1074, x = q0 r + rem exactly (one fma: the remainder is a multiple of g
+// below 2^34 g), and the nearest multiple of g to x / r is q0 + round_half_even(rem / (r g)) g.
+__device__ __noinline__ double div_to_subnormal(double x, double r, double q0) {
+    const double rem = __builtin_fma(-q0, r, x);
+    const double up = 0x1p537;                                 // 2^1074 in two exact steps
+    const long long R = (long long)(rem * up * up);            // rem / g
+    const long long Q = (long long)(fabs(q0) * up * up);       // |q0| / g  (< 2^52)
+    const long long ri = (long long)r;
+    const long long Rs = x < 0.0 ? -R : R;                     // work on |x| / r
+    long long kf = Rs / ri;
+    long long rr = Rs - kf * ri;
+    if (rr < 0) {
+        rr += ri;
+        --kf;
+    }
+    long long k = kf;
+    if (2 * rr > ri || (2 * rr == ri && ((Q + kf) & 1ll))) ++k;
+    const double mag = (double)(Q + k) * 0x1p-537 * 0x1p-537;  // exact: an integer below 2^53 times g
+    return x < 0.0 ? -mag : mag;
+}
+
 __device__ __forceinline__ double bh_value(unsigned long long key_bits, double n_tests, double rank) {
     const double pv = __longlong_as_double((long long)key_bits);
-    double v = pv * n_tests / rank;           // (p*N)/(i+1): mul then div, never fused
+    const double x = pv * n_tests;
+    double v = x / rank;                      // (p*N)/(i+1): mul then div, never fused
+    if (__builtin_expect(fabs(v) < 0x1p-1022 && x != 0.0 && fabs(x) < 0x1p-900 && rank >= 1.0 && rank < 0x1p53, 0))
+        v = div_to_subnormal(x, rank, v);
     if (1.0 < v || pv == 1.0) v = 1.0;        // min(bh, 1); p == 1.0 is 1.0 whatever N / rank says (myStats.py:33-34)
     // The reference's running maximum starts at 0 (myStats.py:30): invisible while N > 0, but fit_Spline can pass a NEGATIVE
     // number of tests (possible-pair counts go negative with unmappable loci) and then every bh value is negative

@@ -43,8 +43,8 @@ def _runs(rng, n, len_lo, len_hi, low_bits=LOW, distinct_low=None):
     mant_hi = rng.integers(0, 1 << (52 - low_bits), m).astype(np.uint64)
     tops = (expo << np.uint64(52)) | (mant_hi << np.uint64(low_bits))
     tops = np.unique(tops)
-    while len(tops) < m:                                        # (collisions of tops would only merge two runs)
-        tops = np.unique(np.concatenate([tops, tops[:m - len(tops)] + (np.uint64(1) << np.uint64(low_bits))]))
+    if len(tops) < m:                                           # fewer distinct tops than runs: some runs share one (they merge)
+        tops = np.concatenate([tops, rng.choice(tops, m - len(tops))])
     tops = rng.permutation(tops[:m])
     keys = np.repeat(tops, lens)
     if distinct_low is None:
@@ -211,3 +211,17 @@ def test_large_sort_fuzz(ctx, seed):
         p[rng.integers(0, n, 9)] = np.nan
     N = float(rng.choice([1.0, 3.0, 0.3 * n, 1.0 * n, 7.5 * n, 1e12]))
     _check(ctx, p, N)
+
+
+@pytest.mark.parametrize("n", [6000, 300_000])
+def test_subnormal_quotients_are_rounded_once(ctx, n):
+    """q = (p N) / rank with a SUBNORMAL quotient: the division the compiler expands rounds it twice (at 53 bits, then when it is
+    scaled back down) and is one unit of 2^-1074 off in a case in some hundreds - seed 20174 of the fuzz above met p = 1.24e-314 at
+    rank 1646.  The %e of such a q shows it in its 7th digit: deep maps put these rows in the file (subnormal p above the zeros)."""
+    rng = np.random.default_rng(n)
+    p = rng.random(n) ** 4
+    k = n // 3
+    p[rng.choice(n, k, replace=False)] = rng.integers(1, 1 << 44, k).astype(np.uint64).view(np.float64)
+    p[rng.integers(0, n, n // 10)] = 0.0
+    for N in (1.0, 3.0, 977.0, 0.37):
+        _check(ctx, p, N)
