@@ -777,7 +777,7 @@ static int os_run_passes(fhx_ctx* ctx, unsigned long long* keys[2], unsigned int
     switch (plan.passes) {
 #define FHX_OS_HIST(P)                                                                                                             \
     case P:                                                                                                                        \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(os_hist<P>), dim3(hgrid), dim3(OS_THREADS), 0, ctx->stream, (const unsigned long long*)keys[*src_io], \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(os_hist<P>), dim3(hgrid), dim3(OS_HIST_THREADS), 0, ctx->stream, (const unsigned long long*)keys[*src_io], \
                            counter, plan.lo, ctrl + OSC_HIST);                                                                     \
         break
         FHX_OS_HIST(1); FHX_OS_HIST(2); FHX_OS_HIST(3); FHX_OS_HIST(4); FHX_OS_HIST(5); FHX_OS_HIST(6); FHX_OS_HIST(7); FHX_OS_HIST(8);
@@ -1228,6 +1228,7 @@ int fhx_bh_sort_stats(fhx_ctx* ctx, int64_t* out8) {
 
 int fhx_bh_local_sort(fhx_ctx* ctx) {
     if (!ctx) return FHX_ERR_ARG;
+    ctx->k3_kept_by_hist = false;            // (sharded runs: the cutoff comes from the all-reduced histogram, the count from the counter)
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
     if (!ctx->have_p) return fail(ctx, FHX_ERR_ARG, "fhx_pvalues must run first");
     FHX_HIP(hipSetDevice(ctx->device));
