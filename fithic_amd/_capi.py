@@ -407,7 +407,7 @@ class Context:
         self._check(self._L.fhx_ingest_contacts_commit_shard(self._h, _ptr(ids, ctypes.c_int32), _ptr(mine, ctypes.c_uint8), len(ids), ctypes.byref(n)))
         return n.value
 
-    def shard_segments(self, cap=1 << 16):
+    def shard_segments(self, cap=1 << 10):
         """[(local start, file position, length)] of the stretches of consecutive file positions this rank holds, or None (> cap)"""
         a, b, c = (np.zeros(int(cap), np.int64) for _ in range(3))
         n = ctypes.c_int64(0)

@@ -1,12 +1,18 @@
 """`fithic --gpus N`: the reference's one-process run (fithic/fithic.py:317-370) over N MI355X of one node.
 
-Rank 0 is the process the user started: it parses the three tables once, shards the contact rows by chromosome
-(greedy by row count; inter-chromosomal rows follow their first chromosome), keeps shard 0 on its own GPU and hands the
-other shards to N-1 worker processes (one per GPU).  `ShardedEngine` offers the subset of `Engine` the stage functions
-of fithic_amd.fithic use, so the same functions write the same files: every stage is forwarded to all ranks, the
-genome-wide steps go through the library's communicator (fhx_pass_stats_distributed: K1 + one all-reduce;
-fhx_bh_distributed: global ranking; fhx_next_pass_distributed: outlier multiset), and rank 0 gathers p, q, ExpCC and
-the biases back into file order for the one significances file.
+Rank 0 is the process the user started; N-1 worker processes (one per GPU) take commands from it.  `ShardedEngine` offers the
+subset of `Engine` the stage functions of fithic_amd.fithic use, so the same functions write the same files: every stage is
+forwarded to all ranks, the genome-wide steps go through the library's communicator (fhx_pass_stats_distributed: K1 + one
+all-reduce; fhx_bh_distributed: global ranking; fhx_next_pass_distributed: outlier multiset).
+
+Where the contact rows come from and where the significances go (fithic.py:404-417, 1167-1219 - half of the reference's time):
+  * default: EVERY RANK reads the contacts file itself on its own GPU (inflate + parse of the whole file), keeps the rows whose
+    first chromosome is its own (greedy owner map by row count, the same on every rank because they count the same file) and
+    later formats + deflates its own stretches of the output file, which the ranks copy into place side by side.  No row passes
+    through rank 0 (ShardedEngine.ingest_file, _CtxFacade.write_significances_device);
+  * a file the device parser does not take, or one that is not sorted by chromosome (a rank's rows would be more than a
+    thousand separate stretches of the output), or FHX_CLI_FUNNEL=1: rank 0 parses on the host cores, hands the columns out
+    over the pipes (load_contacts) and gathers p, q, ExpCC and the biases back for the one host writer (fetch).
 
 Transports: "rccl" (default; fhx_comm_init, RCCL over xGMI) or "pipes" (fhx_comm_init_custom with the collectives
 below, staged through host memory - for boxes where several ranks must share one GPU, which RCCL refuses; used by the
@@ -632,6 +638,10 @@ class ShardedEngine:
         kept = self._all("commit_shard", per_rank=[(ids, (owner == r).astype(np.uint8)) for r in range(self.world)])
         if sum(k[0] for k in kept) != n:
             raise RuntimeError("the ranks kept %d of %d rows" % (sum(k[0] for k in kept), n))
+        if any(k[1] is None for k in kept):
+            # a file that is not sorted by chromosome: some rank's rows are more than a thousand separate stretches of it, each of
+            # which would be a part file and a writer call of its own - the caller parses on the host and hands the columns out
+            return None
         self.n_rows = int(n)
         self.segments = [k[1] for k in kept]
         self._rows_of = None

@@ -494,7 +494,10 @@ def test_cli_gpus_n_writes_the_same_files(name, gpus, tmp_path, monkeypatch, cap
     cli.main(argv)
     # no row went through rank 0: every rank read the file on its own GPU and wrote its own stretches of the output
     said = capsys.readouterr().out
-    assert "every rank: inflate + parse + keep its chromosomes" in said and "(device parser)" in said
+    assert "every rank: inflate + parse + keep its chromosomes" in said
+    # (two of the files are not sorted by chromosome - a rank's rows would be thousands of separate stretches of the output: those
+    # take the route through rank 0 after all, tested on its own below)
+    assert ("(device parser)" in said) == (name not in ("f2_all", "f13_all_p3"))
     assert not [f for f in os.listdir(str(tmp_path)) if ".part-" in f or ".fhx-tmp" in f]
     tag = ".res%d" % kw["resolution"] if kw["resolution"] else ""          # -r 0: no resolution in the file names
     for pi in range(1, meta["n_passes"] + 1):
