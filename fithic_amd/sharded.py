@@ -228,11 +228,11 @@ class _Rank:
                 path = "%s.part-%015d" % (name, file_start)
                 self.eng.ctx.write_significances_range(path, chr_names, local_start, local_start + length, False)
                 parts.append((file_start, path, os.path.getsize(path)))
-        except _capi.FhxError as e:
+        except BaseException as e:                             # nothing is left behind, whatever went wrong
             for _, path, _ in parts:
                 if os.path.exists(path):
                     os.unlink(path)
-            if e.code == _capi.FHX_ERR_UNSUPPORTED:
+            if isinstance(e, _capi.FhxError) and e.code == _capi.FHX_ERR_UNSUPPORTED:
                 return ("unsupported", str(e))
             raise
         return ("ok", parts)
