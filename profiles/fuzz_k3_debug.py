@@ -1,5 +1,9 @@
+"""What a failing seed of tests/test_gpu_k3_sort.py::test_large_sort_fuzz looks like: the case rebuilt, run through the default sort,
+eight one-sweep passes, round 4's passes and the forced full sort, with the rows that differ from the oracle and the keys around them.
+    python profiles/fuzz_k3_debug.py <seed>        (seed 20174 found the twice-rounded subnormal BH quotient)"""
 import os, sys
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import test_gpu_k3_sort as T
 from fithic_amd import _capi
