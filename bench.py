@@ -637,7 +637,7 @@ def main():
         for label, od, hot in (("lognormal rate noise s = 1.0", 1.0, None), ("hotspots phi:m = 0.2:4.5", 0.0, (0.2, 4.5)),
                                ("hotspots phi:m = 0.25:3.9", 0.0, (0.25, 3.9))):
             try:
-                S = measure(replicas, with_cpu_leg=not args.no_parity_check, steps=max(2, min(args.steps, 3)), warmup=1, overdispersion=od,
+                S = measure(replicas, with_cpu_leg=not args.no_parity_check, steps=max(2, min(args.steps, 10)), warmup=min(max(args.warmup, 1), 3), overdispersion=od,
                             hotspots=hot if hot else (), sample_budget=1.0e7)
                 k3_s = max(r[2] for r in S["k_all"])
                 entry = {
