@@ -442,6 +442,18 @@ def test_kernel_seconds_summed_over_passes(name):
     assert all(s >= l > 0.0 for s, l in zip(sums[:3], last)) and 0.0 < sums[3] <= sums[1]
     assert eng.ctx.kernel_seconds_total(reset=True)[1] == [3, 3, 3, 3]      # nothing is counted twice
     assert eng.ctx.kernel_seconds_total()[1] == [0, 0, 0, 0]
+    # A kernel group run again before its event pair was read (K2 and K3 repeated with no statistics call in between) loses no
+    # pass silently: the pair is read where the stream has passed it, else counted in kernel_events_dropped - folded + dropped is
+    # what ran.
+    info = eng.ctx.fit()
+    for _ in range(4):
+        eng.ctx.pvalues()
+        eng.ctx.bh(info.bh_total_tests)
+    _, counts = eng.ctx.kernel_seconds_total()
+    dropped = eng.ctx.kernel_events_dropped()
+    assert counts[1] + dropped[1] == 4 and counts[2] + dropped[2] == 4 and dropped[0] == 0
+    eng.ctx.kernel_seconds_total(reset=True)
+    assert eng.ctx.kernel_events_dropped() == [0, 0, 0, 0]
     eng.close()
 
 

@@ -268,3 +268,13 @@ def test_header_is_plain_c():
     hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fithic_mi355x.h")
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_build_returns_at_once_when_the_library_is_newer_than_every_source():
+    """csrc/_obj is neither in git nor on the GPU box; an up-to-date .so must not recompile nine units to find that out"""
+    import time
+    from fithic_amd import _capi
+    _capi.build()
+    t0 = time.perf_counter()
+    assert _capi.build() == _capi.LIB_PATH
+    assert time.perf_counter() - t0 < 0.5
