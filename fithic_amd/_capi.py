@@ -157,6 +157,8 @@ SYMBOLS = {
                                                       _I32P, _I32P, _I32P, ctypes.c_int64, _I64P, _I64P]),
     "fhx_write_significances_device_range": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int32, ctypes.c_int64,
                                                             ctypes.c_int64, ctypes.c_int32, _I64P, _I64P]),
+    "fhx_ingest_contacts_file_slice": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _I64P, _I32P, _I32P, _I32P]),
+    "fhx_set_global_rows_range": (ctypes.c_int, [_P, ctypes.c_int64]),
     "fhx_ingest_contacts_chr_counts": (ctypes.c_int, [_P, _I64P, ctypes.c_int32]),
     "fhx_ingest_contacts_commit_shard": (ctypes.c_int, [_P, _I32P, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int32, _I64P]),
     "fhx_shard_segments": (ctypes.c_int, [_P, _I64P, _I64P, _I64P, ctypes.c_int64, _I64P]),
@@ -392,6 +394,21 @@ class Context:
         """ids[i] = the run's chromosome id of name i: the parsed rows become the context's contact rows"""
         ids = np.ascontiguousarray(ids, np.int32)
         self._check(self._L.fhx_ingest_contacts_commit(self._h, _ptr(ids, ctypes.c_int32), len(ids)))
+
+    def ingest_contacts_file_slice(self, path, part, n_parts, threads=0):
+        """part `part` of `n_parts` of the contacts FILE inflated and parsed on the GPU -> (rows, names, ends with a newline); raises
+        FhxError(FHX_ERR_UNSUPPORTED) with .refused as ingest_contacts_file"""
+        n, k, why, nl = ctypes.c_int64(0), ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+        rc = self._L.fhx_ingest_contacts_file_slice(self._h, os.fsencode(path), int(threads), int(part), int(n_parts), ctypes.byref(n),
+                                                    ctypes.byref(k), ctypes.byref(why), ctypes.byref(nl))
+        if rc != FHX_OK:
+            e = FhxError(rc, (self._L.fhx_last_error(self._h) or b"").decode())
+            e.refused = why.value
+            raise e
+        return n.value, [self._L.fhx_ingest_contacts_name(self._h, i).decode() for i in range(k.value)], bool(nl.value)
+
+    def set_global_rows_range(self, first):
+        self._check(self._L.fhx_set_global_rows_range(self._h, int(first)))
 
     def ingest_contacts_chr_counts(self, n_names):
         """rows of the parsed text per name, by the chromosome of the first locus"""

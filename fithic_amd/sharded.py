@@ -209,6 +209,29 @@ class _Rank:
     def ingest_discard(self):
         self.eng.ctx.ingest_contacts_discard()
 
+    def ingest_slice(self, path, threads):
+        """inflate + parse this rank's part of the file (whole gzip members) -> ("ok", rows, names, ends with a newline) or
+        ("unsupported", why)"""
+        try:
+            n, names, newline = self.eng.ctx.ingest_contacts_file_slice(path, self.rank, self.world, threads)
+        except _capi.FhxError as e:
+            if e.code != _capi.FHX_ERR_UNSUPPORTED:
+                raise
+            return ("unsupported", str(e))
+        self._parsed = int(n)
+        return ("ok", n, names, newline)
+
+    def commit_slice(self, ids, first):
+        """the parsed part becomes this rank's rows, at file positions first, first + 1, ..."""
+        ctx = self.eng.ctx
+        ctx.ingest_contacts_commit(ids)
+        self.eng.n_rows = self.n_rows = self._parsed
+        self.eng.pass_no = 0
+        ctx.set_global_rows_range(first)
+        self.segments = [(0, int(first), self.n_rows)] if self.n_rows else []
+        self._ensure_comm()
+        return self.n_rows, self.segments
+
     def commit_shard(self, ids, mine):
         """keep the rows whose first chromosome is this rank's -> (rows kept, [(local start, file position, length)] or None)"""
         n = self.eng.ctx.ingest_contacts_commit_shard(ids, mine)
@@ -484,6 +507,7 @@ class ShardedEngine:
         self.ctx = _CtxFacade(self)
         self.n_rows = 0
         self.segments = None                                 # file reader mode: per rank [(local start, file position, length)]
+        self.split = None                                    # file reader mode: "file" (parts of the file) or "chromosome"
         self.rows_of = [np.zeros(0, np.int64) for _ in range(gpus)]
         self.resolution = None
 
@@ -623,6 +647,10 @@ class ShardedEngine:
         host and hands the columns out: load_contacts)."""
         from . import tables
         per = max(1, (os.cpu_count() or 1) // self.world) if not threads else threads
+        if os.environ.get("FHX_CLI_SPLIT", "file") != "chromosome":
+            con = self._ingest_slices(path, chroms, per)
+            if con is not None:
+                return con
         results = self._all("ingest_file", path, per)
         if any(res[0] != "ok" for res in results):
             self._all("ingest_discard")
@@ -645,6 +673,30 @@ class ShardedEngine:
         self.n_rows = int(n)
         self.segments = [k[1] for k in kept]
         self._rows_of = None
+        self.split = "chromosome"
+        return ShardedContacts(self, self.n_rows)
+
+    def _ingest_slices(self, path, chroms, threads):
+        """The cheaper split: rank r inflates and parses part r of the FILE (whole gzip members, cut where the compressed bytes
+        divide evenly), so the file is read once in all, each rank's rows are ONE stretch of the output, and the rows - K2's work -
+        are balanced whatever the chromosomes' sizes.  Nothing in the engine needs a chromosome's rows on one rank (the statistics
+        are sums over rows; the off-grid test and the outlier mask are per row).  Needs members that carry their sizes (this
+        library's writers, bgzip) and parts that end on a row: else None, and the ranks split by chromosome instead."""
+        from . import tables
+        results = self._all("ingest_slice", path, threads)
+        if any(res[0] != "ok" for res in results) or not all(res[3] for res in results[:-1]):
+            self._all("ingest_discard")
+            return None
+        intern = tables._interner(chroms)
+        ids = [intern(res[2]) for res in results]              # in rank order = the file's order of first appearance
+        first = np.concatenate([[0], np.cumsum([res[1] for res in results])])
+        kept = self._all("commit_slice", per_rank=[(ids[r], int(first[r])) for r in range(self.world)])
+        self.n_rows = int(first[-1])
+        if sum(k[0] for k in kept) != self.n_rows:
+            raise RuntimeError("the ranks kept %d of %d rows" % (sum(k[0] for k in kept), self.n_rows))
+        self.segments = [k[1] for k in kept]
+        self._rows_of = None
+        self.split = "file"
         return ShardedContacts(self, self.n_rows)
 
     def file_rows(self, rank, local_rows):

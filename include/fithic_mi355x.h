@@ -177,6 +177,14 @@ int fhx_ingest_contacts_commit(fhx_ctx* ctx, const int32_t* ids, int32_t n_ids);
  *                                     enter the context, in file order, with their file positions (fhx_set_global_rows)
  *   fhx_shard_segments                the maximal stretches of consecutive file positions among the loaded rows: local_start,
  *                                     file_start, length of each, ordered; *n_out > cap: too many (nothing filled in)          */
+/* The cheaper split (round 5, last step): the ranks cut the FILE, not the genome.  fhx_ingest_contacts_file_slice inflates and
+ * parses part `part` of `n_parts` (whole gzip members, cut where the compressed bytes divide evenly; the members must carry their
+ * sizes, else *refused = 1; *ends_with_newline: the part's text ends a row - required of every part but the last);
+ * fhx_ingest_contacts_commit takes its rows; fhx_set_global_rows_range(first) numbers them first, first + 1, ... (first = the rows of
+ * the parts before it).  Nothing in the engine needs a chromosome's rows on one rank. */
+int fhx_ingest_contacts_file_slice(fhx_ctx* ctx, const char* path, int32_t n_threads, int32_t part, int32_t n_parts, int64_t* n_rows,
+                                   int32_t* n_names, int32_t* refused, int32_t* ends_with_newline);
+int fhx_set_global_rows_range(fhx_ctx* ctx, int64_t first);
 int fhx_ingest_contacts_chr_counts(fhx_ctx* ctx, int64_t* counts, int32_t n_names);
 int fhx_ingest_contacts_commit_shard(fhx_ctx* ctx, const int32_t* ids, const uint8_t* mine, int32_t n_ids, int64_t* n_kept);
 int fhx_shard_segments(fhx_ctx* ctx, int64_t* local_start, int64_t* file_start, int64_t* length, int64_t cap, int64_t* n_out);

@@ -524,6 +524,87 @@ def test_cli_gpus_n_writes_the_same_files(name, gpus, tmp_path, monkeypatch, cap
     assert mine == want
 
 
+def _tagged_copy(src, dst, n_members, on_rows=True):
+    """the gzip file `src` rewritten as `n_members` members that carry their sizes (the "FH" extra field of this library's writers,
+    include/fithic_mi355x.h); on_rows=False: cut by bytes, so that members end in the middle of a row"""
+    import gzip
+    import struct
+    import zlib
+    with gzip.open(src, "rb") as f:
+        text = f.read()
+    if on_rows:
+        lines = text.splitlines(keepends=True)
+        per = max(1, -(-len(lines) // n_members))
+        chunks = [b"".join(lines[k:k + per]) for k in range(0, len(lines), per)]
+    else:
+        per = max(1, -(-len(text) // n_members))
+        chunks = [text[k:k + per] for k in range(0, len(text), per)]
+    with open(dst, "wb") as out:
+        for c in chunks:
+            z = zlib.compressobj(6, zlib.DEFLATED, -15)
+            body = z.compress(c) + z.flush()
+            out.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<H2sHQ", 12, b"FH", 8, 24 + len(body) + 8))
+            out.write(body + struct.pack("<II", zlib.crc32(c), len(c) & 0xffffffff))
+    return dst
+
+
+@pytest.mark.parametrize("name,gpus,members", [("f1_bias", 2, 7), ("f2_all", 3, 11), ("f13_all_p3", 2, 5), ("f13_quirk_p4", 3, 9),
+                                               ("f11_offgrid_all", 3, 8), ("f8_nonfixed_all", 2, 6), ("f6_quirk_all", 4, 3)])
+def test_cli_gpus_n_cuts_a_file_of_tagged_members_into_parts(name, gpus, members, tmp_path, monkeypatch, capsys):
+    """A contacts file whose gzip members carry their sizes (this library's writers, bgzip) is cut into N parts of whole members:
+    every rank inflates and parses only its part, holds one stretch of the output, and a chromosome's rows may lie on several
+    ranks (files not sorted by chromosome included: f2_all, f13_all_p3) - the files written are the reference's.  With fewer
+    members than ranks (f6_quirk_all on 4) some ranks hold no rows."""
+    import gzip
+    import hashlib
+    from fithic_amd import cli
+    monkeypatch.setenv("FHX_CLI_TRANSPORT", "pipes")
+    monkeypatch.setenv("FHX_CLI_DEVICES", ",".join(["0"] * gpus))
+    monkeypatch.setenv("FHX_TIMING", "1")
+    meta, g = load_case(name)
+    kw = case_args(meta)
+    contacts = _tagged_copy(kw["contacts"], str(tmp_path / "contacts.tagged.gz"), members)
+    out = tmp_path / "out"
+    out.mkdir()
+    argv = ["-i", contacts, "-f", kw["frags"], "-o", str(out), "-l", "G", "--gpus", str(gpus)] + meta["argv"]
+    if kw["bias_path"]:
+        argv += ["-t", kw["bias_path"]]
+    cli.main(argv)
+    said = capsys.readouterr().out
+    assert "every rank: inflate + parse its part of the file" in said and "(device parser)" in said
+    assert not [f for f in os.listdir(str(out)) if ".part-" in f or ".fhx-tmp" in f]
+    tag = ".res%d" % kw["resolution"] if kw["resolution"] else ""
+    for pi in range(1, meta["n_passes"] + 1):
+        with gzip.open(os.path.join(str(out), "G.spline_pass%d%s.significances.txt.gz" % (pi, tag)), "rb") as f:
+            assert hashlib.md5(f.read()).hexdigest() == meta["sig_md5_pass%d" % pi]
+        with open(os.path.join(str(out), "G.fithic_pass%d%s.txt" % (pi, tag))) as f:
+            assert f.read() == meta["fithic_pass%d_txt" % pi]
+    with open(os.path.join(str(out), "G.fithic.log")) as f:
+        mine = [ln for ln in f.read().splitlines() if not ln.startswith("Means and error written")]
+    assert mine == [ln for ln in meta["log_txt"].splitlines() if not ln.startswith("Means and error written")]
+
+
+def test_cli_gpus_n_splits_by_chromosome_when_members_end_inside_a_row(tmp_path, monkeypatch, capsys):
+    """parts of the file are only taken when each ends a row: members cut anywhere (a bgzip file) fall back to the split by
+    chromosome, where every rank parses the whole text"""
+    import gzip
+    import hashlib
+    from fithic_amd import cli
+    monkeypatch.setenv("FHX_CLI_TRANSPORT", "pipes")
+    monkeypatch.setenv("FHX_CLI_DEVICES", "0,0")
+    monkeypatch.setenv("FHX_TIMING", "1")
+    meta, g = load_case("f1_bias")
+    kw = case_args(meta)
+    contacts = _tagged_copy(kw["contacts"], str(tmp_path / "contacts.tagged.gz"), 5, on_rows=False)
+    out = tmp_path / "out"
+    out.mkdir()
+    cli.main(["-i", contacts, "-f", kw["frags"], "-o", str(out), "-l", "G", "--gpus", "2", "-t", kw["bias_path"]] + meta["argv"])
+    assert "every rank: inflate + parse + keep its chromosomes" in capsys.readouterr().out
+    for pi in range(1, meta["n_passes"] + 1):
+        with gzip.open(os.path.join(str(out), "G.spline_pass%d.res%d.significances.txt.gz" % (pi, kw["resolution"])), "rb") as f:
+            assert hashlib.md5(f.read()).hexdigest() == meta["sig_md5_pass%d" % pi]
+
+
 @pytest.mark.parametrize("name,gpus", [("f2_all", 2), ("f13_quirk_p4", 3)])
 def test_cli_gpus_n_with_rows_handed_out_by_rank_0(name, gpus, tmp_path, monkeypatch):
     """the older route, still what a file outside the device parser's grammar takes: rank 0 parses on the host, hands the columns
