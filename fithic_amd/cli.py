@@ -44,7 +44,7 @@ def parse_args(argv=None):
                         help="Print version and exit")
     parser.add_argument("--device", dest="device", type=int, default=0, help="GPU ordinal (engine option, not in the reference)")
     parser.add_argument("--gpus", dest="gpus", type=int, default=1,
-                        help="engine option, not in the reference: shard the contact rows by chromosome over this many GPUs of the "
+                        help="engine option, not in the reference: shard the contact rows (parts of the file, else by chromosome) over this many GPUs of the "
                              "node (RCCL for the genome-wide steps); the output files are the ones a single GPU writes")
     return parser.parse_args(argv)
 

@@ -43,7 +43,7 @@ toKb, toMb, toProb = 10 ** -3, 10 ** -6, 10 ** 5
 logfile = None
 resolution = None          # engine-only global, see the module docstring
 device = 0                 # GPU ordinal the engine uses
-gpus = 1                   # > 1: contact rows sharded by chromosome over that many GPUs (fithic_amd.sharded)
+gpus = 1                   # > 1: contact rows sharded over that many GPUs (fithic_amd.sharded)
 
 
 class _Session:
