@@ -159,6 +159,7 @@ SYMBOLS = {
                                                             ctypes.c_int64, ctypes.c_int32, _I64P, _I64P]),
     "fhx_ingest_contacts_file_slice": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _I64P, _I32P, _I32P, _I32P]),
     "fhx_set_global_rows_range": (ctypes.c_int, [_P, ctypes.c_int64]),
+    "fhx_ingest_contacts_text_slice": (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _I64P, _I32P]),
     "fhx_ingest_contacts_chr_counts": (ctypes.c_int, [_P, _I64P, ctypes.c_int32]),
     "fhx_ingest_contacts_commit_shard": (ctypes.c_int, [_P, _I32P, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int32, _I64P]),
     "fhx_shard_segments": (ctypes.c_int, [_P, _I64P, _I64P, _I64P, ctypes.c_int64, _I64P]),
@@ -406,6 +407,12 @@ class Context:
             e.refused = why.value
             raise e
         return n.value, [self._L.fhx_ingest_contacts_name(self._h, i).decode() for i in range(k.value)], bool(nl.value)
+
+    def ingest_contacts_text_slice(self, text, part, n_parts, threads=0):
+        """the rows that start in part `part` of `n_parts` of an inflated text (HostText) parsed on the GPU -> (rows, names)"""
+        n, k = ctypes.c_int64(0), ctypes.c_int32(0)
+        self._check(self._L.fhx_ingest_contacts_text_slice(self._h, text._h, int(threads), int(part), int(n_parts), ctypes.byref(n), ctypes.byref(k)))
+        return n.value, [self._L.fhx_ingest_contacts_name(self._h, i).decode() for i in range(k.value)]
 
     def set_global_rows_range(self, first):
         self._check(self._L.fhx_set_global_rows_range(self._h, int(first)))

@@ -219,9 +219,24 @@ class _Rank:
         except _capi.FhxError as e:
             if e.code != _capi.FHX_ERR_UNSUPPORTED:
                 raise
-            return ("unsupported", str(e))
+            return ("container" if getattr(e, "refused", 2) == 1 else "unsupported", str(e))
         self._parsed = int(n)
         return ("ok", n, names, newline)
+
+    def ingest_text_slice(self, path, threads):
+        """a file the device does not inflate (plain gzip): inflated whole on this rank's share of the host cores, then the rows
+        that start in this rank's N-th of the text uploaded and parsed -> as ingest_slice"""
+        text = _capi.HostText(path, threads)
+        try:
+            n, names = self.eng.ctx.ingest_contacts_text_slice(text, self.rank, self.world, threads)
+        except _capi.FhxError as e:
+            if e.code != _capi.FHX_ERR_UNSUPPORTED:
+                raise
+            return ("unsupported", str(e))
+        finally:
+            text.close()
+        self._parsed = int(n)
+        return ("ok", n, names, True)
 
     def commit_slice(self, ids, first):
         """the parsed part becomes this rank's rows, at file positions first, first + 1, ..."""
@@ -509,7 +524,7 @@ class ShardedEngine:
         self.ctx = _CtxFacade(self)
         self.n_rows = 0
         self.segments = None                                 # file reader mode: per rank [(local start, file position, length)]
-        self.split = None                                    # file reader mode: "file" (parts of the file) or "chromosome"
+        self.split = None                                    # file reader mode: "file" / "text" (parts of the file / of its text) or "chromosome"
         self.rows_of = [np.zeros(0, np.int64) for _ in range(gpus)]
         self.resolution = None
 
@@ -683,12 +698,22 @@ class ShardedEngine:
         divide evenly), so the file is read once in all, each rank's rows are ONE stretch of the output, and the rows - K2's work -
         are balanced whatever the chromosomes' sizes.  Nothing in the engine needs a chromosome's rows on one rank (the statistics
         are sums over rows; the off-grid test and the outlier mask are per row).  Needs members that carry their sizes (this
-        library's writers, bgzip) and parts that end on a row: else None, and the ranks split by chromosome instead."""
+        library's writers) and parts that end on a row; a file without such members (plain gzip) is inflated by every rank on the
+        host and its TEXT cut into N parts on row starts, and so is one whose members end inside rows (bgzip).  None (a text outside
+        the device parser's grammar): the caller goes on to the split by chromosome and from there to the host parser."""
         from . import tables
+        cut = "file"
         results = self._all("ingest_slice", path, threads)
         if any(res[0] != "ok" for res in results) or not all(res[3] for res in results[:-1]):
+            # not a chain of size-tagged members (plain gzip), or members that end inside rows (bgzip; the pieces of a row at the
+            # ends of a part may also have made the parser refuse it): every rank inflates the file on its share of the host cores
+            # and takes the rows that start in its N-th of the TEXT - 1/N of the upload and of the parse
             self._all("ingest_discard")
-            return None
+            results = self._all("ingest_text_slice", path, threads)
+            if any(res[0] != "ok" for res in results):
+                self._all("ingest_discard")
+                return None
+            cut = "text"
         intern = tables._interner(chroms)
         ids = [intern(res[2]) for res in results]              # in rank order = the file's order of first appearance
         first = np.concatenate([[0], np.cumsum([res[1] for res in results])])
@@ -698,7 +723,7 @@ class ShardedEngine:
             raise RuntimeError("the ranks kept %d of %d rows" % (sum(k[0] for k in kept), self.n_rows))
         self.segments = [k[1] for k in kept]
         self._rows_of = None
-        self.split = "file"
+        self.split = cut
         return ShardedContacts(self, self.n_rows)
 
     def file_rows(self, rank, local_rows):

@@ -139,8 +139,9 @@ def load_contacts(path, chroms, engine_of, threads=0):
         eng0 = engine_of()
         if hasattr(eng0, "ingest_file"):
             got = eng0.ingest_file(path, chroms, threads)
-            mark("every rank: inflate + parse its part of the file" if getattr(eng0, "split", None) == "file"
-                 else "every rank: inflate + parse + keep its chromosomes")
+            mark({"file": "every rank: inflate + parse its part of the file",
+                  "text": "every rank: inflate on the host, parse its part of the text"}.get(getattr(eng0, "split", None),
+                                                                                             "every rank: inflate + parse + keep its chromosomes"))
             if got is not None:
                 report()
                 return got

@@ -185,6 +185,10 @@ int fhx_ingest_contacts_commit(fhx_ctx* ctx, const int32_t* ids, int32_t n_ids);
 int fhx_ingest_contacts_file_slice(fhx_ctx* ctx, const char* path, int32_t n_threads, int32_t part, int32_t n_parts, int64_t* n_rows,
                                    int32_t* n_names, int32_t* refused, int32_t* ends_with_newline);
 int fhx_set_global_rows_range(fhx_ctx* ctx, int64_t first);
+/* The same for a file the device does not inflate (plain gzip): every rank inflates it (fhx_host_inflate), then uploads and parses
+ * only the rows that start in its N-th of the text's bytes - every row in exactly one part. */
+int fhx_ingest_contacts_text_slice(fhx_ctx* ctx, const struct fhx_text* text, int32_t n_threads, int32_t part, int32_t n_parts, int64_t* n_rows,
+                                   int32_t* n_names);
 int fhx_ingest_contacts_chr_counts(fhx_ctx* ctx, int64_t* counts, int32_t n_names);
 int fhx_ingest_contacts_commit_shard(fhx_ctx* ctx, const int32_t* ids, const uint8_t* mine, int32_t n_ids, int64_t* n_kept);
 int fhx_shard_segments(fhx_ctx* ctx, int64_t* local_start, int64_t* file_start, int64_t* length, int64_t cap, int64_t* n_out);

@@ -486,16 +486,21 @@ def test_cli_writes_the_reference_files(name, tmp_path, capsys):
     assert mine == want
 
 
+@pytest.mark.parametrize("split", ["file", "chromosome"])
 @pytest.mark.parametrize("name,gpus", [("f1_bias", 2), ("f2_all", 3), ("f6_quirk_all", 2), ("f13_all_p3", 2), ("f13_quirk_p4", 3),
                                        ("f8_nonfixed_all", 2), ("f8_nonfixed_hESC", 3), ("f11_offgrid_all", 3)])
-def test_cli_gpus_n_writes_the_same_files(name, gpus, tmp_path, monkeypatch, capsys):
-    """`fithic --gpus N`: rows sharded by chromosome over N ranks (worker processes), genome-wide steps through the library's
-    communicator, rank 0 writes the ONE output set - byte-identical to the reference's.  On this one-GPU box the ranks share
-    GPU 0 and the collectives travel over pipes (FHX_CLI_TRANSPORT=pipes; RCCL refuses two ranks on one device)."""
+def test_cli_gpus_n_writes_the_same_files(name, gpus, split, tmp_path, monkeypatch, capsys):
+    """`fithic --gpus N`: rows sharded over N ranks (worker processes), genome-wide steps through the library's communicator, ONE
+    output set - byte-identical to the reference's.  The fixtures are plain gzip files: every rank inflates them on the host and
+    takes the rows that start in its N-th of the text (split "file"), or parses all of it and keeps its chromosomes
+    (FHX_CLI_SPLIT=chromosome).  On this one-GPU box the ranks share GPU 0 and the collectives travel over pipes
+    (FHX_CLI_TRANSPORT=pipes; RCCL refuses two ranks on one device)."""
     import gzip
     import hashlib
     from fithic_amd import cli
     monkeypatch.setenv("FHX_CLI_TRANSPORT", "pipes")
+    if split == "chromosome":
+        monkeypatch.setenv("FHX_CLI_SPLIT", "chromosome")
     monkeypatch.setenv("FHX_CLI_DEVICES", ",".join(["0"] * gpus))
     monkeypatch.setenv("FHX_TIMING", "1")
     meta, g = load_case(name)
@@ -506,10 +511,13 @@ def test_cli_gpus_n_writes_the_same_files(name, gpus, tmp_path, monkeypatch, cap
     cli.main(argv)
     # no row went through rank 0: every rank read the file on its own GPU and wrote its own stretches of the output
     said = capsys.readouterr().out
-    assert "every rank: inflate + parse + keep its chromosomes" in said
-    # (two of the files are not sorted by chromosome - a rank's rows would be thousands of separate stretches of the output: those
-    # take the route through rank 0 after all, tested on its own below)
-    assert ("(device parser)" in said) == (name not in ("f2_all", "f13_all_p3"))
+    if split == "file":
+        assert "every rank: inflate on the host, parse its part of the text" in said and "(device parser)" in said
+    else:
+        assert "every rank: inflate + parse + keep its chromosomes" in said
+        # (two of the files are not sorted by chromosome - a rank's rows would be thousands of separate stretches of the output:
+        # split by chromosome those take the route through rank 0 after all, tested on its own below)
+        assert ("(device parser)" in said) == (name not in ("f2_all", "f13_all_p3"))
     assert not [f for f in os.listdir(str(tmp_path)) if ".part-" in f or ".fhx-tmp" in f]
     tag = ".res%d" % kw["resolution"] if kw["resolution"] else ""          # -r 0: no resolution in the file names
     for pi in range(1, meta["n_passes"] + 1):
@@ -584,22 +592,23 @@ def test_cli_gpus_n_cuts_a_file_of_tagged_members_into_parts(name, gpus, members
     assert mine == [ln for ln in meta["log_txt"].splitlines() if not ln.startswith("Means and error written")]
 
 
-def test_cli_gpus_n_splits_by_chromosome_when_members_end_inside_a_row(tmp_path, monkeypatch, capsys):
-    """parts of the file are only taken when each ends a row: members cut anywhere (a bgzip file) fall back to the split by
-    chromosome, where every rank parses the whole text"""
+def test_cli_gpus_n_cuts_the_text_when_members_end_inside_a_row(tmp_path, monkeypatch, capsys):
+    """parts of the FILE are only taken when each ends a row: members cut anywhere (a bgzip file) are inflated by every rank on the
+    host, and the TEXT is cut on row starts"""
     import gzip
     import hashlib
     from fithic_amd import cli
     monkeypatch.setenv("FHX_CLI_TRANSPORT", "pipes")
-    monkeypatch.setenv("FHX_CLI_DEVICES", "0,0")
+    monkeypatch.setenv("FHX_CLI_DEVICES", "0,0,0")
     monkeypatch.setenv("FHX_TIMING", "1")
     meta, g = load_case("f1_bias")
     kw = case_args(meta)
     contacts = _tagged_copy(kw["contacts"], str(tmp_path / "contacts.tagged.gz"), 5, on_rows=False)
     out = tmp_path / "out"
     out.mkdir()
-    cli.main(["-i", contacts, "-f", kw["frags"], "-o", str(out), "-l", "G", "--gpus", "2", "-t", kw["bias_path"]] + meta["argv"])
-    assert "every rank: inflate + parse + keep its chromosomes" in capsys.readouterr().out
+    cli.main(["-i", contacts, "-f", kw["frags"], "-o", str(out), "-l", "G", "--gpus", "3", "-t", kw["bias_path"]] + meta["argv"])
+    said = capsys.readouterr().out
+    assert "every rank: inflate on the host, parse its part of the text" in said and "(device parser)" in said
     for pi in range(1, meta["n_passes"] + 1):
         with gzip.open(os.path.join(str(out), "G.spline_pass%d.res%d.significances.txt.gz" % (pi, kw["resolution"])), "rb") as f:
             assert hashlib.md5(f.read()).hexdigest() == meta["sig_md5_pass%d" % pi]
