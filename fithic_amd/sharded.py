@@ -9,9 +9,10 @@ Where the contact rows come from and where the significances go (fithic.py:404-4
   * default: EVERY RANK reads the contacts file itself on its own GPU and later formats + deflates its own stretches of the
     output file, which the ranks copy into place side by side.  No row passes through rank 0 (ShardedEngine.ingest_file,
     _CtxFacade.write_significances_device).  A file of gzip members that carry their sizes is cut into N parts of whole
-    members - rank r inflates and parses part r only, its rows are one stretch of the file (_ingest_slices); any other file is
-    inflated and parsed whole by every rank, which keeps the rows whose first chromosome is its own (greedy owner map by row
-    count, the same on every rank because they count the same file);
+    members - rank r inflates and parses part r only, its rows are one stretch of the file (_ingest_slices); any other gzip
+    file is inflated by every rank on the host and rank r uploads and parses the rows that start in the r-th N-th of the text.
+    (FHX_CLI_SPLIT=chromosome: every rank parses the whole file and keeps the rows whose first chromosome is its own - greedy
+    owner map by row count, the same on every rank because they count the same file);
   * a file the device parser does not take, or one split by chromosome without being sorted by chromosome (a rank's rows would
     be more than a thousand separate stretches of the output), or FHX_CLI_FUNNEL=1: rank 0 parses on the host cores, hands the columns out
     over the pipes (load_contacts) and gathers p, q, ExpCC and the biases back for the one host writer (fetch).
