@@ -159,6 +159,7 @@ SYMBOLS = {
                                                             ctypes.c_int64, ctypes.c_int32, _I64P, _I64P]),
     "fhx_ingest_contacts_file_slice": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _I64P, _I32P, _I32P, _I32P]),
     "fhx_set_global_rows_range": (ctypes.c_int, [_P, ctypes.c_int64]),
+    "fhx_text_part_bounds": (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, _I64P, _I64P]),
     "fhx_ingest_contacts_text_slice": (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _I64P, _I32P]),
     "fhx_ingest_contacts_chr_counts": (ctypes.c_int, [_P, _I64P, ctypes.c_int32]),
     "fhx_ingest_contacts_commit_shard": (ctypes.c_int, [_P, _I32P, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int32, _I64P]),
@@ -785,6 +786,15 @@ class HostText:
         if rc != FHX_OK:
             raise FhxError(rc, "fhx_text_copy")
         return out.tobytes()
+
+    def part_bounds(self, part, n_parts):
+        """bytes [lo, hi) of the text that part `part` of `n_parts` takes (Ctx.ingest_contacts_text_slice): the rows that start in its
+        N-th of the bytes"""
+        lo, hi = ctypes.c_int64(0), ctypes.c_int64(0)
+        rc = self._L.fhx_text_part_bounds(self._h, int(part), int(n_parts), ctypes.byref(lo), ctypes.byref(hi))
+        if rc != FHX_OK:
+            raise FhxError(rc, "fhx_text_part_bounds")
+        return lo.value, hi.value
 
     def close(self):
         if self._h:

@@ -189,6 +189,8 @@ int fhx_set_global_rows_range(fhx_ctx* ctx, int64_t first);
  * only the rows that start in its N-th of the text's bytes - every row in exactly one part. */
 int fhx_ingest_contacts_text_slice(fhx_ctx* ctx, const struct fhx_text* text, int32_t n_threads, int32_t part, int32_t n_parts, int64_t* n_rows,
                                    int32_t* n_names);
+/* bytes [*lo, *hi) of the text that part takes (host only; parts can be empty) */
+int fhx_text_part_bounds(const struct fhx_text* text, int32_t part, int32_t n_parts, int64_t* lo, int64_t* hi);
 int fhx_ingest_contacts_chr_counts(fhx_ctx* ctx, int64_t* counts, int32_t n_names);
 int fhx_ingest_contacts_commit_shard(fhx_ctx* ctx, const int32_t* ids, const uint8_t* mine, int32_t n_ids, int64_t* n_kept);
 int fhx_shard_segments(fhx_ctx* ctx, int64_t* local_start, int64_t* file_start, int64_t* length, int64_t cap, int64_t* n_out);

@@ -278,3 +278,52 @@ def test_build_returns_at_once_when_the_library_is_newer_than_every_source():
     t0 = time.perf_counter()
     assert _capi.build() == _capi.LIB_PATH
     assert time.perf_counter() - t0 < 0.5
+
+
+def _python_part_bounds(text, part, n_parts):
+    """the rule of fhx_text_part_bounds restated: a cut is the first start of a row at or after the N-th's first byte"""
+    T = len(text)
+
+    def cut(at):
+        if at <= 0:
+            return 0
+        k = text.find(b"\n", at - 1)
+        return T if k < 0 else k + 1
+    lo = cut(T // n_parts * part + T % n_parts * part // n_parts)
+    hi = T if part + 1 == n_parts else cut(T // n_parts * (part + 1) + T % n_parts * (part + 1) // n_parts)
+    return lo, hi
+
+
+@pytest.mark.parametrize("shape", ["rows", "no_final_newline", "one_long_row", "no_newline_at_all", "empty", "many_pieces"])
+def test_text_parts_tile_the_text_on_row_starts(shape, tmp_path, monkeypatch):
+    """fhx_text_part_bounds (what `fithic --gpus N` cuts a plain gzip file's text with): for every N the parts tile the text, every
+    part begins at the start of a row, and they are the restated rule's - over one piece and over many (the parallel gunzip's chunks,
+    whose borders fall anywhere), rows longer than a part and texts without a newline included."""
+    import gzip
+    rng = np.random.default_rng(5)
+    rows = [b"chr%d\t%d\tchr%d\t%d\t%d\n" % (rng.integers(1, 23), rng.integers(1, 10**9), rng.integers(1, 23), rng.integers(1, 10**9),
+                                              rng.integers(1, 500)) for _ in range(4000)]
+    text = {"rows": b"".join(rows), "no_final_newline": b"".join(rows)[:-1],
+            "one_long_row": b"".join(rows[:10]) + b"x" * 200000 + b"\n" + b"".join(rows[10:40]),
+            "no_newline_at_all": b"y" * 5000, "empty": b"", "many_pieces": b"".join(rows * 12)}[shape]
+    if shape == "many_pieces":
+        monkeypatch.setenv("FHX_PGUNZIP_MIN", "0")
+        monkeypatch.setenv("FHX_PGUNZIP_CHUNK", "16384")
+    path = str(tmp_path / "t.gz")
+    with gzip.open(path, "wb", 6) as f:
+        f.write(text)
+    ht = _capi.HostText(path, 8)
+    try:
+        assert len(ht) == len(text)
+        for n_parts in (1, 2, 3, 5, 8, 64):
+            bounds = [ht.part_bounds(k, n_parts) for k in range(n_parts)]
+            assert bounds == [_python_part_bounds(text, k, n_parts) for k in range(n_parts)]
+            assert bounds[0][0] == 0 and bounds[-1][1] == len(text)
+            for (lo, hi), (lo2, _) in zip(bounds, bounds[1:]):
+                assert lo <= hi == lo2
+            for lo, hi in bounds:
+                assert lo == 0 or lo == len(text) or text[lo - 1:lo] == b"\n"
+        with pytest.raises(_capi.FhxError):
+            ht.part_bounds(3, 3)
+    finally:
+        ht.close()
