@@ -175,3 +175,62 @@ def test_socket_mesh_between_ranks_of_a_launcher(world, tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     for k in range(world):                                   # (the ranks share one stdout: lines may interleave)
         assert r.stdout.count("mesh-ok-%d" % k) == 1, r.stdout
+
+
+class _ScriptedRanks:
+    """stands in for a ShardedEngine's ranks: answers every command from a script and records what was asked"""
+
+    def __init__(self, world, answers):
+        self.world, self.answers, self.asked = world, answers, []
+        self.segments = self._rows_of = self.split = None
+        self.n_rows = 0
+
+    def _all(self, command, *args, per_rank=None):
+        self.asked.append(command)
+        if command == "commit_slice":
+            self.committed = per_rank
+            return [(self._n[r], [(0, per_rank[r][1], self._n[r])] if self._n[r] else []) for r in range(self.world)]
+        if command == "ingest_discard":
+            return [None] * self.world
+        out = self.answers[command]
+        self._n = [res[1] if res[0] == "ok" else 0 for res in out]
+        return out
+
+
+@pytest.mark.parametrize("case", ["tagged members", "plain gzip", "members end inside rows", "a part the parser refuses",
+                                  "text outside the grammar"])
+def test_how_the_ranks_of_the_cli_split_a_contacts_file(case):
+    """ShardedEngine._ingest_slices, the decisions only (the ranks are scripted): parts of the FILE when every part parsed and all
+    but the last end a row; else parts of the TEXT; None - on to the split by chromosome and the host parser - when that fails too.
+    Names are interned in rank order (the file's order of first appearance), file positions are the prefix of the parts' rows."""
+    from fithic_amd import sharded, tables
+    ok_file = [("ok", 5, ["chr2", "chr1"], True), ("ok", 0, [], True), ("ok", 7, ["chr1", "chr3"], False)]
+    ok_text = [("ok", 4, ["chr2"], True), ("ok", 6, ["chr1", "chr2"], True), ("ok", 2, ["chr3"], True)]
+    refused = [("unsupported", "line 3 has four fields")] * 3
+    script = {
+        "tagged members": {"ingest_slice": ok_file},
+        "plain gzip": {"ingest_slice": [("container", "no member sizes")] * 3, "ingest_text_slice": ok_text},
+        "members end inside rows": {"ingest_slice": [("ok", 5, ["chr2"], False), ("ok", 3, ["chr1"], True), ("ok", 4, ["chr3"], True)],
+                                    "ingest_text_slice": ok_text},
+        "a part the parser refuses": {"ingest_slice": [ok_file[0], refused[0], ok_file[2]], "ingest_text_slice": ok_text},
+        "text outside the grammar": {"ingest_slice": refused, "ingest_text_slice": refused},
+    }[case]
+    ranks = _ScriptedRanks(3, script)
+    chroms = tables.ChromIndex()
+    chroms.intern("chr1")                                     # (the fragments file was read first)
+    got = sharded.ShardedEngine._ingest_slices(ranks, "contacts.gz", chroms, 4)
+    if case == "tagged members":
+        assert ranks.asked == ["ingest_slice", "commit_slice"] and ranks.split == "file"
+        assert chroms.names == ["chr1", "chr2", "chr3"]
+        assert [list(ids) for ids, _ in ranks.committed] == [[1, 0], [], [0, 2]]
+        assert [first for _, first in ranks.committed] == [0, 5, 5]
+        assert len(got) == 12 and ranks.segments == [[(0, 0, 5)], [], [(0, 5, 7)]]
+    elif case == "text outside the grammar":
+        assert got is None and ranks.asked == ["ingest_slice", "ingest_discard", "ingest_text_slice", "ingest_discard"]
+        assert chroms.names == ["chr1"]                       # nothing interned by the attempts
+    else:
+        assert ranks.asked == ["ingest_slice", "ingest_discard", "ingest_text_slice", "commit_slice"] and ranks.split == "text"
+        assert chroms.names == ["chr1", "chr2", "chr3"]
+        assert [list(ids) for ids, _ in ranks.committed] == [[1], [0, 1], [2]]
+        assert [first for _, first in ranks.committed] == [0, 4, 10]
+        assert len(got) == 12 and ranks.segments == [[(0, 0, 4)], [(0, 4, 6)], [(0, 10, 2)]]
