@@ -897,6 +897,35 @@ int fhx_text_copy(const fhx_text* x, void* dst, int64_t cap) {
 const char* fhx_text_error(const fhx_text* x) { return x ? x->error.c_str() : "null text"; }
 void fhx_text_free(fhx_text* x) { delete x; }
 
+// Bytes [*lo, *hi) of an inflated text that part `part` of `n_parts` takes: the rows that START in the part-th N-th of its bytes (a
+// cut moves forward to the next start of a row, so every row is in exactly one part whatever its length; parts can be empty).
+int fhx_text_part_bounds(const fhx_text* text, int32_t part, int32_t n_parts, int64_t* lo_out, int64_t* hi_out) {
+    if (!text || !lo_out || !hi_out || n_parts < 1 || part < 0 || part >= n_parts) return FHX_ERR_ARG;
+    const int64_t T = text->bytes;
+    // the first start of a row at or after byte `at`: 0, T, or the byte after a newline
+    auto cut = [&](int64_t at) -> int64_t {
+        if (at <= 0) return 0;
+        int64_t base = 0;
+        bool searching = false;                             // true: looking for the first newline from the start of this piece on
+        for (const fhx::TextPiece& piece : text->pieces) {
+            const int64_t n = (int64_t)piece.size();
+            if (!searching && at - 1 >= base + n) {
+                base += n;
+                continue;
+            }
+            const int64_t from = searching ? 0 : at - 1 - base;              // the row starting at `at` needs a newline at at - 1
+            const void* hit = n > from ? std::memchr(piece.data() + from, '\n', (size_t)(n - from)) : nullptr;
+            if (hit) return base + ((const char*)hit - piece.data()) + 1;
+            searching = true;
+            base += n;
+        }
+        return T;
+    };
+    *lo_out = cut(T / n_parts * part + T % n_parts * part / n_parts);
+    *hi_out = part + 1 == n_parts ? T : cut(T / n_parts * (part + 1) + T % n_parts * (part + 1) / n_parts);
+    return FHX_OK;
+}
+
 int fhx_host_parse_text(const fhx_text* text, int32_t kind, int32_t n_threads, fhx_table** out) {
     if (!text || !out) return FHX_ERR_ARG;
     return parse_pieces(text->pieces, text->path.c_str(), kind, n_threads, out, inflate_report(text));

@@ -136,6 +136,19 @@ static std::string inflate_all(const std::string& path, int threads, int* rc_out
     if (rc == FHX_OK) {
         text.resize((size_t)fhx_text_bytes(x));
         EXPECT(fhx_text_copy(x, text.empty() ? nullptr : &text[0], (int64_t)text.size()) == FHX_OK, "text copy");
+        // the parts a sharded run cuts the text into: they tile it, and each starts a row
+        const int n_parts = 1 + (int)rnd(9);
+        int64_t end = 0;
+        for (int k = 0; k < n_parts; ++k) {
+            int64_t lo = -1, hi = -1;
+            EXPECT(fhx_text_part_bounds(x, k, n_parts, &lo, &hi) == FHX_OK, "part bounds");
+            EXPECT(lo == end && hi >= lo && hi <= (int64_t)text.size(), "parts follow each other");
+            EXPECT(lo == 0 || lo == (int64_t)text.size() || text[(size_t)lo - 1] == '\n', "a part starts a row");
+            end = hi;
+        }
+        EXPECT(end == (int64_t)text.size(), "parts cover the text");
+        int64_t lo = 0, hi = 0;
+        EXPECT(fhx_text_part_bounds(x, n_parts, n_parts, &lo, &hi) == FHX_ERR_ARG, "part out of range");
     } else {
         EXPECT(x == nullptr || std::strlen(fhx_text_error(x)) > 0, "an error carries a message");
     }
