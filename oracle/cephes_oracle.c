@@ -14,6 +14,11 @@
  *
  * Pinned by: tests/golden/f3_bdtrc.npz (scipy.special.bdtrc / betaln bit patterns generated in the
  * build container by tests/golden/make_golden.py) and, where scipy is importable, live comparison.
+ *
+ * TOTALS AT AND ABOVE 2^31.  scipy's bdtrc takes n as a C int: the reference's Python-int totals are narrowed to 32 bits
+ * (n = 2^31 -> NaN, n = 2^32 + 10^6 -> 10^6).  fho_bdtrc() does the same and is pinned there by
+ * tests/golden/f15_bdtrc_int_n.npz and the f15_* whole runs of the real reference; fho_bdtrc_wide() is the second, explicitly
+ * named mode (the true total as a real number) - "parity unpinned" above 2^31 by construction: no reference computes it.
  */
 #include <math.h>
 #include <stdint.h>
@@ -447,8 +452,10 @@ double fho_incbet(double aa, double bb, double xx)
     return t;
 }
 
-/* scipy.special.bdtrc(k, n, p): the reference passes (count-1, total contacts, prior). */
-double fho_bdtrc(double k, double n, double p)
+/* Cephes' bdtrc with n as a real number: the arithmetic of bdtr.c on a total that is NOT narrowed to a C int.  This is the
+ * oracle's SECOND mode ("wide totals"): for n < 2^31 it is scipy.special.bdtrc bit for bit; at and above 2^31 it is what the
+ * formula would give on the true total - NOT what the reference writes there (see fho_bdtrc below). */
+double fho_bdtrc_wide(double k, double n, double p)
 {
     g_last_branch = -1;
     g_last_iters = 0;
@@ -471,11 +478,36 @@ double fho_bdtrc(double k, double n, double p)
     return fho_incbet(fk + 1, dn, p);
 }
 
+/* What a C `int` holds after scipy's ufunc loop `dld->d` narrows the C long it received: the value modulo 2^32, in
+ * [-2^31, 2^31).  n must be integral and |n| < 2^63 (the reference's totals are Python ints of counts: exact in a double up
+ * to 2^53). */
+double fho_int_narrowed(double n)
+{
+    if (!(fabs(n) < 9.2e18))
+        return n;                                 /* NaN / out of a C long: not the reference's call, left alone */
+    return (double)(int32_t)(uint32_t)(uint64_t)(int64_t)n;
+}
+
+/* scipy.special.bdtrc(k, n, p) as the reference calls it (fithic.py:1070,1101: count-1, a Python int total, prior):
+ * scipy 1.15.3 binds Cephes' `double bdtrc(double k, int n, double p)`, so the total is narrowed to 32 bits first -
+ * n = 2^31 arrives as -2^31 (n < k: NaN), n = 2^32 + 10^6 as 10^6.  Pinned by tests/golden/f15_bdtrc_int_n.npz (scipy's own
+ * values at fifteen totals from 2^31 - 1 to 2^52) and the f15_* whole-run fixtures.  This is the DEFAULT mode of the oracle. */
+double fho_bdtrc(double k, double n, double p)
+{
+    return fho_bdtrc_wide(k, fho_int_narrowed(n), p);
+}
+
 /* ---- vector entry points used through ctypes ------------------------------------------------ */
 void fho_bdtrc_vec(const double *k, const double *n, const double *p, double *out, int64_t len)
 {
     for (int64_t i = 0; i < len; ++i)
         out[i] = fho_bdtrc(k[i], n[i], p[i]);
+}
+
+void fho_bdtrc_wide_vec(const double *k, const double *n, const double *p, double *out, int64_t len)
+{
+    for (int64_t i = 0; i < len; ++i)
+        out[i] = fho_bdtrc_wide(k[i], n[i], p[i]);
 }
 
 void fho_bdtrc_vec_stats(const double *k, const double *n, const double *p, double *out,

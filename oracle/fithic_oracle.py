@@ -59,13 +59,27 @@ def _dptr(a):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
 
 
-def bdtrc(k, n, p):
-    """Vectorised scipy.special.bdtrc(k, n, p) through the C restatement."""
+TOTALS_REFERENCE, TOTALS_WIDE = "reference", "wide"
+
+
+def int_narrowed(n):
+    """What scipy's `int n` holds of a Python-int total: n modulo 2^32 in [-2^31, 2^31) (see cephes_oracle.c: fho_bdtrc)."""
+    return ((int(n) + 2 ** 31) % 2 ** 32) - 2 ** 31
+
+
+def bdtrc(k, n, p, totals=TOTALS_REFERENCE):
+    """Vectorised scipy.special.bdtrc(k, n, p) through the C restatement.
+    totals="reference" (default): n narrowed to a C int first, as scipy does with the reference's Python-int totals
+    (fithic.py:1070,1101) - pinned by tests/golden/f15_*; totals="wide": the same arithmetic on the true n (identical below
+    2^31; above it nothing pins it - it is the engine's wide-totals mode restated, not the reference)."""
+    if totals not in (TOTALS_REFERENCE, TOTALS_WIDE):
+        raise ValueError("totals must be 'reference' or 'wide'")
     k = np.ascontiguousarray(np.broadcast_to(np.asarray(k, np.float64), np.broadcast(k, n, p).shape))
     n = np.ascontiguousarray(np.broadcast_to(np.asarray(n, np.float64), k.shape))
     p = np.ascontiguousarray(np.broadcast_to(np.asarray(p, np.float64), k.shape))
     out = np.empty(k.shape, np.float64)
-    _lib().fho_bdtrc_vec(_dptr(k), _dptr(n), _dptr(p), _dptr(out), ctypes.c_int64(k.size))
+    f = _lib().fho_bdtrc_vec if totals == TOTALS_REFERENCE else _lib().fho_bdtrc_wide_vec
+    f(_dptr(k), _dptr(n), _dptr(p), _dptr(out), ctypes.c_int64(k.size))
     return out
 
 
@@ -581,7 +595,7 @@ class PassResult:
     pass
 
 
-def fit_spline(pairs, dist_keys, x, y, b1, b2, mode, L, U, tL, tU, sums, frag, use_scipy=False):
+def fit_spline(pairs, dist_keys, x, y, b1, b2, mode, L, U, tL, tU, sums, frag, use_scipy=False, totals=TOTALS_REFERENCE):
     """fithic.py:925-1233 minus file output.  sums = (interCount, interSum, intraAllSum, inRangeSum)."""
     inter_count, inter_sum, _intra_all_sum, in_range_sum = sums
     R = PassResult()
@@ -634,7 +648,7 @@ def fit_spline(pairs, dist_keys, x, y, b1, b2, mode, L, U, tL, tU, sums, frag, u
             look = np.minimum(np.maximum(d[sel].astype(np.float64), lo), hi)
             idx = np.minimum(np.searchsorted(R.splineX.astype(np.float64), look, side="left"), len(R.splineX) - 1)
             prior = R.newSplineY[idx] * (b1[sel] * b2[sel])
-            p[sel] = bdtrc(cnt[sel] - 1, float(in_range_sum), prior)
+            p[sel] = bdtrc(cnt[sel] - 1, float(in_range_sum), prior, totals)
             expcc[sel] = np.where(within[sel], in_range_sum * prior, 0.0)
         rest = ~discard & inter                      # branches 3, 4 keep p = 1; inter falls to 5/6
     else:
@@ -643,7 +657,7 @@ def fit_spline(pairs, dist_keys, x, y, b1, b2, mode, L, U, tL, tU, sums, frag, u
         sel = np.flatnonzero(rest)                                                # branch 5
         if len(sel):
             prior = frag["inter_prob"] * (b1[sel] * b2[sel])
-            p[sel] = bdtrc(cnt[sel] - 1, float(inter_sum), prior)
+            p[sel] = bdtrc(cnt[sel] - 1, float(inter_sum), prior, totals)
             expcc[sel] = np.where(within[sel], inter_sum * prior, 0.0)
     # ---- BH dispatch (fithic.py:1126-1164) ------------------------------------------------------
     if all_reg:
@@ -679,8 +693,9 @@ def format_significances(pairs, R, b1, b2):
 
 
 def run(contacts, frags, bias_path, resolution, n_bins=100, passes=1, mode=INTRA_ONLY, L=0, U=float("inf"),
-        mapp_thres=1, tL=0.5, tU=2, use_scipy=False, keep_text=False, bias_dic=None):
-    """main() of the reference after argument parsing (fithic.py:317-370). Returns a list of passes."""
+        mapp_thres=1, tL=0.5, tU=2, use_scipy=False, keep_text=False, bias_dic=None, totals=TOTALS_REFERENCE):
+    """main() of the reference after argument parsing (fithic.py:317-370). Returns a list of passes.
+    totals: how bdtrc sees a total that does not fit a C int - "reference" (scipy narrows it; what fithic.py writes) or "wide"."""
     pairs = read_contacts_file(contacts) if isinstance(contacts, str) else contacts
     frag_rows = read_fragments_file(frags) if isinstance(frags, str) else frags
     if bias_dic is None:
@@ -701,7 +716,7 @@ def run(contacts, frags, bias_path, resolution, n_bins=100, passes=1, mode=INTRA
             frag = generate_frag_pairs_nonfixed(frag_rows, bins, L, U, mapp_thres, icnt)
         x, y, pass_txt = calculate_probabilities(bins, rng_sum)
         R = fit_spline(pairs, keys, x, y, b1, b2, mode, L, U, tL, tU, (icnt, isum, intra_all, rng_sum), frag,
-                       use_scipy=use_scipy)
+                       use_scipy=use_scipy, totals=totals)
         R.dist_keys, R.dist_sumcc = keys, sumcc
         R.sums = (icnt, isum, intra_all, rng_sum)
         R.bins0, R.bins, R.frag, R.x, R.y, R.pass_txt = bins0, bins, frag, x, y, pass_txt

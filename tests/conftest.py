@@ -48,7 +48,9 @@ FIXED_CASES = ["f1_nobias", "f1_bias", "f2_all", "f2_inter", "f2_intra", "f2_all
 NONFIXED_CASES = ["f8_nonfixed_hESC", "f8_nonfixed_all", "f8_nonfixed_nobounds"]        # -r 0
 OFFGRID_CASES = ["f11_offgrid_all", "f11_offgrid_intra"]     # -r N on loci that are not on one grid (fixed-size possible pairs)
 MULTIPASS_CASES = ["f13_all_p3", "f13_quirk_p4", "f13_hESC_p3"]   # -p 3 / -p 4: one outlier list for the whole run (fithic.py:336-370)
-ALL_CASES = FIXED_CASES + NONFIXED_CASES + OFFGRID_CASES + MULTIPASS_CASES
+# in-range and / or inter-chromosomal totals at and above 2^31: scipy's bdtrc narrows n to a C int (fithic.py:1070, 1101)
+WRAP_CASES = ["f15_intra_2p31_all", "f15_intra_2p32_intra", "f15_inter_2p31_inter", "f15_both_2p32_all"]
+ALL_CASES = FIXED_CASES + NONFIXED_CASES + OFFGRID_CASES + MULTIPASS_CASES + WRAP_CASES
 SMALL_CASES = [c for c in ALL_CASES if not c.startswith("f1_") and c != "f13_hESC_p3"]
 
 

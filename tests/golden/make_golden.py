@@ -23,6 +23,7 @@ Fixture sets:
   F10 utils/CombineNearbyInteraction.py: merged loop lists (output files) in the modes its flags offer
 
 Usage:  python tests/golden/make_golden.py [f1] [f2] [f3] [f4] [f5] [f6]     (default: all)
+  F15 totals at and above 2^31: bdtrc known answers with n beyond a C int, and whole runs whose in-range / inter totals wrap
   F13 more than two passes on the F1 / F2 / F6 data (-p 3, -p 4): the outlier lists live for the whole run, duplicates included
 """
 import sys
@@ -768,6 +769,75 @@ def make_f13():
              ["-L", "50000", "-U", "5000000", "-b", "50", "-p", "3", "-x", "intraOnly"], subsample=29)
 
 
+
+# ------------------------------------------------------------------------------------------------ F15
+def _scaled_contacts(src, dst, cis_mul, trans_mul):
+    """Rows of data/<src> with every cis count times cis_mul and every trans count times trans_mul (counts stay < 2^31)."""
+    out = []
+    sums = [0, 0]
+    with gzip.open(os.path.join(DATA, src), "rt") as f:
+        for line in f:
+            c1, m1, c2, m2, cc = line.split()
+            mul = cis_mul if c1 == c2 else trans_mul
+            v = int(float(cc) * mul)                      # e.g. 0.4 x 500 000 -> 200 000
+            assert 0 <= v < 2 ** 31
+            sums[c1 != c2] += v
+            out.append("%s\t%s\t%s\t%s\t%d\n" % (c1, m1, c2, m2, v))
+    _write_gz(os.path.join(DATA, dst), "".join(out))
+    return sums
+
+
+def make_f15():
+    """Totals at and above 2^31.  fit_Spline hands observedIntraInRangeSum / observedInterAllSum - Python ints, accumulated at
+    fithic.py:436-440 - to scipy.special.bdtrc as n (fithic.py:1070, 1101); the ufunc loop that takes them is `dld->d` and its
+    Cephes core takes `int n`: the C long is narrowed to 32 bits.  n = 2^31 arrives as -2^31 (n < k: NaN), n = 2^32 + 10^6 as
+    10^6.  These fixtures pin that behaviour: known-answer vectors of bdtrc itself and whole runs of the reference's main()."""
+    print("F15: totals >= 2^31 (scipy's bdtrc narrows n to a C int)")
+    rng = np.random.default_rng(15)
+    ks, ns, ps = [], [], []
+    totals = [2 ** 31 - 1, 2 ** 31, 2 ** 31 + 1, 3_215_733_208, 2 ** 32 - 1, 2 ** 32, 2 ** 32 + 1, 2 ** 32 + 5, 2 ** 32 + 10 ** 6,
+              2 ** 32 + 6_495_767, 7_150_761_687, 2 ** 33 + 123_456_789, 3 * 2 ** 32 + 649_576, 2 ** 40 + 10 ** 7, 2 ** 52 + 150]
+    for n in totals:
+        w = ((n + 2 ** 31) % 2 ** 32) - 2 ** 31           # what the C int holds
+        for _ in range(260):
+            count = int(min(1 + rng.geometric(0.08 if rng.random() < 0.8 else 0.004), 200000))
+            ratio = math.exp(rng.normal(0.0, 1.2))
+            base = w if (w > 0 and rng.random() < 0.7) else n          # expected ~ observed under the narrowed or the true total
+            prior = min(max(count * ratio / base, 1e-13), 0.999)
+            ks.append(count - 1)
+            ns.append(n)
+            ps.append(prior)
+        for k, p in ((-1, 0.5), (0, 1e-9), (0, 0.3), (1, 1e-9), (3, 1e-9), (3, 0.0), (3, 1.0), (4, 0.3), (5, 0.3), (7, 0.3),
+                     (0, float("nan")), (2, -0.1), (2, 1.5), (-1, 2.0)):
+            ks.append(k)
+            ns.append(n)
+            ps.append(p)
+    ks = np.array(ks, np.float64)
+    ns = np.array(ns, np.int64)
+    ps = np.array(ps, np.float64)
+    with np.errstate(all="ignore"):
+        vals = scsp.bdtrc(ks, ns, ps)                     # float64, int64, float64 -> the `dld->d` loop, as the reference's call
+    np.savez_compressed(os.path.join(HERE, "f15_bdtrc_int_n.npz"), k=ks, n=ns, p=ps, val=vals)
+    print("  %d bdtrc vectors at %d totals (%d NaN)" % (len(ks), len(totals), int(np.isnan(vals).sum())))
+    # whole runs: the quirk set with its counts scaled (cis and trans separately, to put either total where it is wanted)
+    fr, bi = "quirk.frags.gz", "quirk.bias.gz"
+    cases = [
+        # name, cis x, trans x, argv tail
+        ("f15_intra_2p31_all", 500000, 500000, ["-b", "12", "-p", "2", "-x", "All", "-L", "20000", "-U", "400000"]),
+        ("f15_intra_2p32_intra", 450000, 1, ["-b", "10", "-p", "2", "-x", "intraOnly"]),
+        ("f15_inter_2p31_inter", 1, 10000000, ["-b", "12", "-p", "1", "-x", "interOnly"]),
+        ("f15_both_2p32_all", 800000, 20000000, ["-b", "12", "-p", "1", "-x", "All", "-L", "20000", "-U", "400000"]),
+    ]
+    for name, cm, tm, tail in cases:
+        contacts = "quirk_x%d_x%d.contacts.gz" % (cm, tm)
+        sums = _scaled_contacts("quirk.contacts.gz", contacts, cm, tm)
+        print("  %s: sum of cis counts %d, of trans counts %d" % (contacts, sums[0], sums[1]))
+        run_case(name, contacts, fr, bi, 10000, tail)
+        meta = json.load(open(os.path.join(HERE, name + ".json")))
+        g = np.load(os.path.join(HERE, name + ".npz"))
+        s = g["p1_sums"]
+        print("    in-range sum %d, inter sum %d, NaN p in pass 1: %d of %d rows" % (s[3], s[1], meta["pass1"]["n_nan_p"], meta["n_rows"]))
+
 # ------------------------------------------------------------------------------------------------ F14
 def make_f14():
     """The fit at the HEADLINE sizes (bench.py's C3, C3w, C5: 22 autosomes at 5 kb / 1 kb, 576 216 / 2 881 044 loci, 397 / 49 734 /
@@ -888,8 +958,8 @@ def make_calib():
 
 
 if __name__ == "__main__":
-    which = [a.lower() for a in sys.argv[1:]] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13"]
+    which = [a.lower() for a in sys.argv[1:]] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f15"]
     jobs = dict(f1=make_f1, f2=make_f2, f3=make_f3, f4=make_f4, f5=make_f5, f6=make_f6, f7=make_f7, f8=make_f8, f9=make_f9,
-                f10=make_f10, f11=make_f11, f12=make_f12, f13=make_f13, f14=make_f14, calib=make_calib)
+                f10=make_f10, f11=make_f11, f12=make_f12, f13=make_f13, f14=make_f14, f15=make_f15, calib=make_calib)
     for w in which:
         jobs[w]()

@@ -29,6 +29,27 @@ def test_bdtrc_known_answers_bit_exact(g3):
     assert ok.all(), "%d of %d bdtrc vectors differ from scipy" % ((~ok).sum(), len(ok))
 
 
+def test_bdtrc_narrows_the_total_to_a_c_int_like_scipy():
+    """n at and above 2^31 (fithic.py:1070,1101 pass Python ints; scipy's core takes `int n`): scipy's own values at fifteen
+    totals from 2^31 - 1 to 2^52, incl. C3w's 3 215 733 208 and C5's 7 150 761 687 (make_golden.py f15)."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "f15_bdtrc_int_n.npz"))
+    out = fo.bdtrc(g["k"], g["n"].astype(np.float64), g["p"])
+    ref = g["val"]
+    assert np.array_equal(np.isnan(out), np.isnan(ref))
+    ok = np.isnan(ref) | (out.view(np.int64) == ref.view(np.int64))
+    assert ok.all(), "%d of %d vectors differ from scipy" % ((~ok).sum(), len(ok))
+    assert np.isnan(ref).sum() > 1000 and (~np.isnan(ref)).sum() > 1000
+    # the second mode is a different function there - and the same one below 2^31
+    wide = fo.bdtrc(g["k"], g["n"].astype(np.float64), g["p"], totals="wide")
+    big = g["n"] >= 2 ** 31
+    assert bits_equal(wide[~big], ref[~big])
+    assert (np.isnan(ref[big]) & ~np.isnan(wide[big])).sum() > 1000
+    assert [fo.int_narrowed(v) for v in (2 ** 31 - 1, 2 ** 31, 2 ** 32 - 1, 2 ** 32, 2 ** 32 + 10 ** 6, 7150761687)] == [
+        2 ** 31 - 1, -2 ** 31, -1, 0, 10 ** 6, -1439172905]
+
+
 def test_bdtrc_branch_coverage(g3):
     _, br, it = fo.bdtrc_stats(g3["k"], g3["n"].astype(np.float64), g3["p"])
     # closed form, pseries, incbcf, incbd, swapped pseries / incbcf / incbd all present
