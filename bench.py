@@ -247,6 +247,11 @@ def main():
     ap.add_argument("--path", choices=["fithic", "kr", "cni"], default="fithic",
                     help="fithic (default): the headline pass.  kr / cni: the neighbouring steps (Knight-Ruiz bias vectors, merging of "
                          "nearby contacts) measured by profiles/kr_bench.py / profiles/cni_bench.py, plus their cpu_baseline")
+    ap.add_argument("--totals", choices=["auto", "reference", "wide"], default="auto",
+                    help="what bdtrc is given for a total of counts >= 2^31 (include/fithic_mi355x.h FHX_TOTALS_*): 'reference' narrows it to a "
+                         "C int as scipy does under fithic.py (every in-range p-value of C3w and C5 is then nan - nothing to time); 'wide' uses "
+                         "the true total.  auto = wide for C3w / C5, reference elsewhere (C2 / C3 totals are below 2^31: both are the same "
+                         "function).  The line says which ran: totals_semantics")
     ap.add_argument("--no-bias", action="store_true", help="variant: no bias file (p depends on (distance, count) only: table path)")
     ap.add_argument("--replicas", type=int, default=0, help="debug: replicate the genome R times per run regardless of --gpus (size test)")
     args = ap.parse_args()
@@ -329,6 +334,7 @@ def main():
 
     comm_all = comm
     cfg = dict(CONFIGS[args.config])
+    cfg["totals"] = ("wide" if args.config in ("C3w", "C5") else "reference") if args.totals == "auto" else args.totals
     if args.keep > 0:
         cfg["keep"] = args.keep
     res, L, U = cfg["res"], cfg["L"], cfg["U"]
@@ -366,7 +372,7 @@ def main():
         log("[rank %d] generated %d rows (%d cis on %d chromosomes, %d of %d trans) in %.1f s" %
             (rank, n_local, n_cis_local, len(mine), n_local - n_cis_local, n_trans, time.time() - t_gen))
         eng = Engine(dev_index)
-        eng.configure(res, L, U, n_bins=100, mapp_thres=1, mode=cfg["mode"])
+        eng.configure(res, L, U, n_bins=100, mapp_thres=1, mode=cfg["mode"], totals=cfg["totals"])
         eng.load_fragments(*genome.fragments(), genome.sort_rank())
         if not args.no_bias:
             eng.load_bias(*genome.bias_table())
@@ -582,6 +588,7 @@ def main():
             "bh_sort_rank0": M.get("sort_stats"),
             "k2_class_rows_rank0": M.get("class_rows"),
             "whole_pass_hbm_frac": (ALGO_BYTES_K1 + ALGO_BYTES_K2 + ALGO_BYTES_K3) * value / (world * HBM_PEAK_GBS * 1e9),
+            "totals_semantics": totals_semantics(cfg["totals"], M["info"][0], M["info"][1]),
         }
         if passes > 1:
             result["ms_per_pass"] = [float(v) for v in M["pass_ms"]]
@@ -829,6 +836,24 @@ def _oracle_tables(genome, chroms, res, with_bias, cut_loci=None):
     return frags, (bias_dic if with_bias else 0)
 
 
+def totals_semantics(mode, info, stats):
+    """What bdtrc was given for the two totals of the timed pass (fhx_fit_info) and whether that is the reference's answer."""
+    at = [w for b, w in ((1, "observedIntraInRangeSum"), (2, "observedInterAllSum")) if info.get("totals_narrowed", 0) & b]
+    out = {"mode": mode, "observedIntraInRangeSum": int(stats["in_range_sum"]), "observedInterAllSum": int(stats["inter_sum"]),
+           "bdtrc_n_intra": int(info.get("bdtrc_n_intra", stats["in_range_sum"])), "bdtrc_n_inter": int(info.get("bdtrc_n_inter", stats["inter_sum"])),
+           "totals_at_or_above_2p31": at}
+    if not at:
+        out["note"] = "both totals fit a C int: reference and wide semantics are the same function, the output is the reference's"
+    elif mode == "wide":
+        out["note"] = ("%s beyond a C int: this run evaluates bdtrc on the TRUE total (FHX_TOTALS_WIDE). fithic.py itself would write nan / "
+                       "wrong-n values there (scipy narrows n to 32 bits; fixtures tests/golden/f15_*); --totals reference reproduces that "
+                       "bit for bit. parity_check uses the oracle's wide mode: HIP == oracle restatement, not HIP == reference" % " and ".join(at))
+    else:
+        out["note"] = ("%s beyond a C int: bdtrc is given the total narrowed to 32 bits exactly as scipy does under fithic.py "
+                       "(FHX_TOTALS_REFERENCE) - the output is the reference's, nan where the narrowed n is below count - 1" % " and ".join(at))
+    return out
+
+
 def cpu_baseline(genome, sample, cfg, with_bias):
     """The oracle (plain C Cephes + numpy stage logic, 1 thread) on a bounded sample of the same rows, own fit on the sample."""
     import numpy as np
@@ -842,7 +867,7 @@ def cpu_baseline(genome, sample, cfg, with_bias):
     fo.build()
     t0 = time.perf_counter()
     fo.run(pairs, frags, None, cfg["res"], n_bins=100, passes=cfg["passes"], mode=cfg["mode"], L=cfg["L"], U=cfg["U"],
-           bias_dic=bias_dic)
+           bias_dic=bias_dic, totals=cfg.get("totals", "reference"))
     dt = time.perf_counter() - t0
     cal = calibration()
     cpu_model = None

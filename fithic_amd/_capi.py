@@ -18,6 +18,8 @@ CSRC = os.path.join(_PKG, "csrc")
 FHX_OK = 0
 FHX_ERR_ARG, FHX_ERR_NO_DEVICE, FHX_ERR_HIP, FHX_ERR_UNSUPPORTED, FHX_ERR_REFERENCE_EXIT, FHX_ERR_NOMEM = -1, -2, -3, -4, -5, -6
 MODE_INTRA_ONLY, MODE_INTER_ONLY, MODE_ALL = 0, 1, 2
+# FHX_TOTALS_*: how bdtrc sees a total of counts that does not fit a C int (include/fithic_mi355x.h; fithic.py:1070, 1101)
+TOTALS_REFERENCE, TOTALS_WIDE = 0, 1
 INT64_MAX = (1 << 63) - 1
 
 # enum fhx_array
@@ -31,7 +33,7 @@ _ARRAY_DTYPE = {A_BIN_SUMDIST: np.float64, A_X: np.float64, A_Y: np.float64, A_K
 class FhxParams(ctypes.Structure):
     _fields_ = [("resolution", ctypes.c_int64), ("dist_low", ctypes.c_int64), ("dist_up", ctypes.c_int64),
                 ("n_bins", ctypes.c_int32), ("mapp_thres", ctypes.c_int32), ("mode", ctypes.c_int32),
-                ("reserved", ctypes.c_int32), ("bias_low", ctypes.c_double), ("bias_up", ctypes.c_double)]
+                ("totals", ctypes.c_int32), ("bias_low", ctypes.c_double), ("bias_up", ctypes.c_double)]
 
 
 class FhxStats(ctypes.Structure):
@@ -49,7 +51,9 @@ class FhxFitInfo(ctypes.Structure):
                 ("possible_intra_all", ctypes.c_double), ("max_possible_dist", ctypes.c_double),
                 ("inter_chr_prob", ctypes.c_double), ("baseline_intra_prob", ctypes.c_double),
                 ("spline_s", ctypes.c_double), ("spline_fp", ctypes.c_double), ("residual", ctypes.c_double),
-                ("bh_total_tests", ctypes.c_double), ("outlier_thres", ctypes.c_double)]
+                ("bh_total_tests", ctypes.c_double), ("outlier_thres", ctypes.c_double),
+                ("totals", ctypes.c_int32), ("totals_narrowed", ctypes.c_int32), ("bdtrc_n_intra", ctypes.c_int64),
+                ("bdtrc_n_inter", ctypes.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -345,9 +349,10 @@ class Context:
 
     # ---- setup ----
     def set_params(self, resolution, dist_low=0, dist_up=None, n_bins=100, mapp_thres=1, mode=MODE_INTRA_ONLY,
-                   bias_low=0.5, bias_up=2.0):
+                   bias_low=0.5, bias_up=2.0, totals=TOTALS_REFERENCE):
         up = INT64_MAX if dist_up is None or dist_up == float("inf") else int(dist_up)
-        p = FhxParams(int(resolution), int(dist_low), up, int(n_bins), int(mapp_thres), int(mode), 0, float(bias_low), float(bias_up))
+        p = FhxParams(int(resolution), int(dist_low), up, int(n_bins), int(mapp_thres), int(mode), int(totals), float(bias_low),
+                      float(bias_up))
         self._check(self._L.fhx_set_params(self._h, ctypes.byref(p)))
 
     def load_fragments(self, chr_ids, mids, hits, chr_sort_rank):

@@ -46,6 +46,11 @@ def parse_args(argv=None):
     parser.add_argument("--gpus", dest="gpus", type=int, default=1,
                         help="engine option, not in the reference: shard the contact rows (parts of the file, else by chromosome) over this many GPUs of the "
                              "node (RCCL for the genome-wide steps); the output files are the ones a single GPU writes")
+    parser.add_argument("--totals", dest="totals", choices=("reference", "wide"), default="reference",
+                        help="engine option, not in the reference: what the binomial is given when the sum of in-range (or inter-chromosomal) "
+                             "counts reaches 2^31. 'reference' (default) narrows it to a C int exactly as scipy.special.bdtrc does under "
+                             "fithic.py, so the output is the reference's bit for bit - nan p/q for totals in [2^31, 2^32); 'wide' uses the "
+                             "true total. A line on stderr says which ran whenever the two differ")
     return parser.parse_args(argv)
 
 
@@ -151,6 +156,7 @@ def main(argv=None):
             print("Invalid Option. --gpus must be at least 1")
             sys.exit(2)
         F.gpus = args.gpus
+        F.totals = args.totals
         F.logfile = os.path.join(outputPath, libName + ".fithic.log")
 
         (mainDic, observedInterAllCount, observedInterAllSum, observedIntraAllSum, observedIntraInRangeSum) = \

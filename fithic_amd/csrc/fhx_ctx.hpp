@@ -105,6 +105,9 @@ struct K2Params {
     int n_table;
     double min_x, max_x;
     long long dist_low, dist_up;
+    // the true totals (observedIntraInRangeSum, observedInterAllSum) for ExpCC = total * prior (fithic.py:1076, 1106): the n
+    // of intra / inter above is what bdtrc is given, which differs from these once a total reaches 2^31 (bdtrc_total)
+    double total_intra, total_inter;
 };
 
 constexpr int K2_THREADS = 256;
@@ -348,6 +351,15 @@ struct fhx_ctx {
 };
 
 namespace fhx {
+
+// The n scipy.special.bdtrc is given for a total of counts (fithic.py:1070, 1101).  The reference passes a Python int and scipy's
+// Cephes core takes `int n`: the value is narrowed to 32 bits - 2^31 becomes -2^31 (n < k: every p-value NaN), 2^32 + 10^6 becomes
+// 10^6.  FHX_TOTALS_REFERENCE (default) narrows the same way, so the output is fithic.py's bit for bit; FHX_TOTALS_WIDE keeps the
+// true total.  Below 2^31 the two are the same number.  Pinned by tests/golden/f15_*.
+inline double bdtrc_total(const fhx_params& prm, long long sum) {
+    if (prm.totals == FHX_TOTALS_WIDE) return (double)sum;
+    return (double)(int32_t)(uint32_t)(unsigned long long)sum;
+}
 
 inline int fail(fhx_ctx* c, int code, const std::string& msg) {
     if (c) c->err = msg;

@@ -104,6 +104,7 @@ int fhx_set_params(fhx_ctx* ctx, const fhx_params* p) {
     if (p->resolution < 0) return fail(ctx, FHX_ERR_ARG, "resolution must be >= 0 (0 = non-fixed-size data)");
     if (p->resolution > INT32_MAX) return fail(ctx, FHX_ERR_ARG, "resolution too large");
     if (p->n_bins <= 0 || p->mapp_thres < 0 || p->mode < 0 || p->mode > 2) return fail(ctx, FHX_ERR_ARG, "bad parameter");
+    if (p->totals != FHX_TOTALS_REFERENCE && p->totals != FHX_TOTALS_WIDE) return fail(ctx, FHX_ERR_ARG, "totals must be FHX_TOTALS_REFERENCE or FHX_TOTALS_WIDE");
     if (p->bias_low > p->bias_up)
         return fail(ctx, FHX_ERR_REFERENCE_EXIT, "bias lower bound is greater than bias upper bound (fithic.py:261-263)");
     if (ctx->n_rows > 0 && ctx->have_params && p->resolution != ctx->prm.resolution)
@@ -318,8 +319,8 @@ int fhx_fit(fhx_ctx* ctx, fhx_fit_info* out) {
         // staging buffer and sent with one copy; nothing waits for it here (the stream orders it before K2)
         const int64_t mc = std::max<int64_t>(ctx->stats.max_count, 1);
         std::vector<double> lb_a, ib_a, lb_e, ib_e;
-        build_lbeta_table((double)ctx->stats.in_range_sum, mc, lb_a, ib_a);
-        build_lbeta_table((double)ctx->stats.inter_sum, mc, lb_e, ib_e);
+        build_lbeta_table(bdtrc_total(ctx->prm, ctx->stats.in_range_sum), mc, lb_a, ib_a);
+        build_lbeta_table(bdtrc_total(ctx->prm, ctx->stats.inter_sum), mc, lb_e, ib_e);
         t2 = std::chrono::steady_clock::now();
         const size_t n_lut = std::max<size_t>(f.prior_lut.size(), 1), n_tab = (size_t)(mc + 1);
         const size_t n_xy = ctx->nonfixed ? std::max<size_t>(f.table_x.size(), 1) : 0;
@@ -384,6 +385,10 @@ int fhx_fit(fhx_ctx* ctx, fhx_fit_info* out) {
         out->residual = f.residual;
         out->bh_total_tests = f.bh_total_tests;
         out->outlier_thres = 1.0 / f.bh_total_tests;
+        out->totals = ctx->prm.totals;
+        out->totals_narrowed = (ctx->stats.in_range_sum >= (1ll << 31) ? 1 : 0) | (ctx->stats.inter_sum >= (1ll << 31) ? 2 : 0);
+        out->bdtrc_n_intra = (int64_t)bdtrc_total(ctx->prm, ctx->stats.in_range_sum);
+        out->bdtrc_n_inter = (int64_t)bdtrc_total(ctx->prm, ctx->stats.inter_sum);
     }
     return FHX_OK;
 }

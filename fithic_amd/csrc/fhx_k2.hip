@@ -917,7 +917,7 @@ __global__ void k2_extras(K2Params P, double bias_low, double bias_up, double* _
         bool is_inter = false;
         if (row_prior(P, l1, l2, prior, is_inter)) {
             const bool within = b1 >= bias_low && b1 <= bias_up && b2 >= bias_low && b2 <= bias_up;
-            if (within) e = (is_inter ? P.inter.n : P.intra.n) * prior;
+            if (within) e = (is_inter ? P.total_inter : P.total_intra) * prior;
         }
         if (expcc) expcc[i] = e;
         if (ob1) ob1[i] = b1;
@@ -993,9 +993,12 @@ K2Params make_k2_params(fhx_ctx* c) {
     P.no_bias = !c->have_bias;
     P.prior_lut = c->d_lut;
     P.lut_len = (int)std::min<size_t>(std::max<size_t>(c->fit.prior_lut.size(), 1), (size_t)INT32_MAX);
-    const double n_intra = (double)c->stats.in_range_sum, n_inter = (double)c->stats.inter_sum;
+    // the n of the two binomials: narrowed to a C int as scipy does, unless the caller asked for wide totals (bdtrc_total)
+    const double n_intra = bdtrc_total(c->prm, c->stats.in_range_sum), n_inter = bdtrc_total(c->prm, c->stats.inter_sum);
     P.intra = dev::BinomTables{c->d_lbeta_intra, c->d_invb_intra, n_intra, (n_intra + 1.0) < dev::kMaxGam};
     P.inter = dev::BinomTables{c->d_lbeta_inter, c->d_invb_inter, n_inter, (n_inter + 1.0) < dev::kMaxGam};
+    P.total_intra = (double)c->stats.in_range_sum;
+    P.total_inter = (double)c->stats.inter_sum;
     P.inter_chr_prob = c->fit.inter_chr_prob;
     P.outlier_thres = 1.0 / c->fit.bh_total_tests;
     const int64_t res = std::max<int64_t>(c->prm.resolution, 1);          // -r 0 does not use the index window
@@ -1294,6 +1297,9 @@ int fhx_bdtrc_array(fhx_ctx* ctx, double n_total, const int32_t* count, const do
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
     if (n == 0) return FHX_OK;
     FHX_HIP(hipSetDevice(ctx->device));
+    // an integral total is what the reference hands over (a Python int): scipy narrows it to a C int, and so does this entry
+    // unless the context was set to FHX_TOTALS_WIDE (bdtrc_total; a context without parameters is in reference mode)
+    if (std::fabs(n_total) < 9.2e18 && n_total == std::floor(n_total)) n_total = bdtrc_total(ctx->prm, (long long)n_total);
     int64_t mc = 1;
     for (int64_t i = 0; i < n; ++i) mc = std::max<int64_t>(mc, count[i]);
     std::vector<double> lb, ib;

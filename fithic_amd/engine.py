@@ -18,6 +18,29 @@ import numpy as np
 from . import _capi
 
 MODES = {"intraOnly": _capi.MODE_INTRA_ONLY, "interOnly": _capi.MODE_INTER_ONLY, "All": _capi.MODE_ALL}
+# what bdtrc is given for a total of counts at or above 2^31: "reference" = narrowed to a C int, as scipy does with the Python ints
+# of fithic.py:1070 / :1101 (p = q = nan for 2^31 <= total < 2^32, a wrong small n above) - the drop-in answer and the default;
+# "wide" = the true total (what the formula means; no reference computes it)
+TOTALS = {"reference": _capi.TOTALS_REFERENCE, "wide": _capi.TOTALS_WIDE}
+
+
+def totals_notice(info):
+    """One line for stderr when a total of this pass reached 2^31 (info = fhx_fit_info as a dict), else None."""
+    bits = info.get("totals_narrowed", 0)
+    if not bits:
+        return None
+    which = " and ".join(w for b, w in ((1, "observedIntraInRangeSum"), (2, "observedInterAllSum")) if bits & b)
+    if info["totals"] == _capi.TOTALS_WIDE:
+        return ("fithic-mi355x: %s >= 2^31: p-values computed with the true total(s) (--totals wide). The reference (scipy's bdtrc "
+                "takes a C int) would have used n = %d (intra) / %d (inter) there and written nan wherever that is below "
+                "count - 1; --totals reference reproduces that." % (which, _narrow(info["bdtrc_n_intra"]), _narrow(info["bdtrc_n_inter"])))
+    return ("fithic-mi355x: %s >= 2^31: scipy's bdtrc narrows n to a C int, so the reference computes these p-values with n = %d "
+            "(intra) / %d (inter) - nan wherever n < count - 1 - and so does this run (--totals reference, the default: output "
+            "identical to fithic.py). --totals wide uses the true totals instead." % (which, info["bdtrc_n_intra"], info["bdtrc_n_inter"]))
+
+
+def _narrow(n):
+    return ((int(n) + 2 ** 31) % 2 ** 32) - 2 ** 31
 
 
 class PassOutput:
@@ -44,13 +67,16 @@ class Engine:
         self.ctx.close()
 
     def configure(self, resolution, dist_low=0, dist_up=float("inf"), n_bins=100, mapp_thres=1, mode="intraOnly",
-                  bias_low=0.5, bias_up=2.0):
+                  bias_low=0.5, bias_up=2.0, totals="reference"):
         if mode not in MODES:
             raise ValueError("Invalid Option. Only options are 'All', 'interOnly', or 'intraOnly'")
+        if totals not in TOTALS:
+            raise ValueError("totals must be 'reference' or 'wide'")
         self.mode = mode
         self.resolution = int(resolution)
         self.dist_low, self.dist_up = dist_low, dist_up
-        self.ctx.set_params(resolution, dist_low, dist_up, n_bins, mapp_thres, MODES[mode], bias_low, bias_up)
+        self.totals = totals
+        self.ctx.set_params(resolution, dist_low, dist_up, n_bins, mapp_thres, MODES[mode], bias_low, bias_up, TOTALS[totals])
 
     def load_fragments(self, chr_ids, mids, hits, chr_sort_rank):
         self.ctx.load_fragments(chr_ids, mids, hits, chr_sort_rank)

@@ -25,7 +25,7 @@ import time
 import numpy as np
 
 from . import _capi, tables
-from .engine import Engine, MODES
+from .engine import Engine, MODES, totals_notice
 
 # ---- the reference's module globals (defaults as in fithic/fithic.py:203-304) ------------------------
 mappThres = 1
@@ -44,6 +44,10 @@ logfile = None
 resolution = None          # engine-only global, see the module docstring
 device = 0                 # GPU ordinal the engine uses
 gpus = 1                   # > 1: contact rows sharded over that many GPUs (fithic_amd.sharded)
+# What bdtrc is given when observedIntraInRangeSum / observedInterAllSum reach 2^31 (:1070, :1101).  "reference": narrowed to a C
+# int as scipy does with the reference's Python ints, so the files equal fithic.py's (nan p and q for 2^31 <= total < 2^32);
+# "wide": the true total.  A line on stderr says which ran whenever it matters (engine.totals_notice).
+totals = "reference"
 
 
 class _Session:
@@ -88,13 +92,16 @@ class _Session:
     def configure(self):
         self.check_resolution()
         self.ensure_engine().configure(resolution, distLowThres, distUpThres, self.n_bins, mappThres, self.mode(),
-                                       biasLowerBound, biasUpperBound)
+                                       biasLowerBound, biasUpperBound, totals)
 
     def ensure_fit(self):
         if not self.fit_done:
             self.configure()
             info = self.engine.fit()
             self.info = info.as_dict()
+            notice = totals_notice(self.info)
+            if notice:
+                print(notice, file=sys.stderr)
             A = _capi
             for k, w in dict(bin_lb=A.A_BIN_LB, bin_ub=A.A_BIN_UB, bin_poss=A.A_BIN_POSS, bin_poss0=A.A_BIN_POSS0,
                              bin_sumcc=A.A_BIN_SUMCC, bin_sumdist=A.A_BIN_SUMDIST, bin_poss7=A.A_BIN_POSS7, x=A.A_X, y=A.A_Y).items():

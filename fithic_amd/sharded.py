@@ -31,7 +31,7 @@ import time
 import numpy as np
 
 from . import _capi
-from .engine import Engine, MODES
+from .engine import Engine, MODES, TOTALS
 
 
 class PipeTransport:
@@ -628,11 +628,13 @@ class ShardedEngine:
 
     # ---- Engine surface -------------------------------------------------------------------------------------------
     def configure(self, resolution, dist_low=0, dist_up=float("inf"), n_bins=100, mapp_thres=1, mode="intraOnly",
-                  bias_low=0.5, bias_up=2.0):
+                  bias_low=0.5, bias_up=2.0, totals="reference"):
         if mode not in MODES:
             raise ValueError("Invalid Option. Only options are 'All', 'interOnly', or 'intraOnly'")
+        if totals not in TOTALS:
+            raise ValueError("totals must be 'reference' or 'wide'")
         self.resolution = int(resolution)
-        self._all("configure", resolution, dist_low, dist_up, n_bins, mapp_thres, mode, bias_low, bias_up)
+        self._all("configure", resolution, dist_low, dist_up, n_bins, mapp_thres, mode, bias_low, bias_up, totals)
 
     def load_fragments(self, chr_ids, mids, hits, chr_sort_rank):
         self._all("load_fragments", chr_ids, mids, hits, chr_sort_rank)

@@ -46,6 +46,15 @@ extern "C" {
 #define FHX_MODE_INTER_ONLY 1      /* -x interOnly */
 #define FHX_MODE_ALL 2             /* -x All */
 
+/* How the binomial of fithic/fithic.py:1070,1101 sees a total (observedIntraInRangeSum / observedInterAllSum) that does not fit
+ * a C int.  The reference hands Python ints to scipy.special.bdtrc, whose Cephes core takes `int n`: the total is narrowed to
+ * 32 bits (2^31 arrives as -2^31 and every such p-value is NaN; 2^32 + 10^6 arrives as 10^6).
+ *   FHX_TOTALS_REFERENCE (default)  the same narrowing: the output equals fithic.py's bit for bit, NaNs included
+ *   FHX_TOTALS_WIDE                 bdtrc's arithmetic on the true total (no reference computes this; identical below 2^31)
+ * Everything else (expCC, the bin probabilities, BH) uses the true totals in both modes, as the reference does. */
+#define FHX_TOTALS_REFERENCE 0
+#define FHX_TOTALS_WIDE 1
+
 typedef struct fhx_ctx fhx_ctx;
 
 /* The reference's module globals (fithic/fithic.py:203-260) after its "zero means unset" rule. */
@@ -56,7 +65,7 @@ typedef struct fhx_params {
     int32_t n_bins;                /* -b, default 100 */
     int32_t mapp_thres;            /* -m, default 1 */
     int32_t mode;                  /* FHX_MODE_* */
-    int32_t reserved;
+    int32_t totals;                /* FHX_TOTALS_* (this field was `reserved`, always 0 = FHX_TOTALS_REFERENCE) */
     double bias_low;               /* -tL, default 0.5 */
     double bias_up;                /* -tU, default 2 */
 } fhx_params;
@@ -94,6 +103,10 @@ typedef struct fhx_fit_info {
     double residual;               /* sum((y - ius(x))^2), numpy pairwise order */
     double bh_total_tests;         /* N handed to benjamini_hochberg_correction for this mode */
     double outlier_thres;          /* 1/N */
+    int32_t totals;                /* FHX_TOTALS_* this pass ran with */
+    int32_t totals_narrowed;       /* bit 0: observedIntraInRangeSum >= 2^31, bit 1: observedInterAllSum >= 2^31 - the two modes differ */
+    int64_t bdtrc_n_intra;         /* the n bdtrc was given for in-range cis rows (the narrowed value in reference mode) */
+    int64_t bdtrc_n_inter;         /* ... and for inter-chromosomal rows */
 } fhx_fit_info;
 
 /* Arrays a caller can copy out with fhx_get_array (all caller-allocated). */
@@ -280,7 +293,9 @@ int fhx_k2_class_rows(fhx_ctx* ctx, int64_t* out5);
 int fhx_bh_array(fhx_ctx* ctx, const double* p, int64_t n, double n_total_tests, double* q);
 
 /* scipy.special.bdtrc(count - 1, n_total, prior) element-wise on the GPU for integer counts (the only form the
- * reference uses, fithic/fithic.py:1070,1101); host arrays in and out.  Known-answer testing of K2's arithmetic. */
+ * reference uses, fithic/fithic.py:1070,1101); host arrays in and out.  Known-answer testing of K2's arithmetic.  An integral
+ * n_total is narrowed to a C int as scipy does (FHX_TOTALS_REFERENCE, also for a context without parameters) unless the
+ * context's parameters say FHX_TOTALS_WIDE. */
 int fhx_bdtrc_array(fhx_ctx* ctx, double n_total, const int32_t* count, const double* prior, int64_t n, double* out);
 
 /* Test hook: the raw Cephes continued fraction (kind 0 = incbcf, 1 = incbd) of K2 evaluated element-wise on the GPU,

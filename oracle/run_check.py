@@ -171,6 +171,9 @@ def check_engine_run(eng, genome, sample, cfg, info, with_bias, p_stride=1, fit_
     fo.build()
     t0 = time.perf_counter()
     info, st = info
+    # the oracle mode that restates what the engine was asked for: "reference" = bdtrc's n narrowed to a C int as scipy does
+    # (pinned by the f15 fixtures), "wide" = the true total (the oracle's second mode - nothing pins it above 2^31)
+    totals = fo.TOTALS_WIDE if info.get("totals", 0) == _capi.TOTALS_WIDE else fo.TOTALS_REFERENCE
     v = eng.fetch(p=True, q=True) if torch is None else None
     fit_diff = hist_diff = None
     if fit_fixture_name:
@@ -203,10 +206,10 @@ def check_engine_run(eng, genome, sample, cfg, info, with_bias, p_stride=1, fit_
         sel = np.flatnonzero(~discard & ~inter & fo.in_range(d, cfg["L"], cfg["U"]))
         look = np.minimum(np.maximum(d[sel].astype(np.float64), xs.min()), xs.max())
         idx = np.minimum(np.searchsorted(table_x, look, side="left"), len(table_x) - 1)
-        want[sel] = fo.bdtrc(cnt[sel].astype(np.float64) - 1, float(st["in_range_sum"]), table_y[idx] * (b1[sel] * b2[sel]))
+        want[sel] = fo.bdtrc(cnt[sel].astype(np.float64) - 1, float(st["in_range_sum"]), table_y[idx] * (b1[sel] * b2[sel]), totals)
     if mode in ("All", "interOnly"):
         sel = np.flatnonzero(~discard & (inter if mode == "All" else np.ones(len(rows), bool)))
-        want[sel] = fo.bdtrc(cnt[sel].astype(np.float64) - 1, float(st["inter_sum"]), info["inter_chr_prob"] * (b1[sel] * b2[sel]))
+        want[sel] = fo.bdtrc(cnt[sel].astype(np.float64) - 1, float(st["inter_sum"]), info["inter_chr_prob"] * (b1[sel] * b2[sel]), totals)
     extra = {}
     if torch is not None:
         got, qv = _p_and_q_streamed(eng, torch, int(eng.n_rows), info["bh_total_tests"], rows, chunk_rows)
@@ -224,6 +227,13 @@ def check_engine_run(eng, genome, sample, cfg, info, with_bias, p_stride=1, fit_
            "tolerance": 1e-10, "ok": bool(dp <= 1e-10 and dq <= 1e-10 and nan_equal),
            "p_bit_identical_frac": float(np.mean(got.view(np.int64) == want.view(np.int64))) if len(rows) else 1.0}
     out.update(extra)
+    narrowed = int(info.get("totals_narrowed", 0))
+    out["totals_semantics"] = totals
+    out["oracle_mode"] = ("fho_bdtrc (n narrowed to a C int like scipy; pinned by tests/golden/f15_*)" if totals == fo.TOTALS_REFERENCE
+                          else "fho_bdtrc_wide (true total)" + ("; a total is >= 2^31: NOT what the reference computes there, unpinned"
+                                                                if narrowed else "; totals < 2^31: the same function as the reference's"))
+    out["totals_at_or_above_2p31"] = [w for b, w in ((1, "observedIntraInRangeSum"), (2, "observedInterAllSum")) if narrowed & b]
+    out["p_nan_in_sample"] = int(np.isnan(want).sum())
     if fit_fixture_name:
         out["fit_vs_reference"] = {"fixture": "tests/golden/f14_%s_fit.npz" % fit_fixture_name, "k1_histogram_differs": hist_diff,
                                    "fit_differs": fit_diff, "bit_identical": not hist_diff and not fit_diff}

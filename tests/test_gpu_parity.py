@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import load_case, case_args, ALL_CASES, SMALL_CASES, bits_equal, max_abs_diff, GOLDEN
+from conftest import load_case, case_args, ALL_CASES, SMALL_CASES, WRAP_CASES, bits_equal, max_abs_diff, GOLDEN
 
 pytestmark = pytest.mark.gpu
 
@@ -49,6 +49,29 @@ def test_bdtrc_known_answers_on_gpu(ctx):
     print("bdtrc KAT: %d/%d bit-identical, max |diff| %.3e" % (n_bits, total, worst))
     assert worst <= TOL
     assert n_bits >= 0.95 * total
+
+
+def test_bdtrc_narrows_totals_beyond_a_c_int_like_scipy(ctx):
+    """scipy's own values at fifteen totals from 2^31 - 1 to 2^52 (fixture f15_bdtrc_int_n, made by make_golden.py f15): NaN
+    pattern equal, values within 1e-10.  With FHX_TOTALS_WIDE the same entry keeps the true total (the oracle's second mode)."""
+    from oracle import fithic_oracle as fo
+    from fithic_amd._capi import Context, TOTALS_WIDE
+    g = np.load(os.path.join(GOLDEN, "f15_bdtrc_int_n.npz"))
+    k, n, p, ref = g["k"], g["n"], g["p"], g["val"]
+    wide = Context(0)
+    wide.set_params(10000, totals=TOTALS_WIDE)
+    n_nan = 0
+    for nt in np.unique(n):
+        sel = n == nt
+        out = ctx.bdtrc_array(float(nt), (k[sel] + 1).astype(np.int32), p[sel])
+        assert max_abs_diff(out, ref[sel]) <= TOL, nt                  # asserts the NaN pattern too
+        n_nan += int(np.isnan(out).sum())
+        out_w = wide.bdtrc_array(float(nt), (k[sel] + 1).astype(np.int32), p[sel])
+        assert max_abs_diff(out_w, fo.bdtrc(k[sel], float(nt), p[sel], totals="wide")) <= TOL, nt
+        if nt >= 2 ** 31:                                  # a different function there: other NaNs (negative narrowed n) or other values
+            assert not bits_equal(out_w, out)
+    assert n_nan == int(np.isnan(ref).sum()) > 1000
+    wide.close()
 
 
 def test_bdtrc_against_oracle_random(ctx):
@@ -93,7 +116,9 @@ def test_continued_fraction_bit_exact(ctx, kind):
 @pytest.mark.parametrize("kind", [0, 1])
 def test_continued_fraction_bit_exact_large_n(ctx, kind):
     """Totals of 2e8 .. 4e15 contacts: the loop refines the tracked reciprocal with ONE Newton step per denominator
-    (division mode 3); 4e5 fractions x 600 divisions, bit for bit against the oracle's C."""
+    (division mode 3); 4e5 fractions x 600 divisions, bit for bit against the oracle's C.  These are Cephes' incbcf / incbd as
+    functions of three doubles (a, b, x) - faithful whatever bdtrc's caller did to n; arguments with a + b > 2^31 reach them
+    only under FHX_TOTALS_WIDE (the reference's narrowed totals never produce them)."""
     from oracle import fithic_oracle as fo
     rng = np.random.default_rng(300 + kind)
     n = 400000
@@ -288,7 +313,7 @@ def test_bh_rejects_negative_values_and_bad_test_counts(ctx):
     assert np.array_equal(ctx.bh_array(np.array([0.2, -0.0, 0.5]), 10.0), np.array([1.0, 0.0, 1.0]))    # -0.0 is zero
 
 
-def _run_case(name, device=0):
+def _run_case(name, device=0, totals="reference"):
     from fithic_amd import tables
     from fithic_amd.engine import Engine
     meta, g = load_case(name)
@@ -297,7 +322,7 @@ def _run_case(name, device=0):
     con = tables.read_contacts(kw["contacts"], chroms)
     fc, fm, fh = tables.read_fragments(kw["frags"], chroms)
     eng = Engine(device)
-    eng.configure(kw["resolution"], kw["L"], kw["U"], kw["n_bins"], kw["mapp_thres"], kw["mode"], kw["tL"], kw["tU"])
+    eng.configure(kw["resolution"], kw["L"], kw["U"], kw["n_bins"], kw["mapp_thres"], kw["mode"], kw["tL"], kw["tU"], totals)
     eng.load_fragments(fc, fm, fh, chroms.sort_rank())
     if kw["bias_path"]:
         eng.load_bias(*tables.read_bias(kw["bias_path"], chroms))
@@ -369,6 +394,55 @@ def test_pipeline_matches_oracle_every_row(name):
         assert bits_equal(v["expcc"], r.expcc) and bits_equal(v["b1"], r.b1) and bits_equal(v["b2"], r.b2)
         # q is exactly BH of OUR p (the sort/scan path is bit-exact on its own input)
         assert bits_equal(v["q"], fo.benjamini_hochberg(v["p"], out.info["bh_total_tests"]))
+
+
+@pytest.mark.parametrize("name", WRAP_CASES)
+def test_totals_at_and_above_2p31_reference_mode_is_the_reference(name):
+    """FHX_TOTALS_REFERENCE (the default): scipy's bdtrc narrows the Python-int totals of fithic.py:1070 / :1101 to a C int, and so
+    does the engine - the NaN pattern, p, q and ExpCC of the real reference's run (fixtures made by make_golden.py f15; ExpCC keeps
+    the true total, as the reference's `observedIntraInRangeSum * prior_p` does).  fhx_fit_info says what bdtrc was given."""
+    from oracle import fithic_oracle as fo
+    meta, g, kw, passes = _run_case(name)
+    for pi, out in enumerate(passes, 1):
+        P = "p%d_" % pi
+        v, info, st = out.values, out.info, out.stats
+        assert np.array_equal(np.isnan(v["p"]), np.isnan(g[P + "p"])) and np.array_equal(np.isnan(v["q"]), np.isnan(g[P + "q"]))
+        assert max_abs_diff(v["p"], g[P + "p"]) <= TOL and max_abs_diff(v["q"], g[P + "q"]) <= TOL
+        assert bits_equal(v["expcc"], g[P + "expcc"])
+        assert info["totals"] == 0
+        assert info["totals_narrowed"] == (1 if st["in_range_sum"] >= 2 ** 31 else 0) + (2 if st["inter_sum"] >= 2 ** 31 else 0)
+        assert pi > 1 or info["totals_narrowed"] != 0             # (a later pass has lost its outliers' counts: it may fit again)
+        assert info["bdtrc_n_intra"] == fo.int_narrowed(st["in_range_sum"]) and info["bdtrc_n_inter"] == fo.int_narrowed(st["inter_sum"])
+
+
+@pytest.mark.parametrize("name", WRAP_CASES)
+def test_totals_at_and_above_2p31_wide_mode_is_the_oracles_second_mode(name):
+    """FHX_TOTALS_WIDE: bdtrc's arithmetic on the true totals.  No reference computes this - the check is against the oracle's
+    explicitly named second mode (fho_bdtrc_wide, "parity unpinned" above 2^31) - and it must differ from the reference's output
+    exactly where the narrowed total changed the answer."""
+    from oracle import fithic_oracle as fo
+    meta, g, kw, passes = _run_case(name, totals="wide")
+    ref = fo.run(totals="wide", **kw)
+    assert len(ref) == len(passes)
+    for pi, (out, r) in enumerate(zip(passes, ref), 1):
+        v = out.values
+        assert max_abs_diff(v["p"], r.p) <= TOL and max_abs_diff(v["q"], r.q) <= TOL
+        assert bits_equal(v["expcc"], r.expcc)
+        assert out.info["totals"] == 1 and (pi > 1 or out.info["totals_narrowed"] != 0)
+        assert out.info["bdtrc_n_intra"] == out.stats["in_range_sum"] and out.info["bdtrc_n_inter"] == out.stats["inter_sum"]
+        if pi == 1:
+            gp = g["p1_p"]
+            differs = np.isnan(gp) != np.isnan(v["p"])
+            differs |= ~np.isnan(gp) & ~np.isnan(v["p"]) & (np.abs(gp - v["p"]) > 1e-6)
+            assert differs.sum() > 100, "the two modes must disagree on these inputs"
+
+
+def test_totals_below_2p31_the_two_modes_are_the_same_function():
+    a = _run_case("f6_quirk_all")[3]
+    b = _run_case("f6_quirk_all", totals="wide")[3]
+    for x, y in zip(a, b):
+        assert bits_equal(x.values["p"], y.values["p"]) and bits_equal(x.values["q"], y.values["q"])
+        assert x.info["totals_narrowed"] == y.info["totals_narrowed"] == 0
 
 
 def test_off_grid_loci_run_through_the_slotting_path():
@@ -458,7 +532,7 @@ def test_kernel_seconds_summed_over_passes(name):
 
 
 @pytest.mark.parametrize("name", ["f1_nobias", "f1_bias", "f2_all", "f6_quirk_all", "f7_pfal_all", "f8_nonfixed_hESC", "f8_nonfixed_all",
-                                  "f13_all_p3", "f13_quirk_p4", "f13_hESC_p3"])
+                                  "f13_all_p3", "f13_quirk_p4", "f13_hESC_p3"] + WRAP_CASES)
 def test_cli_writes_the_reference_files(name, tmp_path, capsys):
     """The drop-in command line: decompressed .significances.txt and .fithic_passN.txt equal the reference's byte for byte."""
     import gzip
@@ -484,11 +558,31 @@ def test_cli_writes_the_reference_files(name, tmp_path, capsys):
         mine = [ln for ln in f.read().splitlines() if not ln.startswith("Means and error written")]
     want = [ln for ln in meta["log_txt"].splitlines() if not ln.startswith("Means and error written")]
     assert mine == want
+    # a total at or above 2^31: one line per pass on stderr says which semantics ran (and only then)
+    err = capsys.readouterr().err
+    assert ("scipy's bdtrc narrows n to a C int" in err) == (name in WRAP_CASES)
+
+
+def test_cli_totals_wide_says_so_and_differs_from_the_reference(tmp_path, capsys):
+    import gzip
+    import hashlib
+    from fithic_amd import cli
+    meta, g = load_case("f15_intra_2p31_all")
+    kw = case_args(meta)
+    cli.main(["-i", kw["contacts"], "-f", kw["frags"], "-o", str(tmp_path), "-l", "G", "-t", kw["bias_path"], "--totals", "wide"] + meta["argv"])
+    err = capsys.readouterr().err
+    assert "--totals wide" in err and "observedIntraInRangeSum >= 2^31" in err and "observedInterAllSum" not in err
+    with gzip.open(os.path.join(str(tmp_path), "G.spline_pass1.res10000.significances.txt.gz"), "rb") as f:
+        text = f.read()
+    assert text.count(b"\n") - 1 == meta["sig_rows_pass1"]
+    assert hashlib.md5(text).hexdigest() != meta["sig_md5_pass1"]
+    assert text.count(b"nan") < 100          # the reference's file has 1237 nan rows (x 2 columns) here
 
 
 @pytest.mark.parametrize("split", ["file", "chromosome"])
 @pytest.mark.parametrize("name,gpus", [("f1_bias", 2), ("f2_all", 3), ("f6_quirk_all", 2), ("f13_all_p3", 2), ("f13_quirk_p4", 3),
-                                       ("f8_nonfixed_all", 2), ("f8_nonfixed_hESC", 3), ("f11_offgrid_all", 3)])
+                                       ("f8_nonfixed_all", 2), ("f8_nonfixed_hESC", 3), ("f11_offgrid_all", 3), ("f15_intra_2p31_all", 2),
+                                       ("f15_both_2p32_all", 3)])
 def test_cli_gpus_n_writes_the_same_files(name, gpus, split, tmp_path, monkeypatch, capsys):
     """`fithic --gpus N`: rows sharded over N ranks (worker processes), genome-wide steps through the library's communicator, ONE
     output set - byte-identical to the reference's.  The fixtures are plain gzip files: every rank inflates them on the host and

@@ -10,10 +10,10 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-10
 
 
-def _engine_for(genome, res, L, U, n_bins, mode="intraOnly"):
+def _engine_for(genome, res, L, U, n_bins, mode="intraOnly", totals="reference"):
     from fithic_amd.engine import Engine
     eng = Engine(0)
-    eng.configure(res, L, U, n_bins=n_bins, mapp_thres=1, mode=mode)
+    eng.configure(res, L, U, n_bins=n_bins, mapp_thres=1, mode=mode, totals=totals)
     eng.load_fragments(*genome.fragments(), genome.sort_rank())
     eng.load_bias(*genome.bias_table())
     return eng
@@ -375,7 +375,13 @@ def test_c5_at_full_size():
     """BASELINE configs[4] at its full size on one GPU - 22 autosomes at 1 kb, 1.9e9 cis + 1e8 trans rows, -x All, exactly what
     `bench.py --config C5` times: K1 + fit against the real reference's (fixture f14_C5_fit), p of a 1-in-8 sample of the
     smallest chromosome's ~3e7 rows (and the trans rows inside it) against the oracle's Cephes with that table, and q of ALL
-    2.0e9 rows: rows at or above the oracle's pruning threshold must be exactly 1, the rest is ranked by the oracle."""
+    2.0e9 rows: rows at or above the oracle's pruning threshold must be exactly 1, the rest is ranked by the oracle.
+
+    WHICH SEMANTICS.  observedIntraInRangeSum is 7 150 761 687 here, beyond a C int.  The first run is FHX_TOTALS_WIDE (what
+    bench.py times: bdtrc on the true total) against the oracle's second mode fho_bdtrc_wide - HIP == the oracle's wide mode,
+    NOT HIP == reference: no reference computes that.  The second run is FHX_TOTALS_REFERENCE, the default: scipy narrows the
+    total to -1 439 172 905, every in-range cis p-value of the real reference is nan, and the engine's must be too (oracle
+    mode fho_bdtrc, pinned at this very total by tests/golden/f15_bdtrc_int_n.npz); the trans rows (total 1.7e8) stay finite."""
     import torch
     import bench
     from fithic_amd import synth
@@ -386,16 +392,26 @@ def test_c5_at_full_size():
     mine = list(range(len(genome)))
     cols, n, n_cis, n_trans = bench.build_rows(synth, torch, cfg, genome, mine, 0, 1, dev)
     assert 1.9e9 < n < 2.1e9 and n_trans > 9e7
-    eng = _engine_for(genome, cfg["res"], cfg["L"], cfg["U"], 100, mode="All")
+    eng = _engine_for(genome, cfg["res"], cfg["L"], cfg["U"], 100, mode="All", totals="wide")
     eng.load_contacts_device([t.data_ptr() for t in cols], n)
     sample = bench.build_sample(torch, cols, n, n_cis, genome, mine, cfg, cfg["res"], dev)
     del cols
     torch.cuda.empty_cache()
     out = eng.run_pass(collect=False)
+    assert out.info["totals"] == 1 and out.info["totals_narrowed"] == 1 and out.info["bdtrc_n_intra"] == out.stats["in_range_sum"] > 2 ** 32
     chk = run_check.check_engine_run(eng, genome, sample, cfg, (out.info, out.stats), True, p_stride=8, fit_fixture_name="C5", torch=torch)
+    assert chk["totals_semantics"] == "wide" and chk["totals_at_or_above_2p31"] == ["observedIntraInRangeSum"]
     assert chk["rows_q"] == n and chk["rows_p"] > 2_000_000 and chk["q_rows_pruned_not_one"] == 0
     assert chk["nan_pattern_equal"] and chk["max_dp"] <= TOL and chk["max_dq"] == 0.0 and chk["fit_vs_reference"]["bit_identical"], chk
-    assert chk["ok"]
+    assert chk["ok"] and chk["p_nan_in_sample"] < chk["rows_p"] // 100
+    # the reference's own semantics on the same rows: the narrowed total is negative, every in-range cis row is nan
+    eng.configure(cfg["res"], cfg["L"], cfg["U"], n_bins=100, mapp_thres=1, mode="All", totals="reference")
+    eng.reset_passes()
+    out = eng.run_pass(collect=False)
+    assert out.info["totals"] == 0 and out.info["bdtrc_n_intra"] == -1439172905 and out.info["bdtrc_n_inter"] == out.stats["inter_sum"]
+    chk = run_check.check_engine_run(eng, genome, sample, cfg, (out.info, out.stats), True, p_stride=8, fit_fixture_name="C5", torch=torch)
+    assert chk["totals_semantics"] == "reference" and chk["ok"] and chk["nan_pattern_equal"] and chk["max_dq"] == 0.0, chk
+    assert chk["p_nan_in_sample"] > chk["rows_p"] // 2
     eng.close()
 
 
