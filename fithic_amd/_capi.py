@@ -71,6 +71,7 @@ SYMBOLS = {
     "fhx_version": (ctypes.c_char_p, []),
     "fhx_warmup": (ctypes.c_int, [ctypes.c_int]),
     "fhx_set_params": (ctypes.c_int, [_P, ctypes.POINTER(FhxParams)]),
+    "fhx_run_pass": (ctypes.c_int, [_P, ctypes.POINTER(FhxStats), ctypes.POINTER(FhxFitInfo)]),
     "fhx_load_fragments": (ctypes.c_int, [_P, _I32P, _I32P, _I32P, ctypes.c_int64, _I32P, ctypes.c_int32]),
     "fhx_host_inflate": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int32, ctypes.POINTER(_P)]),
     "fhx_text_bytes": (ctypes.c_int64, [_P]),
@@ -499,6 +500,12 @@ class Context:
         info = FhxFitInfo()
         self._check(self._L.fhx_fit(self._h, ctypes.byref(info)))
         return info
+
+    def run_pass(self):
+        """pass_stats -> fit -> pvalues -> bh in one call (fhx_run_pass) -> (FhxStats, FhxFitInfo)"""
+        st, info = FhxStats(), FhxFitInfo()
+        self._check(self._L.fhx_run_pass(self._h, ctypes.byref(st), ctypes.byref(info)))
+        return st, info
 
     def pvalues(self):
         self._check(self._L.fhx_pvalues(self._h))

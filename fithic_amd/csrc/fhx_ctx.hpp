@@ -317,6 +317,14 @@ struct fhx_ctx {
     dev::CfRow* d_cf_tab = nullptr;                   // K2H_GENERIC x 300 rows of iteration constants
     long long *d_stats_stage = nullptr, *h_stats_stage = nullptr;   // K1's sums + histogram window: device block, pinned host copy
     size_t stats_stage_cap = 0;
+    // Results the host waits for in the middle of a pass leave the device by the kernel's own stores into coherent pinned memory,
+    // followed by a ticket in h_flags (system-scope release); the host spins on the ticket (wait_ticket) instead of sleeping in
+    // hipStreamSynchronize: no copy dispatch behind the kernel, no interrupt + wake-up in front of the host fit.
+    //   h_flags[0]  k1_pack_window's ticket (fhx_pass_stats)      h_flags[8]  k3_cutoff's ticket (auto_cutoff)
+    volatile unsigned long long* h_flags = nullptr;
+    unsigned int* d_done = nullptr;                   // [0]: workgroups of k1_pack_window that have stored their part
+    unsigned long long ticket = 0;                    // last ticket handed to a kernel
+    bool k2_prezeroed = false;                        // fhx_pass_stats has zeroed K2's two histograms behind K1 (while the host fits)
     int k2_shards = 0;                                // shards (= k2_classify workgroups) of the last fhx_pvalues
     unsigned int* d_k2h_off = nullptr;                // K2H_BUCKETS + 1 bucket starts
     unsigned char* d_memo = nullptr;                  // no-bias table path: virtual rows, table, overflow list (kept across passes)
@@ -372,6 +380,51 @@ inline int fail(fhx_ctx* c, int code, const std::string& msg) {
         if (e_ != hipSuccess)                                                                             \
             return fail(ctx, FHX_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));            \
     } while (0)
+
+// ---- tickets: a kernel's results read by the host without a stream synchronisation (fhx_ctx::h_flags) -------------------
+constexpr int FLAG_K1 = 0, FLAG_K3 = 8;               // words of h_flags, a cache line apart
+inline int ensure_flags(fhx_ctx* ctx) {
+    if (ctx->h_flags) return FHX_OK;
+    void* h = nullptr;
+    FHX_HIP(hipHostMalloc(&h, 64 * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped));
+    std::memset(h, 0, 64 * sizeof(unsigned long long));
+    ctx->h_flags = reinterpret_cast<volatile unsigned long long*>(h);
+    FHX_HIP(hipMalloc(&ctx->d_done, 16 * sizeof(unsigned int)));
+    FHX_HIP(hipMemsetAsync(ctx->d_done, 0, 16 * sizeof(unsigned int), ctx->stream));
+    return FHX_OK;
+}
+// the last workgroup of a launch publishes `ticket`: every workgroup calls this after its stores to host memory
+__device__ __forceinline__ void publish_ticket(unsigned int* done, volatile unsigned long long* flag, unsigned long long ticket) {
+    __threadfence_system();                           // this thread's stores have reached the host
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int total = gridDim.x * gridDim.y;
+        const unsigned int prev = total > 1 ? atomicAdd(done, 1u) : 0u;
+        if (prev == total - 1) {
+            if (total > 1) atomicExch(done, 0u);     // the next launch on the stream starts from zero
+            __hip_atomic_store(const_cast<unsigned long long*>(flag), ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+// Host side: spin until h_flags[word] shows `ticket`.  The stream is asked now and then: an error (or a stream that has drained
+// without the ticket: cannot happen) ends the wait with that answer instead of hanging.  FHX_NO_SPIN=1: hipStreamSynchronize.
+inline hipError_t wait_ticket(fhx_ctx* ctx, int word, unsigned long long ticket) {
+    static const bool no_spin = std::getenv("FHX_NO_SPIN") != nullptr;
+    if (no_spin) return hipStreamSynchronize(ctx->stream);
+    volatile unsigned long long* f = ctx->h_flags + word;
+    for (unsigned int spins = 1;; ++spins) {
+        if (*f == ticket) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return hipSuccess;
+        }
+        __builtin_ia32_pause();
+        if ((spins & 0x3FFFu) == 0) {                 // every ~16 k polls (a few hundred microseconds)
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) return *f == ticket ? hipSuccess : hipStreamSynchronize(ctx->stream);
+            if (q != hipErrorNotReady) return q;
+        }
+    }
+}
 
 template <typename T>
 inline void dev_free(T*& p) {

@@ -83,6 +83,8 @@ void fhx_destroy(fhx_ctx* ctx) {
         dev_free(ctx->d_cf_tab);
         dev_free(ctx->d_stats_stage);
         if (ctx->h_stats_stage) (void)hipHostFree(ctx->h_stats_stage);
+        if (ctx->h_flags) (void)hipHostFree((void*)ctx->h_flags);
+        dev_free(ctx->d_done);
         dev_free(ctx->d_k2h_off);
         dev_free(ctx->d_k2_counts);
         dev_free(ctx->d_memo);
@@ -400,6 +402,35 @@ int fhx_memcpy_d2d(fhx_ctx* ctx, void* dst, const void* src, int64_t bytes) {
     if (bytes) FHX_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, ctx->stream));
     FHX_HIP(hipStreamSynchronize(ctx->stream));
     return FHX_OK;
+}
+
+// One pass in one call: fhx_pass_stats -> fhx_fit -> fhx_pvalues -> fhx_bh, nothing of the caller's language in between (the four
+// ctypes round trips of the Python driver were ~40 us of a small shard's pass, between K1 and k2_classify with the GPU idle).
+int fhx_run_pass(fhx_ctx* ctx, fhx_stats* stats, fhx_fit_info* info) {
+    if (!ctx) return FHX_ERR_ARG;
+    static const bool pass_times = std::getenv("FHX_PASS_TIMES") != nullptr;    // measurements: host time inside each of the four calls
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = fhx_pass_stats(ctx, stats);
+    if (rc != FHX_OK) return rc;
+    const auto t1 = std::chrono::steady_clock::now();
+    fhx_fit_info mine{};
+    rc = fhx_fit(ctx, &mine);
+    if (rc != FHX_OK) return rc;
+    if (info) *info = mine;
+    const auto t2 = std::chrono::steady_clock::now();
+    rc = fhx_pvalues(ctx);
+    if (rc != FHX_OK) return rc;
+    const auto t3 = std::chrono::steady_clock::now();
+    rc = fhx_bh(ctx, mine.bh_total_tests);
+    if (pass_times) {
+        const auto t4 = std::chrono::steady_clock::now();
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double, std::micro>(b - a).count();
+        };
+        std::fprintf(stderr, "fhx_run_pass: pass_stats %.1f us (launch + wait for K1), fit %.1f, pvalues %.1f (enqueue), bh %.1f (enqueue + wait for K2)\n",
+                     us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4));
+    }
+    return rc;
 }
 
 int fhx_sync(fhx_ctx* ctx) {

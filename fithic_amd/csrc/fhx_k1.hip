@@ -234,7 +234,8 @@ __global__ __launch_bounds__(THREADS) void k1_classify_hist(
 // device in ONE small copy (the histograms are as long as the longest chromosome - 400 KB each at 5 kb - but only the distance
 // window of the run can be non-zero: 397 entries of each on C3)
 __global__ void k1_pack_window(const K1Sums* __restrict__ sums, const unsigned long long* __restrict__ hist_cc,
-                               const unsigned long long* __restrict__ hist_np, int a, int w, long long* __restrict__ pack) {
+                               const unsigned long long* __restrict__ hist_np, int a, int w, long long* __restrict__ pack,
+                               unsigned int* done, volatile unsigned long long* flag, unsigned long long ticket) {
     const int total = 8 + 2 * w;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         long long v;
@@ -248,6 +249,16 @@ __global__ void k1_pack_window(const K1Sums* __restrict__ sums, const unsigned l
             v = (long long)hist_np[a + (i - 8 - w)];
         pack[i] = v;
     }
+    // `pack` is the host's pinned block when a flag is given: the ticket tells the spinning host that every part has arrived
+    if (flag) publish_ticket(done, flag, ticket);
+}
+
+// K2's two histograms (the fused top-bits histogram of p, the count matrix of the heavy class) zeroed behind K1, while the host
+// fits: two fill dispatches less between the fit and k2_classify
+__global__ void k1_prezero(unsigned long long* __restrict__ a, int64_t na, uint4* __restrict__ b, int64_t nb16) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nb16; i += stride) b[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < na; i += stride) a[i] = 0ull;
 }
 
 // ===================================================================================================
@@ -983,19 +994,38 @@ int fhx_pass_stats(fhx_ctx* ctx, fhx_stats* out) {
     const int w = (int)(b - a);
     const size_t pack_len = 8 + 2 * (size_t)w;
     if (pack_len > ctx->stats_stage_cap) {
-        if (ctx->d_stats_stage) (void)hipFree(ctx->d_stats_stage);
+        FHX_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->h_stats_stage) (void)hipHostFree(ctx->h_stats_stage);
-        ctx->d_stats_stage = ctx->h_stats_stage = nullptr;
+        ctx->h_stats_stage = nullptr;
         ctx->stats_stage_cap = 0;
-        FHX_HIP(hipMalloc(&ctx->d_stats_stage, (pack_len + 1024) * sizeof(long long)));
-        FHX_HIP(hipHostMalloc((void**)&ctx->h_stats_stage, (pack_len + 1024) * sizeof(long long), hipHostMallocDefault));
+        FHX_HIP(hipHostMalloc((void**)&ctx->h_stats_stage, (pack_len + 1024) * sizeof(long long), hipHostMallocCoherent | hipHostMallocMapped));
         ctx->stats_stage_cap = pack_len + 1024;
     }
+    {
+        const int rc = ensure_flags(ctx);
+        if (rc != FHX_OK) return rc;
+    }
+    // the kernel stores the block straight into the pinned host buffer and publishes a ticket behind it; the host spins on the
+    // ticket (wait_ticket): no copy dispatch, no interrupt + wake-up between K1 and the fit (a 1/8 shard of C3: the gap between
+    // K1 and k2_classify 203 -> %s us, profiles/r06_*_tl_shard8.txt)
+    long long* d_pack = nullptr;
+    FHX_HIP(hipHostGetDevicePointer((void**)&d_pack, ctx->h_stats_stage, 0));
+    unsigned long long* d_flag = nullptr;
+    FHX_HIP(hipHostGetDevicePointer((void**)&d_flag, (void*)ctx->h_flags, 0));
+    const unsigned long long ticket = ++ctx->ticket;
     hipLaunchKernelGGL(k1_pack_window, dim3(grid_for((int64_t)pack_len, 256, 64)), dim3(256), 0, ctx->stream, (const K1Sums*)ctx->d_sums,
-                       (const unsigned long long*)ctx->d_hist_cc, (const unsigned long long*)ctx->d_hist_np, (int)a, w, ctx->d_stats_stage);
+                       (const unsigned long long*)ctx->d_hist_cc, (const unsigned long long*)ctx->d_hist_np, (int)a, w, d_pack, ctx->d_done,
+                       (volatile unsigned long long*)(d_flag + FLAG_K1), ticket);
     FHX_HIP(hipGetLastError());
-    FHX_HIP(hipMemcpyAsync(ctx->h_stats_stage, ctx->d_stats_stage, pack_len * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
-    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    // behind it, off the host's critical path: what fhx_pvalues would otherwise have to zero before it can classify
+    ctx->k2_prezeroed = false;
+    if (ctx->d_block_hist && ctx->d_k2_hist) {
+        hipLaunchKernelGGL(k1_prezero, dim3(1024), dim3(256), 0, ctx->stream, ctx->d_k2_hist, (int64_t)TOP_BINS,
+                           reinterpret_cast<uint4*>(ctx->d_block_hist), (int64_t)K2H_BUCKETS * K2H_BLOCKS / 4);
+        FHX_HIP(hipGetLastError());
+        ctx->k2_prezeroed = true;
+    }
+    FHX_HIP(wait_ticket(ctx, FLAG_K1, ticket));
     fold_kernel_events(ctx);               // this pass's K1 and, behind it on the stream, the previous pass's K2 and K3
     const long long* pk = ctx->h_stats_stage;
     ctx->h_hist_cc.assign((size_t)nd, 0);

@@ -1075,11 +1075,15 @@ int fhx_pvalues(fhx_ctx* ctx) {
             if (cap >= 8) memo_cap = (int)cap;
         }
     }
+    // fhx_pass_stats zeroes the two histograms of this call behind K1, while the host fits (k1_prezero); any other caller - and
+    // anything that used the count matrix in between (radix_passes clears the mark) - gets them zeroed here
+    const bool prezeroed = ctx->k2_prezeroed;
+    ctx->k2_prezeroed = false;
     // K3's key histogram rides on K2's stores of p - except on the table path, whose class kernels store table entries
     ctx->k2_hist_valid = false;
     if (memo_cap < 0 && !getenv("FHX_NO_FUSED_HIST")) {
         if (!ctx->d_k2_hist) FHX_HIP(hipMalloc(&ctx->d_k2_hist, TOP_BINS * sizeof(unsigned long long)));
-        FHX_HIP(hipMemsetAsync(ctx->d_k2_hist, 0, TOP_BINS * sizeof(unsigned long long), ctx->stream));
+        if (!prezeroed) FHX_HIP(hipMemsetAsync(ctx->d_k2_hist, 0, TOP_BINS * sizeof(unsigned long long), ctx->stream));
         P.top_hist = ctx->d_k2_hist;
         ctx->k2_hist_valid = true;
     }
@@ -1122,7 +1126,8 @@ int fhx_pvalues(fhx_ctx* ctx) {
     Q.heavy_hist = nullptr;
     if (heavy_sorted && !own_count_pass) {
         static_assert((K2H_BLOCKS & (K2H_BLOCKS - 1)) == 0, "shard -> column by masking");
-        FHX_HIP(hipMemsetAsync(ctx->d_block_hist, 0, (size_t)K2H_BUCKETS * K2H_BLOCKS * sizeof(unsigned int), ctx->stream));
+        if (!prezeroed)
+            FHX_HIP(hipMemsetAsync(ctx->d_block_hist, 0, (size_t)K2H_BUCKETS * K2H_BLOCKS * sizeof(unsigned int), ctx->stream));
         Q.heavy_hist = ctx->d_block_hist;
     }
     ctx->k2_shards = n_shards;

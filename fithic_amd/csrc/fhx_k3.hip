@@ -716,6 +716,7 @@ int sort_blocks_for(int64_t n_hint) {
 static int radix_passes(fhx_ctx* ctx, unsigned long long* keys[2], unsigned int* vals[2], const unsigned long long* counter, int nblk,
                         int key_bits, int bits, int src, int* result_buf) {
     const int passes = (key_bits + bits - 1) / bits;
+    ctx->k2_prezeroed = false;                        // the count matrix is K2's heavy-class histogram too (fhx_pass_stats zeroes it ahead)
     for (int pass = 0; pass < passes; ++pass) {
         const int shift = pass * bits;
 #define FHX_RS_PASS(B)                                                                                                               \

@@ -233,6 +233,9 @@ int fhx_fit(fhx_ctx* ctx, fhx_fit_info* out);                           /* host;
 int fhx_pvalues(fhx_ctx* ctx);                                          /* K2 (asynchronous) */
 int fhx_bh(fhx_ctx* ctx, double n_total_tests);                         /* K3 (asynchronous); any finite N: N <= 0 gives
                                                                           * q = 0 like the reference's loop (running max from 0) */
+/* The four calls above as one: K1 -> host fit -> K2 -> K3 of the current pass (asynchronous like fhx_bh; stats and info may be
+ * NULL).  What a driver's loop over passes calls: main() of fithic/fithic.py:317-370 between read_Interactions and the writer. */
+int fhx_run_pass(fhx_ctx* ctx, fhx_stats* stats, fhx_fit_info* info);
 int fhx_sync(fhx_ctx* ctx);
 /* Sharded runs with -p >= 3 only.  The reference stops skipping outlier lines after the first line number that
  * is an outlier in two passes (fithic/fithic.py:408-412 on a SortedList with duplicates); that is a
