@@ -16,7 +16,7 @@ LIB_PATH = _loader.LIB_PATH
 CSRC = os.path.join(_PKG, "csrc")
 
 FHX_OK = 0
-FHX_ERR_ARG, FHX_ERR_NO_DEVICE, FHX_ERR_HIP, FHX_ERR_UNSUPPORTED, FHX_ERR_REFERENCE_EXIT, FHX_ERR_NOMEM = -1, -2, -3, -4, -5, -6
+FHX_ERR_ARG, FHX_ERR_NO_DEVICE, FHX_ERR_HIP, FHX_ERR_UNSUPPORTED, FHX_ERR_REFERENCE_EXIT, FHX_ERR_NOMEM, FHX_ERR_INTERNAL = -1, -2, -3, -4, -5, -6, -7
 MODE_INTRA_ONLY, MODE_INTER_ONLY, MODE_ALL = 0, 1, 2
 # FHX_TOTALS_*: how bdtrc sees a total of counts that does not fit a C int (include/fithic_mi355x.h; fithic.py:1070, 1101)
 TOTALS_REFERENCE, TOTALS_WIDE = 0, 1

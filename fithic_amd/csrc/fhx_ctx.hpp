@@ -310,6 +310,7 @@ struct fhx_ctx {
     unsigned long long* d_k2_hist = nullptr;          // K3's key histogram as K2 gathered it while storing p (4096 bins)
     bool k2_hist_valid = false;
     unsigned char* d_work = nullptr;                  // the K2 queues and the K3 sort buffers are views into this block
+    size_t work_bytes = 0;                            // its size (engine_sort_ctrl carves the one-sweep scratch behind the K3 view)
     QEntry* d_queue[2] = {nullptr, nullptr};          // K2's per-class row queues (sharded, see QSpan)
     int64_t queue_cap = 0;                            // entries per queue buffer
     unsigned long long* d_k2_counts = nullptr;        // (K2_QUEUES + 1) x K2_MAX_SHARDS queue counters
@@ -321,6 +322,7 @@ struct fhx_ctx {
     // followed by a ticket in h_flags (system-scope release); the host spins on the ticket (wait_ticket) instead of sleeping in
     // hipStreamSynchronize: no copy dispatch behind the kernel, no interrupt + wake-up in front of the host fit.
     //   h_flags[0]  k1_pack_window's ticket (fhx_pass_stats)      h_flags[8]  k3_cutoff's ticket (auto_cutoff)
+    //   h_flags[16] K3's fault word (check_fault)
     volatile unsigned long long* h_flags = nullptr;
     unsigned int* d_done = nullptr;                   // [0]: workgroups of k1_pack_window that have stored their part
     unsigned long long ticket = 0;                    // last ticket handed to a kernel
@@ -382,7 +384,7 @@ inline int fail(fhx_ctx* c, int code, const std::string& msg) {
     } while (0)
 
 // ---- tickets: a kernel's results read by the host without a stream synchronisation (fhx_ctx::h_flags) -------------------
-constexpr int FLAG_K1 = 0, FLAG_K3 = 8;               // words of h_flags, a cache line apart
+constexpr int FLAG_K1 = 0, FLAG_K3 = 8, FLAG_FAULT = 16;   // words of h_flags, a cache line apart
 inline int ensure_flags(fhx_ctx* ctx) {
     if (ctx->h_flags) return FHX_OK;
     void* h = nullptr;
@@ -424,6 +426,18 @@ inline hipError_t wait_ticket(fhx_ctx* ctx, int word, unsigned long long ticket)
             if (q != hipErrorNotReady) return q;
         }
     }
+}
+
+// K3 sizes its sort by the histogram's survivor count without waiting for the device counter; a count ABOVE that bound (a stale
+// histogram - p rewritten behind K2's back -, a kernel that stored p without counting it) would have dropped keys.  bh_scan_tiles
+// leaves the counter there; every entry point that hands p / q to the host asks here after its stream wait.  Sticky until
+// fhx_reset_passes / a new load of rows.
+inline int check_fault(fhx_ctx* ctx) {
+    if (!ctx->h_flags) return FHX_OK;
+    const unsigned long long seen = ctx->h_flags[FLAG_FAULT];
+    if (seen == 0) return FHX_OK;
+    return fail(ctx, FHX_ERR_INTERNAL, "K3: " + std::to_string(seen) + " p-values survived the cutoff, more than the key histogram announced - the "
+                                       "ranking would be truncated (was p rewritten after fhx_pvalues?)");
 }
 
 template <typename T>

@@ -438,7 +438,7 @@ int fhx_sync(fhx_ctx* ctx) {
     if (ctx->device < 0) return FHX_OK;
     FHX_HIP(hipSetDevice(ctx->device));
     FHX_HIP(hipStreamSynchronize(ctx->stream));
-    return FHX_OK;
+    return check_fault(ctx);
 }
 
 int fhx_set_global_rows(fhx_ctx* ctx, const int64_t* rows, int64_t n) {
@@ -475,6 +475,7 @@ int fhx_reset_passes(fhx_ctx* ctx) {
     const size_t hist_len = ctx->nonfixed ? cap : (size_t)ctx->n_dist;
     FHX_HIP(hipMemsetAsync(ctx->d_out_hist, 0, hist_len * sizeof(unsigned long long), ctx->stream));
     FHX_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_flags) ctx->h_flags[FLAG_FAULT] = 0;
     ctx->pass_no = 0;
     ctx->skip_active = false;
     ctx->have_stats = ctx->have_fit = ctx->have_bins = ctx->have_p = ctx->have_q = false;
@@ -559,7 +560,7 @@ int fhx_get_array(fhx_ctx* ctx, int which, void* dst, int64_t cap, int64_t* n_ou
 void* fhx_device_ptr(fhx_ctx* ctx, int which) {
     if (!ctx || ctx->device < 0) return nullptr;
     switch (which) {
-        case 0: return ctx->d_p;
+        case 0: ctx->k2_hist_valid = false; return ctx->d_p;   // the caller may write p: K3 counts its keys itself next time
         case 1: return ctx->d_q;
         case 2: return ctx->d_keys[ctx->sorted_buf];
         case 3: return ctx->d_vals[ctx->sorted_buf];

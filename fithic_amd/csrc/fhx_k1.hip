@@ -785,6 +785,7 @@ int alloc_row_arrays(fhx_ctx* ctx, int64_t n, int64_t n_dist) {
     const size_t qcap = std::max<size_t>(cap, (size_t)k2_classify_grid((int64_t)cap) * (size_t)k2_shard_capacity((int64_t)cap));   // sharded queues: k2_classify
     const size_t work_bytes = qcap * 32 + std::max(qcap, cap + (size_t)K2H_BUCKETS * 64 * K2H_MAX_ROWS) * sizeof(QEntry);   // queue 0 | queue 1 | sorted heavy queue / closed-form queue
     FHX_HIP(hipMalloc(&ctx->d_work, work_bytes));
+    ctx->work_bytes = work_bytes;
     ctx->queue_cap = (int64_t)qcap;
     ctx->d_queue[0] = reinterpret_cast<QEntry*>(ctx->d_work);
     ctx->d_queue[1] = reinterpret_cast<QEntry*>(ctx->d_work + qcap * 16);

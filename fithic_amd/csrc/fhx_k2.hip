@@ -1449,7 +1449,7 @@ int fhx_next_pass(fhx_ctx* ctx, int64_t* n_outliers_total) {
     ctx->skip_active = true;
     ctx->pass_no += 1;
     if (n_outliers_total) *n_outliers_total = ctx->n_outliers_total;
-    return FHX_OK;
+    return check_fault(ctx);
 }
 
 int fhx_fetch(fhx_ctx* ctx, double* p, double* q, double* expcc, double* bias1, double* bias2) {
@@ -1475,7 +1475,7 @@ int fhx_fetch(fhx_ctx* ctx, double* p, double* q, double* expcc, double* bias1, 
             if (host[k]) FHX_HIP(hipMemcpyAsync(host[k], d_tmp[k], bytes, hipMemcpyDeviceToHost, ctx->stream));
     }
     FHX_HIP(hipStreamSynchronize(ctx->stream));
-    return FHX_OK;
+    return check_fault(ctx);
 }
 
 int fhx_fetch_flags(fhx_ctx* ctx, uint8_t* outlier, uint8_t* skip) {

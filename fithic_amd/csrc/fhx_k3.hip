@@ -593,11 +593,17 @@ __global__ __launch_bounds__(BH_THREADS) void bh_tile_max(const unsigned long lo
 }
 
 // exclusive running max over the tile maxima (carry-in of every tile); one workgroup
+// (n_bound / fault: the host sized the sort and this grid for n_bound keys - the histogram's count when it did not wait for the
+// device counter; more keys than that would have been dropped without a word, so the one workgroup here leaves the counter's value in
+// the context's fault word - pinned memory, read by every call that hands results to the host: check_fault)
 __global__ __launch_bounds__(1024) void bh_scan_tiles(double* __restrict__ tile_max,
                                                       const unsigned long long* __restrict__ n_ptr, int64_t n_fixed,
-                                                      double carry_in, double* __restrict__ total_max) {
+                                                      double carry_in, double* __restrict__ total_max, int64_t n_bound = -1,
+                                                      unsigned long long* __restrict__ fault = nullptr) {
     __shared__ double part[1024];
     const int64_t n = n_ptr ? (int64_t)*n_ptr : n_fixed;
+    if (fault && threadIdx.x == 0 && n > n_bound)
+        __hip_atomic_store(fault, (unsigned long long)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const int64_t tiles = (n + BH_TILE - 1) / BH_TILE;
     const int64_t per = (tiles + 1023) / 1024;
     const int64_t beg = (int64_t)threadIdx.x * per, end = min(tiles, beg + per);
@@ -1118,8 +1124,11 @@ static int sort_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned lon
 
 // The engine's own sort scratch: the workspace behind the K3 view (alloc_row_arrays: K3 uses 24 of its >= 48 bytes per row; the
 // descriptors of eight passes take 2).
+// nullptr - the sort then takes round 4's three-launch passes, which need no scratch - if the workspace ever stops covering it (a
+// changed queue layout, bucket padding or tile size): never a write past the block.
 static unsigned int* engine_sort_ctrl(fhx_ctx* ctx) {
     const size_t cap = std::max<size_t>(4, ((size_t)ctx->n_rows + 3) / 4 * 4);
+    if (cap * 24 + os_scratch_bytes(ctx->n_rows) > ctx->work_bytes) return nullptr;
     return reinterpret_cast<unsigned int*>(ctx->d_work + cap * 24);
 }
 
@@ -1127,10 +1136,16 @@ static unsigned int* engine_sort_ctrl(fhx_ctx* ctx) {
 static int bh_from_sorted(fhx_ctx* ctx, const unsigned long long* keys, const unsigned int* vals, int64_t n_keys,
                           const unsigned long long* counter, double n_total_tests, double* tile_max, double* d_q) {
     const int tiles = (int)std::max<int64_t>(1, (n_keys + BH_TILE - 1) / BH_TILE);
+    unsigned long long* fault = nullptr;
+    if (ctx->k3_n_is_bound) {                           // n_keys came from the histogram: the device checks it against its counter
+        const int rc = ensure_flags(ctx);
+        if (rc != FHX_OK) return rc;
+        fault = const_cast<unsigned long long*>(ctx->h_flags + FLAG_FAULT);
+    }
     hipLaunchKernelGGL(bh_tile_max, dim3(tiles), dim3(BH_THREADS), 0, ctx->stream, keys, counter, (int64_t)0, n_total_tests,
                        0.0, tile_max);
     hipLaunchKernelGGL(bh_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, tile_max, counter, (int64_t)0, 0.0,
-                       (double*)nullptr);
+                       (double*)nullptr, n_keys, fault);
     hipLaunchKernelGGL(bh_apply, dim3(tiles), dim3(BH_THREADS), 0, ctx->stream, keys, vals, counter, (int64_t)0,
                        n_total_tests, 0.0, tile_max, (const double*)nullptr, d_q);
     FHX_HIP(hipGetLastError());

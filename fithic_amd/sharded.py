@@ -279,7 +279,8 @@ class _Rank:
         return ("ok", parts)
 
     def place_parts(self, target, placements):
-        """copy this rank's parts into `target` at their offsets (all ranks at once: the file is put together in parallel)"""
+        """copy this rank's parts into `target` at their offsets (all ranks at once: the file is put together in parallel).  The
+        parts stay where they are: the caller drops them once EVERY rank has placed its own (or after a failure)."""
         fd = os.open(target, os.O_WRONLY)
         try:
             for path, offset in placements:
@@ -294,7 +295,6 @@ class _Rank:
                         if k <= 0:
                             raise OSError("short copy of %s" % path)
                         done += k
-                os.unlink(path)
         finally:
             os.close(fd)
 
@@ -425,18 +425,30 @@ class _CtxFacade:
             raise _capi.FhxError(_capi.FHX_ERR_UNSUPPORTED, "; ".join(res[1] for res in results if res[0] != "ok"))
         tmp = "%s.fhx-tmp-%d" % (name, os.getpid())
         head = tmp + ".head"
-        o.local.eng.ctx.write_significances_range(head, list(chr_names), 0, 0, True)
-        offsets, at = {}, os.path.getsize(head)
-        for file_start, path, nbytes in sorted(parts):
-            offsets[path] = at
-            at += nbytes
-        with open(tmp, "wb") as f, open(head, "rb") as h:
-            f.write(h.read())
-            f.truncate(at)
+        drop = [([p[1] for p in res[1]],) for res in results]
+        try:
+            o.local.eng.ctx.write_significances_range(head, list(chr_names), 0, 0, True)
+            offsets, at = {}, os.path.getsize(head)
+            for file_start, path, nbytes in sorted(parts):
+                offsets[path] = at
+                at += nbytes
+            with open(tmp, "wb") as f, open(head, "rb") as h:
+                f.write(h.read())
+                f.truncate(at)
+            per_rank = [(tmp, [(p[1], offsets[p[1]]) for p in (res[1])]) for res in results]
+            o._all("place_parts", per_rank=per_rank)
+            os.replace(tmp, name)
+        except BaseException:                                  # a full disk, a rank that died: no litter next to the output
+            for path in (tmp, head):
+                if os.path.exists(path):
+                    os.unlink(path)
+            try:
+                o._all("drop_parts", per_rank=drop)
+            except Exception:
+                pass
+            raise
         os.unlink(head)
-        per_rank = [(tmp, [(p[1], offsets[p[1]]) for p in (res[1])]) for res in results]
-        o._all("place_parts", per_rank=per_rank)
-        os.replace(tmp, name)
+        o._all("drop_parts", per_rank=drop)                    # only now: every rank has placed its parts
 
 
 class ShardedContacts:

@@ -41,6 +41,7 @@ extern "C" {
 #define FHX_ERR_UNSUPPORTED (-4)   /* input outside the accelerated path (e.g. loci off the fixed-size grid) */
 #define FHX_ERR_REFERENCE_EXIT (-5)/* the reference would sys.exit(2) / raise here (message says where) */
 #define FHX_ERR_NOMEM (-6)
+#define FHX_ERR_INTERNAL (-7)      /* a device-side consistency check failed (results would be wrong): message says which */
 
 #define FHX_MODE_INTRA_ONLY 0      /* -x intraOnly (default) */
 #define FHX_MODE_INTER_ONLY 1      /* -x interOnly */

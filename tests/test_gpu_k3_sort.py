@@ -225,3 +225,31 @@ def test_subnormal_quotients_are_rounded_once(ctx, n):
     p[rng.integers(0, n, n // 10)] = 0.0
     for N in (1.0, 3.0, 977.0, 0.37):
         _check(ctx, p, N)
+
+
+def test_p_rewritten_through_the_device_pointer_is_counted_again():
+    """K3 sizes its sort from the key histogram K2 kept while storing p.  A caller that takes fhx_device_ptr(ctx, 0) may write p
+    itself: the library must then count the keys of what is THERE (the stale histogram would announce too few survivors and the
+    ranking would lose keys - the device's own check, FHX_ERR_INTERNAL, is the backstop).  Here every row gets a small p."""
+    import os
+    from fithic_amd import tables
+    from fithic_amd.engine import Engine
+    from oracle import fithic_oracle as fo
+    data = os.path.join(os.path.dirname(__file__), "golden", "data")
+    chroms = tables.ChromIndex()
+    con = tables.read_contacts(os.path.join(data, "quirk.contacts.gz"), chroms)
+    eng = Engine(0)
+    eng.configure(10000, 20000, 400000, 12, 1, "All")
+    fc, fm, fh = tables.read_fragments(os.path.join(data, "quirk.frags.gz"), chroms)
+    eng.load_fragments(fc, fm, fh, chroms.sort_rank())
+    eng.load_contacts(con.chr1, con.mid1, con.chr2, con.mid2, con.count)
+    eng.run_pass()
+    n = len(con)
+    p_new = np.random.default_rng(5).uniform(1e-12, 1e-6, n)          # all far below any cutoff: every row must be ranked
+    eng.ctx.copy(eng.ctx.device_ptr(0), p_new.ctypes.data, 8 * n, 0)
+    n_tests = 1.0e6
+    eng.ctx.bh(n_tests)
+    got = eng.ctx.fetch(n, p=True, q=True)
+    assert bits_equal(got["p"], p_new)
+    assert bits_equal(got["q"], fo.benjamini_hochberg(p_new, n_tests))
+    eng.close()

@@ -63,13 +63,22 @@ def test_myUtils_names_follow_the_reference_predicates():
         assert myUtils.in_range_check(d, lo, up) is want, (d, lo, up)
         assert bool(fo.in_range(np.array([d]), max(lo, 0), float("inf") if up == -1 else up)[0]) is want
     assert myUtils.scale_a_list([1, 2], 0.5) == [0.5, 1.0]
-    assert not hasattr(myUtils, "Interaction")
+    # the record class of fithic/myUtils.py:98-147, for scripts that built such objects themselves
+    it = myUtils.Interaction(["chr1", "15000", "chr1", "45000"])
+    assert (it.type, it.distance, it.getCount(), it.pval, it.qval) == ("intra", 30000, 0, -1.0, -1.0)
+    assert it.getType(20000, 40000) == "intraInRange" and it.getType(30000, -1) == "intraInRange"
+    assert it.getType(40000, -1) == "intraShort" and it.getType(-1, 20000) == "intraLong"
+    it.setCount("7"); it.setPval("0.5"); it.setQval(1); it.setType(3)
+    assert (it.hitCount, it.pval, it.qval, it.type) == (7, 0.5, 1.0, "3")
+    tr = myUtils.Interaction(("chr1", 5, "chr2", 9))
+    assert tr.type == "inter" and tr.getDistance() == -1 and tr.getType(-1, -1) == "inter"
 
 
 def test_myStats_carries_the_one_name_of_the_path():
     """the module imports without a GPU (the BH name binds to the engine lazily)"""
     from fithic_amd import myStats
-    assert callable(myStats.benjamini_hochberg_correction) and not hasattr(myStats, "meanAndVariance")
+    assert callable(myStats.benjamini_hochberg_correction)
+    assert myStats.meanAndVariance([1, 2, 3, 6]) == (3.0, 12.5 - 9.0)
 
 
 def test_session_value_check_treats_untouched_nan_as_equal():

@@ -1,6 +1,7 @@
 """CPU checks of the multi-rank plumbing of `fithic --gpus N` (fithic_amd/sharded.py): the pipe transport's exchange must not
 deadlock on messages far larger than a pipe buffer (both ranks of a pair sending first would), for any world size."""
 import multiprocessing as mp
+import os
 
 import numpy as np
 import pytest
@@ -234,3 +235,55 @@ def test_how_the_ranks_of_the_cli_split_a_contacts_file(case):
         assert [list(ids) for ids, _ in ranks.committed] == [[1], [0, 1], [2]]
         assert [first for _, first in ranks.committed] == [0, 4, 10]
         assert len(got) == 12 and ranks.segments == [[(0, 0, 4)], [(0, 4, 6)], [(0, 10, 2)]]
+
+
+class _FileRanks:
+    """ranks that hold ready-made parts of an output file; place / drop are the real _Rank methods"""
+
+    def __init__(self, tmp_path, name, fail_place_on=None):
+        self.world, self.name, self.fail = 3, name, fail_place_on
+        self.segments = [[(0, 0, 2)], [(0, 2, 1), (1, 5, 1)], [(0, 3, 2)]]
+        self.local = self
+        self.eng = self
+        self.ctx = self
+
+    def write_significances_range(self, path, chr_names, a, b, header):
+        with open(path, "wb") as f:
+            f.write(b"HEAD;")
+
+    def _all(self, command, *args, per_rank=None):
+        from fithic_amd import sharded
+        out = []
+        for r in range(self.world):
+            a = per_rank[r] if per_rank is not None else args
+            if command == "write_parts":
+                parts = []
+                for _, file_start, length in self.segments[r]:
+                    path = "%s.part-%015d" % (self.name, file_start)
+                    with open(path, "wb") as f:
+                        f.write(b"<%d+%d>" % (file_start, length))
+                    parts.append((file_start, path, os.path.getsize(path)))
+                out.append(("ok", parts))
+            elif command == "place_parts" and r == self.fail:
+                raise OSError(28, "No space left on device")
+            else:
+                out.append(getattr(sharded._Rank, command)(None, *a))
+        return out
+
+
+@pytest.mark.parametrize("fail", [None, 1])
+def test_parts_of_the_output_are_dropped_only_after_every_rank_placed_its_own(tmp_path, fail):
+    """_CtxFacade.write_significances_device: header + the ranks' parts in file order; on success and on a failure half way nothing
+    but the output (or nothing at all) stays next to it."""
+    from fithic_amd import sharded
+    name = str(tmp_path / "out.significances.txt.gz")
+    ranks = _FileRanks(tmp_path, name, fail)
+    facade = sharded._CtxFacade(ranks)
+    if fail is None:
+        facade.write_significances_device(name, ["chr1"])
+        assert open(name, "rb").read() == b"HEAD;<0+2><2+1><3+2><5+1>"
+        assert os.listdir(tmp_path) == ["out.significances.txt.gz"]
+    else:
+        with pytest.raises(OSError):
+            facade.write_significances_device(name, ["chr1"])
+        assert os.listdir(tmp_path) == []
