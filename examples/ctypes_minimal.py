@@ -19,7 +19,7 @@ i64, i32, f64 = ctypes.c_int64, ctypes.c_int32, ctypes.c_double
 
 class Params(ctypes.Structure):          # fhx_params
     _fields_ = [("resolution", i64), ("dist_low", i64), ("dist_up", i64), ("n_bins", i32), ("mapp_thres", i32), ("mode", i32),
-                ("reserved", i32), ("bias_low", f64), ("bias_up", f64)]
+                ("totals", i32), ("bias_low", f64), ("bias_up", f64)]
 
 
 class Stats(ctypes.Structure):           # fhx_stats
@@ -31,7 +31,8 @@ class FitInfo(ctypes.Structure):         # fhx_fit_info
     _fields_ = [("n_bins_made", i32), ("n_knots", i32), ("spline_ier", i32), ("spline_restarted", i32), ("n_table", i64),
                 ("n_frags", i64), ("possible_intra_in_range", i64), ("possible_inter_all", f64), ("possible_intra_all", f64),
                 ("max_possible_dist", f64), ("inter_chr_prob", f64), ("baseline_intra_prob", f64), ("spline_s", f64),
-                ("spline_fp", f64), ("residual", f64), ("bh_total_tests", f64), ("outlier_thres", f64)]
+                ("spline_fp", f64), ("residual", f64), ("bh_total_tests", f64), ("outlier_thres", f64), ("totals", i32),
+                ("totals_narrowed", i32), ("bdtrc_n_intra", i64), ("bdtrc_n_inter", i64)]
 
 
 def ptr(a, t):

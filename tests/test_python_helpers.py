@@ -92,3 +92,19 @@ def test_session_value_check_treats_untouched_nan_as_equal():
     for edited in ([1.0, 2.0, float("inf"), 0.0], [1.0, float("nan"), float("inf")], [float("nan")] * 4):
         with pytest.raises(ValueError):
             _check_session_values("x", edited, own)
+
+
+def test_the_ctypes_only_example_declares_the_structs_as_the_bindings_do():
+    """examples/ctypes_minimal.py carries its own copies of fhx_params / fhx_stats / fhx_fit_info (it shows a binding without this
+    package).  A field appended to the header must reach it too: the library writes the whole struct into the caller's memory."""
+    import ctypes
+    import importlib.util
+    import os
+    from fithic_amd import _capi
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "ctypes_minimal.py")
+    spec = importlib.util.spec_from_file_location("ctypes_minimal", path)
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    for theirs, ours in ((ex.Params, _capi.FhxParams), (ex.Stats, _capi.FhxStats), (ex.FitInfo, _capi.FhxFitInfo)):
+        assert ctypes.sizeof(theirs) == ctypes.sizeof(ours), theirs.__name__
+        assert [(n, t) for n, t in theirs._fields_] == [(n, t) for n, t in ours._fields_], theirs.__name__
