@@ -228,6 +228,7 @@ namespace {
 constexpr int K = 3, K1 = 4, K2 = 5;
 constexpr double kTol = 1e-3;
 constexpr int kMaxIt = 20;
+constexpr int kLanes = 4;            // rows whose Givens chains run interleaved (fpcurf below)
 
 struct Rot {
     double cs, sn;
@@ -396,7 +397,8 @@ int fpcurf(int iopt, const double* x, const double* y, int m, double s, int nest
         nrdata[0] = m - 2;
     }
 
-    std::vector<double> a, z, q(static_cast<size_t>(m) * K1);
+    std::vector<double> a, z, q(static_cast<size_t>(m) * K1), hs(static_cast<size_t>(m) * K1), yis(m);
+    std::vector<int> first_row(m), started(m);
     int nk1 = 0;
     double fpms = 0.0;
     bool accepted = false;
@@ -413,31 +415,46 @@ int fpcurf(int iopt, const double* x, const double* y, int m, double s, int nest
         double fp = 0.0;
         z.assign(nk1, 0.0);
         a.assign(static_cast<size_t>(nk1) * K1, 0.0);
+        // (a) the knot interval and the four B-spline values of every observation: no observation waits for another here
         int l = K1;
         for (int it = 0; it < m; ++it) {
             const double xi = x[it];
-            double yi = y[it];
             while (!(xi < t[l] || l == nk1)) ++l;
-            double h[4];
-            bsplines(t.data(), xi, l - 1, h);
-            for (int i = 0; i < K1; ++i) q[static_cast<size_t>(it) * K1 + i] = h[i];
-            int j = l - K1;
-            for (int i = 0; i < K1; ++i) {
-                ++j;
-                const double piv = h[i];
-                if (piv == 0.0) continue;
-                double* row = &a[static_cast<size_t>(j - 1) * K1];
-                const Rot r = givens(piv, row[0]);
-                rotate(r, yi, z[j - 1]);
-                if (i == K1 - 1) break;
-                int i2 = 0;
-                for (int i1 = i + 1; i1 < K1; ++i1) {
-                    ++i2;
-                    rotate(r, h[i1], row[i2]);
-                }
-            }
-            fp = fp + yi * yi;
+            first_row[it] = l - K1;
+            bsplines(t.data(), xi, l - 1, &q[static_cast<size_t>(it) * K1]);
         }
+        // (b) FITPACK rotates observation after observation into the band matrix, four Givens steps each (band rows first_row ..
+        // first_row + 3), every step waiting for the one before it: a division, a square root, two divisions - some 20 ns of latency
+        // and next to no work.  Observation it + 1 needs a band row only after observation `it` has left it, so it may run
+        // 1 + (first_row[it + 1] - first_row[it]) steps behind: up to four observations are under way at a time, oldest first within
+        // a step - the same operations on the same operands as fpcurf's loop, in an order the core can overlap (bit-identical by
+        // construction; pinned by f4_fitpack and f14_*).
+        {
+            int head = 0, tail = 0, next_start = 0;
+            for (int s = 0; head < m; ++s) {
+                if (tail < m && next_start <= s) {
+                    for (int i = 0; i < K1; ++i) hs[static_cast<size_t>(tail) * K1 + i] = q[static_cast<size_t>(tail) * K1 + i];
+                    yis[tail] = y[tail];
+                    started[tail] = s;
+                    if (tail + 1 < m) next_start = s + 1 + (first_row[tail + 1] - first_row[tail]);
+                    ++tail;
+                }
+                for (int ob = head; ob < tail; ++ob) {
+                    const int i = s - started[ob];
+                    double* h = &hs[static_cast<size_t>(ob) * K1];
+                    const double piv = h[i];
+                    if (piv != 0.0) {
+                        const int j = first_row[ob] + i;
+                        double* row = &a[static_cast<size_t>(j) * K1];
+                        const Rot r = givens(piv, row[0]);
+                        rotate(r, yis[ob], z[j]);
+                        for (int i1 = i + 1; i1 < K1; ++i1) rotate(r, h[i1], row[i1 - i]);
+                    }
+                }
+                if (s - started[head] == K1 - 1) ++head;      // the oldest one has taken its last step
+            }
+        }
+        for (int it = 0; it < m; ++it) fp = fp + yis[it] * yis[it];
         if (ier == -2) fp0 = fp;
         fpint[n - 1] = fp0;
         fpint[n - 2] = fpold;
@@ -521,22 +538,37 @@ int fpcurf(int iopt, const double* x, const double* y, int m, double s, int nest
             for (int j = 0; j < K1; ++j) g[static_cast<size_t>(i) * K2 + j] = a[static_cast<size_t>(i) * K1 + j];
             g[static_cast<size_t>(i) * K2 + K1] = 0.0;
         }
-        for (int it = 1; it <= n8; ++it) {
-            double h[K2 + 1];
-            for (int i = 0; i < K2; ++i) h[i] = b[static_cast<size_t>(it - 1) * K2 + i] * pinv;
-            h[K2] = 0.0;
-            double yi = 0.0;
-            for (int j = it; j <= nk1; ++j) {
-                double* row = &g[static_cast<size_t>(j - 1) * K2];
-                const Rot r = givens(h[0], row[0]);
-                rotate(r, yi, c[j - 1]);
-                if (j == nk1) break;
-                const int i2 = (j > n8) ? nk1 - j : K1;
-                for (int i = 1; i <= i2; ++i) {
-                    rotate(r, h[i], row[i]);
-                    h[i - 1] = h[i];
+        // Row `it` of the discontinuity matrix is rotated into band rows it, it + 1, ..., nk1 - one Givens step per band row, each
+        // waiting for the one before it (a division, a square root, two divisions: ~25 ns of latency and next to no work).  Row
+        // it + 1 needs band row j only after row `it` has left it, so kLanes rows go down the band together, each two band rows
+        // behind the one before it: the same operations on the same operands as FITPACK's loop nest (fpcurf's statement 260..300),
+        // in an order the core can overlap.  Bit-identical by construction; pinned by f4_fitpack / f14_*.
+        for (int it0 = 1; it0 <= n8; it0 += kLanes) {
+            double h[kLanes][K2 + 1];
+            double yi[kLanes];
+            const int lanes = std::min(kLanes, n8 - it0 + 1);
+            for (int r = 0; r < lanes; ++r) {
+                for (int i = 0; i < K2; ++i) h[r][i] = b[static_cast<size_t>(it0 + r - 1) * K2 + i] * pinv;
+                h[r][K2] = 0.0;
+                yi[r] = 0.0;
+            }
+            const int steps = (nk1 - it0) + (lanes - 1) + 1;       // lane r takes band row it0 + s - r at step s, from s = 2 r on
+            for (int s = 0; s < steps; ++s) {
+#pragma GCC unroll 4
+                for (int r = 0; r < kLanes; ++r) {
+                    const int j = it0 + s - r;
+                    if (r >= lanes || s < 2 * r || j > nk1) continue;
+                    double* row = &g[static_cast<size_t>(j - 1) * K2];
+                    const Rot rot = givens(h[r][0], row[0]);
+                    rotate(rot, yi[r], c[j - 1]);
+                    if (j == nk1) continue;
+                    const int i2 = (j > n8) ? nk1 - j : K1;
+                    for (int i = 1; i <= i2; ++i) {
+                        rotate(rot, h[r][i], row[i]);
+                        h[r][i - 1] = h[r][i];
+                    }
+                    h[r][i2] = 0.0;
                 }
-                h[i2] = 0.0;
             }
         }
         std::vector<double> sol;

@@ -109,11 +109,24 @@ __global__ __launch_bounds__(1024) void k3_cutoff(const unsigned long long* __re
 
 // compaction: keys of the rows below the cutoff key (IEEE bit pattern: all p are >= 0, so unsigned order is
 // numeric order); rows at or above it get q = 1 and NaN rows get q = NaN right here.
+//
+// DENSE (round 6; the engine's own pass when many rows survive - rank_and_adjust): q is not touched here.  A survivor's value is its
+// COMPACT INDEX (its slot in keys[0]) instead of its row, so that K3c scatters the q of the survivors into a dense array of their
+// number - an eighth to a half of the q column: the scattered 8-byte stores stay in the L2s / the 256 MB Infinity Cache instead of
+// each filling and writing back a 32-byte sector of HBM - and k3_fill_q then writes the whole q column once, in row order, from
+// two bits per row left here (kept / NaN: `mask`, four ballots per 128 rows) + the wave's first slot (`wave_slot`).
+struct DenseQ {
+    double* dense = nullptr;                 // q of the survivors by compact index
+    unsigned long long* mask = nullptr;      // per wave chunk (1024 rows) and step h: keep even rows, keep odd rows, NaN even, NaN odd
+    unsigned long long* wave_slot = nullptr; // per wave chunk: compact index of its first survivor
+};
+
+template <bool DENSE>
 __global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restrict__ p, int64_t n,
                                                            unsigned long long* __restrict__ keys,
                                                            unsigned int* __restrict__ vals, double* __restrict__ q,
                                                            unsigned long long* __restrict__ counter,
-                                                           const unsigned long long* __restrict__ cutoff_key) {
+                                                           const unsigned long long* __restrict__ cutoff_key, DenseQ dq) {
     // rows at or above the cutoff key (see above) have q = 1 and are not sorted; NaN rows get q = NaN.
     // one global atomic per 4096-row tile (a same-address atomic per 256 rows capped this kernel at ~88 M atomics/s)
     __shared__ unsigned int wave_cnt[SORT_WAVES];
@@ -145,13 +158,21 @@ __global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restr
                 keep1 = (w.y == w.y) && (pvalue_key(w.y) < cutoff);
                 // both q of the pair in one 16-byte store, kept rows included: bh_apply overwrites those later on this stream
                 // (partial 8-byte stores around every kept row cost 0.13 ms per 1.2e8 rows with 12 % of them kept)
-                q2[i >> 1] = make_double2((w.x == w.x) ? 1.0 : w.x, (w.y == w.y) ? 1.0 : w.y);
+                if (!DENSE) q2[i >> 1] = make_double2((w.x == w.x) ? 1.0 : w.x, (w.y == w.y) ? 1.0 : w.y);
             } else if (i < n) {                                            // the last row of an odd count
                 v[2 * h] = p[i];
                 keep0 = (v[2 * h] == v[2 * h]) && (pvalue_key(v[2 * h]) < cutoff);
-                if (!keep0) q[i] = (v[2 * h] == v[2 * h]) ? 1.0 : v[2 * h];
+                if (!DENSE && !keep0) q[i] = (v[2 * h] == v[2 * h]) ? 1.0 : v[2 * h];
             }
             const unsigned long long m0 = __ballot(keep0), m1 = __ballot(keep1);
+            if (DENSE) {
+                const unsigned long long n0 = __ballot(v[2 * h] != v[2 * h]), n1 = __ballot(v[2 * h + 1] != v[2 * h + 1]);
+                if (lane == 0) {
+                    ulonglong2* m = reinterpret_cast<ulonglong2*>(dq.mask + ((t * SORT_WAVES + wave) * (SORT_ITEMS / 2) + h) * 4);
+                    m[0] = make_ulonglong2(m0, m1);
+                    m[1] = make_ulonglong2(n0, n1);
+                }
+            }
             before[2 * h] = run + __popcll(m0 & lane_lt);
             run += __popcll(m0);
             before[2 * h + 1] = run + __popcll(m1 & lane_lt);
@@ -172,14 +193,51 @@ __global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restr
         }
         __syncthreads();
         const unsigned long long base = block_base + wave_cnt[wave];
+        if (DENSE && lane == 0) dq.wave_slot[t * SORT_WAVES + wave] = base;
 #pragma unroll
         for (int r = 0; r < SORT_ITEMS; ++r) {
             if ((keepmask >> r) & 1ull) {
                 keys[base + before[r]] = pvalue_key(v[r]);
-                vals[base + before[r]] = (unsigned int)(wave_base + (int64_t)((r >> 1) * 64 + lane) * 2 + (r & 1));
+                vals[base + before[r]] = DENSE ? (unsigned int)(base + before[r])
+                                               : (unsigned int)(wave_base + (int64_t)((r >> 1) * 64 + lane) * 2 + (r & 1));
             }
         }
         __syncthreads();
+    }
+}
+
+// The whole q column in row order, once: 1.0, the row's own NaN, or - for the rows k3_compact<true> kept - the survivor's q from the
+// dense array (consecutive kept rows of a wave step read consecutive entries).  Same tiles and wave chunks as k3_compact.
+__global__ __launch_bounds__(SORT_THREADS) void k3_fill_q(const double* __restrict__ p, int64_t n, DenseQ dq, double* __restrict__ q) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    const int64_t tiles = (n + SORT_TILE - 1) / SORT_TILE;
+    double2* q2 = reinterpret_cast<double2*>(q);
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int64_t chunk = t * SORT_WAVES + wave;
+        const int64_t wave_base = chunk * (64 * SORT_ITEMS);
+        if (wave_base >= n) continue;
+        const double* mine = dq.dense + dq.wave_slot[chunk];
+        const ulonglong2* m = reinterpret_cast<const ulonglong2*>(dq.mask + chunk * (SORT_ITEMS / 2) * 4);
+        unsigned int run = 0;
+#pragma unroll
+        for (int h = 0; h < SORT_ITEMS / 2; ++h) {
+            const ulonglong2 keep = m[2 * h], nan = m[2 * h + 1];
+            const int64_t i = wave_base + (int64_t)(h * 64 + lane) * 2;
+            const unsigned int b0 = run + __popcll(keep.x & lane_lt);
+            run += __popcll(keep.x);
+            const unsigned int b1 = run + __popcll(keep.y & lane_lt);
+            run += __popcll(keep.y);
+            double q0 = 1.0, q1 = 1.0;
+            if ((keep.x >> lane) & 1ull) q0 = mine[b0];
+            if ((keep.y >> lane) & 1ull) q1 = mine[b1];
+            if ((nan.x >> lane) & 1ull) q0 = p[i];
+            if ((nan.y >> lane) & 1ull) q1 = p[i + 1];
+            if (i + 1 < n)
+                q2[i >> 1] = make_double2(q0, q1);
+            else if (i < n)
+                q[i] = q0;
+        }
     }
 }
 
@@ -632,7 +690,8 @@ __global__ __launch_bounds__(BH_THREADS) void bh_apply(const unsigned long long*
                                                        const unsigned int* __restrict__ vals,
                                                        const unsigned long long* __restrict__ n_ptr, int64_t n_fixed,
                                                        double n_tests, double rank0, const double* __restrict__ tile_carry,
-                                                       const double* __restrict__ extra_carry, double* __restrict__ q_out) {
+                                                       const double* __restrict__ extra_carry, double* __restrict__ q_out,
+                                                       bool into_dense = false) {
     __shared__ double wtot[BH_THREADS / 64];
     const int64_t n = n_ptr ? (int64_t)*n_ptr : n_fixed;
     const int64_t base = (int64_t)blockIdx.x * BH_TILE;
@@ -663,7 +722,9 @@ __global__ __launch_bounds__(BH_THREADS) void bh_apply(const unsigned long long*
         const int64_t i = first + r;
         if (i < n) {
             const double qv = fmax(v[r], carry);
-            if (vals)
+            if (vals && into_dense)
+                q_out[vals[i]] = qv;                                     // the dense array: k3_fill_q reads it right behind this launch
+            else if (vals)
                 __builtin_nontemporal_store(qv, q_out + vals[i]);       // one 8-byte store into a line nobody else touches soon: no allocate
             else
                 q_out[i] = qv;
@@ -1043,15 +1104,21 @@ static int auto_cutoff(fhx_ctx* ctx, const double* d_p, int64_t n, double n_tota
 }
 
 // rows below the cutoff -> keys[0] / vals[0] (their number in *counter and, read back, in *n_kept); every other row gets its q here
+// (dq: k3_compact<true> - no q here, compact indices as values, masks for k3_fill_q)
 static int compact_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned long long* keys[2], unsigned int* vals[2], double* d_q,
-                           unsigned long long* counter, const unsigned long long* d_cutoff, int64_t* n_kept_out) {
+                           unsigned long long* counter, const unsigned long long* d_cutoff, int64_t* n_kept_out,
+                           const DenseQ* dq = nullptr) {
     FHX_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
     // one workgroup per tile, not a resident grid walking the column: 0.507 -> 0.451 ms on C3 (profiles/history/r03_x_k3_grid.txt); the
     // plain copy kernel of profiles/hbm_rate.hip shows the same (4.9 TB/s with 2048 grid-striding workgroups, 5.6 with one per
     // chunk).  FHX_K3_GRID caps the grid for measurements.
     static const int k3_cap = std::getenv("FHX_K3_GRID") ? std::atoi(std::getenv("FHX_K3_GRID")) : (1 << 30);
-    hipLaunchKernelGGL(k3_compact, dim3(grid_for(n, SORT_TILE, k3_cap)), dim3(SORT_THREADS), 0, ctx->stream, d_p, n,
-                       keys[0], vals[0], d_q, counter, d_cutoff);
+    if (dq)
+        hipLaunchKernelGGL(k3_compact<true>, dim3(grid_for(n, SORT_TILE, k3_cap)), dim3(SORT_THREADS), 0, ctx->stream, d_p, n,
+                           keys[0], vals[0], d_q, counter, d_cutoff, *dq);
+    else
+        hipLaunchKernelGGL(k3_compact<false>, dim3(grid_for(n, SORT_TILE, k3_cap)), dim3(SORT_THREADS), 0, ctx->stream, d_p, n,
+                           keys[0], vals[0], d_q, counter, d_cutoff, DenseQ{});
     // how many keys survived decides the shape of the sort.  When the cutoff came from this GPU's own histogram (auto_cutoff) the
     // number is already on its way - the histogram's bins below the cutoff bin hold exactly the rows kept here - and the host goes
     // on to enqueue the sort while the compaction runs; otherwise (sharded runs: the histogram is the all-reduced one) the counter
@@ -1131,10 +1198,27 @@ static unsigned int* engine_sort_ctrl(fhx_ctx* ctx) {
     if (cap * 24 + os_scratch_bytes(ctx->n_rows) > ctx->work_bytes) return nullptr;
     return reinterpret_cast<unsigned int*>(ctx->d_work + cap * 24);
 }
+// The dense-q arrays of the engine's own pass, behind the sort's scratch: 8 B per row at most (every row a survivor) + 2 bits per
+// row + 8 B per 1024 rows - 24 + 2.7 + 8.3 of the workspace's >= 48 B per row.  false: they do not fit (then q is scattered as before).
+static bool engine_dense_q(fhx_ctx* ctx, DenseQ* dq) {
+    const size_t cap = std::max<size_t>(4, ((size_t)ctx->n_rows + 3) / 4 * 4);
+    const size_t chunks = (cap + 64 * SORT_ITEMS - 1) / (64 * SORT_ITEMS) + SORT_WAVES;
+    size_t at = (cap * 24 + os_scratch_bytes(ctx->n_rows) + 255) / 256 * 256;
+    const size_t dense_bytes = cap * 8, mask_bytes = chunks * (SORT_ITEMS / 2) * 4 * 8, slot_bytes = chunks * 8;
+    if (at + dense_bytes + mask_bytes + slot_bytes > ctx->work_bytes) return false;
+    dq->dense = reinterpret_cast<double*>(ctx->d_work + at);
+    at += dense_bytes;
+    dq->mask = reinterpret_cast<unsigned long long*>(ctx->d_work + at);
+    at += mask_bytes;
+    dq->wave_slot = reinterpret_cast<unsigned long long*>(ctx->d_work + at);
+    return true;
+}
 
 // n_keys: the number of sorted keys when the host knows it (the grids then cover the keys, not the rows), else an upper bound
+// (dq: the values are compact indices - q goes to the dense array and k3_fill_q writes the column: p_rows / n_rows name it)
 static int bh_from_sorted(fhx_ctx* ctx, const unsigned long long* keys, const unsigned int* vals, int64_t n_keys,
-                          const unsigned long long* counter, double n_total_tests, double* tile_max, double* d_q) {
+                          const unsigned long long* counter, double n_total_tests, double* tile_max, double* d_q,
+                          const DenseQ* dq = nullptr, const double* p_rows = nullptr, int64_t n_rows = 0) {
     const int tiles = (int)std::max<int64_t>(1, (n_keys + BH_TILE - 1) / BH_TILE);
     unsigned long long* fault = nullptr;
     if (ctx->k3_n_is_bound) {                           // n_keys came from the histogram: the device checks it against its counter
@@ -1147,7 +1231,12 @@ static int bh_from_sorted(fhx_ctx* ctx, const unsigned long long* keys, const un
     hipLaunchKernelGGL(bh_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, tile_max, counter, (int64_t)0, 0.0,
                        (double*)nullptr, n_keys, fault);
     hipLaunchKernelGGL(bh_apply, dim3(tiles), dim3(BH_THREADS), 0, ctx->stream, keys, vals, counter, (int64_t)0,
-                       n_total_tests, 0.0, tile_max, (const double*)nullptr, d_q);
+                       n_total_tests, 0.0, tile_max, (const double*)nullptr, dq ? dq->dense : d_q, dq != nullptr);
+    if (dq) {
+        static const int fill_cap = std::getenv("FHX_K3_GRID") ? std::atoi(std::getenv("FHX_K3_GRID")) : (1 << 30);
+        hipLaunchKernelGGL(k3_fill_q, dim3(grid_for(n_rows, SORT_TILE, fill_cap)), dim3(SORT_THREADS), 0, ctx->stream, p_rows, n_rows, *dq,
+                           d_q);
+    }
     FHX_HIP(hipGetLastError());
     return FHX_OK;
 }
@@ -1155,20 +1244,20 @@ static int bh_from_sorted(fhx_ctx* ctx, const unsigned long long* keys, const un
 // compaction, sort and BH of one p column -> q in row order
 static int rank_and_adjust(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned long long* keys[2], unsigned int* vals[2], double* d_q,
                            unsigned long long* counter, const unsigned long long* d_cutoff, double n_total_tests, double* tile_max,
-                           int* sorted_buf, int64_t* n_sorted_out, int key_hi, unsigned int* ctrl) {
+                           int* sorted_buf, int64_t* n_sorted_out, int key_hi, unsigned int* ctrl, const DenseQ* dq = nullptr) {
     int64_t n_kept = 0;
-    int rc = compact_pvalues(ctx, d_p, n, keys, vals, d_q, counter, d_cutoff, &n_kept);
+    int rc = compact_pvalues(ctx, d_p, n, keys, vals, d_q, counter, d_cutoff, &n_kept, dq);
     if (rc != FHX_OK) return rc;
     if (n_sorted_out) *n_sorted_out = n_kept;
     OsPending pend;
     rc = sort_kept(ctx, keys, vals, counter, n_kept, sorted_buf, key_hi, ctrl, &pend);
     if (rc != FHX_OK) return rc;
-    rc = bh_from_sorted(ctx, keys[*sorted_buf], vals[*sorted_buf], n_kept, counter, n_total_tests, tile_max, d_q);
+    rc = bh_from_sorted(ctx, keys[*sorted_buf], vals[*sorted_buf], n_kept, counter, n_total_tests, tile_max, d_q, dq, d_p, n);
     if (rc != FHX_OK) return rc;
     bool moved = false;
     rc = onesweep_finish(ctx, &pend, &moved);          // the BH scan above runs while the host reads the repair's verdict
     if (rc != FHX_OK) return rc;
-    if (moved) rc = bh_from_sorted(ctx, keys[*sorted_buf], vals[*sorted_buf], n_kept, counter, n_total_tests, tile_max, d_q);
+    if (moved) rc = bh_from_sorted(ctx, keys[*sorted_buf], vals[*sorted_buf], n_kept, counter, n_total_tests, tile_max, d_q, dq, d_p, n);
     return rc;
 }
 
@@ -1306,8 +1395,12 @@ int fhx_bh(fhx_ctx* ctx, double n_total_tests) {
     int rc = auto_cutoff(ctx, ctx->d_p, ctx->n_rows, n_total_tests, ctx->d_misc + 6);
     if (rc != FHX_OK) return rc;
     int64_t kept = 0;
+    // FHX_K3_DENSE: 1 = q through the dense array whatever the survivors' number, 0 = never (measurements, tests)
+    static const int dense_env = std::getenv("FHX_K3_DENSE") ? std::atoi(std::getenv("FHX_K3_DENSE")) : -1;
+    DenseQ dq;
+    const bool dense = dense_env != 0 && engine_dense_q(ctx, &dq);
     rc = rank_and_adjust(ctx, ctx->d_p, ctx->n_rows, ctx->d_keys, ctx->d_vals, ctx->d_q, ctx->d_misc, ctx->d_misc + 6, n_total_tests,
-                         ctx->d_tile_max, &ctx->sorted_buf, &kept, 62, engine_sort_ctrl(ctx));
+                         ctx->d_tile_max, &ctx->sorted_buf, &kept, 62, engine_sort_ctrl(ctx), dense ? &dq : nullptr);
     if (rc != FHX_OK) return rc;
     ctx->n_sorted = ctx->k3_n_is_bound ? -2 : kept;      // -2: fhx_n_sorted reads the device counter when somebody asks
     FHX_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
