@@ -166,6 +166,17 @@ SYMBOLS = {
     "fhx_set_global_rows_range": (ctypes.c_int, [_P, ctypes.c_int64]),
     "fhx_text_part_bounds": (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, _I64P, _I64P]),
     "fhx_ingest_contacts_text_slice": (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _I64P, _I32P]),
+    "fhx_host_inflate_part": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_P)]),
+    "fhx_text_part_bytes": (ctypes.c_int64, [_P]),
+    "fhx_text_part_is_last": (ctypes.c_int32, [_P]),
+    "fhx_text_part_tail": (ctypes.c_int, [_P, _P, ctypes.c_int64]),
+    "fhx_text_part_resolve": (ctypes.c_int, [_P, _P, ctypes.c_int64, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_uint32)]),
+    "fhx_text_part_error": (ctypes.c_char_p, [_P]),
+    "fhx_text_part_free": (None, [_P]),
+    "fhx_crc32_combine": (ctypes.c_uint32, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int64]),
+    "fhx_text_first_row_end": (ctypes.c_int64, [_P, _P, ctypes.c_int64]),
+    "fhx_text_ends_with_newline": (ctypes.c_int32, [_P]),
+    "fhx_ingest_contacts_text_own": (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int64, ctypes.c_char_p, ctypes.c_int64, _I64P, _I32P]),
     "fhx_ingest_contacts_chr_counts": (ctypes.c_int, [_P, _I64P, ctypes.c_int32]),
     "fhx_ingest_contacts_commit_shard": (ctypes.c_int, [_P, _I32P, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int32, _I64P]),
     "fhx_shard_segments": (ctypes.c_int, [_P, _I64P, _I64P, _I64P, ctypes.c_int64, _I64P]),
@@ -419,6 +430,15 @@ class Context:
         """the rows that start in part `part` of `n_parts` of an inflated text (HostText) parsed on the GPU -> (rows, names)"""
         n, k = ctypes.c_int64(0), ctypes.c_int32(0)
         self._check(self._L.fhx_ingest_contacts_text_slice(self._h, text._h, int(threads), int(part), int(n_parts), ctypes.byref(n), ctypes.byref(k)))
+        return n.value, [self._L.fhx_ingest_contacts_name(self._h, i).decode() for i in range(k.value)]
+
+    def ingest_contacts_text_own(self, text, skip, extra=b"", threads=0):
+        """the rows whose first byte lies in `text` (a part of a stream: HostText of TextPart.resolve) from byte `skip` on, the last one
+        completed by `extra`, parsed on the GPU -> (rows, names)"""
+        n, k = ctypes.c_int64(0), ctypes.c_int32(0)
+        self._keep_extra = bytes(extra)                       # (referenced until the call returns)
+        self._check(self._L.fhx_ingest_contacts_text_own(self._h, text._h, int(threads), int(skip), self._keep_extra, len(self._keep_extra),
+                                                         ctypes.byref(n), ctypes.byref(k)))
         return n.value, [self._L.fhx_ingest_contacts_name(self._h, i).decode() for i in range(k.value)]
 
     def set_global_rows_range(self, first):
@@ -799,6 +819,18 @@ class HostText:
             raise FhxError(rc, "fhx_text_copy")
         return out.tobytes()
 
+    def first_row_end(self):
+        """(length of the first row with its newline, the row) - (-1, b"") when the text holds no newline"""
+        n = int(self._L.fhx_text_first_row_end(self._h, None, 0))
+        if n < 0:
+            return -1, b""
+        buf = ctypes.create_string_buffer(n)
+        self._L.fhx_text_first_row_end(self._h, buf, n)
+        return n, buf.raw
+
+    def ends_with_newline(self):
+        return bool(self._L.fhx_text_ends_with_newline(self._h))
+
     def part_bounds(self, part, n_parts):
         """bytes [lo, hi) of the text that part `part` of `n_parts` takes (Ctx.ingest_contacts_text_slice): the rows that start in its
         N-th of the bytes"""
@@ -814,6 +846,68 @@ class HostText:
             self._h = _P()
 
     __del__ = close
+
+
+class TextPart:
+    """Part `part` of `n_parts` of one plain gzip stream, decoded without the 32 KB of text before it (fhx_host_inflate_part).
+    tail(): its last 32768 symbols in terms of that window; resolve(window) -> (HostText of the part, CRC-32)."""
+
+    WINDOW = 32768
+
+    def __init__(self, path, part, n_parts, threads=0):
+        L = lib()
+        self._L, self._h = L, _P()
+        rc = L.fhx_host_inflate_part(os.fsencode(path), int(threads), int(part), int(n_parts), ctypes.byref(self._h))
+        if rc != FHX_OK:
+            msg = (L.fhx_text_part_error(self._h) or b"").decode() if self._h else "fhx_host_inflate_part"
+            self.close()
+            raise FhxError(rc, msg)
+
+    def __len__(self):
+        return int(self._L.fhx_text_part_bytes(self._h))
+
+    def is_last(self):
+        return bool(self._L.fhx_text_part_is_last(self._h))
+
+    def tail(self):
+        out = np.empty(self.WINDOW, np.uint16)
+        rc = self._L.fhx_text_part_tail(self._h, out.ctypes.data_as(_P), len(out))
+        if rc != FHX_OK:
+            raise FhxError(rc, "fhx_text_part_tail")
+        return out
+
+    def resolve(self, window):
+        w = np.ascontiguousarray(window, np.uint8)
+        h, crc = _P(), ctypes.c_uint32(0)
+        rc = self._L.fhx_text_part_resolve(self._h, w.ctypes.data_as(_P), len(w), ctypes.byref(h), ctypes.byref(crc))
+        if rc != FHX_OK:
+            raise FhxError(rc, "fhx_text_part_resolve")
+        text = HostText.__new__(HostText)
+        text._L, text._h = self._L, h
+        return text, int(crc.value)
+
+    def close(self):
+        if self._h:
+            self._L.fhx_text_part_free(self._h)
+            self._h = _P()
+
+    __del__ = close
+
+
+def chain_windows(tails):
+    """tails[r] = TextPart.tail() of part r -> the 32 KB of text before every part (part 0: zeros; nothing refers to them)"""
+    windows = [np.zeros(TextPart.WINDOW, np.uint8)]
+    for t in tails[:-1]:
+        t = np.asarray(t, np.uint16)
+        ref = t >= 256
+        w = t.astype(np.uint8)
+        w[ref] = windows[-1][t[ref] - 256]
+        windows.append(w)
+    return windows
+
+
+def crc32_combine(crc_a, crc_b, len_b):
+    return int(lib().fhx_crc32_combine(int(crc_a), int(crc_b), int(len_b)))
 
 
 def _table_out(L, rc, h, kind, name_ids, want_float, what):

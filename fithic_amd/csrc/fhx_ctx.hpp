@@ -168,6 +168,8 @@ __device__ __forceinline__ int k2h_bucket(int signed_count);
 constexpr int MISC_K2_REDO = 64;                         // rows k2h_heavy handed back
 constexpr int MISC_K2_NEXT = 65;                         // + 0: k2h_heavy's next task; + class (1..K2_QUEUES): that kernel's next piece
 constexpr int MISC_K2_WORDS = 8;
+constexpr int MISC_K3_DENSE = 80;                        // k3_cutoff's decision: this pass takes q through the dense array (fhx_k3.hip: DenseQ)
+constexpr int K3_DENSE_PERCENT = 35;                     // ... when at least this share of the rows survives the BH cutoff
 
 constexpr int K2_CL_ITEMS = 4;
 constexpr int K2_CL_TILE = K2_THREADS * K2_CL_ITEMS;     // 1024 rows per workgroup step: four waves of 256 consecutive rows

@@ -6,6 +6,8 @@
 // CDNA4 notes: wave64 everywhere (ballots are 64-bit); pair arrays are streamed with 16-byte-per-lane coalesced loads; the
 // distance histogram is privatised in LDS and flushed with one global atomic per touched bin per workgroup; there is no dense
 // contraction on this path, so no MFMA; every unit is compiled with -ffp-contract=off (see fhx_bdtrc.hpp for why).
+#include <thread>
+
 #include "fhx_ctx.hpp"
 
 extern "C" {
@@ -301,6 +303,37 @@ int fhx_fit(fhx_ctx* ctx, fhx_fit_info* out) {
     if (!ctx->have_stats) return fail(ctx, FHX_ERR_ARG, "fhx_pass_stats (or fhx_set_global_stats) must run first");
     static const bool fit_times = std::getenv("FHX_FIT_TIMES") != nullptr;      // measurements: where the host part of a pass goes
     const auto t0 = std::chrono::steady_clock::now();
+    // The per-count tables (log Beta and 1 / Beta of (count, n - count + 1): two lgamma each) depend on K1's statistics alone, not
+    // on the fit: with large counts (40 kb bins: 16 000 entries, 210 us - as long as the whole fit) they are built on two threads of
+    // their own while this one bins and fits; a thread costs ~15 us to start, so small tables (5 kb bins: 700 entries) stay inline.
+    const int64_t mc = std::max<int64_t>(ctx->stats.max_count, 1);
+    std::vector<double> lb_a, ib_a, lb_e, ib_e;
+    std::thread side[2];
+    const bool tables_aside = ctx->device >= 0 && mc >= 2048 && !std::getenv("FHX_FIT_SERIAL");
+    if (tables_aside) {
+        const double n_a = bdtrc_total(ctx->prm, ctx->stats.in_range_sum), n_e = bdtrc_total(ctx->prm, ctx->stats.inter_sum);
+        lb_a.assign((size_t)mc + 1, 0.0);
+        ib_a.assign((size_t)mc + 1, 0.0);
+        lb_e.assign((size_t)mc + 1, 0.0);
+        ib_e.assign((size_t)mc + 1, 0.0);
+        const int64_t mid = mc / 2;
+        double *la = lb_a.data(), *ia = ib_a.data(), *le = lb_e.data(), *ie = ib_e.data();
+        side[0] = std::thread([=] {
+            fill_lbeta_table(n_a, 1, mid, la, ia);
+            fill_lbeta_table(n_e, 1, mid, le, ie);
+        });
+        side[1] = std::thread([=] {
+            fill_lbeta_table(n_a, mid + 1, mc, la, ia);
+            fill_lbeta_table(n_e, mid + 1, mc, le, ie);
+        });
+    }
+    struct Join {
+        std::thread* t;
+        ~Join() {
+            for (int k = 0; k < 2; ++k)
+                if (t[k].joinable()) t[k].join();
+        }
+    } join_side{side};
     PassInputs in;
     fill_pass_inputs(ctx, in);
     std::string err;
@@ -319,10 +352,13 @@ int fhx_fit(fhx_ctx* ctx, fhx_fit_info* out) {
         }
         // prior LUT (fixed-size) or the spline table itself (-r 0) + the two pairs of per-count tables: packed into the pinned
         // staging buffer and sent with one copy; nothing waits for it here (the stream orders it before K2)
-        const int64_t mc = std::max<int64_t>(ctx->stats.max_count, 1);
-        std::vector<double> lb_a, ib_a, lb_e, ib_e;
-        build_lbeta_table(bdtrc_total(ctx->prm, ctx->stats.in_range_sum), mc, lb_a, ib_a);
-        build_lbeta_table(bdtrc_total(ctx->prm, ctx->stats.inter_sum), mc, lb_e, ib_e);
+        if (tables_aside) {
+            side[0].join();
+            side[1].join();
+        } else {
+            build_lbeta_table(bdtrc_total(ctx->prm, ctx->stats.in_range_sum), mc, lb_a, ib_a);
+            build_lbeta_table(bdtrc_total(ctx->prm, ctx->stats.inter_sum), mc, lb_e, ib_e);
+        }
         t2 = std::chrono::steady_clock::now();
         const size_t n_lut = std::max<size_t>(f.prior_lut.size(), 1), n_tab = (size_t)(mc + 1);
         const size_t n_xy = ctx->nonfixed ? std::max<size_t>(f.table_x.size(), 1) : 0;

@@ -29,6 +29,8 @@
 #include <thread>
 #include <vector>
 
+#include "../../include/fithic_mi355x.h"
+#include "fhx_cpus.hpp"
 #include "fhx_io_internal.hpp"
 
 namespace {
@@ -396,6 +398,50 @@ void decode_chunk(const uint8_t* data, size_t n, Chunk& C, bool first, size_t ex
     C.ok = true;
 }
 
+// offset of the deflate stream behind the header of the file's first member; false + why: not a gzip header / truncated
+bool member_payload(const unsigned char* gz, size_t n, size_t& o, std::string& why) {
+    if (n < 18 || gz[0] != 0x1f || gz[1] != 0x8b || gz[2] != 8 || (gz[3] & 0xe0)) {
+        why = "not a gzip header";
+        return false;
+    }
+    o = 10;
+    const unsigned flg = gz[3];
+    if (flg & 4) {
+        if (o + 2 > n) {
+            why = "truncated";
+            return false;
+        }
+        o += 2 + (gz[o] | ((size_t)gz[o + 1] << 8));
+    }
+    for (int name = 0; name < 2; ++name)
+        if (flg & (name == 0 ? 8u : 16u)) {
+            while (o < n && gz[o]) ++o;
+            ++o;
+        }
+    if (flg & 2) o += 2;
+    if (o + 8 >= n) {
+        why = "truncated";
+        return false;
+    }
+    return true;
+}
+
+template <typename Job>
+void run_jobs(size_t lo, size_t hi, int n_threads, const Job& job) {
+    std::atomic<size_t> next{lo};
+    auto work = [&]() {
+        for (;;) {
+            const size_t k = next.fetch_add(1);
+            if (k >= hi) break;
+            job(k);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads && (size_t)t < hi - lo; ++t) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+}
+
 }  // namespace
 
 // gz = a whole gzip file.  true: `pieces` hold its text (one piece per chunk, in order), checked against the trailer's CRC-32
@@ -410,26 +456,8 @@ bool fhx::io_parallel_gunzip(const unsigned char* gz, size_t n, int n_threads, s
         why = "small file or one thread";
         return false;
     }
-    if (n < 18 || gz[0] != 0x1f || gz[1] != 0x8b || gz[2] != 8 || (gz[3] & 0xe0)) {
-        why = "not a gzip header";
-        return false;
-    }
-    size_t o = 10;
-    const unsigned flg = gz[3];
-    if (flg & 4) {
-        if (o + 2 > n) return false;
-        o += 2 + (gz[o] | ((size_t)gz[o + 1] << 8));
-    }
-    for (int name = 0; name < 2; ++name)
-        if (flg & (name == 0 ? 8u : 16u)) {
-            while (o < n && gz[o]) ++o;
-            ++o;
-        }
-    if (flg & 2) o += 2;
-    if (o + 8 >= n) {
-        why = "truncated";
-        return false;
-    }
+    size_t o = 0;
+    if (!member_payload(gz, n, o, why)) return false;
     const uint8_t* data = gz + o;
     const size_t len = n - o - 8;                                         // if this is the only member: deflate stream, then CRC-32 and ISIZE
     const unsigned char* tail = gz + n - 8;
@@ -599,3 +627,282 @@ bool fhx::io_parallel_gunzip(const unsigned char* gz, size_t n, int n_threads, s
     }
     return true;
 }
+
+
+// ---- ONE plain gzip stream inflated by N processes, each its N-th of the compressed bytes -----------------------------------------
+// (sharded runs: fithic --gpus N on a file `gzip` wrote.  Every rank inflating the whole file is N times the work and N copies of the
+// text in host memory.)  The scheme above already decodes a chunk without the 32 KB before it; here the unknown window is the one
+// before the PART, known only when the ranks before have decoded theirs.  So in two calls:
+//   decode   the part's chunks -> 16-bit symbols, batch after batch as above; of every chunk only its last 32 K symbols are kept,
+//            chained into the part's last 32 K symbols in terms of the window before the part, which go to the caller;
+//   resolve  the caller chains those tails rank after rank (part 0 knows its window: none) and hands every part the 32 KB before it:
+//            the chunks are decoded once more, narrowed to bytes through their windows, and the part's CRC-32 is taken.
+// Part 0 does both in the first call.  Why decode twice instead of keeping the symbols: in text of this kind two thirds of the
+// symbols of a chunk still refer to the unknown window after megabytes ("chr1", the shared digits of neighbouring coordinates are
+// copied on and on, never written as literals again) - the symbols are 2 bytes per byte of text, on every rank at once, where a
+// second decode is 1/N of the file's on 1/N of the cores.  The caller checks the combined CRC-32 (crc32_combine) and the summed
+// length against the file's trailer - as above, the text is zlib's or it is found out.  Chunk grid: n_parts x per_part stretches
+// of the compressed bytes, the same on every rank; a stretch without a block start joins the chunk before it, whichever rank
+// holds that.
+struct fhx_text_part {
+    std::string path, error;
+    int part = 0, n_parts = 1, n_threads = 1;
+    fhx::FileBytes gz;
+    size_t payload = 0, len = 0;           // the deflate stream: gz[payload, payload + len)
+    std::vector<Chunk> chunks;             // start / stop bits of this part's chunks
+    std::vector<uint16_t> tail;            // the part's last kWindow symbols in terms of the window before the part
+    std::vector<fhx::TextPiece> pieces;    // the text, once the window was known
+    uint32_t crc = 0;
+    int64_t bytes = 0;
+    bool last = false;                     // holds the final block, which ends where the trailer begins
+    bool resolved = false;
+    double seconds[3] = {0, 0, 0};         // block starts, first decode, second decode
+};
+
+// All chunks of the part decoded in batches of n_threads.  window0 = the kWindow bytes before the part: pieces, crc, bytes are
+// produced; nullptr: only P.tail (symbolic) and P.bytes.
+static bool part_run(fhx_text_part& P, const uint8_t* window0, std::string& why) {
+    const uint8_t* data = P.gz.data() + P.payload;
+    const size_t len = P.len, readable = len + 8;
+    const int n_threads = P.n_threads;
+    std::vector<Chunk>& chunks = P.chunks;
+    std::vector<SymBuf> pool((size_t)n_threads);
+    std::vector<uint16_t> sym_tail(kWindow), w16(kWindow);
+    for (int j = 0; j < kWindow; ++j) sym_tail[(size_t)j] = (uint16_t)(256 + j);
+    std::vector<uint8_t> carry(kWindow, 0);
+    if (window0) std::memcpy(carry.data(), window0, kWindow);
+    std::vector<uint32_t> crcs(chunks.size(), 0);
+    if (window0) {
+        P.pieces.clear();
+        P.pieces.resize(chunks.size());
+    }
+    int64_t total = 0;
+    for (size_t lo = 0; lo < chunks.size(); lo += (size_t)n_threads) {
+        const size_t hi = std::min(chunks.size(), lo + (size_t)n_threads);
+        for (size_t k = lo; k < hi; ++k) {
+            chunks[k].sym = &pool[k - lo];
+            chunks[k].ok = chunks[k].saw_final = false;
+        }
+        run_jobs(lo, hi, n_threads, [&](size_t k) {
+            Chunk& c = chunks[k];
+            const uint64_t span = (c.stop_bit == UINT64_MAX ? (uint64_t)len * 8 : c.stop_bit) - c.start_bit;
+            decode_chunk(data, readable, c, c.start_bit == 0, (size_t)(span / 8) * 8);
+        });
+        for (size_t k = lo; k < hi; ++k) {
+            if (!chunks[k].ok) {
+                why = "a chunk did not decode from its guessed block start to the next one";
+                return false;
+            }
+            if (chunks[k].saw_final != (P.last && k + 1 == chunks.size())) {
+                why = "the final block is not where the stream ends (more than one member?)";
+                return false;
+            }
+        }
+        // windows down the batch: symbolic (in terms of the window before the part) or, when that window is known, bytes
+        std::vector<std::vector<uint8_t>> window(window0 ? hi - lo : 0);
+        for (size_t k = lo; k < hi; ++k) {
+            const Chunk& c = chunks[k];
+            const uint16_t* end = c.sym->data() + kWindow + c.n_out;      // the last kWindow symbols of [markers of the window, output]
+            if (window0) {
+                window[k - lo] = carry;
+                for (int j = 0; j < kWindow; ++j) {
+                    const uint16_t v = end[j - kWindow];
+                    carry[(size_t)j] = v < 256 ? (uint8_t)v : window[k - lo][(size_t)(v - 256)];
+                }
+            } else {
+                for (int j = 0; j < kWindow; ++j) {
+                    const uint16_t v = end[j - kWindow];
+                    w16[(size_t)j] = v < 256 ? v : sym_tail[(size_t)(v - 256)];
+                }
+                sym_tail.swap(w16);
+            }
+            total += (int64_t)c.n_out;
+        }
+        if (!window0) continue;
+        std::atomic<bool> bad{false};
+        run_jobs(lo, hi, n_threads, [&](size_t k) {
+            Chunk& c = chunks[k];
+            if (!P.pieces[k].allocate(c.n_out)) {
+                bad = true;
+                return;
+            }
+            uint8_t* dst = (uint8_t*)P.pieces[k].data();
+            const uint16_t* src = c.sym->data() + kWindow;
+            const uint8_t* w = window[k - lo].data();
+            for (size_t i = 0; i < c.n_out; ++i) {
+                const uint16_t v = src[i];
+                dst[i] = v < 256 ? (uint8_t)v : w[v - 256];
+            }
+            uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
+            for (size_t i = 0; i < c.n_out; i += (size_t)1 << 30)
+                crc = (uint32_t)crc32(crc, dst + i, (uInt)std::min<size_t>((size_t)1 << 30, c.n_out - i));
+            crcs[k] = crc;
+        });
+        if (bad) {
+            why = "out of memory";
+            return false;
+        }
+    }
+    if (P.last && !chunks.empty() && (chunks.back().end_bit + 7) / 8 != len) {
+        why = "the stream does not end where the file's trailer begins (more than one member?)";
+        return false;
+    }
+    P.bytes = total;
+    if (window0) {
+        P.tail.resize(kWindow);
+        for (int j = 0; j < kWindow; ++j) P.tail[(size_t)j] = carry[(size_t)j];
+        uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
+        for (size_t k = 0; k < chunks.size(); ++k) crc = (uint32_t)crc32_combine(crc, crcs[k], (z_off_t)chunks[k].n_out);
+        P.crc = crc;
+        P.resolved = true;
+    } else {
+        P.tail = sym_tail;
+    }
+    for (Chunk& c : chunks) c.sym = nullptr;
+    return true;
+}
+
+// the part's chunks: block starts inside its stretches of the grid, the last one ending at the first start of a later part
+static bool part_chunks(fhx_text_part& P, std::string& why) {
+    size_t min_bytes = (size_t)4 << 20, chunk_bytes = 0;
+    if (const char* e = std::getenv("FHX_PGUNZIP_MIN")) min_bytes = (size_t)std::max(0ll, std::atoll(e));
+    if (const char* e = std::getenv("FHX_PGUNZIP_CHUNK")) chunk_bytes = (size_t)std::max(1024ll, std::atoll(e));
+    const unsigned char* gz = P.gz.data();
+    const size_t n = P.gz.size();
+    if (n < min_bytes) {
+        why = "small file";
+        return false;
+    }
+    if (!member_payload(gz, n, P.payload, why)) return false;
+    const uint8_t* data = gz + P.payload;
+    P.len = n - P.payload - 8;
+    const size_t len = P.len, readable = len + 8;
+    // chunks small enough that the symbols of n_threads of them (2 B per byte of text, in flight at a time) are a small share of
+    // the part's text
+    const size_t part_len = len / (size_t)P.n_parts;
+    if (!chunk_bytes) chunk_bytes = std::min<size_t>((size_t)4 << 20, std::max<size_t>((size_t)512 << 10, part_len / ((size_t)P.n_threads * 10)));
+    const size_t per_part = std::max<size_t>(1, part_len / chunk_bytes), total = per_part * (size_t)P.n_parts;
+    auto range_bit = [&](size_t k) { return (uint64_t)(len / total * k) * 8; };
+    auto range_end = [&](size_t k) { return k + 1 < total ? range_bit(k + 1) : (uint64_t)len * 8; };
+    const size_t k0 = per_part * (size_t)P.part, k1 = k0 + per_part;
+    std::vector<uint64_t> starts(per_part, UINT64_MAX);
+    run_jobs(0, per_part, P.n_threads, [&](size_t i) {
+        const size_t k = k0 + i;
+        if (k == 0) {
+            starts[i] = 0;
+            return;
+        }
+        Tables* scratch = new Tables();
+        starts[i] = find_block(data, readable, range_bit(k), range_end(k), *scratch);
+        delete scratch;
+    });
+    uint64_t next_start = UINT64_MAX;                                   // where the first chunk of a later part begins
+    {
+        Tables* scratch = new Tables();
+        for (size_t k = k1; k < total && next_start == UINT64_MAX; ++k) next_start = find_block(data, readable, range_bit(k), range_end(k), *scratch);
+        delete scratch;
+    }
+    P.chunks.clear();
+    for (size_t i = 0; i < per_part; ++i)
+        if (starts[i] != UINT64_MAX) {
+            Chunk c;
+            c.start_bit = starts[i];
+            P.chunks.push_back(std::move(c));
+        }
+    for (size_t k = 0; k < P.chunks.size(); ++k) P.chunks[k].stop_bit = k + 1 < P.chunks.size() ? P.chunks[k + 1].start_bit : next_start;
+    P.last = next_start == UINT64_MAX;
+    if (P.last && P.chunks.empty()) {                                     // (the final block lies in an earlier part's last chunk)
+        why = "no block start in the last part";
+        return false;
+    }
+    return true;
+}
+
+extern "C" {
+
+int fhx_host_inflate_part(const char* path, int32_t n_threads, int32_t part, int32_t n_parts, fhx_text_part** out) {
+    if (!path || !out || n_parts < 1 || part < 0 || part >= n_parts) return FHX_ERR_ARG;
+    *out = nullptr;
+    fhx_text_part* P = new (std::nothrow) fhx_text_part();
+    if (!P) return FHX_ERR_NOMEM;
+    *out = P;
+    P->path = path;
+    P->part = part;
+    P->n_parts = n_parts;
+    if (n_threads <= 0) n_threads = fhx::usable_cpus();
+    P->n_threads = n_threads;
+    {
+        const int rc = fhx::io_read_file(path, P->gz, P->error);
+        if (rc != FHX_OK) return rc;
+    }
+    std::vector<fhx::GzMember> members;
+    if (fhx::io_scan_members(P->gz.data(), P->gz.size(), members) && members.size() > 1) {
+        P->error = "a chain of size-tagged members, not one stream";
+        return FHX_ERR_UNSUPPORTED;
+    }
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
+    std::string why;
+    bool ok = part_chunks(*P, why);
+    P->seconds[0] = since();
+    if (ok) {
+        const std::vector<uint8_t> none(kWindow, 0);
+        ok = part_run(*P, part == 0 ? none.data() : nullptr, why);       // part 0 knows the window before it: there is none
+    }
+    P->seconds[1] = since() - P->seconds[0];
+    if (!ok) {
+        P->chunks.clear();
+        P->pieces.clear();
+        P->error = "not inflated in parts: " + why;
+        return FHX_ERR_UNSUPPORTED;
+    }
+    if (std::getenv("FHX_TIMING"))
+        std::fprintf(stderr, "fhx_host_inflate_part(%s, %d of %d): %zu chunks on %d threads: block starts %.3f s; decode %.3f s; %.1f MB of text%s\n",
+                     path, part, n_parts, P->chunks.size(), n_threads, P->seconds[0], P->seconds[1], P->bytes / 1e6,
+                     P->resolved ? "" : " (tails only)");
+    return FHX_OK;
+}
+
+int64_t fhx_text_part_bytes(const fhx_text_part* P) { return P ? P->bytes : 0; }
+int32_t fhx_text_part_is_last(const fhx_text_part* P) { return P && P->last ? 1 : 0; }
+const char* fhx_text_part_error(const fhx_text_part* P) { return P ? P->error.c_str() : "null part"; }
+void fhx_text_part_free(fhx_text_part* P) { delete P; }
+
+int fhx_text_part_tail(const fhx_text_part* P, uint16_t* tail, int64_t cap) {
+    if (!P || !tail || cap < kWindow || P->tail.size() != (size_t)kWindow) return FHX_ERR_ARG;
+    std::memcpy(tail, P->tail.data(), kWindow * sizeof(uint16_t));
+    return FHX_OK;
+}
+
+uint32_t fhx_crc32_combine(uint32_t crc_a, uint32_t crc_b, int64_t len_b) { return (uint32_t)crc32_combine(crc_a, crc_b, (z_off_t)len_b); }
+
+// window: the kWindow bytes of text before the part (ignored by part 0).  The part's pieces move into a new fhx_text (fhx_text_free);
+// *crc32_out = the CRC-32 of the part's text.
+int fhx_text_part_resolve(fhx_text_part* P, const uint8_t* window, int64_t window_bytes, fhx_text** text_out, uint32_t* crc32_out) {
+    if (!P || !window || window_bytes != kWindow || !text_out || !crc32_out) return FHX_ERR_ARG;
+    *text_out = nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    if (!P->resolved) {
+        std::string why;
+        const int64_t announced = P->bytes;
+        if (!part_run(*P, window, why) || P->bytes != announced) {
+            P->error = "second decode: " + (why.empty() ? std::string("another length than the first") : why);
+            return FHX_ERR_UNSUPPORTED;
+        }
+    }
+    fhx_text* x = new (std::nothrow) fhx_text();
+    if (!x) return FHX_ERR_NOMEM;
+    x->path = P->path;
+    x->bytes = P->bytes;
+    x->pieces = std::move(P->pieces);
+    P->pieces.clear();
+    P->chunks.clear();
+    P->seconds[2] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    x->seconds[1] = P->seconds[0] + P->seconds[1] + P->seconds[2];
+    if (std::getenv("FHX_TIMING")) std::fprintf(stderr, "fhx_text_part_resolve(%d of %d): %.3f s\n", P->part, P->n_parts, P->seconds[2]);
+    *crc32_out = P->crc;
+    *text_out = x;
+    return FHX_OK;
+}
+
+}  // extern "C"

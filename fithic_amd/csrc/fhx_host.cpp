@@ -205,18 +205,23 @@ double cephes_beta(double a, double b) {
     return beta_small_args(a, b, false);
 }
 
-void build_lbeta_table(double n_total, int64_t max_count, std::vector<double>& lbeta, std::vector<double>& inv_beta) {
-    if (max_count < 0) max_count = 0;
-    lbeta.assign(static_cast<size_t>(max_count) + 1, 0.0);
-    inv_beta.assign(static_cast<size_t>(max_count) + 1, 0.0);
+// entries [c_lo, c_hi] of the two tables (zero-filled by the caller): every entry on its own, so ranges can be built side by side
+void fill_lbeta_table(double n_total, int64_t c_lo, int64_t c_hi, double* lbeta, double* inv_beta) {
     const bool small = (n_total + 1.0) < kMaxGam;      // incbet's "a + b < MAXGAM" with a + b = n + 1
-    for (int64_t c = 1; c <= max_count; ++c) {
+    for (int64_t c = std::max<int64_t>(c_lo, 1); c <= c_hi; ++c) {
         const double a = static_cast<double>(c);
         const double b = n_total - a + 1.0;            // dn = n - (count-1)
         if (b <= 0.0) break;                           // count > n: bdtrc returns NaN / 0 before incbet
         lbeta[c] = cephes_lbeta(a, b);
         if (small) inv_beta[c] = 1.0 / cephes_beta(a, b);
     }
+}
+
+void build_lbeta_table(double n_total, int64_t max_count, std::vector<double>& lbeta, std::vector<double>& inv_beta) {
+    if (max_count < 0) max_count = 0;
+    lbeta.assign(static_cast<size_t>(max_count) + 1, 0.0);
+    inv_beta.assign(static_cast<size_t>(max_count) + 1, 0.0);
+    fill_lbeta_table(n_total, 1, max_count, lbeta.data(), inv_beta.data());
 }
 
 // ===================================================================================================

@@ -18,6 +18,7 @@ double cephes_lbeta(double a, double b);
 double cephes_beta(double a, double b);
 // table[c] = lbeta(c, n-c+1), inv_beta[c] = 1/beta(c, n-c+1) (only meaningful when n+1 < MAXGAM), c = 0..max_count
 void build_lbeta_table(double n_total, int64_t max_count, std::vector<double>& lbeta, std::vector<double>& inv_beta);
+void fill_lbeta_table(double n_total, int64_t c_lo, int64_t c_hi, double* lbeta, double* inv_beta);   // entries [c_lo, c_hi] of zero-filled tables
 
 // ---------------------------------------------------------------------------------------------------
 // Cubic smoothing spline exactly as scipy.interpolate.UnivariateSpline(x, y, s=s) builds it

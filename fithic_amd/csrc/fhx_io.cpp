@@ -926,6 +926,38 @@ int fhx_text_part_bounds(const fhx_text* text, int32_t part, int32_t n_parts, in
     return FHX_OK;
 }
 
+// length of the text's first row with its newline (what a part of a stream that begins inside a row must leave to the part before
+// it - and hand over as that part's `extra`); -1 when the text holds no newline.  row (cap bytes) receives it when it fits.
+int64_t fhx_text_first_row_end(const fhx_text* text, char* row, int64_t cap) {
+    if (!text) return -1;
+    int64_t base = 0;
+    for (const fhx::TextPiece& piece : text->pieces) {
+        const void* hit = piece.size() ? std::memchr(piece.data(), '\n', piece.size()) : nullptr;
+        if (hit) {
+            const int64_t len = base + ((const char*)hit - piece.data()) + 1;
+            if (row && len <= cap) {
+                int64_t at = 0;
+                for (const fhx::TextPiece& q : text->pieces) {
+                    const int64_t take = std::min<int64_t>((int64_t)q.size(), len - at);
+                    if (take <= 0) break;
+                    std::memcpy(row + at, q.data(), (size_t)take);
+                    at += take;
+                }
+            }
+            return len;
+        }
+        base += (int64_t)piece.size();
+    }
+    return -1;
+}
+
+int32_t fhx_text_ends_with_newline(const fhx_text* text) {
+    if (!text) return 0;
+    for (size_t k = text->pieces.size(); k-- > 0;)
+        if (text->pieces[k].size()) return text->pieces[k].data()[text->pieces[k].size() - 1] == '\n' ? 1 : 0;
+    return 0;
+}
+
 int fhx_host_parse_text(const fhx_text* text, int32_t kind, int32_t n_threads, fhx_table** out) {
     if (!text || !out) return FHX_ERR_ARG;
     return parse_pieces(text->pieces, text->path.c_str(), kind, n_threads, out, inflate_report(text));

@@ -56,8 +56,10 @@ __host__ __device__ inline bool bin_saturates(int b, unsigned long long cum_incl
     return v >= 1.0;
 }
 
+// (dense_flag: 1 when at least dense_min values lie below the cutoff - the pass then takes q through the dense array, k3_compact<true>)
 __global__ __launch_bounds__(1024) void k3_cutoff(const unsigned long long* __restrict__ hist, double n_tests,
-                                                  unsigned long long* __restrict__ cutoff_key, unsigned long long* __restrict__ n_below) {
+                                                  unsigned long long* __restrict__ cutoff_key, unsigned long long* __restrict__ n_below,
+                                                  unsigned long long dense_min = ~0ull, unsigned long long* __restrict__ dense_flag = nullptr) {
     __shared__ unsigned long long part[1024];
     __shared__ unsigned long long below;
     __shared__ unsigned int best;
@@ -101,7 +103,10 @@ __global__ __launch_bounds__(1024) void k3_cutoff(const unsigned long long* __re
             if ((unsigned int)(threadIdx.x * PER + k) < best) mine += local[k];
         if (mine) atomicAdd(&below, mine);
         __syncthreads();
-        if (threadIdx.x == 0) *n_below = below;
+        if (threadIdx.x == 0) {
+            *n_below = below;
+            if (dense_flag) *dense_flag = below >= dense_min ? 1ull : 0ull;
+        }
     }
     if (threadIdx.x == 0)
         *cutoff_key = (best < (unsigned int)TOP_BINS) ? ((unsigned long long)best << TOP_SHIFT) : KEY_KEEP_ALL;
@@ -119,6 +124,7 @@ struct DenseQ {
     double* dense = nullptr;                 // q of the survivors by compact index
     unsigned long long* mask = nullptr;      // per wave chunk (1024 rows) and step h: keep even rows, keep odd rows, NaN even, NaN odd
     unsigned long long* wave_slot = nullptr; // per wave chunk: compact index of its first survivor
+    const unsigned long long* flag = nullptr; // the device's decision (k3_cutoff): non-zero = this pass goes through the dense array
 };
 
 template <bool DENSE>
@@ -134,6 +140,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     const int64_t tiles = (n + SORT_TILE - 1) / SORT_TILE;
+    if (dq.flag && (*dq.flag != 0ull) != DENSE) return;          // both variants are launched; the one the device chose runs
     const unsigned long long cutoff = *cutoff_key;
     const double2* p2 = reinterpret_cast<const double2*>(p);
     double2* q2 = reinterpret_cast<double2*>(q);
@@ -209,6 +216,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restr
 // The whole q column in row order, once: 1.0, the row's own NaN, or - for the rows k3_compact<true> kept - the survivor's q from the
 // dense array (consecutive kept rows of a wave step read consecutive entries).  Same tiles and wave chunks as k3_compact.
 __global__ __launch_bounds__(SORT_THREADS) void k3_fill_q(const double* __restrict__ p, int64_t n, DenseQ dq, double* __restrict__ q) {
+    if (dq.flag && *dq.flag == 0ull) return;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     const int64_t tiles = (n + SORT_TILE - 1) / SORT_TILE;
@@ -691,8 +699,11 @@ __global__ __launch_bounds__(BH_THREADS) void bh_apply(const unsigned long long*
                                                        const unsigned long long* __restrict__ n_ptr, int64_t n_fixed,
                                                        double n_tests, double rank0, const double* __restrict__ tile_carry,
                                                        const double* __restrict__ extra_carry, double* __restrict__ q_out,
-                                                       bool into_dense = false) {
+                                                       double* __restrict__ dense = nullptr,
+                                                       const unsigned long long* __restrict__ dense_flag = nullptr) {
     __shared__ double wtot[BH_THREADS / 64];
+    const bool into_dense = dense && (!dense_flag || *dense_flag != 0ull);    // the values are compact indices: q goes to the dense array
+    if (into_dense) q_out = dense;
     const int64_t n = n_ptr ? (int64_t)*n_ptr : n_fixed;
     const int64_t base = (int64_t)blockIdx.x * BH_TILE;
     if (base >= n) return;
@@ -1080,7 +1091,8 @@ int fhx::fill_top_hist(fhx_ctx* ctx) {
     return FHX_OK;
 }
 
-static int auto_cutoff(fhx_ctx* ctx, const double* d_p, int64_t n, double n_total_tests, unsigned long long* d_cutoff) {
+static int auto_cutoff(fhx_ctx* ctx, const double* d_p, int64_t n, double n_total_tests, unsigned long long* d_cutoff,
+                       unsigned long long dense_min = ~0ull) {
     if (d_p == ctx->d_p) {
         const int rc = fill_top_hist(ctx);
         if (rc != FHX_OK) return rc;
@@ -1095,7 +1107,7 @@ static int auto_cutoff(fhx_ctx* ctx, const double* d_p, int64_t n, double n_tota
         if (rc != FHX_OK) return rc;
     }
     hipLaunchKernelGGL(k3_cutoff, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long*)ctx->d_top_hist, n_total_tests,
-                       d_cutoff, ctx->d_misc + 8);
+                       d_cutoff, ctx->d_misc + 8, dense_min, ctx->d_misc + MISC_K3_DENSE);
     FHX_HIP(hipGetLastError());
     FHX_HIP(hipMemcpyAsync(ctx->h_k3, ctx->d_misc + 8, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     FHX_HIP(hipEventRecord(ctx->ev_k3, ctx->stream));
@@ -1116,9 +1128,12 @@ static int compact_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned 
     if (dq)
         hipLaunchKernelGGL(k3_compact<true>, dim3(grid_for(n, SORT_TILE, k3_cap)), dim3(SORT_THREADS), 0, ctx->stream, d_p, n,
                            keys[0], vals[0], d_q, counter, d_cutoff, *dq);
-    else
+    if (!dq || dq->flag) {                           // (with a flag the device picks one of the two; the other returns at once)
+        DenseQ off;
+        if (dq) off.flag = dq->flag;
         hipLaunchKernelGGL(k3_compact<false>, dim3(grid_for(n, SORT_TILE, k3_cap)), dim3(SORT_THREADS), 0, ctx->stream, d_p, n,
-                           keys[0], vals[0], d_q, counter, d_cutoff, DenseQ{});
+                           keys[0], vals[0], d_q, counter, d_cutoff, off);
+    }
     // how many keys survived decides the shape of the sort.  When the cutoff came from this GPU's own histogram (auto_cutoff) the
     // number is already on its way - the histogram's bins below the cutoff bin hold exactly the rows kept here - and the host goes
     // on to enqueue the sort while the compaction runs; otherwise (sharded runs: the histogram is the all-reduced one) the counter
@@ -1231,7 +1246,8 @@ static int bh_from_sorted(fhx_ctx* ctx, const unsigned long long* keys, const un
     hipLaunchKernelGGL(bh_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, tile_max, counter, (int64_t)0, 0.0,
                        (double*)nullptr, n_keys, fault);
     hipLaunchKernelGGL(bh_apply, dim3(tiles), dim3(BH_THREADS), 0, ctx->stream, keys, vals, counter, (int64_t)0,
-                       n_total_tests, 0.0, tile_max, (const double*)nullptr, dq ? dq->dense : d_q, dq != nullptr);
+                       n_total_tests, 0.0, tile_max, (const double*)nullptr, d_q, dq ? dq->dense : (double*)nullptr,
+                       dq ? dq->flag : (const unsigned long long*)nullptr);
     if (dq) {
         static const int fill_cap = std::getenv("FHX_K3_GRID") ? std::atoi(std::getenv("FHX_K3_GRID")) : (1 << 30);
         hipLaunchKernelGGL(k3_fill_q, dim3(grid_for(n_rows, SORT_TILE, fill_cap)), dim3(SORT_THREADS), 0, ctx->stream, p_rows, n_rows, *dq,
@@ -1392,13 +1408,21 @@ int fhx_bh(fhx_ctx* ctx, double n_total_tests) {
     FHX_HIP(hipSetDevice(ctx->device));
     before_rerecord(ctx, 2);
     FHX_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
-    int rc = auto_cutoff(ctx, ctx->d_p, ctx->n_rows, n_total_tests, ctx->d_misc + 6);
-    if (rc != FHX_OK) return rc;
-    int64_t kept = 0;
-    // FHX_K3_DENSE: 1 = q through the dense array whatever the survivors' number, 0 = never (measurements, tests)
-    static const int dense_env = std::getenv("FHX_K3_DENSE") ? std::atoi(std::getenv("FHX_K3_DENSE")) : -1;
+    // q of the survivors through a dense array + one fill of the q column (k3_compact<true>) when at least K3_DENSE_PERCENT of the
+    // rows survive the cutoff - the device decides, from the count k3_cutoff takes off the histogram, while the host goes on
+    // enqueueing: below that the two extra passes over the rows cost more than the scattered stores into the q column
+    // (profiles/r06_k3_dense_q.txt).  FHX_K3_DENSE: 1 = always, 0 = never, otherwise the percentage (measurements, tests).
+    static const int dense_env = std::getenv("FHX_K3_DENSE") ? std::atoi(std::getenv("FHX_K3_DENSE")) : K3_DENSE_PERCENT;
     DenseQ dq;
     const bool dense = dense_env != 0 && engine_dense_q(ctx, &dq);
+    unsigned long long dense_min = ~0ull;
+    if (dense) {
+        dense_min = dense_env == 1 ? 0ull : (unsigned long long)(((long double)ctx->n_rows * dense_env + 99) / 100);
+        dq.flag = ctx->d_misc + MISC_K3_DENSE;
+    }
+    int rc = auto_cutoff(ctx, ctx->d_p, ctx->n_rows, n_total_tests, ctx->d_misc + 6, dense_min);
+    if (rc != FHX_OK) return rc;
+    int64_t kept = 0;
     rc = rank_and_adjust(ctx, ctx->d_p, ctx->n_rows, ctx->d_keys, ctx->d_vals, ctx->d_q, ctx->d_misc, ctx->d_misc + 6, n_total_tests,
                          ctx->d_tile_max, &ctx->sorted_buf, &kept, 62, engine_sort_ctrl(ctx), dense ? &dq : nullptr);
     if (rc != FHX_OK) return rc;

@@ -9,8 +9,10 @@ Where the contact rows come from and where the significances go (fithic.py:404-4
   * default: EVERY RANK reads the contacts file itself on its own GPU and later formats + deflates its own stretches of the
     output file, which the ranks copy into place side by side.  No row passes through rank 0 (ShardedEngine.ingest_file,
     _CtxFacade.write_significances_device).  A file of gzip members that carry their sizes is cut into N parts of whole
-    members - rank r inflates and parses part r only, its rows are one stretch of the file (_ingest_slices); any other gzip
-    file is inflated by every rank on the host and rank r uploads and parses the rows that start in the r-th N-th of the text.
+    members - rank r inflates and parses part r only, its rows are one stretch of the file (_ingest_slices); ONE plain gzip
+    stream (what `gzip` writes) is inflated by the ranks together, rank r its N-th of the compressed bytes (_ingest_stream_parts);
+    any other gzip file (bgzip, several plain members) is inflated by every rank on the host - when N copies of the text fit its
+    memory - and rank r uploads and parses the rows that start in the r-th N-th of the text.
     (FHX_CLI_SPLIT=chromosome: every rank parses the whole file and keeps the rows whose first chromosome is its own - greedy
     owner map by row count, the same on every rank because they count the same file);
   * a file the device parser does not take, or one split by chromosome without being sorted by chromosome (a rank's rows would
@@ -185,7 +187,7 @@ class _Rank:
         self._ensure_comm()
 
     # ---- the contacts file read by every rank itself (no rows through rank 0) ----
-    def ingest_file(self, path, threads):
+    def ingest_file(self, path, threads, host_text_allowed=True):
         """inflate + parse the whole file on this rank's GPU -> ("ok", rows, names, rows per name) or ("unsupported", why)"""
         ctx = self.eng.ctx
         text = None
@@ -197,6 +199,8 @@ class _Rank:
                     raise
                 if getattr(e, "refused", 1) == 2:
                     return ("unsupported", str(e))
+                if not host_text_allowed:
+                    return ("unsupported", "every rank would hold the whole inflated text in host memory")
                 text = _capi.HostText(path, threads)
                 try:
                     n, names = ctx.ingest_contacts_text(text, threads)
@@ -236,6 +240,57 @@ class _Rank:
             return ("unsupported", str(e))
         finally:
             text.close()
+        self._parsed = int(n)
+        return ("ok", n, names, True)
+
+    # ---- ONE plain gzip stream inflated by all ranks together: rank r decodes its N-th of the compressed bytes (TextPart) ----
+    def inflate_part(self, path, threads):
+        """first call: this rank's chunks decoded without the window before them -> ("ok", tail symbols, bytes of text, holds the
+        end of the stream) or ("unsupported", why)"""
+        self.inflate_part_drop()
+        try:
+            self._part = _capi.TextPart(path, self.rank, self.world, threads)
+        except _capi.FhxError as e:
+            if e.code != _capi.FHX_ERR_UNSUPPORTED:
+                raise
+            return ("unsupported", str(e))
+        return ("ok", self._part.tail().tobytes(), len(self._part), self._part.is_last())
+
+    def inflate_part_resolve(self, window):
+        """second call, with the 32 KB of text before this part -> ("ok", CRC-32, bytes, length of the first (partial) row or -1,
+        that row, the text ends with a newline) or ("unsupported", why)"""
+        try:
+            self._text, crc = self._part.resolve(np.frombuffer(window, np.uint8))
+        except _capi.FhxError as e:
+            if e.code != _capi.FHX_ERR_UNSUPPORTED:
+                raise
+            return ("unsupported", str(e))
+        finally:
+            self._part.close()
+            self._part = None
+        n, row = self._text.first_row_end()
+        if n > (1 << 20):
+            n, row = -1, b""                                   # (no contact row is a megabyte long: not a table of rows)
+        return ("ok", crc, len(self._text), n, row, self._text.ends_with_newline())
+
+    def inflate_part_drop(self):
+        for name in ("_part", "_text"):
+            obj = getattr(self, name, None)
+            if obj is not None:
+                obj.close()
+            setattr(self, name, None)
+
+    def ingest_text_own(self, skip, extra, threads):
+        """the rows whose first byte lies in this rank's part of the text (from byte `skip` on, the last one completed by `extra`)
+        uploaded and parsed -> as ingest_slice"""
+        try:
+            n, names = self.eng.ctx.ingest_contacts_text_own(self._text, skip, extra, threads)
+        except _capi.FhxError as e:
+            if e.code != _capi.FHX_ERR_UNSUPPORTED:
+                raise
+            return ("unsupported", str(e))
+        finally:
+            self.inflate_part_drop()
         self._parsed = int(n)
         return ("ok", n, names, True)
 
@@ -683,7 +738,8 @@ class ShardedEngine:
             con = self._ingest_slices(path, chroms, per)
             if con is not None:
                 return con
-        results = self._all("ingest_file", path, per)
+        # (a file the device does not inflate goes through the host on every rank: only if N copies of the text fit there)
+        results = self._all("ingest_file", path, per, self.world == 1 or self._whole_text_per_rank_fits(path))
         if any(res[0] != "ok" for res in results):
             self._all("ingest_discard")
             return None
@@ -724,11 +780,16 @@ class ShardedEngine:
             # ends of a part may also have made the parser refuse it): every rank inflates the file on its share of the host cores
             # and takes the rows that start in its N-th of the TEXT - 1/N of the upload and of the parse
             self._all("ingest_discard")
-            results = self._all("ingest_text_slice", path, threads)
+            results = self._ingest_stream_parts(path, threads)
+            cut = "stream"
+            if results is None:
+                if not self._whole_text_per_rank_fits(path):
+                    return None
+                results = self._all("ingest_text_slice", path, threads)
+                cut = "text"
             if any(res[0] != "ok" for res in results):
                 self._all("ingest_discard")
                 return None
-            cut = "text"
         intern = tables._interner(chroms)
         ids = [intern(res[2]) for res in results]              # in rank order = the file's order of first appearance
         first = np.concatenate([[0], np.cumsum([res[1] for res in results])])
@@ -740,6 +801,68 @@ class ShardedEngine:
         self._rows_of = None
         self.split = cut
         return ShardedContacts(self, self.n_rows)
+
+    def _ingest_stream_parts(self, path, threads):
+        """ONE plain gzip stream (what `gzip` writes) inflated by the ranks together: rank r decodes the chunks of its N-th of the
+        compressed bytes without the 32 KB before them and reports its last 32 K symbols in terms of that unknown window; chained
+        here rank after rank they give every part its window, with which the rank decodes its chunks into text.  CRC-32 and
+        length of the whole are checked against the file's trailer; a row belongs to the rank whose text holds its first byte
+        (the head of a text that begins inside a row goes to the rank before).  1/N of the inflate and of the text per rank, where
+        every rank inflating the file is N times both.  -> per rank ("ok", rows, names, True) as ingest_text_slice, or None: not
+        such a file (then the whole-text route, if N copies of the text fit the host's memory)."""
+        if os.environ.get("FHX_CLI_STREAM_PARTS", "1") == "0":
+            return None
+        first = self._all("inflate_part", path, threads)
+        if any(res[0] != "ok" for res in first) or not first[-1][3] or any(res[3] for res in first[:-1]):
+            self._all("inflate_part_drop")
+            return None
+        windows = _capi.chain_windows([np.frombuffer(res[1], np.uint16) for res in first])
+        second = self._all("inflate_part_resolve", per_rank=[(w.tobytes(),) for w in windows])
+        ok = all(res[0] == "ok" for res in second)
+        if ok:
+            with open(path, "rb") as f:
+                f.seek(-8, os.SEEK_END)
+                trailer = f.read(8)
+            want_crc, want_isize = int.from_bytes(trailer[:4], "little"), int.from_bytes(trailer[4:], "little")
+            crc, total = second[0][1], second[0][2]
+            for res in second[1:]:
+                crc = _capi.crc32_combine(crc, res[1], res[2])
+                total += res[2]
+            ok = crc == want_crc and total % (1 << 32) == want_isize and all(res[2] == f[2] for res, f in zip(second, first))
+            ok = ok and all(res[3] >= 0 for res in second)             # every part holds the end of a row
+        if not ok:
+            self._all("inflate_part_drop")
+            return None
+        per_rank = []
+        for r, res in enumerate(second):
+            skip = 0 if r == 0 or second[r - 1][5] else res[3]
+            extra = b"" if r + 1 == self.world or res[5] else second[r + 1][4]
+            per_rank.append((skip, extra, threads))
+        return self._all("ingest_text_own", per_rank=per_rank)
+
+    @staticmethod
+    def _available_host_bytes():
+        try:
+            with open("/proc/meminfo") as f:
+                for line in f:
+                    if line.startswith("MemAvailable:"):
+                        return int(line.split()[1]) * 1024
+        except OSError:
+            pass
+        return None
+
+    def _whole_text_per_rank_fits(self, path):
+        """The routes on which EVERY rank inflates the whole file hold N copies of its text in host memory (63 GB each for a
+        2e9-row file).  Texts of this kind compress 4-5 x; with 8 x the file's size per rank as the estimate the routes are taken
+        only when that is under half of what the host has free - else rank 0 parses and hands the columns out (one copy)."""
+        if os.environ.get("FHX_CLI_TEXT_ROUTE", "") == "force":
+            return True
+        free = self._available_host_bytes()
+        try:
+            need = 8 * os.path.getsize(path) * self.world
+        except OSError:
+            return True
+        return free is None or need <= free // 2
 
     def file_rows(self, rank, local_rows):
         """file positions of some local rows of a rank"""

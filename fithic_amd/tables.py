@@ -140,6 +140,7 @@ def load_contacts(path, chroms, engine_of, threads=0):
         if hasattr(eng0, "ingest_file"):
             got = eng0.ingest_file(path, chroms, threads)
             mark({"file": "every rank: inflate + parse its part of the file",
+                  "stream": "every rank: inflate its part of the stream on the host, parse its rows",
                   "text": "every rank: inflate on the host, parse its part of the text"}.get(getattr(eng0, "split", None),
                                                                                              "every rank: inflate + parse + keep its chromosomes"))
             if got is not None:

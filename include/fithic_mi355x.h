@@ -205,6 +205,31 @@ int fhx_ingest_contacts_text_slice(fhx_ctx* ctx, const struct fhx_text* text, in
                                    int32_t* n_names);
 /* bytes [*lo, *hi) of the text that part takes (host only; parts can be empty) */
 int fhx_text_part_bounds(const struct fhx_text* text, int32_t part, int32_t n_parts, int64_t* lo, int64_t* hi);
+/* Round 6: the ranks of a sharded run inflate ONE plain gzip stream together - rank r its N-th of the COMPRESSED bytes (1/N of the
+ * inflate work and of the text in host memory per rank; with fhx_host_inflate every rank did all of it).  Replaces the one
+ * gzip.open of fithic/fithic.py:404 for `fithic --gpus N`.  Protocol (fithic_amd/sharded.py: _ingest_stream_parts):
+ *   fhx_host_inflate_part      this rank's chunks decoded without the 32 KB before them (csrc/fhx_gunzip.cpp); FHX_ERR_UNSUPPORTED:
+ *                              not one plain stream / too small / a stream the decoder refuses - the caller takes the old route
+ *   fhx_text_part_tail         the part's last 32768 symbols in terms of the window before the part (< 256: a byte, 256 + j: byte j
+ *                              of that window): the caller chains them rank after rank into every part's window
+ *   fhx_text_part_resolve      window -> the part's text as a new fhx_text object - the part object is left empty - and its CRC-32; the caller
+ *                              checks fhx_crc32_combine of all parts and the summed lengths against the file's trailer
+ *   fhx_text_first_row_end     length of the text's first (partial) row, newline included; -1: no newline in the text
+ *   fhx_ingest_contacts_text_own   the text from byte `skip` on + `extra` (the rest of its last row: the head of the next rank's text)
+ *                              uploaded and parsed: a row belongs to the rank whose text holds its first byte */
+typedef struct fhx_text_part fhx_text_part;
+int fhx_host_inflate_part(const char* path, int32_t n_threads, int32_t part, int32_t n_parts, fhx_text_part** out);
+int64_t fhx_text_part_bytes(const fhx_text_part* p);
+int32_t fhx_text_part_is_last(const fhx_text_part* p);
+int fhx_text_part_tail(const fhx_text_part* p, uint16_t* tail, int64_t cap);                   /* cap >= 32768 */
+int fhx_text_part_resolve(fhx_text_part* p, const uint8_t* window, int64_t window_bytes, struct fhx_text** text_out, uint32_t* crc32_out);
+const char* fhx_text_part_error(const fhx_text_part* p);
+void fhx_text_part_free(fhx_text_part* p);
+uint32_t fhx_crc32_combine(uint32_t crc_a, uint32_t crc_b, int64_t len_b);
+int64_t fhx_text_first_row_end(const struct fhx_text* text, char* row, int64_t cap);            /* row may be NULL */
+int32_t fhx_text_ends_with_newline(const struct fhx_text* text);
+int fhx_ingest_contacts_text_own(fhx_ctx* ctx, const struct fhx_text* text, int32_t n_threads, int64_t skip, const char* extra,
+                                 int64_t extra_bytes, int64_t* n_rows, int32_t* n_names);
 int fhx_ingest_contacts_chr_counts(fhx_ctx* ctx, int64_t* counts, int32_t n_names);
 int fhx_ingest_contacts_commit_shard(fhx_ctx* ctx, const int32_t* ids, const uint8_t* mine, int32_t n_ids, int64_t* n_kept);
 int fhx_shard_segments(fhx_ctx* ctx, int64_t* local_start, int64_t* file_start, int64_t* length, int64_t cap, int64_t* n_out);

@@ -157,13 +157,65 @@ static std::string inflate_all(const std::string& path, int threads, int* rc_out
     return text;
 }
 
+// The stream inflated in parts (fhx_host_inflate_part .. fhx_text_part_resolve), as sharded._ingest_stream_parts drives it: the
+// windows chained from the tails, the parts' CRC-32s combined.  true + text: every part accepted AND the combined CRC-32 and length
+// are the trailer's (what the caller requires before it believes the text).
+static bool inflate_parts(const std::string& path, const std::string& file_bytes, int n_parts, int threads, std::string* text) {
+    std::vector<fhx_text_part*> parts((size_t)n_parts, nullptr);
+    bool ok = true;
+    for (int r = 0; r < n_parts && ok; ++r) {
+        const int rc = fhx_host_inflate_part(path.c_str(), threads, r, n_parts, &parts[(size_t)r]);
+        if (rc != FHX_OK) {
+            EXPECT(rc == FHX_ERR_UNSUPPORTED || rc == FHX_ERR_REFERENCE_EXIT || rc == FHX_ERR_ARG || rc == FHX_ERR_NOMEM, "part error code");
+            EXPECT(parts[(size_t)r] == nullptr || std::strlen(fhx_text_part_error(parts[(size_t)r])) > 0, "a refused part carries a message");
+            ok = false;
+        }
+    }
+    std::vector<uint8_t> window(32768, 0);
+    uint32_t crc = 0;
+    int64_t total = 0;
+    text->clear();
+    for (int r = 0; r < n_parts && ok; ++r) {
+        std::vector<uint16_t> tail(32768);
+        EXPECT(fhx_text_part_tail(parts[(size_t)r], tail.data(), 32768) == FHX_OK, "tail");
+        EXPECT(fhx_text_part_tail(parts[(size_t)r], tail.data(), 100) == FHX_ERR_ARG, "tail buffer too small");
+        fhx_text* x = nullptr;
+        uint32_t c = 0;
+        const int rc = fhx_text_part_resolve(parts[(size_t)r], window.data(), 32768, &x, &c);
+        if (rc != FHX_OK) {
+            ok = false;
+            fhx_text_free(x);
+            break;
+        }
+        std::string piece((size_t)fhx_text_bytes(x), '\0');
+        EXPECT(fhx_text_copy(x, piece.empty() ? nullptr : &piece[0], (int64_t)piece.size()) == FHX_OK, "part text copy");
+        const int64_t first = fhx_text_first_row_end(x, nullptr, 0);
+        const size_t nl = piece.find('\n');
+        EXPECT(first == (nl == std::string::npos ? -1 : (int64_t)nl + 1), "first row end");
+        EXPECT((fhx_text_ends_with_newline(x) != 0) == (!piece.empty() && piece.back() == '\n'), "ends with newline");
+        fhx_text_free(x);
+        crc = r ? fhx_crc32_combine(crc, c, (int64_t)piece.size()) : c;
+        total += (int64_t)piece.size();
+        *text += piece;
+        std::vector<uint8_t> next(32768);
+        for (int j = 0; j < 32768; ++j) next[(size_t)j] = tail[(size_t)j] < 256 ? (uint8_t)tail[(size_t)j] : window[(size_t)(tail[(size_t)j] - 256)];
+        window.swap(next);
+    }
+    for (fhx_text_part* p : parts) fhx_text_part_free(p);
+    if (!ok || file_bytes.size() < 8) return false;
+    const unsigned char* t = (const unsigned char*)file_bytes.data() + file_bytes.size() - 8;
+    const uint32_t want_crc = t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+    const uint32_t want_n = t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+    return crc == want_crc && (uint32_t)total == want_n;
+}
+
 int main(int argc, char** argv) {
     if (argc < 3) return 2;
     const std::string dir = argv[1];
     const long cases = std::atol(argv[2]);
     rng.seed(argc > 3 ? (uint64_t)std::atoll(argv[3]) : 1);
     const std::string path = dir + "/case.gz";
-    long accepted = 0, refused = 0, routes = 0;
+    long accepted = 0, refused = 0, routes = 0, part_routes = 0;
     for (long it = 0; it < cases; ++it) {
         const int kind = (int)rnd(3);
         const bool odd = rnd(3) != 0;
@@ -243,6 +295,12 @@ int main(int argc, char** argv) {
             EXPECT((rc_a == FHX_OK) == (rc_b == FHX_OK), "both inflate routes accept or both refuse");
             if (rc_a == FHX_OK && rc_b == FHX_OK) EXPECT(a == b, "both inflate routes return the same bytes");
             if (rc_a == FHX_OK && mut == 0) EXPECT(a == text, "inflated text == the text that was compressed");
+            // ... and the stream inflated in parts: whatever it accepts (with its CRC-32 and length check) is zlib's text
+            std::string c;
+            if (inflate_parts(path, bytes, 1 + (int)rnd(5), 1 + (int)rnd(4), &c)) {
+                EXPECT(rc_b == FHX_OK && c == b, "the parts route returns zlib's bytes");
+                ++part_routes;
+            }
             ++routes;
         }
     }
@@ -300,7 +358,7 @@ int main(int argc, char** argv) {
             EXPECT(!err.empty(), "a refused fit says why");
         }
     }
-    std::printf("io_sanitize: %ld table files (%ld accepted, %ld refused), %ld route comparisons, %ld fits (%ld refused), %ld check failures\n",
-                cases, accepted, refused, routes, fits, fit_refused, failures);
+    std::printf("io_sanitize: %ld table files (%ld accepted, %ld refused), %ld route comparisons (%ld through the parts route), %ld fits (%ld refused), %ld check failures\n",
+                cases, accepted, refused, routes, part_routes, fits, fit_refused, failures);
     return failures ? 1 : 0;
 }

@@ -626,6 +626,42 @@ def test_cli_gpus_n_writes_the_same_files(name, gpus, split, tmp_path, monkeypat
     assert mine == want
 
 
+@pytest.mark.parametrize("name,gpus,chunk", [("f1_bias", 2, 20000), ("f2_all", 3, 4096), ("f13_all_p3", 4, 10000), ("f7_pfal_all", 3, 3000),
+                                             ("f8_nonfixed_hESC", 2, 50000), ("f13_hESC_p3", 5, 8192)])
+def test_cli_gpus_n_inflates_one_plain_gzip_stream_in_parts(name, gpus, chunk, tmp_path, monkeypatch, capsys):
+    """ONE plain gzip stream (what `gzip` and the reference's own utilities write; fithic.py:404 reads it with gzip.open): rank r
+    decodes its N-th of the COMPRESSED bytes without the 32 KB before them, the ranks' tails are chained into every part's window,
+    CRC-32 and length are checked against the trailer, and a row belongs to the rank whose text holds its first byte
+    (sharded._ingest_stream_parts).  The fixtures are far below the size from which that pays: FHX_PGUNZIP_MIN / _CHUNK let them
+    through, in chunks of a few blocks.  The files written are the reference's."""
+    import gzip
+    import hashlib
+    from fithic_amd import cli
+    monkeypatch.setenv("FHX_CLI_TRANSPORT", "pipes")
+    monkeypatch.setenv("FHX_CLI_DEVICES", ",".join(["0"] * gpus))
+    monkeypatch.setenv("FHX_TIMING", "1")
+    monkeypatch.setenv("FHX_PGUNZIP_MIN", "0")
+    monkeypatch.setenv("FHX_PGUNZIP_CHUNK", str(chunk))
+    meta, g = load_case(name)
+    kw = case_args(meta)
+    argv = ["-i", kw["contacts"], "-f", kw["frags"], "-o", str(tmp_path), "-l", "G", "--gpus", str(gpus)] + meta["argv"]
+    if kw["bias_path"]:
+        argv += ["-t", kw["bias_path"]]
+    cli.main(argv)
+    said = capsys.readouterr().out
+    assert "every rank: inflate its part of the stream on the host, parse its rows" in said and "(device parser)" in said
+    assert not [f for f in os.listdir(str(tmp_path)) if ".part-" in f or ".fhx-tmp" in f]
+    tag = ".res%d" % kw["resolution"] if kw["resolution"] else ""
+    for pi in range(1, meta["n_passes"] + 1):
+        with gzip.open(os.path.join(str(tmp_path), "G.spline_pass%d%s.significances.txt.gz" % (pi, tag)), "rb") as f:
+            assert hashlib.md5(f.read()).hexdigest() == meta["sig_md5_pass%d" % pi]
+        with open(os.path.join(str(tmp_path), "G.fithic_pass%d%s.txt" % (pi, tag))) as f:
+            assert f.read() == meta["fithic_pass%d_txt" % pi]
+    with open(os.path.join(str(tmp_path), "G.fithic.log")) as f:
+        mine = [ln for ln in f.read().splitlines() if not ln.startswith("Means and error written")]
+    assert mine == [ln for ln in meta["log_txt"].splitlines() if not ln.startswith("Means and error written")]
+
+
 def _tagged_copy(src, dst, n_members, on_rows=True):
     """the gzip file `src` rewritten as `n_members` members that carry their sizes (the "FH" extra field of this library's writers,
     include/fithic_mi355x.h); on_rows=False: cut by bytes, so that members end in the middle of a row"""

@@ -345,3 +345,108 @@ def test_parallel_gunzip_on_random_streams(seed, tmp_path, monkeypatch):
         t = _capi.HostText(path, rng.randrange(2, 8))
         assert t.bytes() == data, (seed, trial)
         t.close()
+
+
+def _inflate_in_parts(path, n_parts, threads):
+    """the protocol of sharded._ingest_stream_parts in one process -> (texts of the parts, combined CRC-32) or None when a part refuses"""
+    parts = []
+    try:
+        for r in range(n_parts):
+            try:
+                parts.append(_capi.TextPart(path, r, n_parts, threads))
+            except _capi.FhxError as e:
+                assert e.code == _capi.FHX_ERR_UNSUPPORTED, e
+                return None
+        assert [p.is_last() for p in parts] == [False] * (n_parts - 1) + [True]
+        windows = _capi.chain_windows([p.tail() for p in parts])
+        texts, crc = [], 0
+        for r, p in enumerate(parts):
+            announced = len(p)
+            t, c = p.resolve(windows[r])
+            b = t.bytes()
+            assert len(b) == announced
+            n, row = t.first_row_end()
+            k = b.find(b"\n")
+            assert (n, row) == ((k + 1, b[:k + 1]) if k >= 0 else (-1, b"")) and t.ends_with_newline() == b.endswith(b"\n")
+            t.close()
+            crc = _capi.crc32_combine(crc, c, len(b)) if r else c
+            texts.append(b)
+        return texts, crc
+    finally:
+        for p in parts:
+            p.close()
+
+
+def test_one_plain_gzip_stream_is_inflated_in_parts(tmp_path, monkeypatch):
+    """fhx_host_inflate_part / fhx_text_part_tail / fhx_text_part_resolve (csrc/fhx_gunzip.cpp): N parts of the compressed bytes, each
+    decoded without the window before it, the windows chained from the parts' tails.  The concatenation is Python's text, the combined
+    CRC-32 the file's, for every N, chunk size and level; what the scheme cannot take is refused (the caller has the other routes)."""
+    import random
+    import zlib
+    rng = random.Random(31)
+    text = "".join("chr%d\t%d\tchr%d\t%d\t%d\n" % (c, rng.randrange(1, 50000) * 5000 + 2500, c, rng.randrange(1, 50000) * 5000 + 2500, rng.randrange(1, 500))
+                   for c in (rng.randrange(1, 23) for _ in range(120_000))).encode()
+    noise = bytes(rng.getrandbits(8) for _ in range(200_000))
+    monkeypatch.setenv("FHX_PGUNZIP_MIN", "0")
+    cases = {"level1": _plain_gzip(text, 1), "level6": _plain_gzip(text, 6), "level9": _plain_gzip(text, 9),
+             "mixed": _plain_gzip(text[:900_000] + noise + text[900_000:1_700_000] + b"\0" * 400_000 + text[1_700_000:], 6),
+             "no_final_newline": _plain_gzip(text[:-1], 6)}
+    for label, blob in cases.items():
+        path = str(tmp_path / (label + ".gz"))
+        with open(path, "wb") as f:
+            f.write(blob)
+        want = gzip.decompress(blob)
+        for n_parts, chunk, threads in ((1, 100_000, 3), (2, 50_000, 2), (3, 200_000, 4), (5, 20_000, 2), (8, 2_000_000, 1)):
+            monkeypatch.setenv("FHX_PGUNZIP_CHUNK", str(chunk))
+            got = _inflate_in_parts(path, n_parts, threads)
+            assert got is not None, (label, n_parts)
+            assert b"".join(got[0]) == want and got[1] == zlib.crc32(want), (label, n_parts, chunk)
+    # refused, not mis-inflated: several members, fixed codes only (no block start to find), too small a file
+    for label, blob in (("two_members", gzip.compress(text[:900_000]) + gzip.compress(text[900_000:])),
+                        ("fixed_only", _plain_gzip(text[:400_000], 6, zlib.Z_FIXED))):
+        path = str(tmp_path / (label + ".gz"))
+        with open(path, "wb") as f:
+            f.write(blob)
+        assert _inflate_in_parts(path, 3, 2) is None, label
+    monkeypatch.delenv("FHX_PGUNZIP_MIN")
+    assert _inflate_in_parts(str(tmp_path / "level6.gz"), 2, 2) is None           # 1 MB: under the size from which it pays
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FHX_FUZZ_SEEDS", "0:3").split(":")[0]),
+                                       int(os.environ.get("FHX_FUZZ_SEEDS", "0:3").split(":")[1])))
+def test_inflate_in_parts_on_random_streams(seed, tmp_path, monkeypatch):
+    """as test_parallel_gunzip_on_random_streams, through the parts protocol: whenever every part accepts its share, the parts'
+    texts are Python's text and the combined CRC-32 is the trailer's (a wrongly guessed block start ends in a refusal or in a
+    CRC-32 that differs - which is what the caller checks)"""
+    import random
+    import zlib
+    rng = random.Random(9000 + seed)
+    monkeypatch.setenv("FHX_PGUNZIP_MIN", "0")
+    taken = 0
+    for trial in range(8):
+        parts = []
+        for _ in range(rng.randrange(1, 6)):
+            kind = rng.randrange(4)
+            if kind == 0:
+                parts.append("".join("chr%d\t%d\tchr%d\t%d\t%d\n" % (rng.randrange(1, 23), rng.randrange(10 ** 8), rng.randrange(1, 23),
+                                                                     rng.randrange(10 ** 8), rng.randrange(999))
+                                     for _ in range(rng.randrange(100, 40000))).encode())
+            elif kind == 1:
+                parts.append(bytes(rng.getrandbits(8) for _ in range(rng.randrange(10, 60_000))))
+            elif kind == 2:
+                parts.append(bytes([rng.randrange(256)]) * rng.randrange(1, 200_000))
+            else:
+                parts.append(("%d\n" % rng.randrange(10 ** 9)).encode() * rng.randrange(1, 30000))
+        data = b"".join(parts)
+        blob = _plain_gzip(data, rng.choice([1, 2, 4, 6, 9]), rng.choice([None, None, zlib.Z_FILTERED, zlib.Z_RLE]))
+        path = str(tmp_path / ("p%d.gz" % trial))
+        with open(path, "wb") as f:
+            f.write(blob)
+        monkeypatch.setenv("FHX_PGUNZIP_CHUNK", str(rng.choice([1024, 5000, 40_000, 300_000])))
+        got = _inflate_in_parts(path, rng.randrange(1, 7), rng.randrange(1, 5))
+        if got is None:
+            continue
+        taken += 1
+        same_crc = got[1] == zlib.crc32(data) and sum(len(b) for b in got[0]) == len(data)
+        assert (b"".join(got[0]) == data) == same_crc, trial       # equal text <=> the check the caller makes passes
+    assert taken >= 1

@@ -186,13 +186,24 @@ class _ScriptedRanks:
         self.segments = self._rows_of = self.split = None
         self.n_rows = 0
 
+    def _ingest_stream_parts(self, path, threads):
+        from fithic_amd import sharded
+        return sharded.ShardedEngine._ingest_stream_parts(self, path, threads)
+
+    def _whole_text_per_rank_fits(self, path):
+        return getattr(self, "host_has_room", True)
+
     def _all(self, command, *args, per_rank=None):
         self.asked.append(command)
+        if command == "ingest_text_own":
+            self.own = per_rank
         if command == "commit_slice":
             self.committed = per_rank
             return [(self._n[r], [(0, per_rank[r][1], self._n[r])] if self._n[r] else []) for r in range(self.world)]
-        if command == "ingest_discard":
+        if command in ("ingest_discard", "inflate_part_drop"):
             return [None] * self.world
+        if command == "inflate_part" and command not in self.answers:
+            return [("unsupported", "not one plain stream")] * self.world
         out = self.answers[command]
         self._n = [res[1] if res[0] == "ok" else 0 for res in out]
         return out
@@ -227,10 +238,12 @@ def test_how_the_ranks_of_the_cli_split_a_contacts_file(case):
         assert [first for _, first in ranks.committed] == [0, 5, 5]
         assert len(got) == 12 and ranks.segments == [[(0, 0, 5)], [], [(0, 5, 7)]]
     elif case == "text outside the grammar":
-        assert got is None and ranks.asked == ["ingest_slice", "ingest_discard", "ingest_text_slice", "ingest_discard"]
+        assert got is None and ranks.asked == ["ingest_slice", "ingest_discard", "inflate_part", "inflate_part_drop", "ingest_text_slice",
+                                               "ingest_discard"]
         assert chroms.names == ["chr1"]                       # nothing interned by the attempts
     else:
-        assert ranks.asked == ["ingest_slice", "ingest_discard", "ingest_text_slice", "commit_slice"] and ranks.split == "text"
+        assert ranks.asked == ["ingest_slice", "ingest_discard", "inflate_part", "inflate_part_drop", "ingest_text_slice",
+                               "commit_slice"] and ranks.split == "text"
         assert chroms.names == ["chr1", "chr2", "chr3"]
         assert [list(ids) for ids, _ in ranks.committed] == [[1], [0, 1], [2]]
         assert [first for _, first in ranks.committed] == [0, 4, 10]
@@ -287,3 +300,48 @@ def test_parts_of_the_output_are_dropped_only_after_every_rank_placed_its_own(tm
         with pytest.raises(OSError):
             facade.write_significances_device(name, ["chr1"])
         assert os.listdir(tmp_path) == []
+
+
+def test_one_plain_gzip_stream_is_inflated_by_the_ranks_together(tmp_path):
+    """ShardedEngine._ingest_stream_parts, the decisions only (scripted ranks, a real trailer): the tails are chained into windows,
+    the parts' CRC-32s and lengths must give the file's trailer, a rank's text starts after the rest of the row the rank before it
+    owns and ends with the head of the next rank's text; anything that does not add up -> the whole-text route, and that only when
+    N copies of the text fit the host."""
+    import gzip
+    import zlib
+    from fithic_amd import sharded, tables
+    parts = [b"chr1\t5\tchr1\t15\t2\nchr1\t5\tch", b"r1\t25\t1\nchr2\t5\tchr2\t15\t7\n", b"chr2\t5\tchr2\t35\t1\nchr3\t5\tchr3\t15\t1\n"]
+    path = str(tmp_path / "c.gz")
+    with open(path, "wb") as f:
+        f.write(gzip.compress(b"".join(parts)))
+    tail = np.arange(256, 256 + 32768, dtype=np.uint16).tobytes()
+
+    def head(b):
+        k = b.find(b"\n")
+        return (k + 1, b[:k + 1]) if k >= 0 else (-1, b"")
+
+    first = [("ok", tail, len(b), r == 2) for r, b in enumerate(parts)]
+    second = [("ok", zlib.crc32(b), len(b)) + head(b) + (b.endswith(b"\n"),) for b in parts]
+    own = [("ok", 1, ["chr1"], True), ("ok", 1, ["chr2"], True), ("ok", 2, ["chr2", "chr3"], True)]
+    ranks = _ScriptedRanks(3, {"ingest_slice": [("container", "no member sizes")] * 3, "inflate_part": first,
+                               "inflate_part_resolve": second, "ingest_text_own": own})
+    chroms = tables.ChromIndex()
+    got = sharded.ShardedEngine._ingest_slices(ranks, path, chroms, 4)
+    assert ranks.asked == ["ingest_slice", "ingest_discard", "inflate_part", "inflate_part_resolve", "ingest_text_own", "commit_slice"]
+    assert ranks.split == "stream" and len(got) == 4 and chroms.names == ["chr1", "chr2", "chr3"]
+    # rank 0 takes its text from the start and the rest of its last row from rank 1; rank 1 starts behind that rest; rank 2 at 0
+    assert [(sk, ex) for sk, ex, _ in ranks.own] == [(0, b"r1\t25\t1\n"), (len(b"r1\t25\t1\n"), b""), (0, b"")]
+    # a part whose CRC-32 is another one: nothing of the stream route is kept, every rank inflates the whole file
+    wrong = list(second)
+    wrong[1] = ("ok", second[1][1] ^ 1) + second[1][2:]
+    text3 = [("ok", 1, ["chr1"], True), ("ok", 1, ["chr2"], True), ("ok", 2, ["chr2", "chr3"], True)]
+    ranks = _ScriptedRanks(3, {"ingest_slice": [("container", "no member sizes")] * 3, "inflate_part": first,
+                               "inflate_part_resolve": wrong, "ingest_text_slice": text3})
+    got = sharded.ShardedEngine._ingest_slices(ranks, path, tables.ChromIndex(), 4)
+    assert ranks.asked == ["ingest_slice", "ingest_discard", "inflate_part", "inflate_part_resolve", "inflate_part_drop", "ingest_text_slice",
+                           "commit_slice"] and ranks.split == "text" and len(got) == 4
+    # ... unless N copies of the text would not fit the host: then not at all (the caller's funnel holds the text once)
+    ranks = _ScriptedRanks(3, {"ingest_slice": [("container", "no member sizes")] * 3, "inflate_part": first, "inflate_part_resolve": wrong})
+    ranks.host_has_room = False
+    assert sharded.ShardedEngine._ingest_slices(ranks, path, tables.ChromIndex(), 4) is None
+    assert ranks.asked[-1] == "inflate_part_drop"
