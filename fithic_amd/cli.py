@@ -207,6 +207,7 @@ def main(argv=None):
     finally:
         stuck = F.session_stuck()
         F.reset_session()
+        F.gpus = 1                             # a --gpus N of this call does not outlive it (callers of the stage functions set their own)
         if stuck:
             # --gpus N lost a rank while this process's own rank sat in a collective: that thread can never return, and a normal
             # interpreter exit (HIP / RCCL teardown) would wait for it.  Say what happened and leave.

@@ -321,7 +321,7 @@ __device__ __forceinline__ double contfrac_lazy(double a, double b, double x) {
 // In the swapped orientation (the "observed < expected" rows: 20 % of the rows and > 90 % of all iterations on Hi-C data)
 // a = n - count + 1 and b = count, so every k1..k8 of incbcf, both denominators D_2i = k3*k4, D_2i+1 = k7*k8 and their
 // reciprocals depend on (n, count) ONLY - never on the row's prior.  When all 64 lanes of a wave hold rows of one
-// (binomial, count), those values come from a table row per iteration (built once per pass by k2h_tables with the
+// (binomial, count), those values come from a table row per iteration (built once per pass by k2h_offsets_and_tables with the
 // same fp64 statements Cephes uses) through scalar loads into SGPR operands, and the lanes execute only what depends
 // on their own x = 1 - prior: 2 products + 3-instruction division + 4 recurrence instructions per half step.
 //

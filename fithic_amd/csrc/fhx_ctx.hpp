@@ -328,6 +328,7 @@ struct fhx_ctx {
     volatile unsigned long long* h_flags = nullptr;
     unsigned int* d_done = nullptr;                   // [0]: workgroups of k1_pack_window that have stored their part
     unsigned long long ticket = 0;                    // last ticket handed to a kernel
+    bool q_prefilled = false;                         // ... and filled the q column with 1.0: k3_compact stores only what differs
     bool k2_prezeroed = false;                        // fhx_pass_stats has zeroed K2's two histograms behind K1 (while the host fits)
     int k2_shards = 0;                                // shards (= k2_classify workgroups) of the last fhx_pvalues
     unsigned int* d_k2h_off = nullptr;                // K2H_BUCKETS + 1 bucket starts
@@ -353,6 +354,8 @@ struct fhx_ctx {
     unsigned int* h_k3 = nullptr;                     // pinned: [0..1] survivors by the histogram, [8..15] the sort repair's verdict
     hipEvent_t ev_k3 = nullptr;                       // the copy into h_k3
     bool k3_n_is_bound = false;                       // the survivors' number compact_pvalues returned is an upper bound
+    unsigned long long k3_ticket = 0;                 // the ticket k3_cutoff publishes behind the survivors' number (h_flags[FLAG_K3 + 1])
+    bool k3_counter_zeroed = false;                   // k3_cutoff zeroes the compaction's counter (auto_cutoff), no fill in front of k3_compact
     bool k3_kept_by_hist = false;                     // auto_cutoff has put the survivors' number on its way into h_k3[0..1]
     int64_t sort_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the last large sort of K3 (fhx_bh_sort_stats)
     std::vector<int64_t> fdr_counts;

@@ -255,10 +255,18 @@ __global__ void k1_pack_window(const K1Sums* __restrict__ sums, const unsigned l
 
 // K2's two histograms (the fused top-bits histogram of p, the count matrix of the heavy class) zeroed behind K1, while the host
 // fits: two fill dispatches less between the fit and k2_classify
-__global__ void k1_prezero(unsigned long long* __restrict__ a, int64_t na, uint4* __restrict__ b, int64_t nb16) {
+// ... and the q column filled with 1.0 - what nearly every row ends with (myStats.py:33-38: min(p N / rank, 1) of everything behind
+// the exact cutoff): k3_compact then only reads p and stores the NaN rows' q, instead of storing 8 bytes for every row while K3
+// is on the critical path; here the stores run while the GPU would idle behind K1
+__global__ void k1_prezero(unsigned long long* __restrict__ a, int64_t na, uint4* __restrict__ b, int64_t nb16, double* __restrict__ q,
+                           int64_t n_q) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nb16; i += stride) b[i] = make_uint4(0u, 0u, 0u, 0u);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < na; i += stride) a[i] = 0ull;
+    double2* q2 = reinterpret_cast<double2*>(q);
+    const int64_t n2 = n_q >> 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) q2[i] = make_double2(1.0, 1.0);
+    if ((n_q & 1) && blockIdx.x == 0 && threadIdx.x == 0) q[n_q - 1] = 1.0;
 }
 
 // ===================================================================================================
@@ -676,6 +684,19 @@ int ingest_device_rows(fhx_ctx* ctx, const int32_t* c1, const int32_t* m1, const
     if (n >= (1ll << 32)) return fail(ctx, FHX_ERR_UNSUPPORTED, "more than 2^32 rows per GPU: shard the contacts");
     const int res = (int)ctx->prm.resolution;
     int n_chr = std::max(ctx->n_chr, 1);
+    // FHX_TIMING=1: where the call's time goes (at 2e9 rows the arrays below are 158 GB: profiles/r06_cli_c5.txt)
+    const bool timing = std::getenv("FHX_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    std::string t_report;
+    auto mark = [&](const char* what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto t = std::chrono::steady_clock::now();
+        char b[96];
+        std::snprintf(b, sizeof(b), " %s %.3f s;", what, std::chrono::duration<double>(t - t_last).count());
+        t_report += b;
+        t_last = t;
+    };
     // the caller's chromosome id space may be larger than the fragments file's: scan for the maximum id is
     // folded into the extent kernel by giving it a generous table
     n_chr = std::max(n_chr, 4096);
@@ -701,6 +722,7 @@ int ingest_device_rows(fhx_ctx* ctx, const int32_t* c1, const int32_t* m1, const
     FHX_HIP(hipMemcpyAsync(maxoff.data(), d_maxoff, n_chr * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     FHX_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     FHX_HIP(hipStreamSynchronize(ctx->stream));
+    mark("extents of the chromosomes");
     if (bad) return fail(ctx, FHX_ERR_ARG, "contact rows hold a negative midpoint or a chromosome id outside [0, 4096)");
     int used = 0;
     for (int c = 0; c < n_chr; ++c)
@@ -735,10 +757,13 @@ int ingest_device_rows(fhx_ctx* ctx, const int32_t* c1, const int32_t* m1, const
         const int rc = alloc_row_arrays(ctx, n, n_dist);
         if (rc != FHX_OK) return rc;
     }
+    mark("row arrays + workspace allocated");
     hipLaunchKernelGGL(k0_slots, dim3(blocks), dim3(256), 0, ctx->stream, c1, m1, c2, m2, cnt, n, res, ctx->d_grid,
                        ctx->d_loc1, ctx->d_loc2, ctx->d_count);
     FHX_HIP(hipGetLastError());
     FHX_HIP(hipStreamSynchronize(ctx->stream));
+    mark("locus slots");
+    if (timing) std::fprintf(stderr, "fhx_load_pairs_device: %lld rows:%s\n", (long long)n, t_report.c_str());
     return FHX_OK;
 }
 
@@ -763,6 +788,7 @@ int alloc_row_arrays(fhx_ctx* ctx, int64_t n, int64_t n_dist) {
     FHX_HIP(hipMalloc(&ctx->d_seen_twice, cap));
     FHX_HIP(hipMalloc(&ctx->d_p, cap * sizeof(double)));
     FHX_HIP(hipMalloc(&ctx->d_q, cap * sizeof(double)));
+    ctx->q_prefilled = false;
     FHX_HIP(hipMemsetAsync(ctx->d_skip, 0, cap, ctx->stream));
     FHX_HIP(hipMemsetAsync(ctx->d_outlier, 0, cap, ctx->stream));
     FHX_HIP(hipMemsetAsync(ctx->d_seen_twice, 0, cap, ctx->stream));
@@ -1008,7 +1034,7 @@ int fhx_pass_stats(fhx_ctx* ctx, fhx_stats* out) {
     }
     // the kernel stores the block straight into the pinned host buffer and publishes a ticket behind it; the host spins on the
     // ticket (wait_ticket): no copy dispatch, no interrupt + wake-up between K1 and the fit (a 1/8 shard of C3: the gap between
-    // K1 and k2_classify 203 -> %s us, profiles/r06_*_tl_shard8.txt)
+    // K1 and k2_classify 203 -> 155 us, profiles/r06_a_tl_shard8.txt)
     long long* d_pack = nullptr;
     FHX_HIP(hipHostGetDevicePointer((void**)&d_pack, ctx->h_stats_stage, 0));
     unsigned long long* d_flag = nullptr;
@@ -1021,10 +1047,13 @@ int fhx_pass_stats(fhx_ctx* ctx, fhx_stats* out) {
     // behind it, off the host's critical path: what fhx_pvalues would otherwise have to zero before it can classify
     ctx->k2_prezeroed = false;
     if (ctx->d_block_hist && ctx->d_k2_hist) {
-        hipLaunchKernelGGL(k1_prezero, dim3(1024), dim3(256), 0, ctx->stream, ctx->d_k2_hist, (int64_t)TOP_BINS,
-                           reinterpret_cast<uint4*>(ctx->d_block_hist), (int64_t)K2H_BUCKETS * K2H_BLOCKS / 4);
+        static const bool prefill = !(std::getenv("FHX_Q_PREFILL") && std::atoi(std::getenv("FHX_Q_PREFILL")) == 0);     // 0: measurements
+        hipLaunchKernelGGL(k1_prezero, dim3(prefill ? 2048 : 1024), dim3(256), 0, ctx->stream, ctx->d_k2_hist, (int64_t)TOP_BINS,
+                           reinterpret_cast<uint4*>(ctx->d_block_hist), (int64_t)K2H_BUCKETS * K2H_BLOCKS / 4, ctx->d_q,
+                           prefill ? ctx->n_rows : (int64_t)0);
         FHX_HIP(hipGetLastError());
         ctx->k2_prezeroed = true;
+        ctx->q_prefilled = prefill;
     }
     FHX_HIP(wait_ticket(ctx, FLAG_K1, ticket));
     fold_kernel_events(ctx);               // this pass's K1 and, behind it on the stream, the previous pass's K2 and K3

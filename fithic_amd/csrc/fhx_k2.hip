@@ -367,9 +367,12 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE,
 
 // count == 1: p = 1 - (1 - prior)^n through Cephes' log1p / expm1 (or pow): bdtrc_closed_form
 // (also zeroes the counters of the class kernels that follow it on the stream - `zero_words`: instead of a memset of their own)
-__global__ __launch_bounds__(K2_THREADS) void k2_closed(K2Params P, QSpan q, unsigned long long* __restrict__ zero_words) {
+// (... and puts "keep every p" into K3's cutoff word - what holds until a cutoff is computed: instead of a copy from the host at the end of K2)
+__global__ __launch_bounds__(K2_THREADS) void k2_closed(K2Params P, QSpan q, unsigned long long* __restrict__ zero_words,
+                                                        unsigned long long* __restrict__ cutoff_word) {
     __shared__ unsigned int hist_lds[K2_HIST_BINS];
     if (blockIdx.x == 0 && threadIdx.x < MISC_K2_WORDS) zero_words[threadIdx.x] = 0ull;
+    if (blockIdx.x == 0 && threadIdx.x == MISC_K2_WORDS) *cutoff_word = KEY_KEEP_ALL;
     FusedHist H;
     H.init(hist_lds, P.top_hist);
     for (int sh = blockIdx.x; sh < q.n_shards; sh += gridDim.x) {
@@ -619,25 +622,6 @@ __global__ __launch_bounds__(K2H_THREADS) void k2h_count(QSpan q, unsigned int* 
     for (int d = threadIdx.x; d < K2H_BUCKETS; d += K2H_THREADS) block_hist[(size_t)d * K2H_BLOCKS + blockIdx.x] = h[d];
 }
 
-// bucket starts, each rounded up to a multiple of `granule` entries (64 x the rows a lane of k2h_heavy takes): off[b] for
-// b = 0..K2H_BUCKETS (the last one = padded total)
-__global__ __launch_bounds__(1024) void k2h_offsets(const unsigned int* __restrict__ digit_total, unsigned int* __restrict__ off,
-                                                    unsigned int granule) {
-    __shared__ unsigned int part[1024];
-    const unsigned int g1 = granule - 1u;
-    const unsigned int a = (digit_total[2 * threadIdx.x] + g1) / granule * granule, b = (digit_total[2 * threadIdx.x + 1] + g1) / granule * granule;
-    // exclusive prefix over the 1024 threads: wave scan + the 16 wave totals (was one thread walking all 1024)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned int incl = wave_incl_sum_u32(a + b);
-    if (lane == 63) part[wave] = incl;
-    __syncthreads();
-    unsigned int excl = incl - (a + b);
-    for (int w = 0; w < wave; ++w) excl += part[w];
-    if (threadIdx.x == 1023) off[K2H_BUCKETS] = excl + a + b;
-    off[2 * threadIdx.x] = excl;
-    off[2 * threadIdx.x + 1] = excl + a;
-}
-
 __global__ __launch_bounds__(K2H_THREADS) void k2h_scatter(QSpan q, const unsigned int* __restrict__ block_hist,
                                                            const unsigned int* __restrict__ off, QEntry* __restrict__ out) {
     __shared__ unsigned int cursor[K2H_BUCKETS];
@@ -652,16 +636,38 @@ __global__ __launch_bounds__(K2H_THREADS) void k2h_scatter(QSpan q, const unsign
     }
 }
 
-// one workgroup per non-empty (binomial, count) bucket, one thread per iteration: the 300 rows of iteration constants
-constexpr int K2H_TABLE_THREADS = 320;
-static_assert(K2H_TABLE_THREADS >= dev::kCfIters, "one thread per table row");
-__global__ __launch_bounds__(K2H_TABLE_THREADS) void k2h_tables(const unsigned int* __restrict__ digit_total, double n_intra, double n_inter,
-                                                                dev::CfRow* __restrict__ tab) {
+// the two consumers of the bucket totals in ONE launch (they do not depend on each other) - a launch less between k2_classify and
+// k2h_heavy.  Workgroups 0..K2H_GENERIC-1: one per non-empty (binomial, count) bucket, one thread per iteration - the 300 rows of
+// iteration constants.  The last workgroup: bucket starts, each rounded up to a multiple of `granule` entries (64 x the rows a lane
+// of k2h_heavy takes): off[b] for b = 0..K2H_BUCKETS (the last one = padded total).
+static_assert(dev::kCfIters <= 1024, "one thread per table row");
+__device__ __forceinline__ void k2h_table_row(const unsigned int* __restrict__ digit_total, double n_intra, double n_inter,
+                                              dev::CfRow* __restrict__ tab) {
     const int b = blockIdx.x;
-    if (b >= K2H_GENERIC || digit_total[b] == 0 || (int)threadIdx.x >= dev::kCfIters) return;
+    if (digit_total[b] == 0 || (int)threadIdx.x >= dev::kCfIters) return;
     const bool inter = b >= K2H_KCAP;
     tab[(size_t)b * dev::kCfIters + threadIdx.x] = dev::cf_swapped_row(inter ? n_inter : n_intra, inter ? b - K2H_KCAP : b, (int)threadIdx.x);
 }
+__global__ __launch_bounds__(1024) void k2h_offsets_and_tables(const unsigned int* __restrict__ digit_total, unsigned int* __restrict__ off,
+                                                               unsigned int granule, double n_intra, double n_inter, dev::CfRow* __restrict__ tab) {
+    if (blockIdx.x < K2H_GENERIC) {
+        k2h_table_row(digit_total, n_intra, n_inter, tab);
+        return;
+    }
+    __shared__ unsigned int part[1024];
+    const unsigned int g1 = granule - 1u;
+    const unsigned int a = (digit_total[2 * threadIdx.x] + g1) / granule * granule, b = (digit_total[2 * threadIdx.x + 1] + g1) / granule * granule;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned int incl = wave_incl_sum_u32(a + b);
+    if (lane == 63) part[wave] = incl;
+    __syncthreads();
+    unsigned int excl = incl - (a + b);
+    for (int w = 0; w < wave; ++w) excl += part[w];
+    if (threadIdx.x == 1023) off[K2H_BUCKETS] = excl + a + b;
+    off[2 * threadIdx.x] = excl;
+    off[2 * threadIdx.x + 1] = excl + a;
+}
+
 
 // Lanes cf_swapped_uniform cannot take (unusual inputs or states, see fhx_bdtrc.hpp) are appended to `redo` - the space the
 // unsorted queue occupied, free once k2h_scatter has run - and k2h_generic evaluates them with the per-lane loop; keeping that
@@ -1166,7 +1172,7 @@ int fhx_pvalues(fhx_ctx* ctx) {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k2_classify<0, 4, 0, true, false>), cgrid, cblock, 0, ctx->stream, P, Q);
     }
     const dim3 qgrid(256 * 8), qblock(K2_THREADS);
-    hipLaunchKernelGGL(k2_closed, qgrid, qblock, 0, ctx->stream, P, Q.q[K2_CLOSED - 1], ctx->d_misc + MISC_K2_REDO);
+    hipLaunchKernelGGL(k2_closed, qgrid, qblock, 0, ctx->stream, P, Q.q[K2_CLOSED - 1], ctx->d_misc + MISC_K2_REDO, ctx->d_misc + 6);
     // totals below 171: the kernels that carry Cephes' pow branch (a binomial without a single contact - no inter-chromosomal
     // rows - classifies every row as trivial and reaches no class kernel: it does not count)
     const bool small_n = (P.intra.small_n && P.intra.n >= 1.0) || (P.inter.small_n && P.inter.n >= 1.0);
@@ -1211,10 +1217,8 @@ int fhx_pvalues(fhx_ctx* ctx) {
         // two rows per lane at eight waves per SIMD halves the task (a 1/8 shard of C3: 876 -> 829 us, profiles/r04_t_rows.txt)
         const int hr = (heavy_rows == 1 || heavy_rows == 2) ? heavy_rows       // the instantiations below: 1, 2 or 4 rows per lane - the
                        : (heavy_rows == 0 && k2_n < 32000000) ? 2 : 4;         // bucket granule must be the launched kernel's task size
-        hipLaunchKernelGGL(k2h_offsets, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned int*)ctx->d_digit_total, ctx->d_k2h_off,
-                           64u * (unsigned int)hr);
-        hipLaunchKernelGGL(k2h_tables, dim3(K2H_GENERIC), dim3(K2H_TABLE_THREADS), 0, ctx->stream, (const unsigned int*)ctx->d_digit_total,
-                           P.intra.n, P.inter.n, ctx->d_cf_tab);
+        hipLaunchKernelGGL(k2h_offsets_and_tables, dim3(K2H_GENERIC + 1), dim3(1024), 0, ctx->stream, (const unsigned int*)ctx->d_digit_total,
+                           ctx->d_k2h_off, 64u * (unsigned int)hr, P.intra.n, P.inter.n, ctx->d_cf_tab);
         hipLaunchKernelGGL(k2h_scatter, dim3(K2H_BLOCKS), dim3(K2H_THREADS), 0, ctx->stream, hs,
                            (const unsigned int*)ctx->d_block_hist, (const unsigned int*)ctx->d_k2h_off, ctx->d_queue_sorted);
         FHX_LAUNCH_QUEUE(dev::BC_PSERIES);               // before the redo list reuses the buffer it shares with the heavy queue
@@ -1290,11 +1294,7 @@ int fhx_pvalues(fhx_ctx* ctx) {
     ctx->have_p = true;
     ctx->have_q = false;
     ctx->n_sorted = -1;
-    {
-        const unsigned long long one = KEY_KEEP_ALL;               // until a cutoff is computed: keep every p
-        FHX_HIP(hipMemcpyAsync(ctx->d_misc + 6, &one, sizeof(one), hipMemcpyHostToDevice, ctx->stream));
-    }
-    return FHX_OK;
+    return FHX_OK;                                                 // (K3's cutoff word says "keep every p": k2_closed)
 }
 
 int fhx_bdtrc_array(fhx_ctx* ctx, double n_total, const int32_t* count, const double* prior, int64_t n, double* out) {

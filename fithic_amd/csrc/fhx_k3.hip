@@ -57,9 +57,18 @@ __host__ __device__ inline bool bin_saturates(int b, unsigned long long cum_incl
 }
 
 // (dense_flag: 1 when at least dense_min values lie below the cutoff - the pass then takes q through the dense array, k3_compact<true>)
+// (host: the engine's own pass - the survivors' number goes straight to the host's pinned words, followed by the ticket the host
+// waits for (fhx_ctx::h_flags: no copy dispatched behind this kernel), and the compaction's counter is zeroed here (no fill before it))
+struct CutoffToHost {
+    volatile unsigned long long* words = nullptr;    // [0] the ticket, [1] the number of values below the cutoff
+    unsigned long long ticket = 0;
+    unsigned int* done = nullptr;
+    unsigned long long* zero_me = nullptr;
+};
 __global__ __launch_bounds__(1024) void k3_cutoff(const unsigned long long* __restrict__ hist, double n_tests,
                                                   unsigned long long* __restrict__ cutoff_key, unsigned long long* __restrict__ n_below,
-                                                  unsigned long long dense_min = ~0ull, unsigned long long* __restrict__ dense_flag = nullptr) {
+                                                  unsigned long long dense_min = ~0ull, unsigned long long* __restrict__ dense_flag = nullptr,
+                                                  CutoffToHost host = CutoffToHost{}) {
     __shared__ unsigned long long part[1024];
     __shared__ unsigned long long below;
     __shared__ unsigned int best;
@@ -106,10 +115,13 @@ __global__ __launch_bounds__(1024) void k3_cutoff(const unsigned long long* __re
         if (threadIdx.x == 0) {
             *n_below = below;
             if (dense_flag) *dense_flag = below >= dense_min ? 1ull : 0ull;
+            if (host.words) const_cast<unsigned long long*>(host.words)[1] = below;
+            if (host.zero_me) *host.zero_me = 0ull;
         }
     }
     if (threadIdx.x == 0)
         *cutoff_key = (best < (unsigned int)TOP_BINS) ? ((unsigned long long)best << TOP_SHIFT) : KEY_KEEP_ALL;
+    if (host.words) publish_ticket(host.done, host.words, host.ticket);
 }
 
 // compaction: keys of the rows below the cutoff key (IEEE bit pattern: all p are >= 0, so unsigned order is
@@ -132,7 +144,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restr
                                                            unsigned long long* __restrict__ keys,
                                                            unsigned int* __restrict__ vals, double* __restrict__ q,
                                                            unsigned long long* __restrict__ counter,
-                                                           const unsigned long long* __restrict__ cutoff_key, DenseQ dq) {
+                                                           const unsigned long long* __restrict__ cutoff_key, DenseQ dq,
+                                                           bool q_is_ones = false) {
     // rows at or above the cutoff key (see above) have q = 1 and are not sorted; NaN rows get q = NaN.
     // one global atomic per 4096-row tile (a same-address atomic per 256 rows capped this kernel at ~88 M atomics/s)
     __shared__ unsigned int wave_cnt[SORT_WAVES];
@@ -165,11 +178,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restr
                 keep1 = (w.y == w.y) && (pvalue_key(w.y) < cutoff);
                 // both q of the pair in one 16-byte store, kept rows included: bh_apply overwrites those later on this stream
                 // (partial 8-byte stores around every kept row cost 0.13 ms per 1.2e8 rows with 12 % of them kept)
-                if (!DENSE) q2[i >> 1] = make_double2((w.x == w.x) ? 1.0 : w.x, (w.y == w.y) ? 1.0 : w.y);
+                // (q_is_ones: the column was filled with 1.0 behind K1 - k1_prezero -, only a NaN is left to store)
+                if (!DENSE && (!q_is_ones || w.x != w.x || w.y != w.y)) q2[i >> 1] = make_double2((w.x == w.x) ? 1.0 : w.x, (w.y == w.y) ? 1.0 : w.y);
             } else if (i < n) {                                            // the last row of an odd count
                 v[2 * h] = p[i];
                 keep0 = (v[2 * h] == v[2 * h]) && (pvalue_key(v[2 * h]) < cutoff);
-                if (!DENSE && !keep0) q[i] = (v[2 * h] == v[2 * h]) ? 1.0 : v[2 * h];
+                if (!DENSE && !keep0 && !(q_is_ones && v[2 * h] == v[2 * h])) q[i] = (v[2 * h] == v[2 * h]) ? 1.0 : v[2 * h];
             }
             const unsigned long long m0 = __ballot(keep0), m1 = __ballot(keep1);
             if (DENSE) {
@@ -1092,8 +1106,11 @@ int fhx::fill_top_hist(fhx_ctx* ctx) {
 }
 
 static int auto_cutoff(fhx_ctx* ctx, const double* d_p, int64_t n, double n_total_tests, unsigned long long* d_cutoff,
-                       unsigned long long dense_min = ~0ull) {
-    if (d_p == ctx->d_p) {
+                       unsigned long long dense_min = ~0ull, unsigned long long* counter_to_zero = nullptr) {
+    const unsigned long long* hist = ctx->d_top_hist;
+    if (d_p == ctx->d_p && ctx->k2_hist_valid) {
+        hist = ctx->d_k2_hist;                          // what K2 counted while it stored p: read where it lies (no copy into d_top_hist)
+    } else if (d_p == ctx->d_p) {
         const int rc = fill_top_hist(ctx);
         if (rc != FHX_OK) return rc;
     } else {
@@ -1103,15 +1120,23 @@ static int auto_cutoff(fhx_ctx* ctx, const double* d_p, int64_t n, double n_tota
     // the survivors' number by the histogram (d_misc[8]) goes to pinned memory right behind the cutoff: compact_pvalues waits for
     // that copy alone, while the compaction it has already enqueued runs
     {
-        const int rc = ensure_k3_host(ctx);
+        int rc = ensure_k3_host(ctx);
+        if (rc == FHX_OK) rc = ensure_flags(ctx);
         if (rc != FHX_OK) return rc;
     }
-    hipLaunchKernelGGL(k3_cutoff, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long*)ctx->d_top_hist, n_total_tests,
-                       d_cutoff, ctx->d_misc + 8, dense_min, ctx->d_misc + MISC_K3_DENSE);
-    FHX_HIP(hipGetLastError());
-    FHX_HIP(hipMemcpyAsync(ctx->h_k3, ctx->d_misc + 8, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    // the stream up to here (K2) gets an event the host can sleep on; what follows it - this one workgroup - is waited for by ticket
     FHX_HIP(hipEventRecord(ctx->ev_k3, ctx->stream));
+    CutoffToHost host;
+    host.words = ctx->h_flags + FLAG_K3;
+    host.ticket = ++ctx->ticket;
+    host.done = ctx->d_done + 1;
+    host.zero_me = counter_to_zero;
+    hipLaunchKernelGGL(k3_cutoff, dim3(1), dim3(1024), 0, ctx->stream, hist, n_total_tests, d_cutoff, ctx->d_misc + 8, dense_min,
+                       ctx->d_misc + MISC_K3_DENSE, host);
+    FHX_HIP(hipGetLastError());
+    ctx->k3_ticket = host.ticket;
     ctx->k3_kept_by_hist = true;
+    ctx->k3_counter_zeroed = counter_to_zero != nullptr;
     return FHX_OK;
 }
 
@@ -1120,7 +1145,8 @@ static int auto_cutoff(fhx_ctx* ctx, const double* d_p, int64_t n, double n_tota
 static int compact_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned long long* keys[2], unsigned int* vals[2], double* d_q,
                            unsigned long long* counter, const unsigned long long* d_cutoff, int64_t* n_kept_out,
                            const DenseQ* dq = nullptr) {
-    FHX_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
+    if (!ctx->k3_counter_zeroed) FHX_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
+    ctx->k3_counter_zeroed = false;                   // (auto_cutoff had k3_cutoff zero it)
     // one workgroup per tile, not a resident grid walking the column: 0.507 -> 0.451 ms on C3 (profiles/history/r03_x_k3_grid.txt); the
     // plain copy kernel of profiles/hbm_rate.hip shows the same (4.9 TB/s with 2048 grid-striding workgroups, 5.6 with one per
     // chunk).  FHX_K3_GRID caps the grid for measurements.
@@ -1131,9 +1157,11 @@ static int compact_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned 
     if (!dq || dq->flag) {                           // (with a flag the device picks one of the two; the other returns at once)
         DenseQ off;
         if (dq) off.flag = dq->flag;
+        const bool ones = ctx->q_prefilled && d_q == ctx->d_q && d_p == ctx->d_p;
         hipLaunchKernelGGL(k3_compact<false>, dim3(grid_for(n, SORT_TILE, k3_cap)), dim3(SORT_THREADS), 0, ctx->stream, d_p, n,
-                           keys[0], vals[0], d_q, counter, d_cutoff, off);
+                           keys[0], vals[0], d_q, counter, d_cutoff, off, ones);
     }
+    if (d_q == ctx->d_q) ctx->q_prefilled = false;      // from here on the column holds this pass's q
     // how many keys survived decides the shape of the sort.  When the cutoff came from this GPU's own histogram (auto_cutoff) the
     // number is already on its way - the histogram's bins below the cutoff bin hold exactly the rows kept here - and the host goes
     // on to enqueue the sort while the compaction runs; otherwise (sharded runs: the histogram is the all-reduced one) the counter
@@ -1144,8 +1172,9 @@ static int compact_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned 
         // (an UPPER BOUND when the histogram is K2's: it counts a wave's values in the bin of the smallest, fhx_k2.hip FusedHist -
         // every launch below takes its true count from the device counter and sizes its grid for the bound)
         ctx->k3_kept_by_hist = false;
-        FHX_HIP(hipEventSynchronize(ctx->ev_k3));
-        const unsigned long long by_hist = *reinterpret_cast<volatile unsigned long long*>(ctx->h_k3);
+        FHX_HIP(hipEventSynchronize(ctx->ev_k3));          // K2 is through (the host sleeps: milliseconds) ...
+        FHX_HIP(wait_ticket(ctx, FLAG_K3, ctx->k3_ticket));   // ... and k3_cutoff's one workgroup (microseconds: spin)
+        const unsigned long long by_hist = ctx->h_flags[FLAG_K3 + 1];
         n_kept = std::min<unsigned long long>(by_hist, (unsigned long long)n);
         ctx->k3_n_is_bound = true;
     } else {
@@ -1391,7 +1420,7 @@ int fhx_bh_array(fhx_ctx* ctx, const double* p, int64_t n, double n_total_tests,
     int buf = 0;
     unsigned long long* counter = ctx->d_misc + 2;
     unsigned long long* cutoff = ctx->d_misc + 7;
-    rc = auto_cutoff(ctx, d_p, n, n_total_tests, cutoff);
+    rc = auto_cutoff(ctx, d_p, n, n_total_tests, cutoff, ~0ull, counter);
     if (rc == FHX_OK) rc = rank_and_adjust(ctx, d_p, n, keys, vals, d_q, counter, cutoff, n_total_tests, tile_max, &buf, nullptr, 64, ctrl);
     if (rc == FHX_OK) {
         FHX_HIP(hipMemcpyAsync(q, d_q, cap * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1420,7 +1449,7 @@ int fhx_bh(fhx_ctx* ctx, double n_total_tests) {
         dense_min = dense_env == 1 ? 0ull : (unsigned long long)(((long double)ctx->n_rows * dense_env + 99) / 100);
         dq.flag = ctx->d_misc + MISC_K3_DENSE;
     }
-    int rc = auto_cutoff(ctx, ctx->d_p, ctx->n_rows, n_total_tests, ctx->d_misc + 6, dense_min);
+    int rc = auto_cutoff(ctx, ctx->d_p, ctx->n_rows, n_total_tests, ctx->d_misc + 6, dense_min, ctx->d_misc);
     if (rc != FHX_OK) return rc;
     int64_t kept = 0;
     rc = rank_and_adjust(ctx, ctx->d_p, ctx->n_rows, ctx->d_keys, ctx->d_vals, ctx->d_q, ctx->d_misc, ctx->d_misc + 6, n_total_tests,

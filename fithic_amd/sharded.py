@@ -231,6 +231,7 @@ class _Rank:
     def ingest_text_slice(self, path, threads):
         """a file the device does not inflate (plain gzip): inflated whole on this rank's share of the host cores, then the rows
         that start in this rank's N-th of the text uploaded and parsed -> as ingest_slice"""
+        self._note_memory()
         text = _capi.HostText(path, threads)
         try:
             n, names = self.eng.ctx.ingest_contacts_text_slice(text, self.rank, self.world, threads)
@@ -240,6 +241,7 @@ class _Rank:
             return ("unsupported", str(e))
         finally:
             text.close()
+            self._report_memory("whole text")
         self._parsed = int(n)
         return ("ok", n, names, True)
 
@@ -248,6 +250,7 @@ class _Rank:
         """first call: this rank's chunks decoded without the window before them -> ("ok", tail symbols, bytes of text, holds the
         end of the stream) or ("unsupported", why)"""
         self.inflate_part_drop()
+        self._note_memory()
         try:
             self._part = _capi.TextPart(path, self.rank, self.world, threads)
         except _capi.FhxError as e:
@@ -291,8 +294,20 @@ class _Rank:
             return ("unsupported", str(e))
         finally:
             self.inflate_part_drop()
+            self._report_memory("part of the stream")
         self._parsed = int(n)
         return ("ok", n, names, True)
+
+    def _report_memory(self, what):
+        if os.environ.get("FHX_TIMING"):
+            import resource
+            sys.stderr.write("rank %d of %d (%s): peak host RSS %.0f MB (%.0f MB before the file was opened)\n" %
+                             (self.rank, self.world, what, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0, getattr(self, "_rss_before", 0.0)))
+
+    def _note_memory(self):
+        if os.environ.get("FHX_TIMING") and not hasattr(self, "_rss_before"):
+            import resource
+            self._rss_before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0
 
     def commit_slice(self, ids, first):
         """the parsed part becomes this rank's rows, at file positions first, first + 1, ..."""

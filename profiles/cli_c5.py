@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--max-chroms", type=int, default=0)
     ap.add_argument("--dir", default="/dev/shm/cli_c5")
     ap.add_argument("--check-rows", type=int, default=200000)
+    ap.add_argument("--again-with", action="append", default=[], metavar="K=V[,K=V]", help="run the CLI once more with these environment settings")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -91,18 +92,34 @@ def main():
     pd.DataFrame({0: names[b_chr], 1: b_mid, 2: b_val}).to_csv(out + "/bias.gz", sep="\t", header=False, index=False, compression="gzip")
     cmd = [sys.executable, "-m", "fithic_amd", "-i", out + "/contacts.gz", "-f", out + "/frags.gz", "-t", out + "/bias.gz", "-o", out + "/run",
            "-r", str(res), "-L", str(L), "-U", str(int(U)), "-x", "All", "-p", "1"]
-    t0 = time.time()
-    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, env=dict(os.environ, FHX_TIMING="1"))
-    wall = time.time() - t0
     sig = out + "/run/FitHiC.spline_pass1.res%d.significances.txt.gz" % res
-    print("fithic -x All -p 1: wall %.1f s for %d rows (%.1f M rows/s end to end), output %.1f GB gz, rc %d" %
-          (wall, n, n / wall / 1e6, os.path.getsize(sig) / 1e9 if os.path.exists(sig) else -1, r.returncode))
-    for ln in r.stdout.splitlines() + r.stderr.splitlines():
-        if ("took" in ln or "stage" in ln or ln.startswith("contacts on the device") or (ln.startswith("fhx_write_significances_device:") and "bytes in" in ln)):
-            print("    " + ln[:300])
-    if r.returncode != 0:
-        print(r.stderr[-3000:])
+
+    def run_cli(command, extra_env, label):
+        t0 = time.time()
+        r = subprocess.run(command, cwd=ROOT, capture_output=True, text=True, env=dict(os.environ, FHX_TIMING="1", **extra_env))
+        wall = time.time() - t0
+        made = command[command.index("-o") + 1] + "/FitHiC.spline_pass1.res%d.significances.txt.gz" % res
+        print("fithic -x All -p 1%s: wall %.1f s for %d rows (%.1f M rows/s end to end), output %.1f GB gz, rc %d" %
+              (label, wall, n, n / wall / 1e6, os.path.getsize(made) / 1e9 if os.path.exists(made) else -1, r.returncode))
+        for ln in r.stdout.splitlines() + r.stderr.splitlines():
+            if ("took" in ln or "stage" in ln or ln.startswith("contacts on the device") or (ln.startswith("fhx_write_significances_device:") and "bytes in" in ln)
+                    or ln.startswith("fhx_load_pairs_device") or ln.startswith("fhx_ingest_contacts_commit")):
+                print("    " + ln[:300])
+        if r.returncode != 0:
+            print(r.stderr[-3000:])
+        return r.returncode, made
+
+    rc, _ = run_cli(cmd, {}, "")
+    if rc != 0:
         return 1
+    for spec in args.again_with:                                  # the same command once more under other settings (A/B on the same files)
+        env2 = dict(kv.split("=", 1) for kv in spec.split(","))
+        cmd2 = [c if c != out + "/run" else out + "/run2" for c in cmd]
+        rc2, made2 = run_cli(cmd2, env2, " [" + spec + "]")
+        if rc2 == 0:
+            same = subprocess.run(["cmp", "-s", sig, made2]).returncode == 0
+            print("    output file %s the first run's, byte for byte" % ("EQUALS" if same else "DIFFERS FROM"))
+        subprocess.run(["rm", "-rf", out + "/run2"])
     # ---- the first and the last rows against Python's formatting of an engine run's values ----
     k = min(args.check_rows, n_cis, n - n_cis if n > n_cis else n_cis)
     t0 = time.time()

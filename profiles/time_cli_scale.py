@@ -21,6 +21,34 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def plain_member(src, dst, level=1, piece=64 << 20):
+    """src (any gzip file) rewritten as ONE plain gzip member - one deflate stream, no size fields: what `gzip` writes - the way
+    pigz does it on many cores: pieces of the text deflated on their own, every one but the last ended by a sync flush (an empty
+    stored block on a byte boundary), concatenated behind one header, one CRC-32 + ISIZE trailer."""
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    from fithic_amd import _capi
+    t = _capi.HostText(src, 0)
+    text = memoryview(t.bytes())
+    t.close()
+    cuts = list(range(0, len(text), piece)) or [0]
+
+    def one(k):
+        z = zlib.compressobj(level, zlib.DEFLATED, -15)
+        last = k + 1 == len(cuts)
+        body = z.compress(text[cuts[k]:cuts[k] + piece])
+        return body + z.flush(zlib.Z_FINISH if last else zlib.Z_FULL_FLUSH), zlib.crc32(text[cuts[k]:cuts[k] + piece]), len(text[cuts[k]:cuts[k] + piece])
+
+    crc = 0
+    with open(dst, "wb") as f, ThreadPoolExecutor(max(1, (os.cpu_count() or 2) // 2)) as pool:
+        f.write(b"\x1f\x8b\x08\x00\0\0\0\0\x04\xff")
+        for k, (body, c, n) in enumerate(pool.map(one, range(len(cuts)))):
+            f.write(body)
+            crc = c if k == 0 else _capi.crc32_combine(crc, c, n)
+        f.write(struct.pack("<II", crc, len(text) & 0xffffffff))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--chroms", type=int, default=22)
@@ -61,8 +89,8 @@ def main():
         t_w = time.time() - t0
         if args.plain:
             t0 = time.time()
-            subprocess.run("gzip -dc %s/contacts.gz | gzip -1 > %s/contacts_plain.gz && mv %s/contacts_plain.gz %s/contacts.gz" % (out, out, out, out),
-                           shell=True, check=True)
+            plain_member(out + "/contacts.gz", out + "/contacts_plain.gz")
+            os.replace(out + "/contacts_plain.gz", out + "/contacts.gz")
             print("rewritten as one plain gzip member in %.1f s" % (time.time() - t0))
         import pandas as pd
         names = np.array(genome.names)
@@ -87,7 +115,7 @@ def main():
               (passes, " --gpus %d" % args.gpus if args.gpus > 1 else "", dt, n, n / dt / 1e6,
                os.path.getsize(sig) / 1e6 if os.path.exists(sig) else -1, r.returncode))
         for ln in r.stdout.splitlines() + r.stderr.splitlines():
-            if "took" in ln or "Time" in ln or "stage" in ln or ln.startswith("fhx_") or ln.startswith("contacts on the device") or ln.startswith("parallel gunzip"):
+            if "took" in ln or "Time" in ln or "stage" in ln or ln.startswith("fhx_") or ln.startswith("contacts on the device") or ln.startswith("parallel gunzip") or ln.startswith("rank "):
                 print("    " + ln)
         if r.returncode != 0:
             print(r.stderr[-2000:])

@@ -838,6 +838,7 @@ def test_mirror_read_biases_returns_the_reference_dictionary_lazily():
     meta, _ = load_case("f1_bias")
     kw = case_args(meta)
     F.reset_session()
+    F.gpus = 1
     F.resolution = kw["resolution"]
     F.biasLowerBound, F.biasUpperBound = kw["tL"], kw["tU"]
     F.distLowThres, F.distUpThres = kw["L"], kw["U"]
