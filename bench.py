@@ -453,6 +453,10 @@ def main():
         per_pass = [ev_s[k] / ev_n[k] if ev_n[k] else 0.0 for k in range(4)]
         kt = np.array(per_pass[:3])
         heavy = np.array([per_pass[3], float(eng.ctx.k2_heavy_launch()[1])])      # rows of the launch: the last pass's
+        try:
+            heavy_ghz = float(eng.ctx.k2_heavy_clock())          # the shader clock that launch ran at on THIS box (a wave's own counters)
+        except Exception:                                        # noqa: BLE001 - informational only
+            heavy_ghz = 0.0
         if comm:
             elapsed = comm.max_float(elapsed)
             n_total = comm.sum_int(n_local)
@@ -486,7 +490,7 @@ def main():
             class_rows = eng.ctx.k2_class_rows()                 # rows per branch class of the last K2 (what each class kernel worked on)
         except Exception:                                        # noqa: BLE001 - informational only
             class_rows = None
-        return dict(sort_stats=sort_stats, class_rows=class_rows, steps=steps, genome=genome, eng=eng, sample=sample, elapsed=elapsed, n_total=n_total, n_local=n_local, k_all=k_all, bh_sorted=bh_sorted,
+        return dict(heavy_ghz=heavy_ghz, sort_stats=sort_stats, class_rows=class_rows, steps=steps, genome=genome, eng=eng, sample=sample, elapsed=elapsed, n_total=n_total, n_local=n_local, k_all=k_all, bh_sorted=bh_sorted,
                     stage_ms=stage_ms, pass_ms=pass_ms / max(steps, 1), info=info, n_trans=n_trans, replicas=replicas,
                     hashes=hashes, hashed_pass1=want_hashes and passes > 1)
 
@@ -534,12 +538,17 @@ def main():
                 traffic = None
         # the bound that matters: every VALU wave-instruction of the pass at one per four cycles and SIMD (counters of the same
         # command on this tree, profiles/valu_floor.json made by profiles/update_valu_floor.py; scaled by this run's rows)
+        # The file holds the COUNT (wave-instructions per pass); the clock is this run's own - k2h_heavy samples it (fhx_k2_heavy_clock) -
+        # so that pass_over_floor means the same thing on a 2.15 GHz and on a 2.24 GHz box.
         floor_ms = floor_src = None
+        clock_ghz = M.get("heavy_ghz") or None
         try:
             vf = json.load(open(os.path.join(ROOT, "profiles", "valu_floor.json"))).get(args.config)
             if vf and world == 1:
-                floor_ms = vf["floor_ms"] * n_total / vf["pairs"]
-                floor_src = vf["source"]
+                ghz = clock_ghz or vf["clock_ghz"]
+                floor_ms = (vf["valu_wave_instructions_per_pass"] * vf["cycles_per_wave_instruction"] / (vf["simds"] * ghz * 1e9) * 1e3
+                            * n_total / vf["pairs"])
+                floor_src = vf["source"] + ("; clock of this run's heavy launch" if clock_ghz else "; clock of the counter run (none measured here)")
         except Exception:                                        # noqa: BLE001 - informational
             floor_ms = None
         fp64_instr = hv_rows * 300.0 * HEAVY_FP64_INSTR_PER_ITER
@@ -577,12 +586,13 @@ def main():
                                  "fraction runs all 300 iterations) is bound by fp64 VALU issue, see fp64_valu_issue_frac: "
                                  "algorithmic bytes = 20 B/row (12 read + 8 written), %g fp64 instructions per row-iteration" % HEAVY_FP64_INSTR_PER_ITER,
                          "valu_issue_floor_ms": floor_ms, "pass_over_floor": (ms / floor_ms) if floor_ms else None,
-                         "valu_issue_floor_source": floor_src,
+                         "valu_issue_floor_source": floor_src, "shader_clock_ghz": clock_ghz,
                          "launch_seconds": hv_s, "rows_per_launch": hv_rows,
                          "fp64_valu_issue_frac": (fp64_instr / hv_s) / fp64_issue_peak if hv_s > 0 else None,
-                         "fp64_note": "loop instructions only, against the nominal 2.4 GHz; by the SQ counters (profiles/r04_z_counters.txt: 3.18e9 VALU "
-                                      "wave-instructions per launch = 25.4 per row-iteration all told, 1.28e7 cycles) the launch fills 97 % of the VALU "
-                                      "issue slots (one wave instruction per 4 cycles and SIMD) at the 2.15-2.24 GHz the boxes run it at"},
+                         "fp64_note": "loop instructions only, against the nominal 2.4 GHz; by the SQ counters (profiles/r05_z_counters.txt; the kernel "
+                                      "is unchanged since: 3.18e9 VALU wave-instructions per launch = 25.4 per row-iteration all told, 1.28e7 cycles) the "
+                                      "launch fills 97 % of the VALU issue slots (one wave instruction per 4 cycles and SIMD) at the clock it runs at "
+                                      "(shader_clock_ghz: this run's)"},
             "kernels_ms": {"k1_classify_hist": 1e3 * worst[0], "k2_pvalue": 1e3 * worst[1], "k3_bh_sort_scan": 1e3 * worst[2]},
             "bh_rows_sorted_rank0": M.get("bh_sorted"),
             "bh_sort_rank0": M.get("sort_stats"),

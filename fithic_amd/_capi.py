@@ -117,6 +117,7 @@ SYMBOLS = {
     "fhx_kernel_seconds_total": (ctypes.c_int, [_P, _F64P, _I64P, ctypes.c_int]),
     "fhx_kernel_events_dropped": (ctypes.c_int, [_P, _I64P]),
     "fhx_k2_heavy_launch": (ctypes.c_int, [_P, _F64P, _I64P]),
+    "fhx_k2_heavy_clock": (ctypes.c_int, [_P, _F64P]),
     "fhx_k2_class_rows": (ctypes.c_int, [_P, _I64P]),
     "fhx_bdtrc_array": (ctypes.c_int, [_P, ctypes.c_double, _I32P, _F64P, ctypes.c_int64, _F64P]),
     "fhx_debug_format": (ctypes.c_int, [_P, _F64P, ctypes.c_int64, ctypes.c_int32, ctypes.c_char_p, _I32P]),
@@ -698,6 +699,12 @@ class Context:
         sec, rows = ctypes.c_double(0), ctypes.c_int64(0)
         self._check(self._L.fhx_k2_heavy_launch(self._h, ctypes.byref(sec), ctypes.byref(rows)))
         return sec.value, rows.value
+
+    def k2_heavy_clock(self):
+        """GHz the last heavy launch ran at (0.0: it held no task)"""
+        ghz = ctypes.c_double(0)
+        self._check(self._L.fhx_k2_heavy_clock(self._h, ctypes.byref(ghz)))
+        return ghz.value
 
     def k2_class_rows(self):
         """rows the last pvalues() queued per class: power series, incbcf, incbd, swapped incbcf (300 iterations), closed form >= 0.01"""

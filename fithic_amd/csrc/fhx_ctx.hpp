@@ -197,7 +197,7 @@ constexpr int SORT_PASSES = 6;                        // even: the result lands 
 // With 2048 digits a 4096-key tile leaves runs of two keys per digit: every 16-byte (keys) / 8-byte (payloads) run dirties a
 // 32-byte sector of its own and a pass wrote 463 MB for 181 MB of data (PMC, profiles/r04_z_od1_pmc.txt); with 256 digits the
 // runs are 16 keys = whole lines, and the two extra passes cost less than that: K3 over 1.5e7 survivors 2.70 -> 2.12 ms
-// (11 / 10 / 9 / 8 bits: 2.70 / 3.12 / 2.15-2.25 / 2.12 ms, same digest of all p and q; profiles/r04_n_rs_bits_ab.txt).
+// (11 / 10 / 9 / 8 bits: 2.70 / 3.12 / 2.15-2.25 / 2.12 ms, same digest of all p and q; profiles/history/r04_n_rs_bits_ab.txt).
 constexpr int SORT_BITS_LARGE = 8;
 
 constexpr int TOP_SHIFT = 50;

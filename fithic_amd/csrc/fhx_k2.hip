@@ -389,12 +389,12 @@ __global__ __launch_bounds__(K2_THREADS) void k2_closed(K2Params P, QSpan q, uns
 
 // A class queue seen as ONE dense list across its shards (round 4).  Until then a consumer workgroup took whole shards - 2048
 // workgroups where the chip holds 1024 (converging classes) to 1536 (power series) at a time, each with whatever its shard held
-// and a partial tile at every shard's end; the timeline of a 1/8 shard of C3 (profiles/r04_tl_shard8.txt) had these kernels a
+// and a partial tile at every shard's end; the timeline of a 1/8 shard of C3 (profiles/history/r04_tl_shard8.txt) had these kernels a
 // third over their share of the full-size run.  Now every consumer workgroup builds the exclusive prefix of the shard counts in
 // LDS (one DPP scan) and takes dense pieces of that list, and the launches are sized to what the chip holds at a time
 // (`resident_grid`).  How the pieces are handed out follows from what a returning atomic on ONE address costs here - 11 ns,
 // whoever asks (profiles/history/r02_s_classify_variants.txt): a counter for every 256 entries of the power-series class took twice the
-// time of the kernel it fed (0.67 against 0.35 ms, profiles/r04_p_kernel_stats.txt), so that class is cut into one contiguous
+// time of the kernel it fed (0.67 against 0.35 ms, profiles/history/r04_p_kernel_stats.txt), so that class is cut into one contiguous
 // range per wave; the 1024-entry tiles of the converging classes and the 300-iteration tasks of k2h_heavy are few enough
 // for a counter, and each taker's FIRST piece is its own number, so that nobody queues for the counter at the start.
 // C3: converging classes 1.11 + 0.96 -> 1.02 + 0.89 ms, k2h_heavy 6.47 -> 5.69 ms (profiles/r04_z_kernel_stats.txt).
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE)
     H.flush(P.top_hist);
 }
 
-// Measured and dropped (round 4, profiles/r04_v_cf_split_ab.txt, profiles/ab_cf_split.sh): the same two classes as a LOOP kernel
+// Measured and dropped (round 4, profiles/history/r04_v_cf_split_ab.txt, profiles/ab_cf_split.sh): the same two classes as a LOOP kernel
 // (count-sorted tile, no histogram, continued fraction only: 72-86 VGPRs, 7 workgroups per CU, result through 8 B per entry) and a
 // FINISH kernel (queue order, Cephes' three logs and exp, histogram: 7 per CU).  Bit-identical, and slower: loop 0.80 + 0.65 ms,
 // finish 0.44 + 0.44 ms against 1.03 + 0.90 ms fused - compiled for 5 or 7 waves per SIMD the loop kernel takes the same time
@@ -677,6 +677,9 @@ struct K2HeavyParams {            // the few fields of K2Params this kernel read
     double* p;
     unsigned long long* top_hist;
 };
+// shader-cycle and constant-rate counters at the start and at the end of the first wave of k2h_heavy's workgroup 0 (a symbol, not a
+// kernel argument: the kernel sits at its SGPR limit and a pointer held across its loop was four more spills)
+__device__ unsigned long long g_k2h_clk[4];
 
 // R rows per lane (a task = 64 R consecutive entries of one bucket: every bucket starts at a multiple of that), WPE waves per
 // SIMD: see cf_swapped_uniform for why more rows per lane beat more waves.
@@ -694,9 +697,15 @@ __global__ __launch_bounds__(K2H_THREADS) __attribute__((amdgpu_waves_per_eu(WPE
     constexpr unsigned int TASK = 64u * R;
     const unsigned int n_tasks = off[K2H_GENERIC] / TASK;        // tasks in front of the generic bucket
     // tasks are handed out by a counter (round 4): with a fixed stride a 1/8 shard of C3 gave 27 % of the waves four tasks and
-    // the others three - the launch took 4/3.3 of its share of the full-size one (profiles/r04_tl_shard8.txt).  One returning
+    // the others three - the launch took 4/3.3 of its share of the full-size one (profiles/history/r04_tl_shard8.txt).  One returning
     // atomic per 300 x 92 instructions of work.
     const unsigned int n_waves = gridDim.x * (K2H_THREADS / 64);
+    // the clock this launch runs at (boxes differ by 4 %: what "the VALU issue floor" is in milliseconds depends on it): one wave
+    // leaves s_memtime (shader cycles) and s_memrealtime (constant rate) at its start and its end - stored at once, nothing kept
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        g_k2h_clk[0] = __builtin_amdgcn_s_memtime();
+        g_k2h_clk[1] = __builtin_amdgcn_s_memrealtime();
+    }
     for (unsigned int task = blockIdx.x * (K2H_THREADS / 64) + wave; task < n_tasks;) {
         const unsigned int first = task * TASK;
         // bucket of this task: the last b with off[b] <= first (empty buckets share their successor's start: skip them)
@@ -750,6 +759,10 @@ __global__ __launch_bounds__(K2H_THREADS) __attribute__((amdgpu_waves_per_eu(WPE
         if (lane == 0) next = atomicAdd(next_task, 1u);
         task = n_waves + (unsigned int)__builtin_amdgcn_readfirstlane((int)next);
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        g_k2h_clk[2] = __builtin_amdgcn_s_memtime();
+        g_k2h_clk[3] = __builtin_amdgcn_s_memrealtime();
+    }
     H.flush(P.top_hist);
 }
 
@@ -777,7 +790,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2h_generic(K2Params P, const QEnt
     H.flush(P.top_hist);
 }
 
-// (Measured and dropped in round 4, profiles/r04_h_cfu_ab.txt: the two CONVERGING classes through the heavy class's machinery -
+// (Measured and dropped in round 4, profiles/history/r04_h_cfu_ab.txt: the two CONVERGING classes through the heavy class's machinery -
 // counting-sorted by (binomial, orientation, count), iteration constants from a table row per iteration through scalar loads,
 // four rows per lane, the loop stopped in blocks of eight iterations.  Bit-identical (same digest of all p and q), and the
 // loop kernels were 15 % (incbcf: 1.12 -> 0.95 ms) and 2 % (incbd: 0.96 -> 0.94 ms) faster than k2_queue_by_count - a wave of 256
@@ -1177,7 +1190,7 @@ int fhx_pvalues(fhx_ctx* ctx) {
     // rows - classifies every row as trivial and reaches no class kernel: it does not count)
     const bool small_n = (P.intra.small_n && P.intra.n >= 1.0) || (P.inter.small_n && P.inter.n >= 1.0);
     // one range per wave of TWICE the resident workgroups: the ranges are cut by entries, not by work, and the second half
-    // evens the first one out (C3: 376 us at 1 x, 358 at 2.3 x, 362 at 4.7 x, profiles/r04_t_ps.txt); FHX_PS_GRID: measurements
+    // evens the first one out (C3: 376 us at 1 x, 358 at 2.3 x, 362 at 4.7 x, profiles/history/r04_t_ps.txt); FHX_PS_GRID: measurements
     static const int ps_grid = std::getenv("FHX_PS_GRID") ? std::atoi(std::getenv("FHX_PS_GRID")) : 0;
 #define FHX_LAUNCH_QUEUE(CLS)                                                                                         \
     do {                                                                                                              \
@@ -1214,7 +1227,7 @@ int fhx_pvalues(fhx_ctx* ctx) {
         const int heavy_rows = heavy_rows_env ? std::atoi(heavy_rows_env) : 0;
         static const int heavy_wpe = std::getenv("FHX_K2H_WAVES") ? std::atoi(std::getenv("FHX_K2H_WAVES")) : 0;
         // a small input (a shard of a strong-scaling run) has a handful of 256-entry tasks per wave and ends with most waves idle:
-        // two rows per lane at eight waves per SIMD halves the task (a 1/8 shard of C3: 876 -> 829 us, profiles/r04_t_rows.txt)
+        // two rows per lane at eight waves per SIMD halves the task (a 1/8 shard of C3: 876 -> 829 us, profiles/history/r04_t_rows.txt)
         const int hr = (heavy_rows == 1 || heavy_rows == 2) ? heavy_rows       // the instantiations below: 1, 2 or 4 rows per lane - the
                        : (heavy_rows == 0 && k2_n < 32000000) ? 2 : 4;         // bucket granule must be the launched kernel's task size
         hipLaunchKernelGGL(k2h_offsets_and_tables, dim3(K2H_GENERIC + 1), dim3(1024), 0, ctx->stream, (const unsigned int*)ctx->d_digit_total,
@@ -1530,6 +1543,22 @@ int fhx_fetch_outlier_rows(fhx_ctx* ctx, int64_t* rows, int64_t cap, int64_t* n_
                        (const unsigned long long*)d_offsets, d_rows);
     FHX_HIP(hipMemcpyAsync(rows, d_rows, (size_t)total * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     FHX_HIP(hipStreamSynchronize(ctx->stream));
+    return FHX_OK;
+}
+
+// the shader clock the last heavy launch ran at, GHz: cycles a wave of it counted (s_memtime) over the constant-rate ticks of the same
+// stretch (s_memrealtime, hipDeviceAttributeWallClockRate); 0 when the launch held no task
+int fhx_k2_heavy_clock(fhx_ctx* ctx, double* ghz) {
+    if (!ctx || !ghz) return FHX_ERR_ARG;
+    if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
+    if (!ctx->ev_valid[1]) return fail(ctx, FHX_ERR_ARG, "fhx_pvalues has not run");
+    FHX_HIP(hipSetDevice(ctx->device));
+    FHX_HIP(hipStreamSynchronize(ctx->stream));
+    unsigned long long w[4] = {0, 0, 0, 0};
+    FHX_HIP(hipMemcpyFromSymbol(w, HIP_SYMBOL(g_k2h_clk), sizeof(w), 0, hipMemcpyDeviceToHost));
+    int khz = 0;
+    FHX_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device));
+    *ghz = (w[3] > w[1] && w[2] > w[0] && khz > 0) ? (double)(w[2] - w[0]) / ((double)(w[3] - w[1]) / ((double)khz * 1e3)) / 1e9 : 0.0;
     return FHX_OK;
 }
 

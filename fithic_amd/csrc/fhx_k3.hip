@@ -329,9 +329,9 @@ __global__ __launch_bounds__(SORT_BLOCKS) void rs_scan(unsigned int* __restrict_
 // LDS decides how many workgroups a CU holds, and with them how much of the ranking's latency (dependent LDS reads and writes,
 // 12 ballots per key) is hidden.  Round 3's layout - counters 16 KB + keys 32 KB + payloads 16 KB + two offset tables - came to
 // 81 936 B: ONE 256-thread workgroup per CU, one wave per SIMD, 271 us per pass over 1.5e7 keys (1.3 TB/s,
-// profiles/r04_b_od1_kernel_stats.txt).  Now 512 threads per tile of 4096 keys and the per-wave counters share their 32 KB with
+// profiles/history/r04_b_od1_kernel_stats.txt).  Now 512 threads per tile of 4096 keys and the per-wave counters share their 32 KB with
 // the staged keys (a key's slot is in a register by the time the counters die): 64 KB, two workgroups = 16 waves per CU.
-// (Measured and dropped, profiles/r04_e_rs_ab.txt: no staging at all - keys written straight from registers to
+// (Measured and dropped, profiles/history/r04_e_rs_ab.txt: no staging at all - keys written straight from registers to
 // global_base[digit] + rank - is 45 % slower, the tile-wide reordering is what coalesces the writes of the passes over the
 // exponent bits; squeezing the kernel to 80 VGPRs for a third workgroup per CU spills and is slower still.)
 
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(KS_THREADS) void ks_tile_sort(const unsigned long l
                                                            unsigned int* __restrict__ vals_out) {
     // The tile lives in LDS; a compare-exchange at stride j pairs element i with i + j.  Strides of 8 and more: four pairs per
     // thread and a barrier per stride; the strides 4, 2, 1 that end every block size: one visit of a thread's eight consecutive
-    // elements, in registers.  (Measured, profiles/r04_l_small_ab.txt: keeping the elements in registers throughout and reaching
+    // elements, in registers.  (Measured, profiles/history/r04_l_small_ab.txt: keeping the elements in registers throughout and reaching
     // the partner lane with wave shuffles for strides 8..256 - 39 of the 78 stages without a barrier - is slower, 75 us
     // against 45 for three tiles: 24 ds_bpermute per stage cost more than the barriers they save.)
     __shared__ unsigned long long sk[KS_TILE];
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(BH_THREADS) void bh_apply(const unsigned long long*
     }
 }
 
-// (Measured and dropped in round 4, profiles/r04_f_small_ab.txt: ONE resident launch for small survivor sets - 64 workgroups,
+// (Measured and dropped in round 4, profiles/history/r04_f_small_ab.txt: ONE resident launch for small survivor sets - 64 workgroups,
 // a tile each, the six passes and the BH scan separated by device-wide barriers instead of 21 launches.  The kernels of a small
 // sort already run back to back without gaps (profiles/history/r03_z_c2_timeline.txt); what a launch boundary costs is what a
 // device-scope barrier costs too - the eight XCDs' L2s are made coherent by writing them back - and 19 such barriers took

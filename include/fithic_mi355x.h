@@ -311,6 +311,9 @@ int fhx_kernel_events_dropped(fhx_ctx* ctx, int64_t* dropped4);
 /* Duration (HIP events on the context's stream) and row count of the dominant launch of the last fhx_pvalues: the queue
  * of rows whose continued fraction runs to Cephes' 300-iteration cap (k2_queue<BC_CF_SWAPPED>). */
 int fhx_k2_heavy_launch(fhx_ctx* ctx, double* seconds, int64_t* rows);
+/* The shader clock (GHz) that launch ran at, sampled by one of its waves (cycle counter over the constant-rate counter): what turns
+ * a count of VALU wave-instructions into the milliseconds of an issue-bound launch on THIS box (bench.py: valu_issue_floor_ms). */
+int fhx_k2_heavy_clock(fhx_ctx* ctx, double* ghz);
 /* Rows the last fhx_pvalues queued per branch class of incbet (the per-pair branch table of fithic/fithic.py:1057-1116 followed
  * into Cephes): out5 = power series, converging incbcf, incbd, swapped incbcf (the 300-iteration class), closed form with
  * prior >= 0.01.  Every other row was finished by the classification launch itself (constants, closed form with a small prior).

@@ -1,5 +1,5 @@
 # (record of a dropped experiment: k2_cf_loop / k2_cf_finish and their FHX_CF_* switches are not in the tree any more; the result is
-# profiles/r04_v_cf_split_ab.txt, the kernels are described where they were, in fhx_k2.hip)
+# profiles/history/r04_v_cf_split_ab.txt, the kernels are described where they were, in fhx_k2.hip)
 # the converging classes as loop kernel + finish kernel against the fused kernel: parity files, then the C3 kernel summary of each
 # variant on one box (FHX_CF_SPLIT=0 fused; loop / finish compiled for 5 or 7 waves per SIMD), digest of all p and q in every line
 mkdir -p gpurun_out/r04

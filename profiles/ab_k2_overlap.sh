@@ -1,4 +1,4 @@
-# (record of a dropped experiment: FHX_K2_OVERLAP and the second stream are not in the tree; result: profiles/r04_ov_k2_overlap_ab.txt)
+# (record of a dropped experiment: FHX_K2_OVERLAP and the second stream are not in the tree; result: profiles/history/r04_ov_k2_overlap_ab.txt)
 # the converging classes on a lowest-priority stream beside k2h_heavy (FHX_K2_OVERLAP=1): both eligible at the same event, the heavy
 # launch takes every register file first, the class kernels' workgroups start as its waves run out of tasks.  C3 and the 1/8 shard,
 # digest of all p and q in every line.

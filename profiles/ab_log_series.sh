@@ -1,4 +1,4 @@
-# (record of a dropped experiment; result: profiles/r04_lg_log_series_ab.txt)  In incbet's tail the logarithm of the operand that is
+# (record of a dropped experiment; result: profiles/history/r04_lg_log_series_ab.txt)  In incbet's tail the logarithm of the operand that is
 # fl(1 - prior) from a 9-instruction series -(d + d^2 (1/2 + d/3 + d^2/4 + d^3/5 + d^4/6)), d = 1 - v exact, for d < 2^-10 (checked on
 # the CPU against 60-digit logarithms: within 0.5 ulp, identical to glibc's log on 40 000 arguments), the library's log otherwise.
 # "nolog" = a second library built with the series compiled out, chosen by FHX_LIB.
