@@ -297,6 +297,8 @@ int fhx_make_bins(fhx_ctx* ctx, int32_t* n_bins_made) {
     return FHX_OK;
 }
 
+#include "fhx_nfpairs.inc"
+
 int fhx_fit(fhx_ctx* ctx, fhx_fit_info* out) {
     if (!ctx) return FHX_ERR_ARG;
     if (!ctx->have_params || !ctx->have_frags) return fail(ctx, FHX_ERR_ARG, "parameters and fragments must be loaded");
@@ -336,6 +338,10 @@ int fhx_fit(fhx_ctx* ctx, fhx_fit_info* out) {
     } join_side{side};
     PassInputs in;
     fill_pass_inputs(ctx, in);
+    if (ctx->device >= 0 && in.resolution == 0)          // -r 0: the walk over all possible pairs runs on the GPU (fhx_nfpairs.inc)
+        in.nf_pairs = [ctx, &in](const std::vector<Bin>& bins, NfPairSums& sums) {
+            return nf_pairs_on_device(ctx, ctx->frags, in.dist_low, in.dist_up, bins, sums);
+        };
     std::string err;
     const int rc = run_host_pass(in, ctx->frags, ctx->fit, err);
     if (rc != FHX_OK) return fail(ctx, rc, err);

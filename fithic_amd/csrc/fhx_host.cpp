@@ -906,7 +906,17 @@ int run_host_pass(const PassInputs& in, const FragTable& frags, PassFit& out, st
                 }
             }
         }
-        if (nb > 0) {
+        NfPairSums given;
+        const bool have_given = nb > 0 && in.nf_pairs && in.nf_pairs(out.bins, given) && (int64_t)given.poss.size() == nb &&
+                                (int64_t)given.poss7.size() == nb && (int64_t)given.sumdist.size() == nb;
+        if (have_given) {                                        // the caller walked the pairs (fhx_fit: on the GPU)
+            for (int64_t b = 0; b < nb; ++b) {
+                out.bins[(size_t)b].poss7 += given.poss7[(size_t)b];
+                out.bins[(size_t)b].poss += given.poss[(size_t)b];
+                out.bins[(size_t)b].sumdist = given.sumdist[(size_t)b];
+                poss_intra_all += given.poss[(size_t)b];
+            }
+        } else if (nb > 0) {
             struct BinSums {
                 int64_t poss7 = 0, poss = 0;
                 double sumdist = 0.0;

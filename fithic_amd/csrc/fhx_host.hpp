@@ -5,6 +5,7 @@
 // The O(#pairs) work lives in fhx_kernels.hip.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -57,7 +58,17 @@ struct FragTable {             // fragments file reduced to what generate_FragPa
     std::vector<std::vector<int32_t>> mids;
 };
 
+// generate_FragPairs' non-fixed-size branch (fithic.py:691-778) as its caller may supply it: the per-bin sums over every in-range
+// pair of mappable fragments.  fhx_fit computes them on the GPU (csrc/fhx_nfpairs.inc) - the bins must exist first, so
+// run_host_pass asks for them between makeBinsFromInteractions and the fit; a host-only context walks the pairs on its threads.
+struct NfPairSums {
+    std::vector<int64_t> poss, poss7;            // binStats[b][1], [7] increments
+    std::vector<double> sumdist;                 // binStats[b][3]: the sequential double sum in (chromosome, x, y) order
+};
+
 struct PassInputs {
+    // (bins after makeBinsFromInteractions) -> sums; false: not available, walk the pairs here
+    std::function<bool(const std::vector<Bin>&, NfPairSums&)> nf_pairs;
     int64_t resolution = 0, dist_low = 0, dist_up = INT64_MAX;
     int32_t n_bins = 100;
     int32_t mode = 0;

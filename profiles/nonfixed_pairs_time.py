@@ -60,6 +60,23 @@ def main():
         ctx.close()
     assert out["1"][1:] == out["0"][1:], "threaded enumeration differs from the single-thread walk"
     print("bin sums of distances and possible-pair counts identical bit for bit; speed-up %.1fx" % (out["1"][0] / out["0"][0]))
+    # round 6: the same fit on a context with a GPU - the walk runs there (csrc/fhx_nfpairs.inc: chains as scans of parity maps)
+    try:
+        for rep in range(2):                                   # (the second call: buffers and code are warm)
+            ctx = _capi.Context(0)
+            ctx.set_params(0, args.lower, args.upper, 100, 1, _capi.MODE_INTRA_ONLY)
+            ctx.load_fragments(chr_ids, mids, np.ones(len(mids), np.int32), rank)
+            ctx.set_dist_keys(keys)
+            ctx.set_global_stats(st, sumcc, np.ones(len(keys), np.int64))
+            t0 = time.perf_counter()
+            info = ctx.fit()
+            dt = time.perf_counter() - t0
+            got = (info.possible_intra_in_range, ctx.get_array(_capi.A_BIN_SUMDIST).tobytes(), ctx.get_array(_capi.A_BIN_POSS7).tobytes())
+            print("GPU context, call %d: fit %.3f s = %.0f e6 pairs/s; %s the host walk bit for bit" %
+                  (rep + 1, dt, info.possible_intra_in_range / dt / 1e6, "EQUALS" if got == out["1"][1:] else "DIFFERS FROM"), flush=True)
+            ctx.close()
+    except _capi.FhxError as e:
+        print("no GPU context: %s" % e)
 
 
 if __name__ == "__main__":
