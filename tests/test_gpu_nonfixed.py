@@ -73,12 +73,23 @@ def test_possible_pair_sums_equal_the_host_walk(seed):
     assert pairs >= 0
 
 
-@pytest.mark.parametrize("seed,n_bins", [(1, 1), (2, 5), (3, 100)])
+@pytest.mark.parametrize("seed,n_bins", [(1, 4), (2, 20), (3, 40), (4, 100)])
 def test_long_chains_cross_many_binades(seed, n_bins):
-    """thousands of fragments per chromosome: chains of up to 10^7 terms (hundreds of windows of 16 384 terms, some twenty binade
-    crossings each, ties among the terms)"""
+    """thousands of fragments per chromosome, contact counts that fall with the distance (so that the fit behind the walk goes
+    through): chains of up to 10^7 terms - hundreds of windows of 16 384 terms, some twenty binade crossings each, ties among them"""
     rng = np.random.default_rng(900 + seed)
-    pairs = _compare(_case(rng, 3, 4000, 40_000_000, n_bins))
+    f_chr, f_mid, f_hit = [], [], []
+    for c in range(3):
+        n = int(rng.integers(2500, 4500))
+        mids = np.sort(rng.integers(0, 40_000_000, n))
+        f_chr += [c] * n
+        f_mid += [int(v) for v in mids]
+        f_hit += [1] * n
+    L, U = 10000, float(rng.choice([np.inf, 20_000_000]))
+    keys = np.unique(rng.integers(L, 30_000_000, 20000)).astype(np.int64)
+    sumcc = np.maximum(1, (3e6 * (keys / 1e4) ** -1.08 * rng.random(len(keys))).astype(np.int64))
+    rank = np.arange(3, dtype=np.int32)
+    pairs = _compare((f_chr, f_mid, f_hit, rank, keys, sumcc, L, U, n_bins))
     assert pairs > 3_000_000
 
 
