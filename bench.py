@@ -439,13 +439,22 @@ def main():
         eng.ctx.kernel_seconds_total(reset=True)           # the library sums its HIP events per pass from here on
         barrier()
         torch.cuda.synchronize()
+        # The interpreter's cyclic garbage collector stays out of the timed region: one full collection over this process's objects
+        # (torch, numpy, the synthetic genome's tables) is a 50 ms pause in whatever Python statement triggers it - it hit one step in
+        # thirty of a 2 ms pass (profiles/r06/forced_dist_step_trace.txt) and is no part of the library's pass.
+        import gc
+        gc.collect()
+        gc.disable()
         t0 = time.perf_counter()
         info = None
-        for _ in range(steps):
-            info = one_step(timed=True)                    # nothing but the K passes in the timed region: the events are read by the
-        torch.cuda.synchronize()                           # library where it waits for its stream anyway (fhx_kernel_seconds_total)
-        barrier()
-        elapsed = time.perf_counter() - t0
+        try:
+            for _ in range(steps):
+                info = one_step(timed=True)                # nothing but the K passes in the timed region: the events are read by the
+            torch.cuda.synchronize()                       # library where it waits for its stream anyway (fhx_kernel_seconds_total)
+            barrier()
+            elapsed = time.perf_counter() - t0
+        finally:
+            gc.enable()
         if eng.call_seconds is not None and eng.call_seconds[4]:
             log("host seconds per pass inside pass_stats / fit / pvalues / bh (FHX_CALL_TIMES): " +
                 " / ".join("%.1f us" % (1e6 * v / eng.call_seconds[4]) for v in eng.call_seconds[:4]))
@@ -827,6 +836,8 @@ class NativeRunner:
         # (the wall time of the one C call next to the sum of its stages, and of the bookkeeping behind it: where a pass's host time goes)
         self.timings["whole_call"] = self.timings.get("whole_call", 0.0) + (t1 - t0)
         self.timings["bookkeeping"] = self.timings.get("bookkeeping", 0.0) + (time.perf_counter() - t1)
+        if os.environ.get("FHX_STEP_TRACE"):
+            sys.stderr.write("step trace: call %.3f ms, behind it %.3f ms\n" % (1e3 * (t1 - t0), 1e3 * (time.perf_counter() - t1)))
         return info
 
     def next_pass(self):
