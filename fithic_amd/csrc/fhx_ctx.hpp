@@ -189,6 +189,13 @@ constexpr int SORT_THREADS = 256;
 constexpr int SORT_WAVES = SORT_THREADS / 64;
 constexpr int SORT_ITEMS = 16;                        // per thread
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 4096 keys per tile
+// k3_compact / k3_fill_q: tiles of 16 384 rows (one workgroup of 16 waves).  A tile costs ONE returning atomic on the survivors'
+// counter, and returning atomics on one address retire at 11 ns each: with 4096-row tiles the 36 000 tiles of C3 were 0.40 of the
+// kernel's 0.42 ms whatever it read or wrote (profiles/r06/k3_compact_tiles.txt)
+constexpr int CP_THREADS = 1024;
+constexpr int CP_WAVES = CP_THREADS / 64;
+constexpr int CP_ITEMS = 16;
+constexpr int CP_TILE = CP_THREADS * CP_ITEMS;
 constexpr int SORT_BLOCKS = 1024;                     // persistent: 4 workgroups per CU
 constexpr int RADIX_BITS = 11;                       // 6 passes cover 66 >= 64 key bits
 constexpr int RADIX = 1 << RADIX_BITS;

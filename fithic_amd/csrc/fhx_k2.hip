@@ -696,6 +696,10 @@ __global__ __launch_bounds__(K2H_THREADS) __attribute__((amdgpu_waves_per_eu(WPE
     const int lane = threadIdx.x & 63;
     constexpr unsigned int TASK = 64u * R;
     const unsigned int n_tasks = off[K2H_GENERIC] / TASK;        // tasks in front of the generic bucket
+    // (Round 6 tried two launches for small inputs - whole rounds of <4 rows, 4 waves>, the remainder as <1 row, 8 waves> - against
+    // the one <2, 8> launch: 918 against 824 us on a 1/8 shard of C3, 768 against 681 on C2, profiles/r06/heavy_split.txt.  A round
+    // of four-row tasks at four waves per SIMD takes 257 us where the full-size run's rate would make it 222, and the remainder
+    // 170 us: dropped.)
     // tasks are handed out by a counter (round 4): with a fixed stride a 1/8 shard of C3 gave 27 % of the waves four tasks and
     // the others three - the launch took 4/3.3 of its share of the full-size one (profiles/history/r04_tl_shard8.txt).  One returning
     // atomic per 300 x 92 instructions of work.

@@ -140,7 +140,7 @@ struct DenseQ {
 };
 
 template <bool DENSE>
-__global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restrict__ p, int64_t n,
+__global__ __launch_bounds__(CP_THREADS) void k3_compact(const double* __restrict__ p, int64_t n,
                                                            unsigned long long* __restrict__ keys,
                                                            unsigned int* __restrict__ vals, double* __restrict__ q,
                                                            unsigned long long* __restrict__ counter,
@@ -148,25 +148,25 @@ __global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restr
                                                            bool q_is_ones = false) {
     // rows at or above the cutoff key (see above) have q = 1 and are not sorted; NaN rows get q = NaN.
     // one global atomic per 4096-row tile (a same-address atomic per 256 rows capped this kernel at ~88 M atomics/s)
-    __shared__ unsigned int wave_cnt[SORT_WAVES];
+    __shared__ unsigned int wave_cnt[CP_WAVES];
     __shared__ unsigned long long block_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
-    const int64_t tiles = (n + SORT_TILE - 1) / SORT_TILE;
+    const int64_t tiles = (n + CP_TILE - 1) / CP_TILE;
     if (dq.flag && (*dq.flag != 0ull) != DENSE) return;          // both variants are launched; the one the device chose runs
     const unsigned long long cutoff = *cutoff_key;
     const double2* p2 = reinterpret_cast<const double2*>(p);
     double2* q2 = reinterpret_cast<double2*>(q);
     for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
-        const int64_t wave_base = t * SORT_TILE + (int64_t)wave * (64 * SORT_ITEMS);
+        const int64_t wave_base = t * CP_TILE + (int64_t)wave * (64 * CP_ITEMS);
         // two consecutive rows per lane and step: 16-byte loads of p and (for the rows that are not ranked: nearly all) 16-byte
         // stores of q
-        double v[SORT_ITEMS];
-        unsigned int before[SORT_ITEMS];
+        double v[CP_ITEMS];
+        unsigned int before[CP_ITEMS];
         unsigned long long keepmask = 0;          // bit r: this lane keeps item r
         unsigned int run = 0;
 #pragma unroll
-        for (int h = 0; h < SORT_ITEMS / 2; ++h) {
+        for (int h = 0; h < CP_ITEMS / 2; ++h) {
             const int64_t i = wave_base + (int64_t)(h * 64 + lane) * 2;
             bool keep0 = false, keep1 = false;
             v[2 * h] = v[2 * h + 1] = 1.0;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restr
             if (DENSE) {
                 const unsigned long long n0 = __ballot(v[2 * h] != v[2 * h]), n1 = __ballot(v[2 * h + 1] != v[2 * h + 1]);
                 if (lane == 0) {
-                    ulonglong2* m = reinterpret_cast<ulonglong2*>(dq.mask + ((t * SORT_WAVES + wave) * (SORT_ITEMS / 2) + h) * 4);
+                    ulonglong2* m = reinterpret_cast<ulonglong2*>(dq.mask + ((t * CP_WAVES + wave) * (CP_ITEMS / 2) + h) * 4);
                     m[0] = make_ulonglong2(m0, m1);
                     m[1] = make_ulonglong2(n0, n1);
                 }
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restr
         __syncthreads();
         if (threadIdx.x == 0) {
             unsigned int tot = 0;
-            for (int w = 0; w < SORT_WAVES; ++w) {
+            for (int w = 0; w < CP_WAVES; ++w) {
                 const unsigned int c = wave_cnt[w];
                 wave_cnt[w] = tot;
                 tot += c;
@@ -214,9 +214,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restr
         }
         __syncthreads();
         const unsigned long long base = block_base + wave_cnt[wave];
-        if (DENSE && lane == 0) dq.wave_slot[t * SORT_WAVES + wave] = base;
+        if (DENSE && lane == 0) dq.wave_slot[t * CP_WAVES + wave] = base;
 #pragma unroll
-        for (int r = 0; r < SORT_ITEMS; ++r) {
+        for (int r = 0; r < CP_ITEMS; ++r) {
             if ((keepmask >> r) & 1ull) {
                 keys[base + before[r]] = pvalue_key(v[r]);
                 vals[base + before[r]] = DENSE ? (unsigned int)(base + before[r])
@@ -229,21 +229,21 @@ __global__ __launch_bounds__(SORT_THREADS) void k3_compact(const double* __restr
 
 // The whole q column in row order, once: 1.0, the row's own NaN, or - for the rows k3_compact<true> kept - the survivor's q from the
 // dense array (consecutive kept rows of a wave step read consecutive entries).  Same tiles and wave chunks as k3_compact.
-__global__ __launch_bounds__(SORT_THREADS) void k3_fill_q(const double* __restrict__ p, int64_t n, DenseQ dq, double* __restrict__ q) {
+__global__ __launch_bounds__(CP_THREADS) void k3_fill_q(const double* __restrict__ p, int64_t n, DenseQ dq, double* __restrict__ q) {
     if (dq.flag && *dq.flag == 0ull) return;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
-    const int64_t tiles = (n + SORT_TILE - 1) / SORT_TILE;
+    const int64_t tiles = (n + CP_TILE - 1) / CP_TILE;
     double2* q2 = reinterpret_cast<double2*>(q);
     for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
-        const int64_t chunk = t * SORT_WAVES + wave;
-        const int64_t wave_base = chunk * (64 * SORT_ITEMS);
+        const int64_t chunk = t * CP_WAVES + wave;
+        const int64_t wave_base = chunk * (64 * CP_ITEMS);
         if (wave_base >= n) continue;
         const double* mine = dq.dense + dq.wave_slot[chunk];
-        const ulonglong2* m = reinterpret_cast<const ulonglong2*>(dq.mask + chunk * (SORT_ITEMS / 2) * 4);
+        const ulonglong2* m = reinterpret_cast<const ulonglong2*>(dq.mask + chunk * (CP_ITEMS / 2) * 4);
         unsigned int run = 0;
 #pragma unroll
-        for (int h = 0; h < SORT_ITEMS / 2; ++h) {
+        for (int h = 0; h < CP_ITEMS / 2; ++h) {
             const ulonglong2 keep = m[2 * h], nan = m[2 * h + 1];
             const int64_t i = wave_base + (int64_t)(h * 64 + lane) * 2;
             const unsigned int b0 = run + __popcll(keep.x & lane_lt);
@@ -1152,13 +1152,13 @@ static int compact_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned 
     // chunk).  FHX_K3_GRID caps the grid for measurements.
     static const int k3_cap = std::getenv("FHX_K3_GRID") ? std::atoi(std::getenv("FHX_K3_GRID")) : (1 << 30);
     if (dq)
-        hipLaunchKernelGGL(k3_compact<true>, dim3(grid_for(n, SORT_TILE, k3_cap)), dim3(SORT_THREADS), 0, ctx->stream, d_p, n,
+        hipLaunchKernelGGL(k3_compact<true>, dim3(grid_for(n, CP_TILE, k3_cap)), dim3(CP_THREADS), 0, ctx->stream, d_p, n,
                            keys[0], vals[0], d_q, counter, d_cutoff, *dq);
     if (!dq || dq->flag) {                           // (with a flag the device picks one of the two; the other returns at once)
         DenseQ off;
         if (dq) off.flag = dq->flag;
         const bool ones = ctx->q_prefilled && d_q == ctx->d_q && d_p == ctx->d_p;
-        hipLaunchKernelGGL(k3_compact<false>, dim3(grid_for(n, SORT_TILE, k3_cap)), dim3(SORT_THREADS), 0, ctx->stream, d_p, n,
+        hipLaunchKernelGGL(k3_compact<false>, dim3(grid_for(n, CP_TILE, k3_cap)), dim3(CP_THREADS), 0, ctx->stream, d_p, n,
                            keys[0], vals[0], d_q, counter, d_cutoff, off, ones);
     }
     if (d_q == ctx->d_q) ctx->q_prefilled = false;      // from here on the column holds this pass's q
@@ -1246,9 +1246,9 @@ static unsigned int* engine_sort_ctrl(fhx_ctx* ctx) {
 // row + 8 B per 1024 rows - 24 + 2.7 + 8.3 of the workspace's >= 48 B per row.  false: they do not fit (then q is scattered as before).
 static bool engine_dense_q(fhx_ctx* ctx, DenseQ* dq) {
     const size_t cap = std::max<size_t>(4, ((size_t)ctx->n_rows + 3) / 4 * 4);
-    const size_t chunks = (cap + 64 * SORT_ITEMS - 1) / (64 * SORT_ITEMS) + SORT_WAVES;
+    const size_t chunks = (cap + 64 * CP_ITEMS - 1) / (64 * CP_ITEMS) + CP_WAVES;
     size_t at = (cap * 24 + os_scratch_bytes(ctx->n_rows) + 255) / 256 * 256;
-    const size_t dense_bytes = cap * 8, mask_bytes = chunks * (SORT_ITEMS / 2) * 4 * 8, slot_bytes = chunks * 8;
+    const size_t dense_bytes = cap * 8, mask_bytes = chunks * (CP_ITEMS / 2) * 4 * 8, slot_bytes = chunks * 8;
     if (at + dense_bytes + mask_bytes + slot_bytes > ctx->work_bytes) return false;
     dq->dense = reinterpret_cast<double*>(ctx->d_work + at);
     at += dense_bytes;
@@ -1279,7 +1279,7 @@ static int bh_from_sorted(fhx_ctx* ctx, const unsigned long long* keys, const un
                        dq ? dq->flag : (const unsigned long long*)nullptr);
     if (dq) {
         static const int fill_cap = std::getenv("FHX_K3_GRID") ? std::atoi(std::getenv("FHX_K3_GRID")) : (1 << 30);
-        hipLaunchKernelGGL(k3_fill_q, dim3(grid_for(n_rows, SORT_TILE, fill_cap)), dim3(SORT_THREADS), 0, ctx->stream, p_rows, n_rows, *dq,
+        hipLaunchKernelGGL(k3_fill_q, dim3(grid_for(n_rows, CP_TILE, fill_cap)), dim3(CP_THREADS), 0, ctx->stream, p_rows, n_rows, *dq,
                            d_q);
     }
     FHX_HIP(hipGetLastError());
