@@ -1105,8 +1105,10 @@ int fhx::fill_top_hist(fhx_ctx* ctx) {
     return FHX_OK;
 }
 
+// (k2_done: an event the caller has just recorded on the stream - the host sleeps on it before it spins for k3_cutoff's ticket;
+// nullptr: one is recorded here)
 static int auto_cutoff(fhx_ctx* ctx, const double* d_p, int64_t n, double n_total_tests, unsigned long long* d_cutoff,
-                       unsigned long long dense_min = ~0ull, unsigned long long* counter_to_zero = nullptr) {
+                       unsigned long long dense_min = ~0ull, unsigned long long* counter_to_zero = nullptr, hipEvent_t k2_done = nullptr) {
     const unsigned long long* hist = ctx->d_top_hist;
     if (d_p == ctx->d_p && ctx->k2_hist_valid) {
         hist = ctx->d_k2_hist;                          // what K2 counted while it stored p: read where it lies (no copy into d_top_hist)
@@ -1124,8 +1126,12 @@ static int auto_cutoff(fhx_ctx* ctx, const double* d_p, int64_t n, double n_tota
         if (rc == FHX_OK) rc = ensure_flags(ctx);
         if (rc != FHX_OK) return rc;
     }
-    // the stream up to here (K2) gets an event the host can sleep on; what follows it - this one workgroup - is waited for by ticket
-    FHX_HIP(hipEventRecord(ctx->ev_k3, ctx->stream));
+    // the stream up to here (K2) has an event the host can sleep on; what follows it - this one workgroup - is waited for by ticket
+    if (!k2_done) {
+        FHX_HIP(hipEventRecord(ctx->ev_k3, ctx->stream));
+        k2_done = ctx->ev_k3;
+    }
+    ctx->k3_wait_ev = k2_done;
     CutoffToHost host;
     host.words = ctx->h_flags + FLAG_K3;
     host.ticket = ++ctx->ticket;
@@ -1172,7 +1178,7 @@ static int compact_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned 
         // (an UPPER BOUND when the histogram is K2's: it counts a wave's values in the bin of the smallest, fhx_k2.hip FusedHist -
         // every launch below takes its true count from the device counter and sizes its grid for the bound)
         ctx->k3_kept_by_hist = false;
-        FHX_HIP(hipEventSynchronize(ctx->ev_k3));          // K2 is through (the host sleeps: milliseconds) ...
+        FHX_HIP(hipEventSynchronize(ctx->k3_wait_ev));     // K2 is through (the host sleeps: milliseconds) ...
         FHX_HIP(wait_ticket(ctx, FLAG_K3, ctx->k3_ticket));   // ... and k3_cutoff's one workgroup (microseconds: spin)
         const unsigned long long by_hist = ctx->h_flags[FLAG_K3 + 1];
         n_kept = std::min<unsigned long long>(by_hist, (unsigned long long)n);
@@ -1449,7 +1455,7 @@ int fhx_bh(fhx_ctx* ctx, double n_total_tests) {
         dense_min = dense_env == 1 ? 0ull : (unsigned long long)(((long double)ctx->n_rows * dense_env + 99) / 100);
         dq.flag = ctx->d_misc + MISC_K3_DENSE;
     }
-    int rc = auto_cutoff(ctx, ctx->d_p, ctx->n_rows, n_total_tests, ctx->d_misc + 6, dense_min, ctx->d_misc);
+    int rc = auto_cutoff(ctx, ctx->d_p, ctx->n_rows, n_total_tests, ctx->d_misc + 6, dense_min, ctx->d_misc, ctx->ev[4]);
     if (rc != FHX_OK) return rc;
     int64_t kept = 0;
     rc = rank_and_adjust(ctx, ctx->d_p, ctx->n_rows, ctx->d_keys, ctx->d_vals, ctx->d_q, ctx->d_misc, ctx->d_misc + 6, n_total_tests,
