@@ -749,6 +749,8 @@ class ShardedEngine:
         host and hands the columns out: load_contacts)."""
         from . import tables
         per = max(1, (os.cpu_count() or 1) // self.world) if not threads else threads
+        if os.environ.get("FHX_CLI_THREADS_PER_RANK"):         # measurements: a fixed number of host threads per rank, whatever N
+            per = max(1, int(os.environ["FHX_CLI_THREADS_PER_RANK"]))
         if os.environ.get("FHX_CLI_SPLIT", "file") != "chromosome":
             con = self._ingest_slices(path, chroms, per)
             if con is not None:
