@@ -361,6 +361,7 @@ struct fhx_ctx {
     unsigned int* h_k3 = nullptr;                     // pinned: [0..1] survivors by the histogram, [8..15] the sort repair's verdict
     hipEvent_t ev_k3 = nullptr;                       // the copy into h_k3
     bool k3_n_is_bound = false;                       // the survivors' number compact_pvalues returned is an upper bound
+    int64_t k3_last_kept = -1, k3_last_rows = -1;     // survivors and rows of the last fhx_bh: whether the dense-q launches are worth enqueueing
     hipEvent_t k3_wait_ev = nullptr;                  // the event recorded in front of k3_cutoff (K2's end) the host sleeps on
     unsigned long long k3_ticket = 0;                 // the ticket k3_cutoff publishes behind the survivors' number (h_flags[FLAG_K3 + 1])
     bool k3_counter_zeroed = false;                   // k3_cutoff zeroes the compaction's counter (auto_cutoff), no fill in front of k3_compact

@@ -1385,6 +1385,7 @@ int fhx_bh_sort_stats(fhx_ctx* ctx, int64_t* out8) {
 int fhx_bh_local_sort(fhx_ctx* ctx) {
     if (!ctx) return FHX_ERR_ARG;
     ctx->k3_kept_by_hist = false;            // (sharded runs: the cutoff comes from the all-reduced histogram, the count from the counter)
+    ctx->k3_counter_zeroed = false;          // (... and nothing has zeroed the counter ahead of the compaction)
     if (ctx->device < 0) return fail(ctx, FHX_ERR_NO_DEVICE, "host-only context");
     if (!ctx->have_p) return fail(ctx, FHX_ERR_ARG, "fhx_pvalues must run first");
     FHX_HIP(hipSetDevice(ctx->device));
@@ -1449,7 +1450,11 @@ int fhx_bh(fhx_ctx* ctx, double n_total_tests) {
     // (profiles/r06_k3_dense_q.txt).  FHX_K3_DENSE: 1 = always, 0 = never, otherwise the percentage (measurements, tests).
     static const int dense_env = std::getenv("FHX_K3_DENSE") ? std::atoi(std::getenv("FHX_K3_DENSE")) : K3_DENSE_PERCENT;
     DenseQ dq;
-    const bool dense = dense_env != 0 && engine_dense_q(ctx, &dq);
+    // (a row set whose last pass left under a tenth of its rows below the cutoff will not leave 35 % now: the dense variant's two
+    // launches - which would return at once - are not even enqueued then; the decision itself stays the device's whenever they are)
+    const bool far_below = dense_env != 1 && ctx->k3_last_rows == ctx->n_rows && ctx->k3_last_kept >= 0 &&
+                           ctx->k3_last_kept * 10 < ctx->n_rows;
+    const bool dense = dense_env != 0 && !far_below && engine_dense_q(ctx, &dq);
     unsigned long long dense_min = ~0ull;
     if (dense) {
         dense_min = dense_env == 1 ? 0ull : (unsigned long long)(((long double)ctx->n_rows * dense_env + 99) / 100);
@@ -1462,6 +1467,8 @@ int fhx_bh(fhx_ctx* ctx, double n_total_tests) {
                          ctx->d_tile_max, &ctx->sorted_buf, &kept, 62, engine_sort_ctrl(ctx), dense ? &dq : nullptr);
     if (rc != FHX_OK) return rc;
     ctx->n_sorted = ctx->k3_n_is_bound ? -2 : kept;      // -2: fhx_n_sorted reads the device counter when somebody asks
+    ctx->k3_last_kept = kept;                            // (the histogram's bound or the exact number: either serves the guess above)
+    ctx->k3_last_rows = ctx->n_rows;
     FHX_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
     ctx->ev_valid[2] = true;
     ctx->ev_folded[2] = false;
