@@ -306,11 +306,10 @@ int fhx_fit(fhx_ctx* ctx, fhx_fit_info* out) {
     static const bool fit_times = std::getenv("FHX_FIT_TIMES") != nullptr;      // measurements: where the host part of a pass goes
     const auto t0 = std::chrono::steady_clock::now();
     // The per-count tables (log Beta and 1 / Beta of (count, n - count + 1): two lgamma each) depend on K1's statistics alone, not
-    // on the fit: with large counts (40 kb bins: 16 000 entries, 210 us - as long as the whole fit) they are built on two threads of
-    // their own while this one bins and fits; a thread costs ~15 us to start, so small tables (5 kb bins: 700 entries) stay inline.
+    // on the fit: with large counts (40 kb bins: 16 000 entries, 210 us - as long as the whole fit) they are built by the context's two
+    // parked side threads while this one bins and fits; small tables (5 kb bins: 700 entries, 10 us) stay inline.
     const int64_t mc = std::max<int64_t>(ctx->stats.max_count, 1);
     std::vector<double> lb_a, ib_a, lb_e, ib_e;
-    std::thread side[2];
     const bool tables_aside = ctx->device >= 0 && mc >= 2048 && !std::getenv("FHX_FIT_SERIAL");
     if (tables_aside) {
         const double n_a = bdtrc_total(ctx->prm, ctx->stats.in_range_sum), n_e = bdtrc_total(ctx->prm, ctx->stats.inter_sum);
@@ -320,22 +319,23 @@ int fhx_fit(fhx_ctx* ctx, fhx_fit_info* out) {
         ib_e.assign((size_t)mc + 1, 0.0);
         const int64_t mid = mc / 2;
         double *la = lb_a.data(), *ia = ib_a.data(), *le = lb_e.data(), *ie = ib_e.data();
-        side[0] = std::thread([=] {
+        ctx->side.start();
+        ctx->side.run(0, [=] {
             fill_lbeta_table(n_a, 1, mid, la, ia);
             fill_lbeta_table(n_e, 1, mid, le, ie);
         });
-        side[1] = std::thread([=] {
+        ctx->side.run(1, [=] {
             fill_lbeta_table(n_a, mid + 1, mc, la, ia);
             fill_lbeta_table(n_e, mid + 1, mc, le, ie);
         });
     }
-    struct Join {
-        std::thread* t;
+    struct Join {                                        // (the tables' vectors must outlive the workers on every return path)
+        SideWorkers* w;
+        bool on;
         ~Join() {
-            for (int k = 0; k < 2; ++k)
-                if (t[k].joinable()) t[k].join();
+            if (on) w->wait();
         }
-    } join_side{side};
+    } join_side{&ctx->side, tables_aside};
     PassInputs in;
     fill_pass_inputs(ctx, in);
     if (ctx->device >= 0 && in.resolution == 0)          // -r 0: the walk over all possible pairs runs on the GPU (fhx_nfpairs.inc)
@@ -359,8 +359,7 @@ int fhx_fit(fhx_ctx* ctx, fhx_fit_info* out) {
         // prior LUT (fixed-size) or the spline table itself (-r 0) + the two pairs of per-count tables: packed into the pinned
         // staging buffer and sent with one copy; nothing waits for it here (the stream orders it before K2)
         if (tables_aside) {
-            side[0].join();
-            side[1].join();
+            ctx->side.wait();
         } else {
             build_lbeta_table(bdtrc_total(ctx->prm, ctx->stats.in_range_sum), mc, lb_a, ib_a);
             build_lbeta_table(bdtrc_total(ctx->prm, ctx->stats.inter_sum), mc, lb_e, ib_e);
