@@ -598,8 +598,8 @@ def main():
                          "valu_issue_floor_source": floor_src, "shader_clock_ghz": clock_ghz,
                          "launch_seconds": hv_s, "rows_per_launch": hv_rows,
                          "fp64_valu_issue_frac": (fp64_instr / hv_s) / fp64_issue_peak if hv_s > 0 else None,
-                         "fp64_note": "loop instructions only, against the nominal 2.4 GHz; by the SQ counters (profiles/r05_z_counters.txt; the kernel "
-                                      "is unchanged since: 3.18e9 VALU wave-instructions per launch = 25.4 per row-iteration all told, 1.28e7 cycles) the "
+                         "fp64_note": "loop instructions only, against the nominal 2.4 GHz; by the SQ counters (profiles/r06/z_counters.txt: 3.176e9 VALU "
+                                      "wave-instructions per launch = 25.4 per row-iteration all told, GRBM_GUI_ACTIVE 1.026e8 / 8 XCDs = 1.28e7 cycles) the "
                                       "launch fills 97 % of the VALU issue slots (one wave instruction per 4 cycles and SIMD) at the clock it runs at "
                                       "(shader_clock_ghz: this run's)"},
             "kernels_ms": {"k1_classify_hist": 1e3 * worst[0], "k2_pvalue": 1e3 * worst[1], "k3_bh_sort_scan": 1e3 * worst[2]},
