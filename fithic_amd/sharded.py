@@ -149,6 +149,20 @@ def socket_mesh(rank, world, tag, barrier, directory=None):
     return conns
 
 
+def rows_owned_by_parts(first_rows, ends_with_newline):
+    """A text cut into consecutive parts anywhere: a row belongs to the part that holds its first byte.  first_rows[r] = (length of
+    part r's first row with its newline, that row) - every part must hold a newline -, ends_with_newline[r]: part r ends a row.
+    -> per part (bytes to skip at its start: the rest of a row the part before owns; bytes to append: the rest of its last row,
+    which is the head of the next part)."""
+    out = []
+    last = len(first_rows) - 1
+    for r, (n, row) in enumerate(first_rows):
+        skip = 0 if r == 0 or ends_with_newline[r - 1] else n
+        extra = b"" if r == last or ends_with_newline[r] else first_rows[r + 1][1]
+        out.append((skip, extra))
+    return out
+
+
 class _Rank:
     """One rank's engine + communicator; the same object serves rank 0 (in process) and the workers' command loop."""
 
@@ -850,12 +864,8 @@ class ShardedEngine:
         if not ok:
             self._all("inflate_part_drop")
             return None
-        per_rank = []
-        for r, res in enumerate(second):
-            skip = 0 if r == 0 or second[r - 1][5] else res[3]
-            extra = b"" if r + 1 == self.world or res[5] else second[r + 1][4]
-            per_rank.append((skip, extra, threads))
-        return self._all("ingest_text_own", per_rank=per_rank)
+        own = rows_owned_by_parts([(res[3], res[4]) for res in second], [res[5] for res in second])
+        return self._all("ingest_text_own", per_rank=[(skip, extra, threads) for skip, extra in own])
 
     @staticmethod
     def _available_host_bytes():

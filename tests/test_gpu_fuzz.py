@@ -224,6 +224,11 @@ def test_sharded_command_line_on_random_cases(seed, tmp_path, capsys, monkeypatc
     monkeypatch.setenv("FHX_CLI_TRANSPORT", "pipes")
     gpus = 2 + seed % 2
     monkeypatch.setenv("FHX_CLI_DEVICES", ",".join(["0"] * gpus))
+    if seed % 3 != 0:
+        # the ranks inflate the (one-stream) contacts file together wherever the stream has a block start for every part - rows that
+        # straddle parts, parts that end on a newline, a last row without one - and fall back to the whole text where it has not
+        monkeypatch.setenv("FHX_PGUNZIP_MIN", "0")
+        monkeypatch.setenv("FHX_PGUNZIP_CHUNK", str(1024 << (seed % 5)))
     _cli_case(seed, tmp_path, capsys, gpus=gpus)
 
 

@@ -346,3 +346,53 @@ def test_host_writer_after_device_parser_fetches_the_columns_back(tmp_path, monk
             with gzip.open(os.path.join(str(out), "G.spline_pass%d%s.significances.txt.gz" % (pi, tag)), "rb") as f:
                 digests[which].append(hashlib.md5(f.read()).hexdigest())
     assert digests["device"] == digests["host"] == [meta["sig_md5_pass%d" % pi] for pi in range(1, meta["n_passes"] + 1)]
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FHX_FUZZ_SEEDS", "0:8").split(":")[0]),
+                                       int(os.environ.get("FHX_FUZZ_SEEDS", "0:8").split(":")[1])))
+def test_rows_of_a_text_cut_anywhere_are_each_parsed_by_one_part(seed, tmp_path):
+    """fhx_ingest_contacts_text_own + sharded.rows_owned_by_parts (the ranks of `fithic --gpus N` inflating one gzip stream
+    together): the text is cut at arbitrary bytes - inside a row, right behind a newline, right in front of one, inside a name -
+    and every part parses the rows whose first byte it holds, the last one completed from the next part's head.  All parts' rows,
+    in order, are the host parser's rows of the whole text; names in order of first appearance inside each part."""
+    from fithic_amd import _capi, sharded
+    rng = np.random.default_rng(700 + seed)
+    names = ["chr%d" % k for k in range(1, 6)] + ["chrX", "scaffold_%d" % seed]
+    n = int(rng.integers(50, 4000))
+    rows = ["%s\t%d\t%s\t%d\t%d\n" % (names[rng.integers(len(names))], rng.integers(0, 10 ** int(rng.integers(1, 9))),
+                                     names[rng.integers(len(names))], rng.integers(0, 10 ** 8), rng.integers(1, 500)) for _ in range(n)]
+    text = "".join(rows).encode()
+    if seed % 3 == 2:
+        text = text[:-1]                                           # a last row without its newline
+    whole = _write(tmp_path, "whole.gz", text)
+    want_names, want_cols = _host(whole)
+    n_parts = int(rng.integers(2, 7))
+    # cuts: random bytes, plus on purpose the byte behind a newline and the newline itself
+    nl = [i for i, b in enumerate(text) if b == 10]
+    cuts = sorted(set([int(rng.integers(1, len(text) - 1)) for _ in range(n_parts - 1)]))
+    if seed % 2 == 0 and len(cuts) >= 1:
+        cuts[0] = nl[len(nl) // 3] + 1                             # the part before ends a row
+    if seed % 4 == 1 and len(cuts) >= 2:
+        cuts[1] = nl[len(nl) // 2]                                 # the part begins with the newline of the row before
+    cuts = sorted(set(c for c in cuts if 0 < c < len(text)))
+    parts = [text[a:b] for a, b in zip([0] + cuts, cuts + [len(text)])]
+    if any(b"\n" not in p for p in parts):
+        pytest.skip("a part without a newline: the driver takes another route")
+    texts = [_capi.HostText(_write(tmp_path, "part%d.gz" % k, p), 2) for k, p in enumerate(parts)]
+    firsts = [t.first_row_end() for t in texts]
+    ends = [t.ends_with_newline() for t in texts]
+    assert [f[1] for f in firsts] == [p[:p.index(b"\n") + 1] for p in parts] and ends == [p.endswith(b"\n") for p in parts]
+    own = sharded.rows_owned_by_parts(firsts, ends)
+    got = [[] for _ in range(5)]
+    for t, (skip, extra) in zip(texts, own):
+        eng = _engine()
+        k, seen = eng.ctx.ingest_contacts_text_own(t, skip, extra)
+        ids = np.array([want_names.index(s) for s in seen], np.int32)     # (the whole text's id space)
+        eng.commit_contacts_text(ids, k)
+        cols = eng.ctx.fetch_pairs(n=k)
+        for c, g in zip(got, cols):
+            c.append(g)
+        eng.close()
+        t.close()
+    for k in range(5):
+        assert np.array_equal(np.concatenate(got[k]), want_cols[k]), k
