@@ -1,4 +1,5 @@
 #!/bin/bash
+# (working script of round 6, kept because evidence files name it)
 mkdir -p gpurun_out/r06
 (timeout 1200 python -m pytest tests -m gpu -x -q -n 2 2>&1 | tail -30) > gpurun_out/r06/d_gputests.txt
 B="--steps 8 --warmup 2"
