@@ -197,6 +197,7 @@ constexpr int CP_THREADS = 1024;
 constexpr int CP_WAVES = CP_THREADS / 64;
 constexpr int CP_ITEMS = 16;
 constexpr int CP_TILE = CP_THREADS * CP_ITEMS;
+constexpr int CP_STRIP = 2048;                        // survivors a workgroup of k3_compact holds in LDS across its tiles (24 KB)
 constexpr int SORT_BLOCKS = 1024;                     // persistent: 4 workgroups per CU
 constexpr int RADIX_BITS = 11;                       // 6 passes cover 66 >= 64 key bits
 constexpr int RADIX = 1 << RADIX_BITS;

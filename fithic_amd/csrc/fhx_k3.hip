@@ -145,11 +145,18 @@ __global__ __launch_bounds__(CP_THREADS) void k3_compact(const double* __restric
                                                            unsigned int* __restrict__ vals, double* __restrict__ q,
                                                            unsigned long long* __restrict__ counter,
                                                            const unsigned long long* __restrict__ cutoff_key, DenseQ dq,
-                                                           bool q_is_ones = false) {
+                                                           bool q_is_ones = false, int tiles_per_wg = 1) {
     // rows at or above the cutoff key (see above) have q = 1 and are not sorted; NaN rows get q = NaN.
-    // one global atomic per 4096-row tile (a same-address atomic per 256 rows capped this kernel at ~88 M atomics/s)
+    // One returning atomic on the survivors' counter per tile - and those retire at ~11 ns each on one address (a same-address
+    // atomic per 256 rows capped this kernel at 88 M atomics/s; per 4096 rows it still was 0.40 of 0.42 ms on C3).  A workgroup
+    // therefore takes tiles_per_wg consecutive tiles of 16 384 rows, and a tile with few survivors (the rule on a Hi-C map: 8 per
+    // tile on C3) leaves them in an LDS strip instead of asking for slots; the strip goes out behind the workgroup's last tile
+    // with ONE atomic (a tile that does not fit it asks as before).  The order of the survivors among themselves is free.
     __shared__ unsigned int wave_cnt[CP_WAVES];
     __shared__ unsigned long long block_base;
+    __shared__ unsigned long long strip_k[CP_STRIP];
+    __shared__ unsigned int strip_v[CP_STRIP];
+    __shared__ unsigned int strip_n, strip_at;                   // entries in the strip; this tile's first one, or ~0u: global slots
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     const int64_t tiles = (n + CP_TILE - 1) / CP_TILE;
@@ -157,7 +164,11 @@ __global__ __launch_bounds__(CP_THREADS) void k3_compact(const double* __restric
     const unsigned long long cutoff = *cutoff_key;
     const double2* p2 = reinterpret_cast<const double2*>(p);
     double2* q2 = reinterpret_cast<double2*>(q);
-    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const bool strip_ok = !DENSE && tiles_per_wg > 1;            // (the dense variant's payload IS the slot: it must be known here)
+    if (threadIdx.x == 0) strip_n = 0u;
+    const int64_t groups = (tiles + tiles_per_wg - 1) / tiles_per_wg;
+    for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    for (int64_t t = grp * tiles_per_wg; t < tiles && t < (grp + 1) * tiles_per_wg; ++t) {
         const int64_t wave_base = t * CP_TILE + (int64_t)wave * (64 * CP_ITEMS);
         // two consecutive rows per lane and step: 16-byte loads of p and (for the rows that are not ranked: nearly all) 16-byte
         // stores of q
@@ -210,20 +221,53 @@ __global__ __launch_bounds__(CP_THREADS) void k3_compact(const double* __restric
                 wave_cnt[w] = tot;
                 tot += c;
             }
-            block_base = tot ? atomicAdd(counter, (unsigned long long)tot) : 0ull;
-        }
-        __syncthreads();
-        const unsigned long long base = block_base + wave_cnt[wave];
-        if (DENSE && lane == 0) dq.wave_slot[t * CP_WAVES + wave] = base;
-#pragma unroll
-        for (int r = 0; r < CP_ITEMS; ++r) {
-            if ((keepmask >> r) & 1ull) {
-                keys[base + before[r]] = pvalue_key(v[r]);
-                vals[base + before[r]] = DENSE ? (unsigned int)(base + before[r])
-                                               : (unsigned int)(wave_base + (int64_t)((r >> 1) * 64 + lane) * 2 + (r & 1));
+            if (strip_ok && strip_n + tot <= (unsigned int)CP_STRIP) {
+                strip_at = strip_n;
+                strip_n += tot;
+            } else {
+                strip_at = ~0u;
+                block_base = tot ? atomicAdd(counter, (unsigned long long)tot) : 0ull;
             }
         }
         __syncthreads();
+        if (strip_at != ~0u) {
+            const unsigned int at = strip_at + wave_cnt[wave];
+#pragma unroll
+            for (int r = 0; r < CP_ITEMS; ++r) {
+                if ((keepmask >> r) & 1ull) {
+                    strip_k[at + before[r]] = pvalue_key(v[r]);
+                    strip_v[at + before[r]] = (unsigned int)(wave_base + (int64_t)((r >> 1) * 64 + lane) * 2 + (r & 1));
+                }
+            }
+        } else {
+            const unsigned long long base = block_base + wave_cnt[wave];
+            if (DENSE && lane == 0) dq.wave_slot[t * CP_WAVES + wave] = base;
+#pragma unroll
+            for (int r = 0; r < CP_ITEMS; ++r) {
+                if ((keepmask >> r) & 1ull) {
+                    keys[base + before[r]] = pvalue_key(v[r]);
+                    vals[base + before[r]] = DENSE ? (unsigned int)(base + before[r])
+                                                   : (unsigned int)(wave_base + (int64_t)((r >> 1) * 64 + lane) * 2 + (r & 1));
+                }
+            }
+        }
+        __syncthreads();
+    }
+        // the strip of this group of tiles: one atomic, then out
+        if (strip_ok) {
+            const unsigned int held = strip_n;
+            if (held) {
+                if (threadIdx.x == 0) block_base = atomicAdd(counter, (unsigned long long)held);
+                __syncthreads();
+                for (unsigned int i = threadIdx.x; i < held; i += CP_THREADS) {
+                    keys[block_base + i] = strip_k[i];
+                    vals[block_base + i] = strip_v[i];
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) strip_n = 0u;
+                __syncthreads();
+            }
+        }
     }
 }
 
@@ -1159,13 +1203,17 @@ static int compact_pvalues(fhx_ctx* ctx, const double* d_p, int64_t n, unsigned 
     static const int k3_cap = std::getenv("FHX_K3_GRID") ? std::atoi(std::getenv("FHX_K3_GRID")) : (1 << 30);
     if (dq)
         hipLaunchKernelGGL(k3_compact<true>, dim3(grid_for(n, CP_TILE, k3_cap)), dim3(CP_THREADS), 0, ctx->stream, d_p, n,
-                           keys[0], vals[0], d_q, counter, d_cutoff, *dq);
+                           keys[0], vals[0], d_q, counter, d_cutoff, *dq, false, 1);
     if (!dq || dq->flag) {                           // (with a flag the device picks one of the two; the other returns at once)
         DenseQ off;
         if (dq) off.flag = dq->flag;
         const bool ones = ctx->q_prefilled && d_q == ctx->d_q && d_p == ctx->d_p;
-        hipLaunchKernelGGL(k3_compact<false>, dim3(grid_for(n, CP_TILE, k3_cap)), dim3(CP_THREADS), 0, ctx->stream, d_p, n,
-                           keys[0], vals[0], d_q, counter, d_cutoff, off, ones);
+        // tiles per workgroup: as many as leave every CU its two workgroups several times over (a shard keeps one tile per workgroup)
+        static const int per_env = std::getenv("FHX_K3_TILES_PER_WG") ? std::atoi(std::getenv("FHX_K3_TILES_PER_WG")) : 0;
+        const int64_t n_tiles = (n + CP_TILE - 1) / CP_TILE;
+        const int per = per_env > 0 ? per_env : (int)std::max<int64_t>(1, std::min<int64_t>(4, n_tiles / 2048));
+        hipLaunchKernelGGL(k3_compact<false>, dim3(grid_for((n_tiles + per - 1) / per, 1, k3_cap)), dim3(CP_THREADS), 0, ctx->stream, d_p, n,
+                           keys[0], vals[0], d_q, counter, d_cutoff, off, ones, per);
     }
     if (d_q == ctx->d_q) ctx->q_prefilled = false;      // from here on the column holds this pass's q
     // how many keys survived decides the shape of the sort.  When the cutoff came from this GPU's own histogram (auto_cutoff) the
