@@ -345,3 +345,27 @@ def test_one_plain_gzip_stream_is_inflated_by_the_ranks_together(tmp_path):
     ranks.host_has_room = False
     assert sharded.ShardedEngine._ingest_slices(ranks, path, tables.ChromIndex(), 4) is None
     assert ranks.asked[-1] == "inflate_part_drop"
+
+
+def test_a_row_belongs_to_the_part_that_holds_its_first_byte():
+    """sharded.rows_owned_by_parts on texts cut at random bytes: skipping / appending as it says and splitting every part into rows
+    gives back the rows of the whole text, each once, in order"""
+    from fithic_amd import sharded
+    rng = np.random.default_rng(11)
+    for trial in range(300):
+        rows = [b"r%d\t%d\n" % (k, rng.integers(0, 10 ** int(rng.integers(1, 9)))) for k in range(int(rng.integers(3, 60)))]
+        text = b"".join(rows)
+        if trial % 3 == 0:
+            text = text[:-1]
+        cuts = sorted(set(int(c) for c in rng.integers(1, len(text) - 1, int(rng.integers(1, 6)))))
+        parts = [text[a:b] for a, b in zip([0] + cuts, cuts + [len(text)])]
+        if any(b"\n" not in p for p in parts):
+            continue
+        firsts = [(p.index(b"\n") + 1, p[:p.index(b"\n") + 1]) for p in parts]
+        own = sharded.rows_owned_by_parts(firsts, [p.endswith(b"\n") for p in parts])
+        got = []
+        for p, (skip, extra) in zip(parts, own):
+            mine = p[skip:] + extra
+            got += [ln + b"\n" for ln in mine.split(b"\n") if ln] if mine else []
+        want = [ln + b"\n" for ln in text.split(b"\n") if ln]
+        assert got == want, (trial, cuts)
