@@ -53,6 +53,22 @@ __device__ __forceinline__ double cephes_log1p(double x) {
     return x + z;
 }
 
+// log1p(-x) for 0 <= x < 0.01 without Cephes' rational function and its division: the series x + x^2/2 + ... + x^9/9 (the next term
+// is below 1e-19 of the first) in Horner form with fused multiply-adds.  NOT Cephes' arithmetic: within ~1 ulp of it, not its bits
+// (the experiment of VERDICT r04-r05, item "count == 1 strip"; measured in profiles/r06/lean_closed_form.txt).
+__device__ __forceinline__ double lean_log1p_neg(double x) {
+    double t = 1.0 / 9.0;
+    t = fma(t, x, 1.0 / 8.0);
+    t = fma(t, x, 1.0 / 7.0);
+    t = fma(t, x, 1.0 / 6.0);
+    t = fma(t, x, 1.0 / 5.0);
+    t = fma(t, x, 1.0 / 4.0);
+    t = fma(t, x, 1.0 / 3.0);
+    t = fma(t, x, 0.5);
+    t = fma(t, x, 1.0);
+    return -(x * t);
+}
+
 __device__ __forceinline__ double cephes_expm1(double x) {
     if (!isfinite(x)) {
         if (isnan(x) || x > 0) return x;

@@ -109,6 +109,7 @@ struct K2Params {
     // the true totals (observedIntraInRangeSum, observedInterAllSum) for ExpCC = total * prior (fithic.py:1076, 1106): the n
     // of intra / inter above is what bdtrc is given, which differs from these once a total reaches 2^31 (bdtrc_total)
     double total_intra, total_inter;
+    int lean_closed;              // experiment (FHX_LEAN_CLOSED=1): count == 1 rows with prior < 0.01 through a division-free log1p
 };
 
 constexpr int K2_THREADS = 256;

@@ -350,7 +350,9 @@ __global__ __launch_bounds__(K2_THREADS) __attribute__((amdgpu_waves_per_eu(WPE,
         for (unsigned int j = lane; j < n_local; j += 64) {
             const unsigned int ix = cf_idx[wave][j];
             const double n_total = (ix & 0x8000u) ? P.inter.n : P.intra.n;
-            const double pv = -dev::cephes_expm1(n_total * dev::cephes_log1p(-cf_prior[wave][j]));        // bdtrc_closed_form, prior < 0.01
+            const double pr = cf_prior[wave][j];
+            const double pv = P.lean_closed ? -dev::cephes_expm1(n_total * dev::lean_log1p_neg(pr))
+                                            : -dev::cephes_expm1(n_total * dev::cephes_log1p(-pr));             // bdtrc_closed_form, prior < 0.01
             P.p[wave_row0 + (ix & 0x7FFFu)] = pv;
             H.add(pv);
         }
@@ -1014,6 +1016,8 @@ K2Params make_k2_params(fhx_ctx* c) {
     P.count = c->d_count;
     P.slot_bias = c->d_slot_bias;
     P.no_bias = !c->have_bias;
+    static const int lean = std::getenv("FHX_LEAN_CLOSED") ? std::atoi(std::getenv("FHX_LEAN_CLOSED")) : 0;
+    P.lean_closed = lean;
     P.prior_lut = c->d_lut;
     P.lut_len = (int)std::min<size_t>(std::max<size_t>(c->fit.prior_lut.size(), 1), (size_t)INT32_MAX);
     // the n of the two binomials: narrowed to a C int as scipy does, unless the caller asked for wide totals (bdtrc_total)
